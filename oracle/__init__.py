@@ -1,0 +1,24 @@
+"""TEST INFRASTRUCTURE ONLY -- the CPU oracle for the bilateral-grid hot path.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this package; nothing under ``hdrnet_amd/`` does (enforced by
+``tests/test_no_oracle_in_product.py``).
+
+Two checkers live here, both operating on C-contiguous float32 numpy arrays in
+the reference's NHWC layouts (``hdrnet/ops/bilateral_slice_apply_op.cc:201-227``):
+
+* ``port``  -- ``liboracle.so``: the C99 restatement ``bilateral_oracle.c``.
+* ``ref``   -- ``_ref/libhdrnet_ref.so``: the reference's own
+  ``bilateral_slice_apply.cc`` / ``bilateral_slice.cc`` compiled unchanged
+  (``oracle/Makefile``).  Exists wherever ``/root/reference`` existed at build
+  time; the prebuilt library travels to the GPU box.
+
+``jax_np`` restates ``jax/bilateral_slice.py`` in numpy (jax is not installed).
+"""
+from .cpu_oracle import (  # noqa: F401
+    Oracle,
+    build,
+    have_ref,
+    port,
+    ref,
+)
