@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- BilateralSliceApply forward throughput on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 4k|1080p|hdrp]
+
+Metric (BASELINE.json): megapixels/s of BilateralSliceApply forward @4K (3840x2160 fp32 NHWC,
+grid 16x16x8x12, batch 1), reported with the fraction of the MI355X HBM roofline; for N > 1
+each rank (one process per GPU, launched by torch.distributed.run) processes its OWN frames
+-- the path shards by image with no data-path collective -- so scaling is
+"weak" and `value` is the whole-job aggregate.
+
+A "step" is one pass of the hot path over one frame: ONE kernel launch through the C-ABI
+(hdrnet_bilateral_slice_apply_f32) on the current HIP stream.  Inputs are resident in HBM
+before the timed region.  Steps rotate over enough independent buffer sets that the
+working set exceeds the 256 MiB Infinity Cache + L2 (232 MB per 4K frame x 3 sets), so the
+number is an HBM number, not a cache number; the cache-resident rate is reported separately
+under "extra".
+
+Adds to the JSON line:
+  roofline     -- algorithmic bytes / average kernel duration (HIP events on the launch
+                  stream around the timed region) vs the 8 TB/s HBM3E peak
+  cpu_baseline -- the reference's own CPU op (oracle/_ref, kind "reference") or the C port,
+                  timed on this host on a bounded sample (rank 0, N = 1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+CACHE_BYTES = 256 * 2 ** 20 + 32 * 2 ** 20  # Infinity Cache + aggregate L2
+
+WORKLOADS = {
+    # name: (H, W, GH, GW, GD, description)
+    "4k": (2160, 3840, 16, 16, 8, "BilateralSliceApply fwd 3840x2160 fp32 NHWC, grid 16x16x8x12, batch=1/GPU"),
+    "1080p": (1080, 1920, 16, 16, 8, "BilateralSliceApply fwd 1920x1080 fp32 NHWC, grid 16x16x8x12, batch=1/GPU"),
+    "hdrp": (3000, 4000, 32, 32, 8, "BilateralSliceApply fwd 4000x3000 fp32 NHWC, grid 32x32x8x12, 1 image/GPU"),
+}
+
+
+def algorithmic_bytes(B, H, W, GH, GW, GD, Cin=3, Cout=3, has_offset=True):
+    """4*B*[H*W*(1 + Cin + Cout) + GH*GW*GD*Cout*Cj]."""
+    Cj = Cin + int(has_offset)
+    return 4 * B * (H * W * (1 + Cin + Cout) + GH * GW * GD * Cout * Cj)
+
+
+def make_sets(dev, nsets, H, W, GH, GW, GD, seed):
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    sets = []
+    for _ in range(nsets):
+        grid = torch.rand((1, GH, GW, GD, 12), device=dev, generator=gen)
+        guide = torch.rand((1, H, W), device=dev, generator=gen)
+        inp = torch.rand((1, H, W, 3), device=dev, generator=gen)
+        out = torch.empty((1, H, W, 3), device=dev)
+        sets.append((grid, guide, inp, out))
+    return sets
+
+
+def run_steps(lib, sets, dims, stream, n, start=0):
+    H, W, GH, GW, GD = dims
+    ns = len(sets)
+    fn = lib.hdrnet_bilateral_slice_apply_f32
+    for k in range(n):
+        grid, guide, inp, out = sets[(start + k) % ns]
+        rc = fn(grid.data_ptr(), guide.data_ptr(), inp.data_ptr(), out.data_ptr(),
+                1, H, W, GH, GW, GD, 3, 3, 1, stream)
+        if rc != 0:
+            raise RuntimeError(f"hdrnet_bilateral_slice_apply_f32 rc={rc}: {lib.hdrnet_last_error().decode()}")
+
+
+def timed(lib, sets, dims, stream, steps, dist_on, dev):
+    """Barrier + sync, K launches bracketed by HIP events on the launch stream, sync + barrier."""
+    import torch.distributed as dist
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    ev0.record()
+    run_steps(lib, sets, dims, stream, steps)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    if dist_on:
+        dist.barrier()
+    return t1 - t0, ev0.elapsed_time(ev1) * 1e-3
+
+
+def cpu_baseline(H, W, GH, GW, GD, budget_s=20.0):
+    """The reference's CPU op timed on this host's cores, bounded sample (whole frames)."""
+    import oracle
+    rng = np.random.default_rng(1234)
+    grid = rng.random((1, GH, GW, GD, 12), dtype=np.float32)
+    guide = rng.random((1, H, W), dtype=np.float32)
+    inp = rng.random((1, H, W, 3), dtype=np.float32)
+    if oracle.have_ref():
+        impl, kind, cores = oracle.ref(), "reference", 1
+    else:
+        impl, kind = oracle.port(), "port"
+        cores = impl.set_threads(os.cpu_count() or 1)
+    # one short probe to size the sample
+    hp = max(8, H // 16)
+    t = time.perf_counter()
+    impl.bilateral_slice_apply(grid, guide[:, :hp], inp[:, :hp], True)
+    per_px = (time.perf_counter() - t) / (hp * W)
+    frames = int(max(1, min(8, budget_s / max(per_px * H * W, 1e-9))))
+    t = time.perf_counter()
+    for _ in range(frames):
+        impl.bilateral_slice_apply(grid, guide, inp, True)
+    dt = time.perf_counter() - t
+    return {
+        "value": round(frames * H * W / 1e6 / dt, 4), "unit": "MP/s", "cores": cores, "kind": kind,
+        "sample": f"{frames} frame(s) of {W}x{H}, grid {GH}x{GW}x{GD}x12, "
+                  + ("oracle/_ref (reference bilateral_slice_apply.cc compiled unchanged, -O2, serial)"
+                     if kind == "reference" else f"oracle C port, OpenMP {cores} threads"),
+        "host_cpus": os.cpu_count(), "seconds": round(dt, 2),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--workload", default="4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the cache-resident / 1080p extras")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run "
+                     "(one process per GPU); see the module docstring")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL; control plane only
+
+    from hdrnet_amd import _lib
+    lib = _lib.load()  # raises loudly if the HIP library is missing
+
+    H, W, GH, GW, GD, desc = WORKLOADS[args.workload]
+    dims = (H, W, GH, GW, GD)
+    abytes = algorithmic_bytes(1, H, W, GH, GW, GD)
+    nsets = max(3, -(-int(CACHE_BYTES * 1.5) // abytes))
+    sets = make_sets(dev, nsets, H, W, GH, GW, GD, seed=1234 + rank)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    run_steps(lib, sets, dims, stream, args.warmup)
+    wall, gpu_s = timed(lib, sets, dims, stream, args.steps, dist_on, dev)
+    kernel = lib.hdrnet_last_kernel().decode()
+
+    elapsed = torch.tensor([wall, gpu_s], dtype=torch.float64, device=dev)
+    if dist_on:
+        import torch.distributed as dist
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    wall_max, gpu_max = float(elapsed[0]), float(elapsed[1])
+
+    mp_per_step = H * W / 1e6
+    value = world * args.steps * mp_per_step / wall_max
+    avg_kernel_s = gpu_max / args.steps  # events bracket K back-to-back launches of ONE kernel
+    achieved = abytes / avg_kernel_s / 1e9
+
+    result = {
+        "metric": "megapixels/sec BilateralSliceApply fwd @4K" if args.workload == "4k"
+                  else f"megapixels/sec BilateralSliceApply fwd @{args.workload}",
+        "value": round(value, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(wall_max / args.steps * 1e3, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": desc, "images_per_gpu_per_step": 1, "layout": "NHWC fp32",
+                   "has_offset": True, "rotating_buffer_sets": nsets,
+                   "working_set_MB": round(nsets * abytes / 1e6, 1), "parallelism": f"image-shard x{world}",
+                   "kernel": kernel},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": abytes, "avg_kernel_us": round(avg_kernel_s * 1e6, 3),
+                     "timing": "HIP events on the launch stream around the timed region / steps"},
+    }
+
+    if rank == 0 and world == 1:
+        extra = {}
+        if not args.no_extra:
+            # cache-resident rate (one buffer set, stays in the 256 MiB Infinity Cache): labelled, not `value`
+            one = sets[:1]
+            run_steps(lib, one, dims, stream, 10)
+            _, g1 = timed(lib, one, dims, stream, args.steps, False, dev)
+            extra["cache_resident_MPps"] = round(args.steps * mp_per_step / g1, 1)
+            extra["cache_resident_GBps"] = round(abytes * args.steps / g1 / 1e9, 1)
+            if args.workload == "4k":
+                h2, w2, gh2, gw2, gd2, _ = WORKLOADS["1080p"]
+                ab2 = algorithmic_bytes(1, h2, w2, gh2, gw2, gd2)
+                n2 = max(3, -(-int(CACHE_BYTES * 1.5) // ab2))
+                del sets
+                torch.cuda.empty_cache()
+                s2 = make_sets(dev, n2, h2, w2, gh2, gw2, gd2, seed=99)
+                d2 = (h2, w2, gh2, gw2, gd2)
+                run_steps(lib, s2, d2, stream, args.warmup)
+                w_, g2 = timed(lib, s2, d2, stream, args.steps * 2, False, dev)
+                extra["1080p_MPps"] = round(args.steps * 2 * h2 * w2 / 1e6 / w_, 1)
+                extra["1080p_avg_kernel_us"] = round(g2 / (args.steps * 2) * 1e6, 3)
+                extra["1080p_hbm_frac"] = round(ab2 / (g2 / (args.steps * 2)) / 1e9 / HBM_PEAK_GBPS, 4)
+        result["extra"] = extra
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(H, W, GH, GW, GD)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist_on:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,120 @@
+"""ctypes binding of libhdrnet_amd.so -- the C-ABI declared in include/hdrnet_amd.h.
+
+The library is the product: there is NO fallback.  If it cannot be built / loaded the
+import of the ops fails loudly (``HdrnetLibraryError``); nothing here routes to PyTorch
+eager code or to any CPU checker.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from typing import Optional
+
+HDRNET_OK = 0
+HDRNET_INVALID_ARGUMENT = 1
+HDRNET_RUNTIME_FAILURE = 2
+
+KERNEL_AUTO = 0
+KERNEL_GENERIC = 1
+KERNEL_FAST = 2
+
+_FP = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
+_I = ctypes.c_int
+_U = ctypes.c_uint
+_SZ = ctypes.c_size_t
+_VP = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/hdrnet_amd.h declares
+# (tests/test_capi_symbols.py cross-checks this table against the header).
+SIGNATURES = {
+    "hdrnet_version": (_I, []),
+    "hdrnet_last_error": (ctypes.c_char_p, []),
+    "hdrnet_last_kernel": (ctypes.c_char_p, []),
+    "hdrnet_bilateral_slice_apply_f32": (_I, [_FP] * 4 + [_I] * 9 + [_VP]),
+    "hdrnet_bilateral_slice_apply_f32_ex": (_I, [_FP] * 4 + [_I] * 9 + [_U, _VP]),
+    "hdrnet_bilateral_slice_apply_grad_workspace_bytes": (_SZ, [_I] * 9),
+    "hdrnet_bilateral_slice_apply_grad_f32": (_I, [_FP] * 7 + [_I] * 9 + [_VP, _SZ, _VP]),
+    "hdrnet_bilateral_slice_apply_grad_f32_ex": (_I, [_FP] * 7 + [_I] * 9 + [_VP, _SZ, _U, _VP]),
+    "hdrnet_bilateral_slice_f32": (_I, [_FP] * 3 + [_I] * 7 + [_VP]),
+    "hdrnet_bilateral_slice_f32_ex": (_I, [_FP] * 3 + [_I] * 7 + [_U, _VP]),
+    "hdrnet_bilateral_slice_grad_workspace_bytes": (_SZ, [_I] * 7),
+    "hdrnet_bilateral_slice_grad_f32": (_I, [_FP] * 5 + [_I] * 7 + [_VP, _SZ, _VP]),
+    "hdrnet_bilateral_slice_grad_f32_ex": (_I, [_FP] * 5 + [_I] * 7 + [_VP, _SZ, _U, _VP]),
+}
+
+
+class HdrnetLibraryError(RuntimeError):
+    """libhdrnet_amd.so is missing, failed to build, or failed to load."""
+
+
+class HdrnetInvalidArgument(ValueError):
+    """HDRNET_INVALID_ARGUMENT (the reference: tensorflow::errors::InvalidArgument)."""
+
+
+class HdrnetRuntimeError(RuntimeError):
+    """HDRNET_RUNTIME_FAILURE (the reference: errors::Internal("... kernel failed."))."""
+
+
+_lock = threading.Lock()
+_lib: Optional[ctypes.CDLL] = None
+
+
+def lib_path() -> str:
+    from . import build as _build
+
+    return _build.LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load (building first if the in-tree library is missing or stale)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        # torch must be imported first so that its bundled libamdhip64.so.7 is the
+        # HIP runtime both sides share (same SONAME => the loader reuses it).
+        import torch  # noqa: F401
+
+        from . import build as _build
+
+        try:
+            path = _build.build()
+        except Exception as e:  # noqa: BLE001
+            if os.path.exists(_build.LIB_PATH):
+                path = _build.LIB_PATH  # stale but usable (e.g. no hipcc on this host)
+            else:
+                raise HdrnetLibraryError(
+                    f"cannot build libhdrnet_amd.so (hipcc for gfx950 required): {e}") from e
+        try:
+            lib = ctypes.CDLL(path)
+        except OSError as e:
+            raise HdrnetLibraryError(f"cannot load {path}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise HdrnetLibraryError(f"{path} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    return load().hdrnet_last_error().decode()
+
+
+def last_kernel() -> str:
+    return load().hdrnet_last_kernel().decode()
+
+
+def check(rc: int, what: str) -> None:
+    if rc == HDRNET_OK:
+        return
+    msg = f"{what}: {last_error()}"
+    if rc == HDRNET_INVALID_ARGUMENT:
+        raise HdrnetInvalidArgument(msg)
+    raise HdrnetRuntimeError(msg)

@@ -1,0 +1,345 @@
+// BilateralSliceApply forward for gfx950 -- the north-star kernel.
+//
+// Reference semantics: hdrnet/ops/bilateral_slice_apply.cc:24-82 (the CUDA twin,
+// bilateral_slice_apply.cu.cc:36-126, assigns one thread per output CHANNEL and
+// re-derives all weights for each of its 32 scattered grid loads).
+//
+// Design: the op is a pure HBM stream -- 4 B guide + 4*Cin B input
+// in, 4*Cout B out per pixel -- next to a 96 KiB grid that never leaves L2.  So:
+//   * a workgroup owns one SEGMENT OF ONE IMAGE ROW.  For a row, gy0/gy1 and the
+//     two y-weights are wave-uniform scalars, so the workgroup first blends the two
+//     grid rows it needs into LDS ("y-pre-lerp": colY[gx][gz][c] =
+//     wy0*grid[gy0c][gx] + wy1*grid[gy1c][gx], only the gx columns the segment
+//     touches).  A pixel then gathers 2(x) x 2(z) coefficient vectors instead of 8.
+//   * the LDS image keeps the grid's own [gx][gz][c] order: one (gx,gz) vector is
+//     C contiguous floats (48 B for C=12), read as ds_read_b128.  With a 48-B
+//     stride the eight gz vectors of a column start at dword banks
+//     {0,12,24,36,48,60,8,20} mod 64 -- disjoint 4-bank slots -- so the
+//     data-dependent gz gather is conflict-free across a 16-lane b128 group.
+//   * a thread owns 4 CONSECUTIVE pixels: guide is one 16-B load, input and output
+//     are three 16-B loads / stores each (global_load/store_dwordx4), all issued
+//     before the arithmetic; rows are contiguous so every wave streams a dense
+//     3 KiB span.  (Scalar variant for W % 4 != 0 or unaligned pointers.)
+//   * per pixel: 2 sqrt (the reference: 96), 4 weights, 4*C FMAs for the blend,
+//     Cout*Cj FMAs for the affine.  No MFMA: this is a gather/interpolate with 8
+//     non-zeros per pixel, not a dense contraction.
+//
+// Numerics: same coordinate / weight expressions as the reference, evaluated in
+// the same order; the only re-association is wy folded into the LDS image, i.e.
+// (wy0*g0 + wy1*g1)*(wx*wz) instead of sum((wx*wy)*wz*g).  Differences stay at the
+// 1e-7 relative level (tests/test_gpu_parity.py holds rtol=atol=1e-5 and reports
+// the reference's own 1e-6 bar).
+#include <hip/hip_runtime.h>
+
+#include "launch.hip.h"
+#include "numerics.hip.h"
+
+namespace hdrnet_amd {
+namespace {
+
+constexpr int kPxPerThread = 4;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int C>
+struct CoefVec {
+  static constexpr int kPairs = (C + 1) / 2;
+  f32x2 v[kPairs];  // coefficient c lives in v[c / 2][c % 2]
+  __device__ __forceinline__ float get(int c) const { return v[c >> 1][c & 1]; }
+};
+
+// coef += w * colY[base .. base+C)   (base in floats, multiple of C).
+// Written on explicit 2-wide vectors so that the blend maps onto v_pk_fma_f32 with
+// the weight broadcast through op_sel and the ds_read_b128 result consumed in
+// place (no cross-pixel SLP pairing, no register shuffles).
+template <int C>
+__device__ __forceinline__ void accum_vec(CoefVec<C>& coef, const float* __restrict__ colY,
+                                          int base, float w) {
+  const f32x2 w2 = {w, w};
+  if constexpr (C % 4 == 0) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(colY + base);
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q) {
+      const f32x4 t = p[q];
+      coef.v[2 * q + 0] = __builtin_elementwise_fma(w2, t.xy, coef.v[2 * q + 0]);
+      coef.v[2 * q + 1] = __builtin_elementwise_fma(w2, t.zw, coef.v[2 * q + 1]);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < C; ++q) coef.v[q >> 1][q & 1] = fmaf(w, colY[base + q], coef.v[q >> 1][q & 1]);
+  }
+}
+
+struct RowCtx {
+  const float* colY;  // LDS image, [ncol][GD][C]
+  float scale_x;
+  int GW, GD, gxlo;
+};
+
+// One pixel: slice the y-pre-lerped columns at (x, guide) and apply the affine.
+template <int CIN, int COUT, bool OFFSET>
+__device__ __forceinline__ void slice_apply_pixel(const RowCtx& r, int x, float g,
+                                                  const float (&in)[CIN],
+                                                  float (&out)[COUT]) {
+  constexpr int CJ = CIN + (OFFSET ? 1 : 0);
+  constexpr int C = COUT * CJ;
+  // bilateral_slice_apply.cc:41,44,46,48
+  const float gxf = (x + 0.5f) * r.scale_x;
+  const float gzf = g * r.GD;
+  const int gx0 = floor_to_int(gxf - 0.5f);
+  const int gz0 = floor_to_int(gzf - 0.5f);
+  // :59-60, :63-64 -- weights from the UNclamped corner, indices clamped.
+  const float wx0 = tent_weight(gx0 + 0.5f, gxf);
+  const float wx1 = tent_weight(gx0 + 1 + 0.5f, gxf);
+  const float wz0 = smoothed_tent_weight(gz0 + 0.5f, gzf);
+  const float wz1 = smoothed_tent_weight(gz0 + 1 + 0.5f, gzf);
+  const int c0 = clamp_index(gx0, 0, r.GW - 1) - r.gxlo;
+  const int c1 = clamp_index(gx0 + 1, 0, r.GW - 1) - r.gxlo;
+  const int z0 = clamp_index(gz0, 0, r.GD - 1);
+  const int z1 = clamp_index(gz0 + 1, 0, r.GD - 1);
+  const int col0 = c0 * r.GD, col1 = c1 * r.GD;
+
+  CoefVec<C> coef;
+#pragma unroll
+  for (int q = 0; q < CoefVec<C>::kPairs; ++q) coef.v[q] = f32x2{0.0f, 0.0f};
+  accum_vec<C>(coef, r.colY, (col0 + z0) * C, wx0 * wz0);
+  accum_vec<C>(coef, r.colY, (col0 + z1) * C, wx0 * wz1);
+  accum_vec<C>(coef, r.colY, (col1 + z0) * C, wx1 * wz0);
+  accum_vec<C>(coef, r.colY, (col1 + z1) * C, wx1 * wz1);
+
+  // :72-80 -- per-pixel (Cout x Cj) . [in; 1]
+#pragma unroll
+  for (int i = 0; i < COUT; ++i) {
+    float v = 0.0f;
+#pragma unroll
+    for (int j = 0; j < CIN; ++j) v = fmaf(coef.get(i * CJ + j), in[j], v);
+    if (OFFSET) v += coef.get(i * CJ + CIN);
+    out[i] = v;
+  }
+}
+
+// Blend the two grid rows this image row needs into LDS; returns the row context.
+template <int C>
+__device__ __forceinline__ RowCtx stage_row(float* __restrict__ colY,
+                                            const float* __restrict__ grid_b, int y, int xs,
+                                            int xe, int GH, int GW, int GD, float scale_x,
+                                            float scale_y) {
+  // Wave-uniform y terms (bilateral_slice_apply.cc:42,47,55-56).
+  const float gyf = (y + 0.5f) * scale_y;
+  const int gy0 = floor_to_int(gyf - 0.5f);
+  const float wy0 = tent_weight(gy0 + 0.5f, gyf);
+  const float wy1 = tent_weight(gy0 + 1 + 0.5f, gyf);
+  const int gy0c = clamp_index(gy0, 0, GH - 1);
+  const int gy1c = clamp_index(gy0 + 1, 0, GH - 1);
+  // Grid columns touched by pixels [xs, xe).
+  const int gxlo = clamp_index(floor_to_int((xs + 0.5f) * scale_x - 0.5f), 0, GW - 1);
+  const int gxhi =
+      clamp_index(floor_to_int((xe - 1 + 0.5f) * scale_x - 0.5f) + 1, 0, GW - 1);
+  const int n = (gxhi - gxlo + 1) * GD * C;  // floats; contiguous in the grid row
+  const float* r0 = grid_b + ((size_t)(gy0c * GW + gxlo) * GD) * C;
+  const float* r1 = grid_b + ((size_t)(gy1c * GW + gxlo) * GD) * C;
+  if constexpr (C % 4 == 0) {
+    const float4* a4 = reinterpret_cast<const float4*>(r0);
+    const float4* b4 = reinterpret_cast<const float4*>(r1);
+    float4* d4 = reinterpret_cast<float4*>(colY);
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+    for (int e = threadIdx.x; e < n / 4; e += blockDim.x) {
+      const float4 a = a4[e], b = b4[e];
+      d4[e] = make_float4(wy0 * a.x + wy1 * b.x, wy0 * a.y + wy1 * b.y,
+                          wy0 * a.z + wy1 * b.z, wy0 * a.w + wy1 * b.w);
+    }
+  } else {
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+    for (int e = threadIdx.x; e < n; e += blockDim.x) colY[e] = wy0 * r0[e] + wy1 * r1[e];
+  }
+  __syncthreads();
+  return RowCtx{colY, scale_x, GW, GD, gxlo};
+}
+
+// ---- 4 consecutive pixels per thread, 16-byte global accesses -----------------------
+// Requires W % 4 == 0, seg % 4 == 0 and 16-B aligned guide / input / out.
+template <int CIN, int COUT, bool OFFSET>
+__global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
+    const float* __restrict__ grid, const float* __restrict__ guide,
+    const float* __restrict__ input, float* __restrict__ out, int H, int W, int GH, int GW,
+    int GD, int nseg, int seg, float scale_x, float scale_y) {
+  constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
+  extern __shared__ __attribute__((aligned(16))) float colY[];
+  const int bid = blockIdx.x;
+  const int segi = bid % nseg;
+  const int row = bid / nseg;  // = b * H + y
+  const int y = row % H;
+  const int b = row / H;
+  const int xs = segi * seg;
+  const int xe = min(xs + seg, W);
+  const float* grid_b = grid + (size_t)b * GH * GW * GD * C;
+
+  const int x = xs + kPxPerThread * threadIdx.x;
+  const bool active = x < xe;
+  const size_t p = (size_t)row * W + x;
+
+  // Issue this thread's streaming loads before the staging pass so their HBM
+  // latency overlaps the (L2-resident) grid reads and the barrier.
+  float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 iv[(CIN * kPxPerThread) / 4];
+  if (active) {
+    g4 = *reinterpret_cast<const float4*>(guide + p);
+    const float4* ip = reinterpret_cast<const float4*>(input + p * CIN);
+#pragma unroll
+    for (int q = 0; q < (CIN * kPxPerThread) / 4; ++q) iv[q] = ip[q];
+  }
+
+  const RowCtx r = stage_row<C>(colY, grid_b, y, xs, xe, GH, GW, GD, scale_x, scale_y);
+  if (!active) return;
+
+  const float gs[4] = {g4.x, g4.y, g4.z, g4.w};
+  const float* inf = reinterpret_cast<const float*>(iv);
+  float4 ov[(COUT * kPxPerThread) / 4];
+  float* of = reinterpret_cast<float*>(ov);
+#pragma unroll
+  for (int k = 0; k < kPxPerThread; ++k) {
+    float in[CIN], o[COUT];
+#pragma unroll
+    for (int j = 0; j < CIN; ++j) in[j] = inf[k * CIN + j];
+    slice_apply_pixel<CIN, COUT, OFFSET>(r, x + k, gs[k], in, o);
+#pragma unroll
+    for (int i = 0; i < COUT; ++i) of[k * COUT + i] = o[i];
+  }
+  float4* op = reinterpret_cast<float4*>(out + p * COUT);
+#pragma unroll
+  for (int q = 0; q < (COUT * kPxPerThread) / 4; ++q) op[q] = ov[q];
+}
+
+// ---- scalar variant: any W / alignment; thread t takes pixels xs + t + k*blockDim ------
+template <int CIN, int COUT, bool OFFSET>
+__global__ __launch_bounds__(256) void apply_fwd_rows_scalar(
+    const float* __restrict__ grid, const float* __restrict__ guide,
+    const float* __restrict__ input, float* __restrict__ out, int H, int W, int GH, int GW,
+    int GD, int nseg, int seg, float scale_x, float scale_y) {
+  constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
+  extern __shared__ __attribute__((aligned(16))) float colY[];
+  const int bid = blockIdx.x;
+  const int segi = bid % nseg;
+  const int row = bid / nseg;
+  const int y = row % H;
+  const int b = row / H;
+  const int xs = segi * seg;
+  const int xe = min(xs + seg, W);
+  const float* grid_b = grid + (size_t)b * GH * GW * GD * C;
+  const size_t prow = (size_t)row * W;
+
+  float gs[kPxPerThread];
+  float in[kPxPerThread][CIN];
+#pragma unroll
+  for (int k = 0; k < kPxPerThread; ++k) {
+    const int x = xs + threadIdx.x + k * blockDim.x;
+    if (x < xe) {
+      gs[k] = guide[prow + x];
+#pragma unroll
+      for (int j = 0; j < CIN; ++j) in[k][j] = input[(prow + x) * CIN + j];
+    }
+  }
+
+  const RowCtx r = stage_row<C>(colY, grid_b, y, xs, xe, GH, GW, GD, scale_x, scale_y);
+
+#pragma unroll
+  for (int k = 0; k < kPxPerThread; ++k) {
+    const int x = xs + threadIdx.x + k * blockDim.x;
+    if (x < xe) {
+      float o[COUT];
+      slice_apply_pixel<CIN, COUT, OFFSET>(r, x, gs[k], in[k], o);
+#pragma unroll
+      for (int i = 0; i < COUT; ++i) out[(prow + x) * COUT + i] = o[i];
+    }
+  }
+}
+
+struct Plan {
+  int threads, nseg, seg, max_cols;
+  bool vec4;
+};
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+Plan make_plan(const ApplyArgs& a) {
+  const bool aligned = (((uintptr_t)a.guide | (uintptr_t)a.input | (uintptr_t)a.out |
+                         (uintptr_t)a.grid) & 15u) == 0;
+  Plan best{};
+  long long best_waste = -1;
+  const int cands[3] = {256, 192, 128};
+  for (int T : cands) {
+    const int span = T * kPxPerThread;
+    const int nseg = (a.W + span - 1) / span;
+    const long long waste = (long long)nseg * span - a.W;
+    if (best_waste < 0 || waste < best_waste) {
+      best_waste = waste;
+      best.threads = T;
+      best.nseg = nseg;
+    }
+  }
+  best.vec4 = aligned && (a.W % 4 == 0) && ((a.Cin * kPxPerThread) % 4 == 0) &&
+              ((a.Cout * kPxPerThread) % 4 == 0);
+  best.seg = round_up((a.W + best.nseg - 1) / best.nseg, 4);
+  // Threads actually needed for the (balanced) segment.
+  best.threads = round_up((best.seg + kPxPerThread - 1) / kPxPerThread, 64);
+  if (best.threads > 256) best.threads = 256;
+  // Upper bound of grid columns a segment can touch: floor differences of
+  // gx0 over seg-1 pixels (<= floor(d)+1), +1 for the upper neighbour, +1 for
+  // the count, +1 slack for float rounding of the coordinates.
+  const long long cols = ((long long)(best.seg - 1) * a.GW) / a.W + 4;
+  best.max_cols = (int)(cols < a.GW ? cols : a.GW);
+  return best;
+}
+
+template <int CIN, int COUT, bool OFFSET>
+hipError_t launch_t(const ApplyArgs& a, hipStream_t s, const char** name) {
+  constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
+  const Plan pl = make_plan(a);
+  const size_t lds = (size_t)pl.max_cols * a.GD * C * sizeof(float);
+  const long long nblocks = (long long)a.B * a.H * pl.nseg;
+  const float sx = (float)a.GW / a.W, sy = (float)a.GH / a.H;
+  if (pl.vec4) {
+    apply_fwd_rows_vec4<CIN, COUT, OFFSET><<<(unsigned)nblocks, pl.threads, lds, s>>>(
+        a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, pl.nseg, pl.seg, sx, sy);
+    *name = "apply_fwd_rows/vec4";
+  } else {
+    apply_fwd_rows_scalar<CIN, COUT, OFFSET><<<(unsigned)nblocks, pl.threads, lds, s>>>(
+        a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, pl.nseg, pl.seg, sx, sy);
+    *name = "apply_fwd_rows/scalar";
+  }
+  return hipGetLastError();
+}
+
+constexpr size_t kMaxLdsBytes = 64 * 1024;  // keep >= 2 workgroups per CU
+
+}  // namespace
+
+bool apply_fwd_rows_supported(const ApplyArgs& a) {
+  const bool shape = (a.Cin == 3 && a.Cout == 3) || (a.Cin == 3 && a.Cout == 4 && a.has_offset) ||
+                     (a.Cin == 1 && a.Cout == 1) || (a.Cin == 1 && a.Cout == 3 && a.has_offset) ||
+                     (a.Cin == 4 && a.Cout == 4 && a.has_offset);
+  if (!shape) return false;
+  // stage_row reads the grid as float4 when C % 4 == 0.
+  if ((a.Cout * a.Cj) % 4 == 0 && ((uintptr_t)a.grid & 15u)) return false;
+  if ((long long)a.B * a.H * ((a.W + 511) / 512) > 0x7fffffffLL) return false;
+  const Plan pl = make_plan(a);
+  const size_t lds = (size_t)pl.max_cols * a.GD * a.Cout * a.Cj * sizeof(float);
+  return lds <= kMaxLdsBytes;
+}
+
+hipError_t launch_apply_fwd_rows(const ApplyArgs& a, hipStream_t s, const char** name) {
+#define HDRNET_CASE(CI, CO, OFF) \
+  if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF) return launch_t<CI, CO, OFF>(a, s, name)
+  HDRNET_CASE(3, 3, true);
+  HDRNET_CASE(3, 3, false);
+  HDRNET_CASE(3, 4, true);
+  HDRNET_CASE(1, 1, true);
+  HDRNET_CASE(1, 1, false);
+  HDRNET_CASE(1, 3, true);
+  HDRNET_CASE(4, 4, true);
+#undef HDRNET_CASE
+  return hipErrorInvalidValue;
+}
+
+}  // namespace hdrnet_amd

@@ -1,0 +1,241 @@
+// C-ABI front-end of libhdrnet_amd.so: argument validation (the OP_REQUIRES checks
+// of hdrnet/ops/bilateral_slice_apply_op.cc:147-193 and bilateral_slice_op.cc:129-147
+// re-expressed as return codes), kernel selection, asynchronous launch on the
+// caller's stream.  See include/hdrnet_amd.h for the contract.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/hdrnet_amd.h"
+#include "launch.hip.h"
+
+namespace {
+
+thread_local char g_error[512] = "";
+thread_local const char* g_kernel = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof(g_error), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_launch(hipError_t e, const char* what) {
+  if (e != hipSuccess) {
+    // TF: errors::Internal("BilateralSliceApply kernel failed.")
+    return fail(HDRNET_RUNTIME_FAILURE, "%s kernel failed: %s", what, hipGetErrorString(e));
+  }
+  g_error[0] = '\0';
+  return HDRNET_OK;
+}
+
+bool positive(int v) { return v > 0; }
+
+// Extents >= 0; a zero-sized batch / image is a legal no-op, a zero-sized grid is not.
+int check_common(int B, int H, int W, int GH, int GW, int GD) {
+  if (B < 0 || H < 0 || W < 0)
+    return fail(HDRNET_INVALID_ARGUMENT, "negative image extent (B=%d, H=%d, W=%d)", B, H, W);
+  if (!positive(GH) || !positive(GW) || !positive(GD))
+    return fail(HDRNET_INVALID_ARGUMENT, "grid extents must be positive (GH=%d, GW=%d, GD=%d)",
+                GH, GW, GD);
+  if ((long long)B * H * W > 0x7fffffffLL * 64)
+    return fail(HDRNET_INVALID_ARGUMENT, "image too large");
+  if ((long long)GH * GW * GD > 0x7fffffffLL / 4096)
+    return fail(HDRNET_INVALID_ARGUMENT, "grid too large");
+  return HDRNET_OK;
+}
+
+int check_flags(unsigned flags) {
+  if (flags > HDRNET_KERNEL_FAST) return fail(HDRNET_INVALID_ARGUMENT, "unknown flags %u", flags);
+  return HDRNET_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hdrnet_version(void) { return 100; /* 0.1.0 */ }
+
+const char* hdrnet_last_error(void) { return g_error; }
+
+const char* hdrnet_last_kernel(void) { return g_kernel; }
+
+int hdrnet_bilateral_slice_apply_f32_ex(const float* grid, const float* guide,
+                                        const float* input, float* out, int B, int H, int W,
+                                        int GH, int GW, int GD, int Cin, int Cout,
+                                        int has_offset, unsigned flags, void* stream) {
+  using namespace hdrnet_amd;
+  if (int rc = check_common(B, H, W, GH, GW, GD)) return rc;
+  if (int rc = check_flags(flags)) return rc;
+  if (Cin < 0 || Cout <= 0 || Cin + (has_offset ? 1 : 0) <= 0)
+    return fail(HDRNET_INVALID_ARGUMENT,
+                "grid should have output_channels * (input_channels%s) channels "
+                "(Cin=%d, Cout=%d)", has_offset ? " + 1" : "", Cin, Cout);
+  const long long npix = (long long)B * H * W;
+  if (npix == 0) {
+    g_kernel = "noop";
+    g_error[0] = '\0';
+    return HDRNET_OK;
+  }
+  if (!grid || !guide || !out || (Cin > 0 && !input))
+    return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  ApplyArgs a{grid, guide, input, out, B, H, W, GH, GW, GD, Cin, Cout,
+              Cin + (has_offset ? 1 : 0), has_offset != 0};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool fast_ok = apply_fwd_rows_supported(a);
+  if (flags == HDRNET_KERNEL_FAST && !fast_ok)
+    return fail(HDRNET_INVALID_ARGUMENT, "no fast BilateralSliceApply variant for this shape");
+  if (flags != HDRNET_KERNEL_GENERIC && fast_ok) {
+    const char* name = "";
+    const hipError_t e = launch_apply_fwd_rows(a, s, &name);
+    const int rc = check_launch(e, "BilateralSliceApply");
+    if (rc == HDRNET_OK) g_kernel = name;
+    return rc;
+  }
+  const int rc = check_launch(launch_apply_fwd_generic(a, s), "BilateralSliceApply");
+  if (rc == HDRNET_OK) g_kernel = "apply_fwd_generic";
+  return rc;
+}
+
+int hdrnet_bilateral_slice_apply_f32(const float* grid, const float* guide, const float* input,
+                                     float* out, int B, int H, int W, int GH, int GW, int GD,
+                                     int Cin, int Cout, int has_offset, void* stream) {
+  return hdrnet_bilateral_slice_apply_f32_ex(grid, guide, input, out, B, H, W, GH, GW, GD, Cin,
+                                             Cout, has_offset, HDRNET_KERNEL_AUTO, stream);
+}
+
+size_t hdrnet_bilateral_slice_apply_grad_workspace_bytes(int, int, int, int, int, int, int, int,
+                                                         int) {
+  return 0;
+}
+
+int hdrnet_bilateral_slice_apply_grad_f32_ex(const float* grid, const float* guide,
+                                             const float* input, const float* dout,
+                                             float* dgrid, float* dguide, float* dinput, int B,
+                                             int H, int W, int GH, int GW, int GD, int Cin,
+                                             int Cout, int has_offset, void* workspace,
+                                             size_t workspace_bytes, unsigned flags,
+                                             void* stream) {
+  using namespace hdrnet_amd;
+  if (int rc = check_common(B, H, W, GH, GW, GD)) return rc;
+  if (int rc = check_flags(flags)) return rc;
+  if (Cin < 0 || Cout <= 0 || Cin + (has_offset ? 1 : 0) <= 0)
+    return fail(HDRNET_INVALID_ARGUMENT, "bad channel counts (Cin=%d, Cout=%d)", Cin, Cout);
+  if (!dgrid && !dguide && !dinput) {
+    g_kernel = "noop";
+    g_error[0] = '\0';
+    return HDRNET_OK;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int Cj = Cin + (has_offset ? 1 : 0);
+  const long long npix = (long long)B * H * W;
+  if (npix == 0) {
+    // Gradients of an empty image: dgrid is all zeros, the others are empty.
+    if (dgrid && B > 0) {
+      const hipError_t e =
+          hipMemsetAsync(dgrid, 0, sizeof(float) * (size_t)B * GH * GW * GD * Cout * Cj, s);
+      if (e != hipSuccess) return check_launch(e, "BilateralSliceApplyGrad");
+    }
+    g_kernel = "noop";
+    g_error[0] = '\0';
+    return HDRNET_OK;
+  }
+  if (!guide || !dout || (Cin > 0 && !input) || ((dguide || dinput) && !grid))
+    return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  ApplyGradArgs a{grid, guide, input, dout, dgrid, dguide, dinput, B, H, W, GH, GW, GD,
+                  Cin, Cout, Cj, has_offset != 0, workspace, workspace_bytes};
+  if (flags == HDRNET_KERNEL_FAST)
+    return fail(HDRNET_INVALID_ARGUMENT, "no fast BilateralSliceApplyGrad variant yet");
+  const int rc = check_launch(launch_apply_grad_generic(a, s), "BilateralSliceApplyGrad");
+  if (rc == HDRNET_OK) g_kernel = "apply_grad_generic";
+  return rc;
+}
+
+int hdrnet_bilateral_slice_apply_grad_f32(const float* grid, const float* guide,
+                                          const float* input, const float* dout, float* dgrid,
+                                          float* dguide, float* dinput, int B, int H, int W,
+                                          int GH, int GW, int GD, int Cin, int Cout,
+                                          int has_offset, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  return hdrnet_bilateral_slice_apply_grad_f32_ex(grid, guide, input, dout, dgrid, dguide, dinput,
+                                                  B, H, W, GH, GW, GD, Cin, Cout, has_offset,
+                                                  workspace, workspace_bytes, HDRNET_KERNEL_AUTO,
+                                                  stream);
+}
+
+int hdrnet_bilateral_slice_f32_ex(const float* grid, const float* guide, float* out, int B, int H,
+                                  int W, int GH, int GW, int GD, int C, unsigned flags,
+                                  void* stream) {
+  using namespace hdrnet_amd;
+  if (int rc = check_common(B, H, W, GH, GW, GD)) return rc;
+  if (int rc = check_flags(flags)) return rc;
+  if (C <= 0) return fail(HDRNET_INVALID_ARGUMENT, "grid_channels must be positive (C=%d)", C);
+  if ((long long)B * H * W == 0) {
+    g_kernel = "noop";
+    g_error[0] = '\0';
+    return HDRNET_OK;
+  }
+  if (!grid || !guide || !out) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  if (flags == HDRNET_KERNEL_FAST)
+    return fail(HDRNET_INVALID_ARGUMENT, "no fast BilateralSlice variant yet");
+  SliceArgs a{grid, guide, out, B, H, W, GH, GW, GD, C};
+  const int rc =
+      check_launch(launch_slice_fwd_generic(a, static_cast<hipStream_t>(stream)), "BilateralSlice");
+  if (rc == HDRNET_OK) g_kernel = "slice_fwd_generic";
+  return rc;
+}
+
+int hdrnet_bilateral_slice_f32(const float* grid, const float* guide, float* out, int B, int H,
+                               int W, int GH, int GW, int GD, int C, void* stream) {
+  return hdrnet_bilateral_slice_f32_ex(grid, guide, out, B, H, W, GH, GW, GD, C,
+                                       HDRNET_KERNEL_AUTO, stream);
+}
+
+size_t hdrnet_bilateral_slice_grad_workspace_bytes(int, int, int, int, int, int, int) { return 0; }
+
+int hdrnet_bilateral_slice_grad_f32_ex(const float* grid, const float* guide, const float* dout,
+                                       float* dgrid, float* dguide, int B, int H, int W, int GH,
+                                       int GW, int GD, int C, void* workspace,
+                                       size_t workspace_bytes, unsigned flags, void* stream) {
+  using namespace hdrnet_amd;
+  if (int rc = check_common(B, H, W, GH, GW, GD)) return rc;
+  if (int rc = check_flags(flags)) return rc;
+  if (C <= 0) return fail(HDRNET_INVALID_ARGUMENT, "grid_channels must be positive (C=%d)", C);
+  if (!dgrid && !dguide) {
+    g_kernel = "noop";
+    g_error[0] = '\0';
+    return HDRNET_OK;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if ((long long)B * H * W == 0) {
+    if (dgrid && B > 0) {
+      const hipError_t e = hipMemsetAsync(dgrid, 0, sizeof(float) * (size_t)B * GH * GW * GD * C, s);
+      if (e != hipSuccess) return check_launch(e, "BilateralSliceGrad");
+    }
+    g_kernel = "noop";
+    g_error[0] = '\0';
+    return HDRNET_OK;
+  }
+  if (!guide || !dout || (dguide && !grid)) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  if (flags == HDRNET_KERNEL_FAST)
+    return fail(HDRNET_INVALID_ARGUMENT, "no fast BilateralSliceGrad variant yet");
+  SliceGradArgs a{grid, guide, dout, dgrid, dguide, B, H, W, GH, GW, GD, C, workspace,
+                  workspace_bytes};
+  const int rc = check_launch(launch_slice_grad_generic(a, s), "BilateralSliceGrad");
+  if (rc == HDRNET_OK) g_kernel = "slice_grad_generic";
+  return rc;
+}
+
+int hdrnet_bilateral_slice_grad_f32(const float* grid, const float* guide, const float* dout,
+                                    float* dgrid, float* dguide, int B, int H, int W, int GH,
+                                    int GW, int GD, int C, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  return hdrnet_bilateral_slice_grad_f32_ex(grid, guide, dout, dgrid, dguide, B, H, W, GH, GW, GD,
+                                            C, workspace, workspace_bytes, HDRNET_KERNEL_AUTO,
+                                            stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+// Argument bundles and launcher prototypes shared by the kernel translation
+// units and the C-ABI front-end (capi.hip).  All pointers are device pointers in
+// the layouts documented in include/hdrnet_amd.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <stddef.h>
+
+namespace hdrnet_amd {
+
+struct ApplyArgs {
+  const float* grid;
+  const float* guide;
+  const float* input;
+  float* out;
+  int B, H, W, GH, GW, GD, Cin, Cout, Cj;  // Cj = Cin + has_offset
+  bool has_offset;
+};
+
+struct ApplyGradArgs {
+  const float* grid;
+  const float* guide;
+  const float* input;
+  const float* dout;
+  float* dgrid;   // may be null
+  float* dguide;  // may be null
+  float* dinput;  // may be null
+  int B, H, W, GH, GW, GD, Cin, Cout, Cj;
+  bool has_offset;
+  void* workspace;
+  size_t workspace_bytes;
+};
+
+struct SliceArgs {
+  const float* grid;
+  const float* guide;
+  float* out;
+  int B, H, W, GH, GW, GD, C;
+};
+
+struct SliceGradArgs {
+  const float* grid;
+  const float* guide;
+  const float* dout;
+  float* dgrid;   // may be null
+  float* dguide;  // may be null
+  int B, H, W, GH, GW, GD, C;
+  void* workspace;
+  size_t workspace_bytes;
+};
+
+// generic_kernels.hip -- any shape, bit-exact vs the reference CPU op.
+hipError_t launch_apply_fwd_generic(const ApplyArgs& a, hipStream_t s);
+hipError_t launch_apply_grad_generic(const ApplyGradArgs& a, hipStream_t s);
+hipError_t launch_slice_fwd_generic(const SliceArgs& a, hipStream_t s);
+hipError_t launch_slice_grad_generic(const SliceGradArgs& a, hipStream_t s);
+
+// apply_fwd_rows.hip -- LDS-staged row-segment forward.  `*_supported` says whether a
+// specialisation exists for the shape; `name` receives a static string naming
+// the variant launched.
+bool apply_fwd_rows_supported(const ApplyArgs& a);
+hipError_t launch_apply_fwd_rows(const ApplyArgs& a, hipStream_t s, const char** name);
+
+}  // namespace hdrnet_amd

@@ -1,0 +1,265 @@
+"""Python interface to the MI355X bilateral-grid ops -- the drop-in for
+``hdrnet/hdrnet_ops.py`` of the reference.
+
+Same two callables, same argument order / keyword, same NHWC float32 layouts, same
+registered gradients:
+
+=============================================  =======================================
+reference (TensorFlow custom op)               here (torch.autograd.Function on ROCm)
+=============================================  =======================================
+``hdrnet_ops.bilateral_slice(grid, guide)``    ``bilateral_slice(grid, guide)``
+  hdrnet/hdrnet_ops.py:30                        -> [B, H, W, C]
+``hdrnet_ops.bilateral_slice_apply(grid,       ``bilateral_slice_apply(grid, guide,
+  guide, input, has_offset=...)``  :31           input, has_offset=...)`` -> [B, H, W, Cout]
+``@RegisterGradient('BilateralSlice')`` :34    ``_BilateralSlice.backward``  (dgrid, dguide)
+``@RegisterGradient('BilateralSliceApply')``   ``_BilateralSliceApply.backward``
+  :41-48                                         (dgrid, dguide, dinput)
+=============================================  =======================================
+
+Shapes (``bilateral_slice_apply_op.cc:147-193``): grid ``[B, GH, GW, GD, Cout*Cj]`` with
+``Cj = Cin + has_offset`` and channel ``c = i*Cj + j``; guide ``[B, H, W]``; input
+``[B, H, W, Cin]``.  Violations raise ``ValueError`` (TF: ``InvalidArgument``).
+
+Every call goes through the C-ABI of ``include/hdrnet_amd.h`` on the current HIP stream
+of the tensors' device, asynchronously.  There is no CPU or eager fallback: tensors
+must live on an AMD GPU and ``libhdrnet_amd.so`` must load, otherwise the call raises.
+"""
+from __future__ import annotations
+
+import contextlib
+import threading
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+__all__ = ["bilateral_slice", "bilateral_slice_apply", "kernel_override", "last_kernel"]
+
+_tls = threading.local()
+
+
+def _flags() -> int:
+    return getattr(_tls, "flags", _lib.KERNEL_AUTO)
+
+
+@contextlib.contextmanager
+def kernel_override(which: str):
+    """Force a kernel family inside the block: 'auto' | 'generic' | 'fast' (tests/bench)."""
+    table = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "fast": _lib.KERNEL_FAST}
+    old = _flags()
+    _tls.flags = table[which]
+    try:
+        yield
+    finally:
+        _tls.flags = old
+
+
+def last_kernel() -> str:
+    """Name of the kernel variant this thread's last call launched."""
+    return _lib.last_kernel()
+
+
+# ---- argument checking (mirrors the OP_REQUIRES of the reference op wrappers) --------
+def _require_f32(name: str, t: torch.Tensor) -> None:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(t).__name__}")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32 (the op is registered for float only), got {t.dtype}")
+
+
+def _require_gpu(name: str, t: torch.Tensor) -> None:
+    # Checked AFTER the shape rules so that shape errors surface as ValueError on any
+    # device (tests/test_host_logic.py runs them without a GPU).
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on {t.device}: hdrnet_amd ops run on an MI355X (HIP) device only; "
+            "there is no CPU path in this package")
+
+
+def _check_slice(grid: torch.Tensor, guide: torch.Tensor) -> Tuple[int, ...]:
+    _require_f32("grid", grid)
+    _require_f32("guide", guide)
+    if grid.dim() != 5:
+        raise ValueError("Grid should be 5D (batch_size, grid_height, grid_width, grid_depth, "
+                         f"grid_channels), got {tuple(grid.shape)}")
+    if guide.dim() != 3:
+        raise ValueError(f"Guide image should be 3D (batch_size, height, width), got {tuple(guide.shape)}")
+    if grid.device != guide.device:
+        raise ValueError("grid and guide must be on the same device")
+    B, GH, GW, GD, C = grid.shape
+    if guide.shape[0] != B:
+        raise ValueError("Batch sizes should match.")
+    if min(GH, GW, GD, C) <= 0:
+        raise ValueError(f"grid extents must be positive, got {tuple(grid.shape)}")
+    _require_gpu("grid", grid)
+    _require_gpu("guide", guide)
+    return B, guide.shape[1], guide.shape[2], GH, GW, GD, C
+
+
+def _check_apply(grid, guide, inp, has_offset: bool) -> Tuple[int, ...]:
+    _require_f32("grid", grid)
+    _require_f32("guide", guide)
+    _require_f32("input", inp)
+    if grid.dim() != 5:
+        raise ValueError("Input grid should be 5D (batch_size, height, width, depth, "
+                         f"output_channels * input_channels), got {tuple(grid.shape)}")
+    if guide.dim() != 3:
+        raise ValueError(f"Guide image should be 3D (batch_size, height, width), got {tuple(guide.shape)}")
+    if inp.dim() != 4:
+        raise ValueError("Input image should be 4D (batch_size, height, width, input_channels), "
+                         f"got {tuple(inp.shape)}")
+    if not (grid.device == guide.device == inp.device):
+        raise ValueError("grid, guide and input must be on the same device")
+    B, GH, GW, GD, C = grid.shape
+    if tuple(inp.shape[:3]) != tuple(guide.shape):
+        raise ValueError("Input and guide size should match.")
+    if guide.shape[0] != B:
+        raise ValueError("Batch sizes should match.")
+    Cin = inp.shape[3]
+    Cj = Cin + (1 if has_offset else 0)
+    if Cj <= 0 or C % Cj != 0 or C == 0:
+        if has_offset:
+            raise ValueError("Slicing with affine offset, grid should have "
+                             "output_channels * (input_channels + 1) channels.")
+        raise ValueError("Slicing without affine offset, grid should have "
+                         "output_channels * input_channels channels.")
+    if min(GH, GW, GD) <= 0:
+        raise ValueError(f"grid extents must be positive, got {tuple(grid.shape)}")
+    for n, t in (("grid", grid), ("guide", guide), ("input", inp)):
+        _require_gpu(n, t)
+    return B, guide.shape[1], guide.shape[2], GH, GW, GD, Cin, C // Cj
+
+
+def _stream(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# ---- raw forward / backward launches (no autograd) ------------------------------------
+def _apply_forward(grid, guide, inp, has_offset: bool) -> torch.Tensor:
+    B, H, W, GH, GW, GD, Cin, Cout = _check_apply(grid, guide, inp, has_offset)
+    grid, guide, inp = grid.contiguous(), guide.contiguous(), inp.contiguous()
+    out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=guide.device)
+    lib = _lib.load()
+    with torch.cuda.device(guide.device):
+        rc = lib.hdrnet_bilateral_slice_apply_f32_ex(
+            grid.data_ptr(), guide.data_ptr(), inp.data_ptr(), out.data_ptr(),
+            B, H, W, GH, GW, GD, Cin, Cout, int(has_offset), _flags(), _stream(guide.device))
+    _lib.check(rc, "BilateralSliceApply")
+    return out
+
+
+def _apply_backward(grid, guide, inp, dout, has_offset: bool, need):
+    B, H, W, GH, GW, GD, Cin, Cout = _check_apply(grid, guide, inp, has_offset)
+    if tuple(dout.shape) != (B, H, W, Cout):
+        raise ValueError(f"backprop should have shape {(B, H, W, Cout)}, got {tuple(dout.shape)}")
+    _require_f32("backprop", dout)
+    _require_gpu("backprop", dout)
+    grid, guide, inp, dout = grid.contiguous(), guide.contiguous(), inp.contiguous(), dout.contiguous()
+    dev = guide.device
+    dgrid = torch.empty_like(grid) if need[0] else None
+    dguide = torch.empty_like(guide) if need[1] else None
+    dinput = torch.empty_like(inp) if need[2] else None
+    lib = _lib.load()
+    wbytes = lib.hdrnet_bilateral_slice_apply_grad_workspace_bytes(
+        B, H, W, GH, GW, GD, Cin, Cout, int(has_offset)) if need[0] else 0
+    ws = torch.empty((wbytes,), dtype=torch.uint8, device=dev) if wbytes else None
+    with torch.cuda.device(dev):
+        rc = lib.hdrnet_bilateral_slice_apply_grad_f32_ex(
+            grid.data_ptr(), guide.data_ptr(), inp.data_ptr(), dout.data_ptr(),
+            _ptr(dgrid), _ptr(dguide), _ptr(dinput),
+            B, H, W, GH, GW, GD, Cin, Cout, int(has_offset),
+            _ptr(ws), wbytes, _flags(), _stream(dev))
+    _lib.check(rc, "BilateralSliceApplyGrad")
+    return dgrid, dguide, dinput
+
+
+def _slice_forward(grid, guide) -> torch.Tensor:
+    B, H, W, GH, GW, GD, C = _check_slice(grid, guide)
+    grid, guide = grid.contiguous(), guide.contiguous()
+    out = torch.empty((B, H, W, C), dtype=torch.float32, device=guide.device)
+    lib = _lib.load()
+    with torch.cuda.device(guide.device):
+        rc = lib.hdrnet_bilateral_slice_f32_ex(
+            grid.data_ptr(), guide.data_ptr(), out.data_ptr(),
+            B, H, W, GH, GW, GD, C, _flags(), _stream(guide.device))
+    _lib.check(rc, "BilateralSlice")
+    return out
+
+
+def _slice_backward(grid, guide, dout, need):
+    B, H, W, GH, GW, GD, C = _check_slice(grid, guide)
+    if dout.dim() != 4:
+        raise ValueError("Codomain tangent should be 4D (batch, height, width, nchannels).")
+    if tuple(dout.shape) != (B, H, W, C):
+        raise ValueError(f"backprop should have shape {(B, H, W, C)}, got {tuple(dout.shape)}")
+    _require_f32("backprop", dout)
+    _require_gpu("backprop", dout)
+    grid, guide, dout = grid.contiguous(), guide.contiguous(), dout.contiguous()
+    dev = guide.device
+    dgrid = torch.empty_like(grid) if need[0] else None
+    dguide = torch.empty_like(guide) if need[1] else None
+    lib = _lib.load()
+    wbytes = lib.hdrnet_bilateral_slice_grad_workspace_bytes(B, H, W, GH, GW, GD, C) if need[0] else 0
+    ws = torch.empty((wbytes,), dtype=torch.uint8, device=dev) if wbytes else None
+    with torch.cuda.device(dev):
+        rc = lib.hdrnet_bilateral_slice_grad_f32_ex(
+            grid.data_ptr(), guide.data_ptr(), dout.data_ptr(), _ptr(dgrid), _ptr(dguide),
+            B, H, W, GH, GW, GD, C, _ptr(ws), wbytes, _flags(), _stream(dev))
+    _lib.check(rc, "BilateralSliceGrad")
+    return dgrid, dguide
+
+
+# ---- autograd registration (hdrnet/hdrnet_ops.py:34-48) -------------------------------
+class _BilateralSlice(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, grid, guide):
+        ctx.save_for_backward(grid, guide)
+        return _slice_forward(grid, guide)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad):
+        grid, guide = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        if not (need[0] or need[1]):
+            return None, None
+        return _slice_backward(grid, guide, grad, need)
+
+
+class _BilateralSliceApply(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, grid, guide, inp, has_offset):
+        ctx.save_for_backward(grid, guide, inp)
+        ctx.has_offset = bool(has_offset)
+        return _apply_forward(grid, guide, inp, bool(has_offset))
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad):
+        grid, guide, inp = ctx.saved_tensors
+        need = ctx.needs_input_grad[:3]
+        if not any(need):
+            return None, None, None, None
+        dgrid, dguide, dinput = _apply_backward(grid, guide, inp, grad, ctx.has_offset, need)
+        return dgrid, dguide, dinput, None
+
+
+def bilateral_slice(grid: torch.Tensor, guide: torch.Tensor, name: Optional[str] = None) -> torch.Tensor:
+    """``BilateralSlice``: out[b,y,x,c] = trilinear sample of grid[b,...,c] at
+    ((x+.5)*GW/W, (y+.5)*GH/H, guide[b,y,x]*GD).  (bilateral_slice_op.cc:274-290)"""
+    del name
+    return _BilateralSlice.apply(grid, guide)
+
+
+def bilateral_slice_apply(grid: torch.Tensor, guide: torch.Tensor, input: torch.Tensor,  # noqa: A002
+                          has_offset: bool, name: Optional[str] = None) -> torch.Tensor:
+    """``BilateralSliceApply``: slice then per-pixel (Cout x Cj) . [input; 1].
+    ``has_offset`` is a required attribute, as in the reference op
+    (bilateral_slice_apply_op.cc:382-386)."""
+    del name
+    return _BilateralSliceApply.apply(grid, guide, input, has_offset)

@@ -1,0 +1,153 @@
+/* hdrnet_amd.h -- C-ABI of the MI355X-native bilateral-grid slice / slice-apply
+ * library (libhdrnet_amd.so, built for gfx950 only).
+ *
+ * This is the drop-in boundary for the ONE hot path of google/hdrnet: the four
+ * TensorFlow custom ops of hdrnet/ops.  Each entry point below replaces the
+ * device dispatch of one reference op and is what a binding for that op would
+ * call (INTEGRATION.md shows the ctypes / TF-op / torch stubs):
+ *
+ *   hdrnet_bilateral_slice_apply_f32       <- BilateralSliceApplyOp<GpuDevice>::Compute
+ *       hdrnet/ops/bilateral_slice_apply_op.cc:140-235 -> BilateralSliceApplyCudaLauncher
+ *       hdrnet/ops/bilateral_slice_apply.cu.cc:368-382
+ *   hdrnet_bilateral_slice_apply_grad_f32  <- BilateralSliceApplyGradOp<GpuDevice>::Compute
+ *       bilateral_slice_apply_op.cc:249-362 -> BilateralSliceApplyGradCudaLauncher
+ *       bilateral_slice_apply.cu.cc:384-417
+ *   hdrnet_bilateral_slice_f32             <- BilateralSliceOp<GpuDevice>::Compute
+ *       hdrnet/ops/bilateral_slice_op.cc:120-174 -> BilateralSliceCudaLauncher
+ *       hdrnet/ops/bilateral_slice.cu.cc:230-244
+ *   hdrnet_bilateral_slice_grad_f32        <- BilateralSliceGradOp<GpuDevice>::Compute
+ *       bilateral_slice_op.cc:183-256 -> BilateralSliceGradCudaLauncher
+ *       bilateral_slice.cu.cc:246-272
+ *
+ * Conventions (same as the reference ops, bilateral_slice_apply_op.cc:201-227):
+ *   - every buffer is a DEVICE pointer to dense, C-contiguous float32 in the
+ *     reference's NHWC layouts:
+ *         grid  [B][GH][GW][GD][C]      C = Cout*Cj, channel c = i*Cj + j,
+ *                                       Cj = Cin + (has_offset ? 1 : 0)
+ *         guide [B][H][W]
+ *         input [B][H][W][Cin]
+ *         out   [B][H][W][Cout]         (slice: [B][H][W][C])
+ *   - the caller owns and allocates every buffer, outputs included (the
+ *     reference: OpKernelContext::allocate_output); the library keeps no
+ *     state and allocates nothing;
+ *   - work is enqueued asynchronously on `stream` (a hipStream_t passed as
+ *     void*; NULL = the null stream) and the call returns without
+ *     synchronising, like the reference launchers on device.stream();
+ *   - re-entrant and thread-safe: no globals besides a thread-local error text;
+ *   - never throws, never exits.  Return codes:
+ *         HDRNET_OK                0
+ *         HDRNET_INVALID_ARGUMENT  1   (TF: errors::InvalidArgument)
+ *         HDRNET_RUNTIME_FAILURE   2   (TF: errors::Internal("... kernel failed."))
+ *   - in the *_grad entry points a NULL output pointer skips that VJP (the
+ *     reference skips outputs whose size() == 0, bilateral_slice_apply.cu.cc:393,401,409).
+ *
+ * Gradients follow the reference's CPU implementation
+ * (bilateral_slice_apply.cc:84-259), which is the semantics its tests pin; the
+ * reference CUDA backward kernels carry two indexing bugs.
+ */
+#ifndef HDRNET_AMD_H_
+#define HDRNET_AMD_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HDRNET_OK 0
+#define HDRNET_INVALID_ARGUMENT 1
+#define HDRNET_RUNTIME_FAILURE 2
+
+/* Kernel-selection flags for the *_ex entry points (testing / benchmarking).
+ * 0 = automatic (what the plain entry points use). */
+#define HDRNET_KERNEL_AUTO 0u
+#define HDRNET_KERNEL_GENERIC 1u /* runtime-shape one-thread-per-pixel kernels; \
+                                    forward is bit-exact vs the reference CPU op */
+#define HDRNET_KERNEL_FAST 2u    /* LDS-staged specialisations; INVALID_ARGUMENT \
+                                    if the shape has none */
+
+/* ABI version: major*10000 + minor*100 + patch. */
+int hdrnet_version(void);
+
+/* Text of the last error raised on the calling thread ("" if none). */
+const char* hdrnet_last_error(void);
+
+/* Name of the kernel variant the calling thread's last successful call
+ * launched (e.g. "apply_fwd_rows<3,3,1>/vec4"); for tests and benchmarks. */
+const char* hdrnet_last_kernel(void);
+
+/* BilateralSliceApply forward.
+ * out[b,y,x,i] = sum_j trilerp(grid[.., i, j]; x, y, guide[b,y,x]) * (j < Cin ? input[b,y,x,j] : 1)
+ * Reference semantics: hdrnet/ops/bilateral_slice_apply.cc:24-82. */
+int hdrnet_bilateral_slice_apply_f32(const float* grid, const float* guide,
+                                     const float* input, float* out, int B,
+                                     int H, int W, int GH, int GW, int GD,
+                                     int Cin, int Cout, int has_offset,
+                                     void* stream);
+
+int hdrnet_bilateral_slice_apply_f32_ex(const float* grid, const float* guide,
+                                        const float* input, float* out, int B,
+                                        int H, int W, int GH, int GW, int GD,
+                                        int Cin, int Cout, int has_offset,
+                                        unsigned flags, void* stream);
+
+/* Scratch (bytes) the grad entry point wants for its deterministic two-stage
+ * grid-gradient reduction; 0 is a legal answer.  The caller passes a device
+ * buffer of at least this size as `workspace` (contents undefined on entry and
+ * exit).  With workspace == NULL the library falls back to float atomics
+ * (correct, summation order not reproducible run to run). */
+size_t hdrnet_bilateral_slice_apply_grad_workspace_bytes(int B, int H, int W,
+                                                         int GH, int GW, int GD,
+                                                         int Cin, int Cout,
+                                                         int has_offset);
+
+/* BilateralSliceApply VJPs.  dgrid like grid, dguide like guide, dinput like
+ * input; any of the three may be NULL (skipped).
+ * Reference semantics: bilateral_slice_apply.cc:84-138 (grid), :140-206
+ * (guide), :208-259 (input). */
+int hdrnet_bilateral_slice_apply_grad_f32(
+    const float* grid, const float* guide, const float* input,
+    const float* dout, float* dgrid, float* dguide, float* dinput, int B, int H,
+    int W, int GH, int GW, int GD, int Cin, int Cout, int has_offset,
+    void* workspace, size_t workspace_bytes, void* stream);
+
+int hdrnet_bilateral_slice_apply_grad_f32_ex(
+    const float* grid, const float* guide, const float* input,
+    const float* dout, float* dgrid, float* dguide, float* dinput, int B, int H,
+    int W, int GH, int GW, int GD, int Cin, int Cout, int has_offset,
+    void* workspace, size_t workspace_bytes, unsigned flags, void* stream);
+
+/* BilateralSlice forward: out[b,y,x,c] = trilerp(grid[.., c]; x, y, guide).
+ * Reference semantics: hdrnet/ops/bilateral_slice.cc:25-70. */
+int hdrnet_bilateral_slice_f32(const float* grid, const float* guide, float* out,
+                               int B, int H, int W, int GH, int GW, int GD,
+                               int C, void* stream);
+
+int hdrnet_bilateral_slice_f32_ex(const float* grid, const float* guide,
+                                  float* out, int B, int H, int W, int GH,
+                                  int GW, int GD, int C, unsigned flags,
+                                  void* stream);
+
+size_t hdrnet_bilateral_slice_grad_workspace_bytes(int B, int H, int W, int GH,
+                                                   int GW, int GD, int C);
+
+/* BilateralSlice VJPs (dgrid and/or dguide may be NULL).
+ * Reference semantics: bilateral_slice.cc:72-118 (grid), :120-168 (guide). */
+int hdrnet_bilateral_slice_grad_f32(const float* grid, const float* guide,
+                                    const float* dout, float* dgrid,
+                                    float* dguide, int B, int H, int W, int GH,
+                                    int GW, int GD, int C, void* workspace,
+                                    size_t workspace_bytes, void* stream);
+
+int hdrnet_bilateral_slice_grad_f32_ex(const float* grid, const float* guide,
+                                       const float* dout, float* dgrid,
+                                       float* dguide, int B, int H, int W,
+                                       int GH, int GW, int GD, int C,
+                                       void* workspace, size_t workspace_bytes,
+                                       unsigned flags, void* stream);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* HDRNET_AMD_H_ */

@@ -1,0 +1,374 @@
+"""Parity of the HIP path (through the C-ABI, via hdrnet_amd.hdrnet_ops) with the CPU oracle.
+
+Bars:
+* generic kernels (HDRNET_KERNEL_GENERIC, -ffp-contract=off): forward, guide VJP, input VJP
+  and the gather-form grid VJP are BIT-EXACT against the oracle / the reference CPU op;
+* fast kernels: forward rtol = atol = 1e-5 REQUIRED (the reference's own JAX-vs-CUDA bar of
+  1e-6, hdrnet_ops_jax_tf2_test.py:48, is measured and printed); gradients rtol 1e-4 with
+  atol scaled to the tensor's magnitude.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+FWD_RTOL = FWD_ATOL = 1e-5
+REF_BAR = 1e-6
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu-marked tests need an MI355X"
+    name = torch.cuda.get_device_name(0)
+    print("device:", name, torch.version.hip)
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from hdrnet_amd import hdrnet_ops
+    return hdrnet_ops
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def rand_case(rng, B, H, W, GH, GW, GD, Cin, Cout, ho, lo=0.0, hi=1.0):
+    Cj = Cin + int(ho)
+    grid = rng.standard_normal((B, GH, GW, GD, Cout * Cj)).astype(np.float32)
+    guide = (rng.random((B, H, W)) * (hi - lo) + lo).astype(np.float32)
+    inp = rng.random((B, H, W, Cin)).astype(np.float32)
+    dout = rng.standard_normal((B, H, W, Cout)).astype(np.float32)
+    return grid, guide, inp, dout
+
+
+def grads_close(got, want, what, rtol=1e-4):
+    scale = float(np.abs(want).max()) if want.size else 0.0
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=1e-5 * max(scale, 1.0), err_msg=what)
+
+
+# ---- library really is the thing running ---------------------------------------------------
+def test_native_library_loaded(dev, ops):
+    from hdrnet_amd import _lib
+    lib = _lib.load()
+    assert lib.hdrnet_version() >= 100
+    maps = open("/proc/self/maps").read()
+    assert "libhdrnet_amd.so" in maps
+    g = load_golden("apply_forward_default")
+    ops.bilateral_slice_apply(T(g["grid"], dev), T(g["guide"], dev), T(g["input"], dev), has_offset=True)
+    assert ops.last_kernel().startswith("apply_fwd_rows")  # AUTO picks the LDS-staged kernel
+
+
+# ---- golden fixtures (made from the reference's own CPU code) ---------------------------------
+@pytest.mark.parametrize("name", golden_names("apply_"))
+@pytest.mark.parametrize("which", ["generic", "auto"])
+def test_apply_golden(dev, ops, name, which):
+    g = load_golden(name)
+    ho = bool(g["has_offset"])
+    grid = T(g["grid"], dev).requires_grad_(True)
+    guide = T(g["guide"], dev).requires_grad_(True)
+    inp = T(g["input"], dev).requires_grad_(True)
+    with ops.kernel_override(which):
+        out = ops.bilateral_slice_apply(grid, guide, inp, has_offset=ho)
+        kern_fwd = ops.last_kernel()
+        out.backward(T(g["dout"], dev))
+    assert list(out.shape) == list(g["out"].shape)
+    if which == "generic":
+        assert kern_fwd == "apply_fwd_generic"
+        assert np.array_equal(N(out), g["out"]), np.abs(N(out) - g["out"]).max()
+        assert np.array_equal(N(guide.grad), g["dguide"])
+        assert np.array_equal(N(inp.grad), g["dinput"])
+        assert np.array_equal(N(grid.grad), g["dgrid"])
+    else:
+        np.testing.assert_allclose(N(out), g["out"], rtol=FWD_RTOL, atol=FWD_ATOL)
+        grads_close(N(guide.grad), g["dguide"], "dguide")
+        grads_close(N(inp.grad), g["dinput"], "dinput")
+        grads_close(N(grid.grad), g["dgrid"], "dgrid")
+    assert list(grid.grad.shape) == list(g["grid"].shape)     # hdrnet_ops_test.py:304-315
+    assert list(guide.grad.shape) == list(g["guide"].shape)
+    assert list(inp.grad.shape) == list(g["input"].shape)
+
+
+@pytest.mark.parametrize("name", golden_names("slice_"))
+@pytest.mark.parametrize("which", ["generic", "auto"])
+def test_slice_golden(dev, ops, name, which):
+    g = load_golden(name)
+    grid = T(g["grid"], dev).requires_grad_(True)
+    guide = T(g["guide"], dev).requires_grad_(True)
+    with ops.kernel_override(which):
+        out = ops.bilateral_slice(grid, guide)
+        out.backward(T(g["dout"], dev))
+    assert list(out.shape) == list(g["out"].shape)            # hdrnet_ops_test.py:115-123
+    if which == "generic":
+        assert np.array_equal(N(out), g["out"])
+        assert np.array_equal(N(guide.grad), g["dguide"])
+        assert np.array_equal(N(grid.grad), g["dgrid"])
+    else:
+        np.testing.assert_allclose(N(out), g["out"], rtol=FWD_RTOL, atol=FWD_ATOL)
+        grads_close(N(guide.grad), g["dguide"], "dguide")
+        grads_close(N(grid.grad), g["dgrid"], "dgrid")
+
+
+def test_interpolate_known_answer(dev, ops):
+    """hdrnet/test/ops_test.py:61-86."""
+    k = load_golden("slice_interpolate_kat")
+    for val in range(3):
+        guide = torch.full((3, 5, 9), (val + 0.5) / 3.0, dtype=torch.float32, device=dev)
+        out = N(ops.bilateral_slice(T(k["grid"], dev), guide))
+        assert list(out.shape) == [3, 5, 9, 1]
+        assert np.amax(np.abs(val - out)) < 5e-4
+        np.testing.assert_allclose(out, k["outs"][val], rtol=0, atol=1e-6)
+
+
+# ---- seeded random shapes against the oracle ---------------------------------------------------
+APPLY_SHAPES = [  # B, H, W, GH, GW, GD, Cin, Cout, has_offset, guide range
+    (1, 1, 1, 1, 1, 1, 3, 3, True, 0.0, 1.0),        # degenerate extents
+    (2, 37, 53, 16, 16, 8, 3, 3, True, 0.0, 1.0),    # ragged W (scalar variant), HDRNet shape
+    (1, 64, 256, 16, 16, 8, 3, 3, True, -0.3, 1.3),  # vec4 variant, guide out of range
+    (1, 128, 1024, 16, 16, 8, 3, 3, True, 0.0, 1.0),
+    (3, 30, 25, 16, 12, 8, 3, 3, False, 0.0, 1.0),   # no offset: C = 9 (non-float4 LDS image)
+    (2, 19, 40, 6, 3, 7, 3, 4, True, 0.0, 1.0),      # reference grad-test grid, Cout=4
+    (1, 24, 36, 3, 9, 7, 1, 1, True, 0.0, 1.0),      # Cin = Cout = 1
+    (1, 24, 36, 3, 9, 7, 1, 1, False, 0.0, 1.0),
+    (1, 40, 60, 8, 8, 4, 1, 3, True, 0.0, 1.0),      # grey -> colour
+    (1, 20, 28, 4, 4, 4, 4, 4, True, 0.0, 1.0),
+    (1, 12, 20, 4, 4, 4, 2, 5, True, 0.0, 1.0),      # no specialisation -> generic
+    (1, 6, 4, 32, 32, 8, 3, 3, True, 0.0, 1.0),      # image smaller than the grid
+    (1, 48, 2048, 64, 256, 8, 3, 3, True, 0.0, 1.0), # many grid columns per segment
+]
+
+
+@pytest.mark.parametrize("shape", APPLY_SHAPES)
+def test_apply_forward_random(dev, ops, port, shape):
+    B, H, W, GH, GW, GD, Cin, Cout, ho, lo, hi = shape
+    rng = np.random.default_rng(abs(hash(shape)) % (2 ** 31))
+    grid, guide, inp, _ = rand_case(rng, B, H, W, GH, GW, GD, Cin, Cout, ho, lo, hi)
+    want = port.bilateral_slice_apply(grid, guide, inp, ho)
+    tg, tgu, ti = T(grid, dev), T(guide, dev), T(inp, dev)
+    with ops.kernel_override("generic"):
+        got = N(ops.bilateral_slice_apply(tg, tgu, ti, has_offset=ho))
+    assert np.array_equal(got, want), ("generic not bit-exact", np.abs(got - want).max())
+    got = N(ops.bilateral_slice_apply(tg, tgu, ti, has_offset=ho))
+    kern = ops.last_kernel()
+    np.testing.assert_allclose(got, want, rtol=FWD_RTOL, atol=FWD_ATOL, err_msg=kern)
+    worst = float(np.max(np.abs(got - want) / (REF_BAR + REF_BAR * np.abs(want))))
+    print(f"{shape} kernel={kern} max|err|={np.abs(got - want).max():.3e} "
+          f"worst/(1e-6 bar)={worst:.2f}")
+
+
+@pytest.mark.parametrize("shape", APPLY_SHAPES[:10])
+def test_apply_backward_random(dev, ops, port, shape):
+    B, H, W, GH, GW, GD, Cin, Cout, ho, lo, hi = shape
+    rng = np.random.default_rng(abs(hash(shape)) % (2 ** 31) + 1)
+    grid, guide, inp, dout = rand_case(rng, B, H, W, GH, GW, GD, Cin, Cout, ho, lo, hi)
+    wg, wgu, wi = port.bilateral_slice_apply_grad(grid, guide, inp, dout, ho)
+    for which in ("generic", "auto"):
+        tg = T(grid, dev).requires_grad_(True)
+        tgu = T(guide, dev).requires_grad_(True)
+        ti = T(inp, dev).requires_grad_(True)
+        with ops.kernel_override(which):
+            ops.bilateral_slice_apply(tg, tgu, ti, has_offset=ho).backward(T(dout, dev))
+        if which == "generic":
+            assert np.array_equal(N(tg.grad), wg)
+            assert np.array_equal(N(tgu.grad), wgu)
+            assert np.array_equal(N(ti.grad), wi)
+        else:
+            grads_close(N(tg.grad), wg, "dgrid")
+            grads_close(N(tgu.grad), wgu, "dguide")
+            grads_close(N(ti.grad), wi, "dinput")
+
+
+def test_partial_gradients(dev, ops, port):
+    """A NULL output pointer skips that VJP (bilateral_slice_apply.cu.cc:393,401,409)."""
+    rng = np.random.default_rng(5)
+    grid, guide, inp, dout = rand_case(rng, 1, 16, 24, 4, 4, 4, 3, 3, True)
+    _, wgu, _ = port.bilateral_slice_apply_grad(grid, guide, inp, dout, True)
+    tg, ti = T(grid, dev), T(inp, dev)
+    tgu = T(guide, dev).requires_grad_(True)
+    ops.bilateral_slice_apply(tg, tgu, ti, has_offset=True).backward(T(dout, dev))
+    assert tg.grad is None and ti.grad is None
+    grads_close(N(tgu.grad), wgu, "dguide only")
+
+
+SLICE_SHAPES = [(2, 37, 53, 16, 12, 8, 12), (1, 64, 256, 16, 16, 8, 2), (1, 9, 7, 3, 4, 5, 1),
+                (4, 64, 48, 16, 12, 8, 2)]  # last: hdrnet_ops_jax_tf2_test.py:28-34 at 1/10 size
+
+
+@pytest.mark.parametrize("shape", SLICE_SHAPES)
+def test_slice_random(dev, ops, port, shape):
+    B, H, W, GH, GW, GD, C = shape
+    rng = np.random.default_rng(abs(hash(shape)) % (2 ** 31))
+    grid = rng.random((B, GH, GW, GD, C)).astype(np.float32)
+    guide = (rng.random((B, H, W)) * 1.2 - 0.1).astype(np.float32)
+    dout = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    want = port.bilateral_slice(grid, guide)
+    wg, wgu = port.bilateral_slice_grad(grid, guide, dout)
+    tg = T(grid, dev).requires_grad_(True)
+    tgu = T(guide, dev).requires_grad_(True)
+    out = ops.bilateral_slice(tg, tgu)
+    out.backward(T(dout, dev))
+    np.testing.assert_allclose(N(out), want, rtol=FWD_RTOL, atol=FWD_ATOL)
+    grads_close(N(tg.grad), wg, "dgrid")
+    grads_close(N(tgu.grad), wgu, "dguide")
+
+
+# ---- layers.py wrappers (6-D grids) -----------------------------------------------------------------
+def test_layers_6d(dev, ops, port):
+    from hdrnet_amd import layers
+    rng = np.random.default_rng(11)
+    B, H, W, GH, GW, GD, n_out, n_in = 2, 20, 24, 4, 5, 6, 3, 4
+    grid6 = rng.random((B, GH, GW, GD, n_out, n_in)).astype(np.float32)
+    guide = rng.random((B, H, W)).astype(np.float32)
+    inp = rng.random((B, H, W, n_in - 1)).astype(np.float32)
+    want = port.bilateral_slice_apply(grid6.reshape(B, GH, GW, GD, n_out * n_in), guide, inp, True)
+    got = N(layers.bilateral_slice_apply(T(grid6, dev), T(guide, dev), T(inp, dev), has_offset=True, name="slice"))
+    np.testing.assert_allclose(got, want, rtol=FWD_RTOL, atol=FWD_ATOL)
+    # hdrnet/test/ops_test.py:345-365: has_offset True -> 3 channels, False -> 4 from a 12-ch grid
+    inp4 = rng.random((B, H, W, 3)).astype(np.float32)
+    g12 = T(grid6.reshape(B, GH, GW, GD, 12), dev)
+    assert layers.bilateral_slice_apply(g12, T(guide, dev), T(inp4, dev), has_offset=True).shape[-1] == 3
+    assert layers.bilateral_slice_apply(g12, T(guide, dev), T(inp4, dev), has_offset=False).shape[-1] == 4
+    # layers.bilateral_slice on a 6-D grid: [B,H,W,n_out,n_in] with channel order j*n_out+i inside
+    s = N(layers.bilateral_slice(T(grid6, dev), T(guide, dev)))
+    assert s.shape == (B, H, W, n_out, n_in)
+    flat = np.concatenate([grid6[..., j] for j in range(n_in)], axis=4)
+    want_s = port.bilateral_slice(flat, guide).reshape(B, H, W, n_in, n_out).transpose(0, 1, 2, 4, 3)
+    np.testing.assert_allclose(s, want_s, rtol=FWD_RTOL, atol=FWD_ATOL)
+
+
+# ---- full-size frames: size-independent properties (the oracle takes seconds there) ----------------
+FULL = [(1080, 1920, 16, 16), (2160, 3840, 16, 16)]
+
+
+@pytest.mark.parametrize("H,W,GH,GW", FULL)
+def test_full_frame_identity_grid_returns_input(dev, ops, H, W, GH, GW):
+    """A grid holding the identity affine [I | 0] in every cell must return the input for ANY
+    guide -- up to the 0.9999 peak of the smoothed tent (numerics.h:108-113): the two z-weights
+    sum to 1 - O(1e-8) away from exact cell centres, so out == input to ~1e-6 relative."""
+    g = torch.zeros((1, GH, GW, 8, 3, 4), device=dev)
+    for i in range(3):
+        g[..., i, i] = 1.0
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    guide = torch.rand((1, H, W), device=dev, generator=gen)
+    inp = torch.rand((1, H, W, 3), device=dev, generator=gen)
+    out = ops.bilateral_slice_apply(g.reshape(1, GH, GW, 8, 12), guide, inp, has_offset=True)
+    assert ops.last_kernel() == "apply_fwd_rows/vec4"
+    err = (out - inp).abs().max().item()
+    assert err < 2.5e-4, err  # bound: |in| * (1 - (wz0 + wz1)) <= 1e-4-ish at cell centres
+    frac = ((out - inp).abs() > 1e-5).float().mean().item()
+    assert frac < 2e-3, frac  # only pixels within ~1e-3 of a cell centre in z see the dip
+
+
+@pytest.mark.parametrize("H,W,GH,GW", FULL)
+def test_full_frame_fast_equals_generic(dev, ops, H, W, GH, GW):
+    """Fast (LDS-staged) vs generic (bit-exact-to-reference) kernel on the whole frame."""
+    gen = torch.Generator(device=dev).manual_seed(4321)
+    grid = torch.rand((1, GH, GW, 8, 12), device=dev, generator=gen)
+    guide = torch.rand((1, H, W), device=dev, generator=gen) * 1.1 - 0.05
+    inp = torch.rand((1, H, W, 3), device=dev, generator=gen)
+    with ops.kernel_override("generic"):
+        a = ops.bilateral_slice_apply(grid, guide, inp, has_offset=True)
+    b = ops.bilateral_slice_apply(grid, guide, inp, has_offset=True)
+    assert ops.last_kernel() == "apply_fwd_rows/vec4"
+    torch.testing.assert_close(b, a, rtol=FWD_RTOL, atol=FWD_ATOL)
+    print(f"{H}x{W}: max|fast-generic| = {(a - b).abs().max().item():.3e}")
+
+
+def test_full_frame_rows_vs_oracle(dev, ops, port):
+    """A horizontal band of a 4K frame against the oracle: the band is computed as a full-height
+    problem on the GPU, and on the CPU from the same rows (the op is row-separable given H)."""
+    H, W = 2160, 3840
+    rng = np.random.default_rng(99)
+    grid = rng.random((1, 16, 16, 8, 12)).astype(np.float32)
+    guide = rng.random((1, H, W)).astype(np.float32)
+    inp = rng.random((1, H, W, 3)).astype(np.float32)
+    got = N(ops.bilateral_slice_apply(T(grid, dev), T(guide, dev), T(inp, dev), has_offset=True))
+    port.set_threads(0)
+    want = port.bilateral_slice_apply(grid, guide, inp, True)
+    np.testing.assert_allclose(got, want, rtol=FWD_RTOL, atol=FWD_ATOL)
+    worst = float(np.max(np.abs(got - want) / (REF_BAR + REF_BAR * np.abs(want))))
+    print(f"4K vs oracle: max|err|={np.abs(got - want).max():.3e}, worst/(1e-6 bar)={worst:.2f}")
+
+
+def test_linearity_in_grid_full_frame(dev, ops):
+    H, W = 1080, 1920
+    gen = torch.Generator(device=dev).manual_seed(7)
+    g1 = torch.rand((1, 16, 16, 8, 12), device=dev, generator=gen)
+    g2 = torch.rand((1, 16, 16, 8, 12), device=dev, generator=gen)
+    guide = torch.rand((1, H, W), device=dev, generator=gen)
+    inp = torch.rand((1, H, W, 3), device=dev, generator=gen)
+    f = lambda g: ops.bilateral_slice_apply(g, guide, inp, has_offset=True)  # noqa: E731
+    torch.testing.assert_close(f(g1 + 2 * g2), f(g1) + 2 * f(g2), rtol=1e-5, atol=2e-5)
+
+
+# ---- streams, batching, error paths ---------------------------------------------------------------
+def test_non_default_stream_and_batch(dev, ops, port):
+    rng = np.random.default_rng(3)
+    grid, guide, inp, _ = rand_case(rng, 4, 32, 64, 8, 8, 8, 3, 3, True)
+    want = port.bilateral_slice_apply(grid, guide, inp, True)
+    s = torch.cuda.Stream(device=dev)
+    tg, tgu, ti = T(grid, dev), T(guide, dev), T(inp, dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        out = ops.bilateral_slice_apply(tg, tgu, ti, has_offset=True)
+    s.synchronize()
+    np.testing.assert_allclose(N(out), want, rtol=FWD_RTOL, atol=FWD_ATOL)
+    # batch elements are independent: per-image calls agree with the batched call
+    for b in range(4):
+        o = ops.bilateral_slice_apply(tg[b:b + 1], tgu[b:b + 1], ti[b:b + 1], has_offset=True)
+        assert torch.equal(o[0], out[b])
+
+
+def test_empty_batch(dev, ops):
+    out = ops.bilateral_slice_apply(torch.rand((0, 4, 4, 4, 12), device=dev), torch.rand((0, 8, 8), device=dev),
+                                    torch.rand((0, 8, 8, 3), device=dev), has_offset=True)
+    assert tuple(out.shape) == (0, 8, 8, 3)
+    out = ops.bilateral_slice(torch.rand((2, 4, 4, 4, 5), device=dev), torch.rand((2, 0, 8), device=dev))
+    assert tuple(out.shape) == (2, 0, 8, 5)
+
+
+def test_non_contiguous_inputs(dev, ops, port):
+    rng = np.random.default_rng(8)
+    grid, guide, inp, _ = rand_case(rng, 1, 24, 32, 4, 4, 4, 3, 3, True)
+    want = port.bilateral_slice_apply(grid, guide, inp, True)
+    ti = T(np.ascontiguousarray(inp.transpose(0, 3, 1, 2)), dev).permute(0, 2, 3, 1)  # NCHW storage
+    assert not ti.is_contiguous()
+    got = N(ops.bilateral_slice_apply(T(grid, dev), T(guide, dev), ti, has_offset=True))
+    np.testing.assert_allclose(got, want, rtol=FWD_RTOL, atol=FWD_ATOL)
+
+
+def test_fast_flag_rejects_unsupported_shape(dev, ops):
+    from hdrnet_amd import _lib
+    with ops.kernel_override("fast"):
+        with pytest.raises(_lib.HdrnetInvalidArgument):
+            ops.bilateral_slice_apply(torch.rand((1, 4, 4, 4, 15), device=dev), torch.rand((1, 8, 8), device=dev),
+                                      torch.rand((1, 8, 8, 2), device=dev), has_offset=True)
+
+
+# ---- the reference's optimisation-convergence test (hdrnet/test/ops_test.py:189-230), shortened ------
+def test_grid_optimisation_converges(dev, ops):
+    """SGD on the grid only, fitting a sine along a 1 x W strip; the reference runs 10 000 steps to
+    SSE < 0.0085 -- here the loss must fall by > 50x in 400 steps (same mechanics, CI-sized)."""
+    torch.manual_seed(0)
+    W, GD = 100, 8
+    x = torch.linspace(0, 1, W, device=dev)
+    target = (0.5 + 0.4 * torch.sin(2 * np.pi * x)).reshape(1, 1, W, 1)
+    guide = x.reshape(1, 1, W).contiguous()
+    grid = (torch.rand((1, 1, 1, GD, 1), device=dev) * 0.1).requires_grad_(True)
+    opt = torch.optim.SGD([grid], lr=0.02)
+    first = None
+    for _ in range(400):
+        opt.zero_grad()
+        loss = ((ops.bilateral_slice(grid, guide) - target) ** 2).sum()
+        loss.backward()
+        opt.step()
+        first = loss.item() if first is None else first
+    assert loss.item() < first / 50, (first, loss.item())

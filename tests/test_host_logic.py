@@ -1,0 +1,82 @@
+"""Host-side mirror of the reference's operator interface: names, argument order, shape
+rules and error behaviour (hdrnet/hdrnet_ops.py:27-48; bilateral_slice_apply_op.cc:147-193;
+bilateral_slice_op.cc:129-147; hdrnet/layers.py:99-148).  Runs without a GPU."""
+import inspect
+
+import pytest
+import torch
+
+from hdrnet_amd import hdrnet_ops as ops
+from hdrnet_amd import layers
+
+
+def test_signatures_match_reference():
+    assert list(inspect.signature(ops.bilateral_slice).parameters)[:2] == ["grid", "guide"]
+    p = list(inspect.signature(ops.bilateral_slice_apply).parameters)
+    assert p[:4] == ["grid", "guide", "input", "has_offset"]
+    # has_offset is a REQUIRED attr of the reference op (bilateral_slice_apply_op.cc:386)
+    assert inspect.signature(ops.bilateral_slice_apply).parameters["has_offset"].default is inspect.Parameter.empty
+    p = inspect.signature(layers.bilateral_slice_apply).parameters
+    assert list(p) == ["grid", "guide", "input_image", "has_offset", "name"]
+    assert p["has_offset"].default is True  # hdrnet/layers.py:125
+    assert list(inspect.signature(layers.bilateral_slice).parameters) == ["grid", "guide", "name"]
+
+
+def _t(*shape):
+    return torch.rand(*shape)
+
+
+@pytest.mark.parametrize("grid,guide,inp,ho,msg", [
+    (_t(1, 4, 4, 4), _t(1, 8, 8), _t(1, 8, 8, 3), True, "grid should be 5D"),
+    (_t(1, 4, 4, 4, 12), _t(1, 8, 8, 1), _t(1, 8, 8, 3), True, "Guide image should be 3D"),
+    (_t(1, 4, 4, 4, 12), _t(1, 8, 8), _t(1, 8, 8), True, "Input image should be 4D"),
+    (_t(1, 4, 4, 4, 12), _t(1, 8, 8), _t(1, 8, 9, 3), True, "Input and guide size should match"),
+    (_t(2, 4, 4, 4, 12), _t(1, 8, 8), _t(1, 8, 8, 3), True, "Batch sizes should match"),
+    (_t(1, 4, 4, 4, 13), _t(1, 8, 8), _t(1, 8, 8, 3), True, "with affine offset"),
+    (_t(1, 4, 4, 4, 10), _t(1, 8, 8), _t(1, 8, 8, 3), False, "without affine offset"),
+])
+def test_apply_shape_rules(grid, guide, inp, ho, msg):
+    with pytest.raises(ValueError, match=msg):
+        ops.bilateral_slice_apply(grid, guide, inp, has_offset=ho)
+
+
+def test_slice_shape_rules():
+    with pytest.raises(ValueError, match="Grid should be 5D"):
+        ops.bilateral_slice(_t(1, 4, 4, 4), _t(1, 8, 8))
+    with pytest.raises(ValueError, match="Guide image should be 3D"):
+        ops.bilateral_slice(_t(1, 4, 4, 4, 2), _t(1, 8, 8, 1))
+    with pytest.raises(ValueError, match="Batch sizes"):
+        ops.bilateral_slice(_t(2, 4, 4, 4, 2), _t(1, 8, 8))
+
+
+def test_dtype_rule():
+    with pytest.raises(TypeError, match="float32"):
+        ops.bilateral_slice(_t(1, 4, 4, 4, 2).double(), _t(1, 8, 8).double())
+
+
+def test_no_cpu_path():
+    """The product has no CPU / eager fallback: well-formed CPU tensors are refused loudly."""
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.bilateral_slice_apply(_t(1, 4, 4, 4, 12), _t(1, 8, 8), _t(1, 8, 8, 3), has_offset=True)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.bilateral_slice(_t(1, 4, 4, 4, 2), _t(1, 8, 8))
+
+
+def test_layers_6d_grid_routes_through_shape_checks():
+    # 6-D [B,GH,GW,GD,n_out,n_in] is flattened to 5-D before the op (layers.py:139-144): a
+    # mismatching n_in must be reported by the op's channel rule.
+    with pytest.raises(ValueError, match="with affine offset"):
+        layers.bilateral_slice_apply(_t(1, 4, 4, 4, 3, 5), _t(1, 8, 8), _t(1, 8, 8, 3), has_offset=True)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        layers.bilateral_slice_apply(_t(1, 4, 4, 4, 3, 4), _t(1, 8, 8), _t(1, 8, 8, 3), has_offset=True)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        layers.bilateral_slice(_t(1, 4, 4, 4, 3, 4), _t(1, 8, 8))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from hdrnet_amd import _lib, build
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(build, "LIB_PATH", str(tmp_path / "nope" / "libhdrnet_amd.so"))
+    monkeypatch.setattr(build, "build", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("no hipcc")))
+    with pytest.raises(_lib.HdrnetLibraryError):
+        _lib.load()

@@ -1,0 +1,229 @@
+"""Pins the CPU oracle (oracle/) before anything is compared against it.
+
+1. oracle port (C99 restatement)  ==  golden fixtures made from the reference's own
+   CPU code (tests/golden/make_golden.py), BIT-EXACT, all seven functions.
+2. oracle port == oracle/_ref (the compiled reference) bit-exact on extra random
+   shapes, when the compiled reference is present.
+3. The reference's known-answer test (hdrnet/test/ops_test.py:61-86).
+4. The numpy restatement of jax/bilateral_slice.py == the op at the reference's own
+   JAX-vs-op bar (assertAllClose defaults, hdrnet_ops_jax_tf2_test.py:48).
+5. The reference's finite-difference gradient checks, with its extents and thresholds
+   (hdrnet_ops_test.py:139-210, :319-408), re-hosted on the oracle.
+6. Adjointness <GridGrad(u), g> == <u, Apply(g)> (grid-linearity of the op).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+
+
+# ---- 1. golden fixtures ------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_names("apply_"))
+def test_port_matches_golden_apply(port, name):
+    g = load_golden(name)
+    ho = bool(g["has_offset"])
+    out = port.bilateral_slice_apply(g["grid"], g["guide"], g["input"], ho)
+    assert np.array_equal(out, g["out"])
+    dgrid, dguide, dinput = port.bilateral_slice_apply_grad(g["grid"], g["guide"], g["input"], g["dout"], ho)
+    assert np.array_equal(dgrid, g["dgrid"])
+    assert np.array_equal(dguide, g["dguide"])
+    assert np.array_equal(dinput, g["dinput"])
+
+
+@pytest.mark.parametrize("name", golden_names("slice_"))
+def test_port_matches_golden_slice(port, name):
+    g = load_golden(name)
+    assert np.array_equal(port.bilateral_slice(g["grid"], g["guide"]), g["out"])
+    dgrid, dguide = port.bilateral_slice_grad(g["grid"], g["guide"], g["dout"])
+    assert np.array_equal(dgrid, g["dgrid"])
+    assert np.array_equal(dguide, g["dguide"])
+
+
+def test_port_threads_do_not_change_results(port):
+    g = load_golden("apply_forward_default")
+    n = port.set_threads(1)
+    a = port.bilateral_slice_apply(g["grid"], g["guide"], g["input"], True)
+    port.set_threads(4)
+    b = port.bilateral_slice_apply(g["grid"], g["guide"], g["input"], True)
+    port.set_threads(n)
+    assert np.array_equal(a, b)
+
+
+# ---- 2. against the compiled reference ------------------------------------------------------
+SHAPES = [  # B, H, W, GH, GW, GD, Cin, Cout, has_offset
+    (1, 1, 1, 1, 1, 1, 1, 1, True),
+    (2, 5, 7, 3, 2, 4, 3, 3, True),
+    (1, 33, 65, 16, 16, 8, 3, 3, True),
+    (2, 9, 4, 12, 12, 8, 1, 3, True),
+    (1, 16, 16, 2, 2, 1, 4, 2, False),
+    (1, 40, 24, 5, 3, 2, 2, 5, True),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_port_matches_compiled_reference(port, ref_or_none, shape):
+    if ref_or_none is None:
+        pytest.skip("oracle/_ref not built here (no /root/reference); golden fixtures cover this box")
+    B, H, W, GH, GW, GD, Cin, Cout, ho = shape
+    rng = np.random.default_rng(hash(shape) & 0xFFFF)
+    Cj = Cin + int(ho)
+    grid = rng.standard_normal((B, GH, GW, GD, Cout * Cj)).astype(np.float32)
+    guide = (rng.random((B, H, W)) * 1.6 - 0.3).astype(np.float32)
+    inp = rng.random((B, H, W, Cin)).astype(np.float32)
+    dout = rng.standard_normal((B, H, W, Cout)).astype(np.float32)
+    R = ref_or_none
+    assert np.array_equal(port.bilateral_slice_apply(grid, guide, inp, ho),
+                          R.bilateral_slice_apply(grid, guide, inp, ho))
+    for a, b in zip(port.bilateral_slice_apply_grad(grid, guide, inp, dout, ho),
+                    R.bilateral_slice_apply_grad(grid, guide, inp, dout, ho)):
+        assert np.array_equal(a, b)
+    assert np.array_equal(port.bilateral_slice(grid, guide), R.bilateral_slice(grid, guide))
+    d2 = rng.standard_normal((B, H, W, Cout * Cj)).astype(np.float32)
+    for a, b in zip(port.bilateral_slice_grad(grid, guide, d2), R.bilateral_slice_grad(grid, guide, d2)):
+        assert np.array_equal(a, b)
+
+
+def test_apply_equals_slice_plus_matmul(port):
+    # bilateral_slice_apply.h:22-29: the fused op == slice -> reshape (Cout x Cj) -> per-pixel multiply
+    g = load_golden("apply_forward_default")
+    sliced = port.bilateral_slice(g["grid"], g["guide"])  # [B,H,W,12]
+    B, H, W, _ = sliced.shape
+    m = sliced.reshape(B, H, W, 3, 4)
+    ref = np.zeros((B, H, W, 3), np.float32)
+    for i in range(3):
+        v = np.zeros((B, H, W), np.float32)
+        for j in range(4):
+            v = v + (m[..., i, j] * g["input"][..., j] if j < 3 else m[..., i, j])
+        ref[..., i] = v
+    assert np.array_equal(port.bilateral_slice_apply(g["grid"], g["guide"], g["input"], True), ref)
+
+
+# ---- 3. known-answer test ---------------------------------------------------------------------
+def test_interpolate_known_answer(port):
+    """hdrnet/test/ops_test.py:61-86: depth planes 0,1,2 sliced at (val+0.5)/d return val +- 5e-4."""
+    k = load_golden("slice_interpolate_kat")
+    d = 3
+    for val in range(d):
+        guide = (((val + 0.5) / (1.0 * d)) * np.ones((3, 5, 9))).astype(np.float32)
+        out = port.bilateral_slice(k["grid"], guide)
+        assert list(out.shape) == [3, 5, 9, 1]
+        assert np.amax(np.abs(val - out)) < 5e-4
+        assert np.array_equal(out, k["outs"][val])
+    # The smoothed tent peaks at 1 - sqrt(1e-8) = 0.9999, not 1 (numerics.h:108-113): the
+    # answer for val=2 sits 2e-4 low; a plain-lerp implementation would return exactly 2.
+    assert abs(float(k["outs"][2].max()) - (2.0 - 2.0e-4)) < 2e-6
+
+
+# ---- 4. JAX twin -------------------------------------------------------------------------------
+def test_jax_numpy_restatement_matches_op():
+    from oracle import jax_np as J
+    g = load_golden("slice_jax_shape_small")
+    out = J.batched(J.bilateral_slice, g["grid"], g["guide"])
+    np.testing.assert_allclose(out, g["out"], rtol=1e-6, atol=1e-6)
+    B = g["grid"].shape[0]
+    dguide = np.stack([J.bilateral_slice_guide_vjp(g["grid"][b], g["guide"][b], g["dout"][b]) for b in range(B)])
+    np.testing.assert_allclose(dguide, g["dguide"], rtol=1e-5, atol=1e-5)
+    dgrid = np.stack([J.bilateral_slice_grid_vjp(g["guide"][b], g["dout"][b], g["grid"][b].shape)
+                      for b in range(B)])
+    np.testing.assert_allclose(dgrid, g["dgrid"], rtol=1e-5, atol=1e-5 * np.abs(g["dgrid"]).max())
+
+
+def test_jax_config1_plumbing(port):
+    """BASELINE.json configs[0]: bilateral_slice 256x256, 16x16x8 grid (unbatched JAX API) on CPU."""
+    from oracle import jax_np as J
+    rng = np.random.default_rng(1234)
+    grid = rng.random((16, 16, 8, 12), dtype=np.float32)
+    guide = rng.random((256, 256), dtype=np.float32)
+    out = J.bilateral_slice(grid, guide)
+    assert out.shape == (256, 256, 12)
+    np.testing.assert_allclose(out, port.bilateral_slice(grid[None], guide[None])[0], rtol=1e-6, atol=1e-6)
+
+
+# ---- 5. the reference's finite-difference gradient checks --------------------------------------
+def _max_fd_error(f, x, analytic_vjp_rows, delta):
+    """tf.test.compute_gradient_error: max |J_analytic - J_numeric| over the full Jacobian.
+    analytic_vjp_rows(k) returns d out_flat[k] / d x (shape of x)."""
+    x = x.copy()
+    y0 = f(x).ravel()
+    num = np.zeros((x.size, y0.size), np.float64)
+    flat = x.ravel()
+    for i in range(flat.size):
+        old = flat[i]
+        flat[i] = old + delta
+        yp = f(x).ravel().astype(np.float64)
+        flat[i] = old - delta
+        ym = f(x).ravel().astype(np.float64)
+        flat[i] = old
+        num[i] = (yp - ym) / (2 * delta)
+    ana = np.stack([analytic_vjp_rows(k).ravel() for k in range(y0.size)], axis=1)
+    return np.abs(ana - num).max()
+
+
+def _fd_case(port, B, H, W, Cin, GH, GW, GD, Cout, wrt, apply, delta, thresh):
+    rng = np.random.RandomState(7)
+    Cj = Cin + 1
+    C = Cout * Cj
+    grid = rng.rand(B, GH, GW, GD, C).astype(np.float32)
+    guide = rng.rand(B, H, W).astype(np.float32)
+    # The trilinear tent is not differentiable where guide*GD crosses a half-integer; the
+    # reference's (unseeded) random test only passes when no sample lies within `delta` of
+    # such a kink.  Make that deterministic: keep every sample >= 0.1 cell away from one.
+    t = guide.astype(np.float64) * GD - 0.5
+    frac = t - np.floor(t)
+    guide = ((np.floor(t) + np.clip(frac, 0.1, 0.9) + 0.5) / GD).astype(np.float32)
+    inp = rng.rand(B, H, W, Cin).astype(np.float32)
+    oshape = (B, H, W, Cout if apply else C)
+
+    def fwd(g=grid, gu=guide, i=inp):
+        return port.bilateral_slice_apply(g, gu, i, True) if apply else port.bilateral_slice(g, gu)
+
+    def rows(k):
+        d = np.zeros(oshape, np.float32)
+        d.ravel()[k] = 1.0
+        if apply:
+            gs = port.bilateral_slice_apply_grad(grid, guide, inp, d, True)
+            return {"grid": gs[0], "guide": gs[1], "input": gs[2]}[wrt]
+        gs = port.bilateral_slice_grad(grid, guide, d)
+        return {"grid": gs[0], "guide": gs[1]}[wrt]
+
+    x = {"grid": grid, "guide": guide, "input": inp}[wrt]
+    f = {"grid": lambda v: fwd(g=v), "guide": lambda v: fwd(gu=v), "input": lambda v: fwd(i=v)}[wrt]
+    err = _max_fd_error(f, x, rows, delta)
+    assert err < thresh, err
+
+
+def test_fd_slice_grid_gradient(port):      # hdrnet_ops_test.py:183-195, delta 1e-4, err < 3e-3
+    _fd_case(port, 3, 8, 5, 3, 6, 3, 7, 4, "grid", False, 1e-4, 3e-3)
+
+
+def test_fd_slice_guide_gradient(port):     # hdrnet_ops_test.py:198-210
+    _fd_case(port, 1, 6, 18, 1, 3, 9, 7, 1, "guide", False, 1e-4, 3e-3)
+
+
+def test_fd_apply_grid_gradient(port):      # hdrnet_ops_test.py:366-378, default delta 1e-3, err < 1e-2
+    _fd_case(port, 3, 8, 5, 3, 6, 3, 7, 4, "grid", True, 1e-3, 1e-2)
+
+
+def test_fd_apply_guide_gradient(port):     # hdrnet_ops_test.py:380-393
+    _fd_case(port, 1, 6, 18, 1, 3, 9, 7, 1, "guide", True, 1e-3, 1e-2)
+
+
+def test_fd_apply_input_gradient(port):     # hdrnet_ops_test.py:396-408
+    _fd_case(port, 3, 8, 5, 3, 6, 3, 7, 4, "input", True, 1e-3, 1e-2)
+
+
+# ---- 6. adjointness ------------------------------------------------------------------------------
+def test_grid_grad_is_adjoint_of_apply(port):
+    g = load_golden("apply_guide_out_of_range")
+    ho = bool(g["has_offset"])
+    u = g["dout"].astype(np.float64)
+    out = port.bilateral_slice_apply(g["grid"], g["guide"], g["input"], ho).astype(np.float64)
+    dgrid, _, dinput = port.bilateral_slice_apply_grad(g["grid"], g["guide"], g["input"], g["dout"], ho)
+    lhs = float((dgrid.astype(np.float64) * g["grid"]).sum())   # <A^T u, g>
+    rhs = float((u * out).sum())                                 # <u, A g>
+    assert abs(lhs - rhs) <= 2e-5 * abs(rhs)
+    # input-linearity: <dinput, in> + offset part == <u, out>
+    zero_in = np.zeros_like(g["input"])
+    off = port.bilateral_slice_apply(g["grid"], g["guide"], zero_in, ho).astype(np.float64)
+    lhs2 = float((dinput.astype(np.float64) * g["input"]).sum() + (u * off).sum())
+    assert abs(lhs2 - rhs) <= 2e-5 * abs(rhs)
