@@ -38,6 +38,7 @@ namespace hdrnet_amd {
 namespace {
 
 constexpr int kPxPerThread = 4;
+constexpr int kVariantRows = 1, kVariantWave = 2;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -49,78 +50,105 @@ struct CoefVec {
   __device__ __forceinline__ float get(int c) const { return v[c >> 1][c & 1]; }
 };
 
-// coef += w * colY[base .. base+C)   (base in floats, multiple of C).
-// Written on explicit 2-wide vectors so that the blend maps onto v_pk_fma_f32 with
-// the weight broadcast through op_sel and the ds_read_b128 result consumed in
-// place (no cross-pixel SLP pairing, no register shuffles).
-template <int C>
+// coef (+)= w * vec, vec = the C floats at byte offset `off` of the LDS image.
+// Explicit 2-wide vectors: the blend maps onto v_pk_fma_f32 / v_pk_mul_f32 with the
+// weight broadcast through op_sel and the ds_read_b128 result consumed in place.
+template <int C, bool FIRST>
 __device__ __forceinline__ void accum_vec(CoefVec<C>& coef, const float* __restrict__ colY,
-                                          int base, float w) {
+                                          int off, float w) {
   const f32x2 w2 = {w, w};
+  const char* base = reinterpret_cast<const char*>(colY) + off;
   if constexpr (C % 4 == 0) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(colY + base);
+    const f32x4* p = reinterpret_cast<const f32x4*>(base);
 #pragma unroll
     for (int q = 0; q < C / 4; ++q) {
       const f32x4 t = p[q];
-      coef.v[2 * q + 0] = __builtin_elementwise_fma(w2, t.xy, coef.v[2 * q + 0]);
-      coef.v[2 * q + 1] = __builtin_elementwise_fma(w2, t.zw, coef.v[2 * q + 1]);
+      if constexpr (FIRST) {
+        coef.v[2 * q + 0] = w2 * t.xy;
+        coef.v[2 * q + 1] = w2 * t.zw;
+      } else {
+        coef.v[2 * q + 0] = __builtin_elementwise_fma(w2, t.xy, coef.v[2 * q + 0]);
+        coef.v[2 * q + 1] = __builtin_elementwise_fma(w2, t.zw, coef.v[2 * q + 1]);
+      }
     }
   } else {
+    const float* p = reinterpret_cast<const float*>(base);
 #pragma unroll
-    for (int q = 0; q < C; ++q) coef.v[q >> 1][q & 1] = fmaf(w, colY[base + q], coef.v[q >> 1][q & 1]);
+    for (int q = 0; q < C; ++q)
+      coef.v[q >> 1][q & 1] = FIRST ? w * p[q] : fmaf(w, p[q], coef.v[q >> 1][q & 1]);
   }
 }
 
 struct RowCtx {
   const float* colY;  // LDS image, [ncol][GD][C]
-  float scale_x;
-  int GW, GD, gxlo;
+  float scale_x, gd_f;
+  // Byte-space addressing of the LDS image: column stride and the clamp windows of
+  // (gx - gxlo) * col_bytes and gz * vec_bytes.
+  int gxlo, col_bytes, x_lo_b, x_hi_b, z_hi_b;
 };
 
 // One pixel: slice the y-pre-lerped columns at (x, guide) and apply the affine.
+//
+// Coordinates and weights follow bilateral_slice_apply.cc:41-64:
+//   gxf = (x + .5) * scale_x, gx0 = floor(gxf - .5), dx0 = (gx0 + .5) - gxf  in (-1, 0]
+//   gzf = guide * GD,         gz0 = floor(gzf - .5), dz0 = (gz0 + .5) - gzf  in (-1, 0]
+//   wx0 = 1 - |dx0| = 1 + dx0,   wx1 = 1 - |dx0 + 1| = -dx0          (tent, numerics.h:53)
+//   wz0 = 1 - sqrt(dz0^2 + eps), wz1 = 1 - sqrt((dz0 + 1)^2 + eps)  (smoothed, :108)
+// floor() puts both corners within one cell of the sample, so the reference's
+// max(., 0) never binds and is dropped; weights still come from the UNclamped
+// corner and only the indices are clamped (in byte space).  v_sqrt_f32 (1 ulp)
+// stands in for the correctly-rounded expansion: its argument lies in
+// [1e-8, 1 + 1e-8], nowhere near a denormal, and one ulp of a weight is 6e-8.
 template <int CIN, int COUT, bool OFFSET>
-__device__ __forceinline__ void slice_apply_pixel(const RowCtx& r, int x, float g,
+__device__ __forceinline__ void slice_apply_pixel(const RowCtx& r, float xf, float g,
                                                   const float (&in)[CIN],
                                                   float (&out)[COUT]) {
   constexpr int CJ = CIN + (OFFSET ? 1 : 0);
   constexpr int C = COUT * CJ;
-  // bilateral_slice_apply.cc:41,44,46,48
-  const float gxf = (x + 0.5f) * r.scale_x;
-  const float gzf = g * r.GD;
-  const int gx0 = floor_to_int(gxf - 0.5f);
-  const int gz0 = floor_to_int(gzf - 0.5f);
-  // :59-60, :63-64 -- weights from the UNclamped corner, indices clamped.
-  const float wx0 = tent_weight(gx0 + 0.5f, gxf);
-  const float wx1 = tent_weight(gx0 + 1 + 0.5f, gxf);
-  const float wz0 = smoothed_tent_weight(gz0 + 0.5f, gzf);
-  const float wz1 = smoothed_tent_weight(gz0 + 1 + 0.5f, gzf);
-  const int c0 = clamp_index(gx0, 0, r.GW - 1) - r.gxlo;
-  const int c1 = clamp_index(gx0 + 1, 0, r.GW - 1) - r.gxlo;
-  const int z0 = clamp_index(gz0, 0, r.GD - 1);
-  const int z1 = clamp_index(gz0 + 1, 0, r.GD - 1);
-  const int col0 = c0 * r.GD, col1 = c1 * r.GD;
+  constexpr int kVecBytes = C * (int)sizeof(float);
+  const float gxf = xf * r.scale_x;  // xf = x + 0.5f, exact
+  const float fxl = floorf(gxf - 0.5f);
+  const float dx0 = (fxl + 0.5f) - gxf;
+  const float wx0 = 1.0f + dx0, wx1 = -dx0;
+  const float gzf = g * r.gd_f;
+  // floor of a wild guide is clamped in float before the int conversion so that the
+  // byte-space arithmetic below cannot overflow (v_med3_f32).
+  const float fzl = floorf(gzf - 0.5f);
+  const float dz0 = (fzl + 0.5f) - gzf;
+  const float dz1 = dz0 + 1.0f;
+  const float wz0 = 1.0f - __builtin_amdgcn_sqrtf(fmaf(dz0, dz0, kSmoothEps));
+  const float wz1 = 1.0f - __builtin_amdgcn_sqrtf(fmaf(dz1, dz1, kSmoothEps));
+  const int iz = (int)__builtin_amdgcn_fmed3f(fzl, -2.0f, r.gd_f + 1.0f);
+  const int zb = __mul24(iz, kVecBytes);  // |iz| <= GD + 1: 24-bit multiply is exact
+  const int zb0 = min(max(zb, 0), r.z_hi_b);
+  const int zb1 = min(max(zb + kVecBytes, 0), r.z_hi_b);
+  // x needs no guard: gxf in (0, GW) by construction, so gx0 in [-1, GW - 1].
+  const int xb = __mul24((int)fxl - r.gxlo, r.col_bytes);
+  const int xb0 = max(xb, r.x_lo_b);
+  const int xb1 = min(xb + r.col_bytes, r.x_hi_b);
 
   CoefVec<C> coef;
-#pragma unroll
-  for (int q = 0; q < CoefVec<C>::kPairs; ++q) coef.v[q] = f32x2{0.0f, 0.0f};
-  accum_vec<C>(coef, r.colY, (col0 + z0) * C, wx0 * wz0);
-  accum_vec<C>(coef, r.colY, (col0 + z1) * C, wx0 * wz1);
-  accum_vec<C>(coef, r.colY, (col1 + z0) * C, wx1 * wz0);
-  accum_vec<C>(coef, r.colY, (col1 + z1) * C, wx1 * wz1);
+  accum_vec<C, true>(coef, r.colY, xb0 + zb0, wx0 * wz0);
+  accum_vec<C, false>(coef, r.colY, xb0 + zb1, wx0 * wz1);
+  accum_vec<C, false>(coef, r.colY, xb1 + zb0, wx1 * wz0);
+  accum_vec<C, false>(coef, r.colY, xb1 + zb1, wx1 * wz1);
 
   // :72-80 -- per-pixel (Cout x Cj) . [in; 1]
 #pragma unroll
   for (int i = 0; i < COUT; ++i) {
-    float v = 0.0f;
+    float v = OFFSET ? coef.get(i * CJ + CIN) : 0.0f;
 #pragma unroll
     for (int j = 0; j < CIN; ++j) v = fmaf(coef.get(i * CJ + j), in[j], v);
-    if (OFFSET) v += coef.get(i * CJ + CIN);
     out[i] = v;
   }
 }
 
 // Blend the two grid rows this image row needs into LDS; returns the row context.
-template <int C>
+// WAVE = false: the whole workgroup fills one image and meets at a barrier.
+// WAVE = true : each wavefront fills its own private image; LDS operations of one
+//               wave complete in order, so no s_barrier is needed -- waves never wait
+//               for each other.
+template <int C, bool WAVE>
 __device__ __forceinline__ RowCtx stage_row(float* __restrict__ colY,
                                             const float* __restrict__ grid_b, int y, int xs,
                                             int xe, int GH, int GW, int GD, float scale_x,
@@ -143,18 +171,36 @@ __device__ __forceinline__ RowCtx stage_row(float* __restrict__ colY,
     const float4* a4 = reinterpret_cast<const float4*>(r0);
     const float4* b4 = reinterpret_cast<const float4*>(r1);
     float4* d4 = reinterpret_cast<float4*>(colY);
+    const int e0 = WAVE ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
+    const int estep = WAVE ? 64 : (int)blockDim.x;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-    for (int e = threadIdx.x; e < n / 4; e += blockDim.x) {
+    for (int e = e0; e < n / 4; e += estep) {
       const float4 a = a4[e], b = b4[e];
       d4[e] = make_float4(wy0 * a.x + wy1 * b.x, wy0 * a.y + wy1 * b.y,
                           wy0 * a.z + wy1 * b.z, wy0 * a.w + wy1 * b.w);
     }
   } else {
+    const int e0 = WAVE ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
+    const int estep = WAVE ? 64 : (int)blockDim.x;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-    for (int e = threadIdx.x; e < n; e += blockDim.x) colY[e] = wy0 * r0[e] + wy1 * r1[e];
+    for (int e = e0; e < n; e += estep) colY[e] = wy0 * r0[e] + wy1 * r1[e];
   }
-  __syncthreads();
-  return RowCtx{colY, scale_x, GW, GD, gxlo};
+  if constexpr (WAVE) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+  const int col_bytes = GD * C * (int)sizeof(float);
+  return RowCtx{colY,
+                scale_x,
+                (float)GD,
+                gxlo,
+                col_bytes,
+                (0 - gxlo) * col_bytes,
+                (GW - 1 - gxlo) * col_bytes,
+                (GD - 1) * C * (int)sizeof(float)};
 }
 
 // ---- 4 consecutive pixels per thread, 16-byte global accesses -----------------------
@@ -190,10 +236,11 @@ __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
     for (int q = 0; q < (CIN * kPxPerThread) / 4; ++q) iv[q] = ip[q];
   }
 
-  const RowCtx r = stage_row<C>(colY, grid_b, y, xs, xe, GH, GW, GD, scale_x, scale_y);
+  const RowCtx r = stage_row<C, false>(colY, grid_b, y, xs, xe, GH, GW, GD, scale_x, scale_y);
   if (!active) return;
 
   const float gs[4] = {g4.x, g4.y, g4.z, g4.w};
+  const float xf0 = (float)x + 0.5f;  // (x + k) + 0.5f == xf0 + k exactly (x < 2^23)
   const float* inf = reinterpret_cast<const float*>(iv);
   float4 ov[(COUT * kPxPerThread) / 4];
   float* of = reinterpret_cast<float*>(ov);
@@ -202,7 +249,7 @@ __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
     float in[CIN], o[COUT];
 #pragma unroll
     for (int j = 0; j < CIN; ++j) in[j] = inf[k * CIN + j];
-    slice_apply_pixel<CIN, COUT, OFFSET>(r, x + k, gs[k], in, o);
+    slice_apply_pixel<CIN, COUT, OFFSET>(r, xf0 + (float)k, gs[k], in, o);
 #pragma unroll
     for (int i = 0; i < COUT; ++i) of[k * COUT + i] = o[i];
   }
@@ -241,18 +288,79 @@ __global__ __launch_bounds__(256) void apply_fwd_rows_scalar(
     }
   }
 
-  const RowCtx r = stage_row<C>(colY, grid_b, y, xs, xe, GH, GW, GD, scale_x, scale_y);
+  const RowCtx r = stage_row<C, false>(colY, grid_b, y, xs, xe, GH, GW, GD, scale_x, scale_y);
 
 #pragma unroll
   for (int k = 0; k < kPxPerThread; ++k) {
     const int x = xs + threadIdx.x + k * blockDim.x;
     if (x < xe) {
       float o[COUT];
-      slice_apply_pixel<CIN, COUT, OFFSET>(r, x, gs[k], in[k], o);
+      slice_apply_pixel<CIN, COUT, OFFSET>(r, (float)x + 0.5f, gs[k], in[k], o);
 #pragma unroll
       for (int i = 0; i < COUT; ++i) out[(prow + x) * COUT + i] = o[i];
     }
   }
+}
+
+// ---- one wavefront per output tile ------------------------------------------------------
+// A tile is `tile_w` consecutive pixels of one image row (tile_w <= 256, 4 per lane).
+// Each wave stages its own y-pre-lerped columns (<= ~5 of them) in a private LDS
+// region and then slices its pixels: no workgroup barrier, waves are independent, and a
+// workgroup is just `waves_per_block` consecutive tiles.
+template <int CIN, int COUT, bool OFFSET>
+__global__ __launch_bounds__(256) void apply_fwd_wave_vec4(
+    const float* __restrict__ grid, const float* __restrict__ guide,
+    const float* __restrict__ input, float* __restrict__ out, int H, int W, int GH, int GW,
+    int GD, int tiles_per_row, int tile_w, long long ntiles, int lds_floats_per_wave,
+    float scale_x, float scale_y) {
+  constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
+  extern __shared__ __attribute__((aligned(16))) float colY_all[];
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const long long tile = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
+  if (tile >= ntiles) return;
+  float* colY = colY_all + wave * lds_floats_per_wave;
+  const int ti = (int)(tile % tiles_per_row);
+  const long long row = tile / tiles_per_row;  // = b * H + y
+  const int y = (int)(row % H);
+  const long long b = row / H;
+  const int xs = ti * tile_w;
+  const int xe = min(xs + tile_w, W);
+  const float* grid_b = grid + (size_t)b * GH * GW * GD * C;
+
+  const int x = xs + kPxPerThread * lane;
+  const bool active = x < xe;
+  const size_t p = (size_t)row * W + x;
+
+  float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 iv[(CIN * kPxPerThread) / 4];
+  if (active) {
+    g4 = *reinterpret_cast<const float4*>(guide + p);
+    const float4* ip = reinterpret_cast<const float4*>(input + p * CIN);
+#pragma unroll
+    for (int q = 0; q < (CIN * kPxPerThread) / 4; ++q) iv[q] = ip[q];
+  }
+
+  const RowCtx r = stage_row<C, true>(colY, grid_b, y, xs, xe, GH, GW, GD, scale_x, scale_y);
+  if (!active) return;
+
+  const float gs[4] = {g4.x, g4.y, g4.z, g4.w};
+  const float xf0 = (float)x + 0.5f;
+  const float* inf = reinterpret_cast<const float*>(iv);
+  float4 ov[(COUT * kPxPerThread) / 4];
+  float* of = reinterpret_cast<float*>(ov);
+#pragma unroll
+  for (int k = 0; k < kPxPerThread; ++k) {
+    float in[CIN], o[COUT];
+#pragma unroll
+    for (int j = 0; j < CIN; ++j) in[j] = inf[k * CIN + j];
+    slice_apply_pixel<CIN, COUT, OFFSET>(r, xf0 + (float)k, gs[k], in, o);
+#pragma unroll
+    for (int i = 0; i < COUT; ++i) of[k * COUT + i] = o[i];
+  }
+  float4* op = reinterpret_cast<float4*>(out + p * COUT);
+#pragma unroll
+  for (int q = 0; q < (COUT * kPxPerThread) / 4; ++q) op[q] = ov[q];
 }
 
 struct Plan {
@@ -299,6 +407,23 @@ hipError_t launch_t(const ApplyArgs& a, hipStream_t s, const char** name) {
   const size_t lds = (size_t)pl.max_cols * a.GD * C * sizeof(float);
   const long long nblocks = (long long)a.B * a.H * pl.nseg;
   const float sx = (float)a.GW / a.W, sy = (float)a.GH / a.H;
+  if (pl.vec4 && a.variant == kVariantWave) {
+    // One wavefront per tile of <= 256 pixels, balanced over the row.
+    const int tiles_per_row = (a.W + 64 * kPxPerThread - 1) / (64 * kPxPerThread);
+    const int tile_w = round_up((a.W + tiles_per_row - 1) / tiles_per_row, 4);
+    const long long ncol = ((long long)(tile_w - 1) * a.GW) / a.W + 4;
+    const int cols = (int)(ncol < a.GW ? ncol : a.GW);
+    const int lds_floats = round_up(cols * a.GD * C, 4);
+    const long long ntiles = (long long)a.B * a.H * tiles_per_row;
+    const int waves = 4;
+    apply_fwd_wave_vec4<CIN, COUT, OFFSET>
+        <<<(unsigned)((ntiles + waves - 1) / waves), waves * 64,
+           (size_t)waves * lds_floats * sizeof(float), s>>>(
+            a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, tiles_per_row, tile_w,
+            ntiles, lds_floats, sx, sy);
+    *name = "apply_fwd_wave/vec4";
+    return hipGetLastError();
+  }
   if (pl.vec4) {
     apply_fwd_rows_vec4<CIN, COUT, OFFSET><<<(unsigned)nblocks, pl.threads, lds, s>>>(
         a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, pl.nseg, pl.seg, sx, sy);

@@ -48,10 +48,15 @@ int check_common(int B, int H, int W, int GH, int GW, int GD) {
   return HDRNET_OK;
 }
 
+// flags: bits 0..7 kernel family (HDRNET_KERNEL_*), bits 8..15 variant inside the family
+// (0 = the library's default; used by benchmarks for A/B runs), rest must be zero.
 int check_flags(unsigned flags) {
-  if (flags > HDRNET_KERNEL_FAST) return fail(HDRNET_INVALID_ARGUMENT, "unknown flags %u", flags);
+  if ((flags & 0xffu) > HDRNET_KERNEL_FAST || (flags >> 16) != 0)
+    return fail(HDRNET_INVALID_ARGUMENT, "unknown flags 0x%x", flags);
   return HDRNET_OK;
 }
+unsigned family(unsigned flags) { return flags & 0xffu; }
+int variant(unsigned flags) { return (int)((flags >> 8) & 0xffu); }
 
 }  // namespace
 
@@ -83,12 +88,12 @@ int hdrnet_bilateral_slice_apply_f32_ex(const float* grid, const float* guide,
   if (!grid || !guide || !out || (Cin > 0 && !input))
     return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
   ApplyArgs a{grid, guide, input, out, B, H, W, GH, GW, GD, Cin, Cout,
-              Cin + (has_offset ? 1 : 0), has_offset != 0};
+              Cin + (has_offset ? 1 : 0), has_offset != 0, variant(flags)};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool fast_ok = apply_fwd_rows_supported(a);
-  if (flags == HDRNET_KERNEL_FAST && !fast_ok)
+  if (family(flags) == HDRNET_KERNEL_FAST && !fast_ok)
     return fail(HDRNET_INVALID_ARGUMENT, "no fast BilateralSliceApply variant for this shape");
-  if (flags != HDRNET_KERNEL_GENERIC && fast_ok) {
+  if (family(flags) != HDRNET_KERNEL_GENERIC && fast_ok) {
     const char* name = "";
     const hipError_t e = launch_apply_fwd_rows(a, s, &name);
     const int rc = check_launch(e, "BilateralSliceApply");
@@ -147,7 +152,7 @@ int hdrnet_bilateral_slice_apply_grad_f32_ex(const float* grid, const float* gui
     return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
   ApplyGradArgs a{grid, guide, input, dout, dgrid, dguide, dinput, B, H, W, GH, GW, GD,
                   Cin, Cout, Cj, has_offset != 0, workspace, workspace_bytes};
-  if (flags == HDRNET_KERNEL_FAST)
+  if (family(flags) == HDRNET_KERNEL_FAST)
     return fail(HDRNET_INVALID_ARGUMENT, "no fast BilateralSliceApplyGrad variant yet");
   const int rc = check_launch(launch_apply_grad_generic(a, s), "BilateralSliceApplyGrad");
   if (rc == HDRNET_OK) g_kernel = "apply_grad_generic";
@@ -179,7 +184,7 @@ int hdrnet_bilateral_slice_f32_ex(const float* grid, const float* guide, float* 
     return HDRNET_OK;
   }
   if (!grid || !guide || !out) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
-  if (flags == HDRNET_KERNEL_FAST)
+  if (family(flags) == HDRNET_KERNEL_FAST)
     return fail(HDRNET_INVALID_ARGUMENT, "no fast BilateralSlice variant yet");
   SliceArgs a{grid, guide, out, B, H, W, GH, GW, GD, C};
   const int rc =
@@ -220,7 +225,7 @@ int hdrnet_bilateral_slice_grad_f32_ex(const float* grid, const float* guide, co
     return HDRNET_OK;
   }
   if (!guide || !dout || (dguide && !grid)) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
-  if (flags == HDRNET_KERNEL_FAST)
+  if (family(flags) == HDRNET_KERNEL_FAST)
     return fail(HDRNET_INVALID_ARGUMENT, "no fast BilateralSliceGrad variant yet");
   SliceGradArgs a{grid, guide, dout, dgrid, dguide, B, H, W, GH, GW, GD, C, workspace,
                   workspace_bytes};

@@ -16,6 +16,7 @@ struct ApplyArgs {
   float* out;
   int B, H, W, GH, GW, GD, Cin, Cout, Cj;  // Cj = Cin + has_offset
   bool has_offset;
+  int variant;  // 0 = library default; >0 selects a kernel variant (flags bits 8..15)
 };
 
 struct ApplyGradArgs {

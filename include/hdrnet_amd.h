@@ -66,6 +66,10 @@ extern "C" {
 #define HDRNET_KERNEL_FAST 2u    /* LDS-staged specialisations; INVALID_ARGUMENT \
                                     if the shape has none */
 
+/* Bits 8..15 of `flags` select a variant inside the family (0 = library default);
+ * benchmarks use it for in-process A/B runs.  Variants are not part of the stable ABI. */
+#define HDRNET_VARIANT(n) (((unsigned)(n) & 0xffu) << 8)
+
 /* ABI version: major*10000 + minor*100 + patch. */
 int hdrnet_version(void);
 
