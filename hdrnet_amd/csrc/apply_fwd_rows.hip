@@ -38,7 +38,7 @@ namespace hdrnet_amd {
 namespace {
 
 constexpr int kPxPerThread = 4;
-constexpr int kVariantRows = 1, kVariantWave = 2;
+constexpr int kVariantRows = 1, kVariantWave = 2, kVariantStream = 3;  // 3..6: 4/6/8/2 blocks per CU
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -205,11 +205,14 @@ __device__ __forceinline__ RowCtx stage_row(float* __restrict__ colY,
 
 // ---- 4 consecutive pixels per thread, 16-byte global accesses -----------------------
 // Requires W % 4 == 0, seg % 4 == 0 and 16-B aligned guide / input / out.
-template <int CIN, int COUT, bool OFFSET>
+// ABLATE (benchmark-only instantiations): 0 = the real kernel; 1 = same loads / stores
+// and launch shape but no staging and no slicing (memory skeleton); 2 = staging +
+// slicing of ONE pixel per quad (quarter of the VALU / LDS work, same memory traffic).
+template <int CIN, int COUT, bool OFFSET, int ABLATE = 0>
 __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
     const float* __restrict__ grid, const float* __restrict__ guide,
     const float* __restrict__ input, float* __restrict__ out, int H, int W, int GH, int GW,
-    int GD, int nseg, int seg, float scale_x, float scale_y) {
+    int GD, int nseg, int seg, int slab_offset_floats, float scale_x, float scale_y) {
   constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
   extern __shared__ __attribute__((aligned(16))) float colY[];
   const int bid = blockIdx.x;
@@ -231,31 +234,105 @@ __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
   float4 iv[(CIN * kPxPerThread) / 4];
   if (active) {
     g4 = *reinterpret_cast<const float4*>(guide + p);
-    const float4* ip = reinterpret_cast<const float4*>(input + p * CIN);
+    if constexpr (ABLATE < 3) {
+      const float4* ip = reinterpret_cast<const float4*>(input + p * CIN);
 #pragma unroll
-    for (int q = 0; q < (CIN * kPxPerThread) / 4; ++q) iv[q] = ip[q];
+      for (int q = 0; q < (CIN * kPxPerThread) / 4; ++q) iv[q] = ip[q];
+    }
   }
 
+  if constexpr (ABLATE >= 3) {
+    // (3: both contiguous; 4: contiguous loads, strided stores; 5: strided loads, contiguous stores)
+    // memory skeleton with LANE-CONTIGUOUS 16-B accesses: thread t touches float4 number
+    // t + k * blockDim of the segment's input / output (guide stays as is).
+    const int nthreads = blockDim.x;
+    const size_t seg_p = (size_t)row * W + xs;
+    const int nq = (xe - xs) * CIN / 4;  // float4 count of the segment's input
+    const float4* ip = reinterpret_cast<const float4*>(input + seg_p * CIN);
+    float4* op = reinterpret_cast<float4*>(out + seg_p * COUT);
+    float4 v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int e = (ABLATE == 5) ? (int)threadIdx.x * 3 + k : (int)threadIdx.x + k * nthreads;
+      if (e < nq) v[k] = ip[e];
+    }
+    float gq = 0.f;
+    if (active) gq = g4.x + g4.y + g4.z + g4.w;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int e = (ABLATE == 4) ? (int)threadIdx.x * 3 + k : (int)threadIdx.x + k * nthreads;
+      if (e < nq) {
+        v[k].x *= gq; v[k].y *= gq; v[k].z *= gq; v[k].w *= gq;
+        op[e] = v[k];
+      }
+    }
+    return;
+  }
+  if constexpr (ABLATE == 1) {
+    if (!active) return;
+    float4* op = reinterpret_cast<float4*>(out + p * COUT);
+    const float* gsf = reinterpret_cast<const float*>(&g4);
+#pragma unroll
+    for (int q = 0; q < (COUT * kPxPerThread) / 4; ++q) {
+      float4 v = iv[q % ((CIN * kPxPerThread) / 4)];
+      v.x *= gsf[0]; v.y *= gsf[1]; v.z *= gsf[2]; v.w *= gsf[3];
+      op[q] = v;
+    }
+    return;
+  }
   const RowCtx r = stage_row<C, false>(colY, grid_b, y, xs, xe, GH, GW, GD, scale_x, scale_y);
-  if (!active) return;
+  float* out_slabs = colY + slab_offset_floats;  // per-wave output transpose slabs
 
   const float gs[4] = {g4.x, g4.y, g4.z, g4.w};
   const float xf0 = (float)x + 0.5f;  // (x + k) + 0.5f == xf0 + k exactly (x < 2^23)
   const float* inf = reinterpret_cast<const float*>(iv);
   float4 ov[(COUT * kPxPerThread) / 4];
   float* of = reinterpret_cast<float*>(ov);
+  if constexpr (ABLATE == 2) {
 #pragma unroll
-  for (int k = 0; k < kPxPerThread; ++k) {
-    float in[CIN], o[COUT];
-#pragma unroll
-    for (int j = 0; j < CIN; ++j) in[j] = inf[k * CIN + j];
-    slice_apply_pixel<CIN, COUT, OFFSET>(r, xf0 + (float)k, gs[k], in, o);
-#pragma unroll
-    for (int i = 0; i < COUT; ++i) of[k * COUT + i] = o[i];
+    for (int q = 0; q < COUT * kPxPerThread; ++q) of[q] = inf[q % (CIN * kPxPerThread)] * gs[q & 3];
   }
-  float4* op = reinterpret_cast<float4*>(out + p * COUT);
+  if (active) {
 #pragma unroll
-  for (int q = 0; q < (COUT * kPxPerThread) / 4; ++q) op[q] = ov[q];
+    for (int k = 0; k < (ABLATE == 2 ? 1 : kPxPerThread); ++k) {
+      float in[CIN], o[COUT];
+#pragma unroll
+      for (int j = 0; j < CIN; ++j) in[j] = inf[k * CIN + j];
+      slice_apply_pixel<CIN, COUT, OFFSET>(r, xf0 + (float)k, gs[k], in, o);
+#pragma unroll
+      for (int i = 0; i < COUT; ++i) of[k * COUT + i] = o[i];
+    }
+  }
+  if constexpr (ABLATE == 6) {  // direct per-lane stores: 16 B at a 16*COUT-byte lane stride
+    if (!active) return;
+    float4* op = reinterpret_cast<float4*>(out + p * COUT);
+#pragma unroll
+    for (int q = 0; q < (COUT * kPxPerThread) / 4; ++q) op[q] = ov[q];
+    return;
+  }
+  // Store phase.  A lane's 4 pixels are 4*COUT contiguous floats, i.e. per-lane 16-B
+  // stores at a 16*COUT-byte stride -- measured 6.5 us slower per 4K frame than
+  // lane-contiguous stores (the LOADS do not care).  So each wave transposes its tile
+  // through a private LDS slab: ds_write_b128 at the per-pixel stride (conflict-free:
+  // 12-dword stride over 8-lane groups), then lane l reads float4 number l + 64k and
+  // stores it -- every global_store_dwordx4 covers one dense 1 KiB run.
+  float4* slab = reinterpret_cast<float4*>(out_slabs) + (threadIdx.x >> 6) * (64 * COUT);
+  const int lane = threadIdx.x & 63;
+  if (active) {
+#pragma unroll
+    for (int q = 0; q < COUT; ++q) slab[lane * COUT + q] = ov[q];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int wave_x0 = xs + kPxPerThread * (int)(threadIdx.x & ~63u);
+  const int nvalid = (min(xe, wave_x0 + 64 * kPxPerThread) - wave_x0) * COUT / 4;  // float4s
+  float4* gp = reinterpret_cast<float4*>(out + ((size_t)row * W + wave_x0) * COUT);
+#pragma unroll
+  for (int k = 0; k < COUT; ++k) {
+    const int e = lane + 64 * k;
+    if (e < nvalid) gp[e] = slab[e];
+  }
 }
 
 // ---- scalar variant: any W / alignment; thread t takes pixels xs + t + k*blockDim ------
@@ -363,12 +440,138 @@ __global__ __launch_bounds__(256) void apply_fwd_wave_vec4(
   for (int q = 0; q < (COUT * kPxPerThread) / 4; ++q) op[q] = ov[q];
 }
 
+// ---- persistent, balanced streaming variant ------------------------------------------------
+// The launch is sized to what the chip holds at once (CUs x blocks_per_cu workgroups of 4
+// waves) and every WAVE owns one contiguous, equal share of the image's pixel quads, which
+// it walks in chunks of <= 64 quads (256 pixels, never across a row end).  Per chunk it
+// stages its private y-pre-lerped columns, issues the NEXT chunk's guide/input loads, then
+// slices and stores the current chunk -- so each wave keeps a continuous stream of HBM
+// requests in flight, all waves finish together (no partially filled last round of
+// workgroups), and the only ramp left is one load latency at each end of the launch.
+template <int CIN, int COUT, bool OFFSET>
+struct QuadData {
+  float4 g;
+  float4 in[CIN];
+};
+
+template <int CIN, int COUT, bool OFFSET>
+__device__ __forceinline__ QuadData<CIN, COUT, OFFSET> load_quad(
+    const float* __restrict__ guide, const float* __restrict__ input, long long quad, bool on) {
+  QuadData<CIN, COUT, OFFSET> d;
+  d.g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int q = 0; q < CIN; ++q) d.in[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (on) {
+    d.g = reinterpret_cast<const float4*>(guide)[quad];
+    const float4* ip = reinterpret_cast<const float4*>(input) + quad * CIN;
+#pragma unroll
+    for (int q = 0; q < CIN; ++q) d.in[q] = ip[q];
+  }
+  return d;
+}
+
+template <int CIN, int COUT, bool OFFSET>
+__global__ __launch_bounds__(256) void apply_fwd_stream_vec4(
+    const float* __restrict__ grid, const float* __restrict__ guide,
+    const float* __restrict__ input, float* __restrict__ out, int H, int Wq, int GH, int GW,
+    int GD, long long nquads, long long quads_per_wave, int lds_floats_per_wave, float scale_x,
+    float scale_y) {
+  constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
+  extern __shared__ __attribute__((aligned(16))) float colY_all[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  float* colY = colY_all + wave * lds_floats_per_wave;
+  const long long wid = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
+  long long pos = wid * quads_per_wave;
+  const long long end = min(pos + quads_per_wave, nquads);
+  if (pos >= end) return;
+  const int W = Wq * 4;
+  // (b, y, xq) of `pos`, advanced incrementally afterwards; all wave-uniform.
+  long long row = pos / Wq;
+  int xq = (int)(pos - row * Wq);
+  int y = (int)(row % H);
+  long long b = row / H;
+
+  int len = (int)min((long long)min(64, Wq - xq), end - pos);
+  QuadData<CIN, COUT, OFFSET> cur = load_quad<CIN, COUT, OFFSET>(guide, input, pos + lane, lane < len);
+
+  while (true) {
+    const long long npos = pos + len;
+    int nxq = xq + len;
+    int ny = y;
+    long long nb = b;
+    if (nxq == Wq) {
+      nxq = 0;
+      if (++ny == H) {
+        ny = 0;
+        ++nb;
+      }
+    }
+    const int nlen = npos < end ? (int)min((long long)min(64, Wq - nxq), end - npos) : 0;
+
+    const float* grid_b = grid + (size_t)b * GH * GW * GD * C;
+    const int xs = xq * 4;
+    const RowCtx r =
+        stage_row<C, true>(colY, grid_b, y, xs, xs + len * 4, GH, GW, GD, scale_x, scale_y);
+
+    // Prefetch the next chunk while this one is being sliced.
+    const QuadData<CIN, COUT, OFFSET> nxt =
+        load_quad<CIN, COUT, OFFSET>(guide, input, npos + lane, lane < nlen);
+
+    if (lane < len) {
+      const float gs[4] = {cur.g.x, cur.g.y, cur.g.z, cur.g.w};
+      const float xf0 = (float)(xs + 4 * lane) + 0.5f;
+      const float* inf = reinterpret_cast<const float*>(cur.in);
+      float4 ov[COUT];
+      float* of = reinterpret_cast<float*>(ov);
+#pragma unroll
+      for (int k = 0; k < kPxPerThread; ++k) {
+        float in[CIN], o[COUT];
+#pragma unroll
+        for (int j = 0; j < CIN; ++j) in[j] = inf[k * CIN + j];
+        slice_apply_pixel<CIN, COUT, OFFSET>(r, xf0 + (float)k, gs[k], in, o);
+#pragma unroll
+        for (int i = 0; i < COUT; ++i) of[k * COUT + i] = o[i];
+      }
+      float4* op = reinterpret_cast<float4*>(out) + (pos + lane) * COUT;
+#pragma unroll
+      for (int q = 0; q < COUT; ++q) op[q] = ov[q];
+    }
+    if (nlen == 0) break;
+    // The next stage_row overwrites this wave's LDS image: its reads above are done
+    // (same wave, in order); keep the compiler from hoisting the writes.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    cur = nxt;
+    pos = npos;
+    len = nlen;
+    xq = nxq;
+    y = ny;
+    b = nb;
+  }
+  (void)W;
+}
+
 struct Plan {
   int threads, nseg, seg, max_cols;
   bool vec4;
 };
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Compute units of the current device (cached per device ordinal; benign race).
+int num_cus() {
+  static int cache[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (cache[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cache[dev] = n;
+  }
+  return cache[dev];
+}
 
 Plan make_plan(const ApplyArgs& a) {
   const bool aligned = (((uintptr_t)a.guide | (uintptr_t)a.input | (uintptr_t)a.out |
@@ -404,7 +607,9 @@ template <int CIN, int COUT, bool OFFSET>
 hipError_t launch_t(const ApplyArgs& a, hipStream_t s, const char** name) {
   constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
   const Plan pl = make_plan(a);
-  const size_t lds = (size_t)pl.max_cols * a.GD * C * sizeof(float);
+  // dynamic LDS: [colY image][one 64 x 4*COUT-float output slab per wave (vec4 kernel)]
+  const int slab_off = round_up(pl.max_cols * a.GD * C, 4);
+  const size_t lds = ((size_t)slab_off + (size_t)(pl.threads / 64) * 64 * kPxPerThread * COUT) * sizeof(float);
   const long long nblocks = (long long)a.B * a.H * pl.nseg;
   const float sx = (float)a.GW / a.W, sy = (float)a.GH / a.H;
   if (pl.vec4 && a.variant == kVariantWave) {
@@ -424,9 +629,62 @@ hipError_t launch_t(const ApplyArgs& a, hipStream_t s, const char** name) {
     *name = "apply_fwd_wave/vec4";
     return hipGetLastError();
   }
+  if (pl.vec4 && a.variant >= kVariantStream && a.variant < kVariantStream + 4) {
+    // Persistent balanced stream: CUs x blocks_per_cu workgroups of 4 waves.
+    const int bpc_table[4] = {4, 6, 8, 2};
+    const int blocks_per_cu = bpc_table[(a.variant - kVariantStream) & 3];
+    const int waves = 4;
+    const long long nquads = (long long)a.B * a.H * (a.W / 4);
+    long long nwaves = (long long)num_cus() * blocks_per_cu * waves;
+    if (nwaves > (nquads + 63) / 64) nwaves = (nquads + 63) / 64;  // small images: 1 chunk each
+    nwaves = (nwaves + waves - 1) / waves * waves;
+    const long long qpw = (nquads + nwaves - 1) / nwaves;
+    const long long ncol = ((long long)(64 * 4 - 1) * a.GW) / a.W + 4;
+    const int cols = (int)(ncol < a.GW ? ncol : a.GW);
+    const int lds_floats = round_up(cols * a.GD * C, 4);
+    apply_fwd_stream_vec4<CIN, COUT, OFFSET>
+        <<<(unsigned)(nwaves / waves), waves * 64, (size_t)waves * lds_floats * sizeof(float), s>>>(
+            a.grid, a.guide, a.input, a.out, a.H, a.W / 4, a.GH, a.GW, a.GD, nquads, qpw,
+            lds_floats, sx, sy);
+    *name = "apply_fwd_stream/vec4";
+    return hipGetLastError();
+  }
+  if constexpr (CIN == 3 && COUT == 3 && OFFSET) {
+    if (pl.vec4 && a.variant >= 103 && a.variant <= 105) {
+      if (a.variant == 103)
+        apply_fwd_rows_vec4<CIN, COUT, OFFSET, 3><<<(unsigned)nblocks, pl.threads, lds, s>>>(
+            a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, pl.nseg, pl.seg, slab_off, sx, sy);
+      else if (a.variant == 104)
+        apply_fwd_rows_vec4<CIN, COUT, OFFSET, 4><<<(unsigned)nblocks, pl.threads, lds, s>>>(
+            a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, pl.nseg, pl.seg, slab_off, sx, sy);
+      else
+        apply_fwd_rows_vec4<CIN, COUT, OFFSET, 5><<<(unsigned)nblocks, pl.threads, lds, s>>>(
+            a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, pl.nseg, pl.seg, slab_off, sx, sy);
+      *name = a.variant == 103 ? "ABLATION/skeleton ld-contig st-contig"
+              : a.variant == 104 ? "ABLATION/skeleton ld-contig st-strided"
+                                 : "ABLATION/skeleton ld-strided st-contig";
+      return hipGetLastError();
+    }
+    if (pl.vec4 && (a.variant == 101 || a.variant == 102)) {  // benchmark-only ablations
+      if (a.variant == 101)
+        apply_fwd_rows_vec4<CIN, COUT, OFFSET, 1><<<(unsigned)nblocks, pl.threads, lds, s>>>(
+            a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, pl.nseg, pl.seg, slab_off, sx, sy);
+      else
+        apply_fwd_rows_vec4<CIN, COUT, OFFSET, 2><<<(unsigned)nblocks, pl.threads, lds, s>>>(
+            a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, pl.nseg, pl.seg, slab_off, sx, sy);
+      *name = a.variant == 101 ? "ABLATION/memory-skeleton" : "ABLATION/quarter-compute";
+      return hipGetLastError();
+    }
+  }
+  if (pl.vec4 && a.variant == 7) {
+    apply_fwd_rows_vec4<CIN, COUT, OFFSET, 6><<<(unsigned)nblocks, pl.threads, lds, s>>>(
+        a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, pl.nseg, pl.seg, slab_off, sx, sy);
+    *name = "apply_fwd_rows/vec4-direct-stores";
+    return hipGetLastError();
+  }
   if (pl.vec4) {
     apply_fwd_rows_vec4<CIN, COUT, OFFSET><<<(unsigned)nblocks, pl.threads, lds, s>>>(
-        a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, pl.nseg, pl.seg, sx, sy);
+        a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, pl.nseg, pl.seg, slab_off, sx, sy);
     *name = "apply_fwd_rows/vec4";
   } else {
     apply_fwd_rows_scalar<CIN, COUT, OFFSET><<<(unsigned)nblocks, pl.threads, lds, s>>>(
@@ -449,7 +707,8 @@ bool apply_fwd_rows_supported(const ApplyArgs& a) {
   if ((a.Cout * a.Cj) % 4 == 0 && ((uintptr_t)a.grid & 15u)) return false;
   if ((long long)a.B * a.H * ((a.W + 511) / 512) > 0x7fffffffLL) return false;
   const Plan pl = make_plan(a);
-  const size_t lds = (size_t)pl.max_cols * a.GD * a.Cout * a.Cj * sizeof(float);
+  const size_t lds = ((size_t)pl.max_cols * a.GD * a.Cout * a.Cj + 4 +
+                      (size_t)(pl.threads / 64) * 64 * kPxPerThread * a.Cout) * sizeof(float);
   return lds <= kMaxLdsBytes;
 }
 

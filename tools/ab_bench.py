@@ -74,7 +74,7 @@ def main():
         names[v] = lib.hdrnet_last_kernel().decode()
         err = (out - ref).abs().max().item()
         print(f"variant {v} [{names[v]}]: max|fast - generic| = {err:.3e}")
-        assert err < 1e-5, err
+        assert err < 1e-5 or names[v].startswith("ABLATION"), err
 
     results = {v: [] for v in variants}
     yard = {"copy(out<-in, 2x100MB)": [], "elementwise(out=in*a+b, in 133MB out 100MB)": []}
