@@ -33,106 +33,29 @@
 
 #include "launch.hip.h"
 #include "numerics.hip.h"
+#include "rows_common.hip.h"
 
 namespace hdrnet_amd {
 namespace {
 
-constexpr int kPxPerThread = 4;
+using namespace rows;
+
 constexpr int kVariantRows = 1, kVariantWave = 2, kVariantStream = 3;  // 3..6: 4/6/8/2 blocks per CU
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <int C>
-struct CoefVec {
-  static constexpr int kPairs = (C + 1) / 2;
-  f32x2 v[kPairs];  // coefficient c lives in v[c / 2][c % 2]
-  __device__ __forceinline__ float get(int c) const { return v[c >> 1][c & 1]; }
-};
-
-// coef (+)= w * vec, vec = the C floats at byte offset `off` of the LDS image.
-// Explicit 2-wide vectors: the blend maps onto v_pk_fma_f32 / v_pk_mul_f32 with the
-// weight broadcast through op_sel and the ds_read_b128 result consumed in place.
-template <int C, bool FIRST>
-__device__ __forceinline__ void accum_vec(CoefVec<C>& coef, const float* __restrict__ colY,
-                                          int off, float w) {
-  const f32x2 w2 = {w, w};
-  const char* base = reinterpret_cast<const char*>(colY) + off;
-  if constexpr (C % 4 == 0) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(base);
-#pragma unroll
-    for (int q = 0; q < C / 4; ++q) {
-      const f32x4 t = p[q];
-      if constexpr (FIRST) {
-        coef.v[2 * q + 0] = w2 * t.xy;
-        coef.v[2 * q + 1] = w2 * t.zw;
-      } else {
-        coef.v[2 * q + 0] = __builtin_elementwise_fma(w2, t.xy, coef.v[2 * q + 0]);
-        coef.v[2 * q + 1] = __builtin_elementwise_fma(w2, t.zw, coef.v[2 * q + 1]);
-      }
-    }
-  } else {
-    const float* p = reinterpret_cast<const float*>(base);
-#pragma unroll
-    for (int q = 0; q < C; ++q)
-      coef.v[q >> 1][q & 1] = FIRST ? w * p[q] : fmaf(w, p[q], coef.v[q >> 1][q & 1]);
-  }
-}
-
-struct RowCtx {
-  const float* colY;  // LDS image, [ncol][GD][C]
-  float scale_x, gd_f;
-  // Byte-space addressing of the LDS image: column stride and the clamp windows of
-  // (gx - gxlo) * col_bytes and gz * vec_bytes.
-  int gxlo, col_bytes, x_lo_b, x_hi_b, z_hi_b;
-};
-
-// One pixel: slice the y-pre-lerped columns at (x, guide) and apply the affine.
-//
-// Coordinates and weights follow bilateral_slice_apply.cc:41-64:
-//   gxf = (x + .5) * scale_x, gx0 = floor(gxf - .5), dx0 = (gx0 + .5) - gxf  in (-1, 0]
-//   gzf = guide * GD,         gz0 = floor(gzf - .5), dz0 = (gz0 + .5) - gzf  in (-1, 0]
-//   wx0 = 1 - |dx0| = 1 + dx0,   wx1 = 1 - |dx0 + 1| = -dx0          (tent, numerics.h:53)
-//   wz0 = 1 - sqrt(dz0^2 + eps), wz1 = 1 - sqrt((dz0 + 1)^2 + eps)  (smoothed, :108)
-// floor() puts both corners within one cell of the sample, so the reference's
-// max(., 0) never binds and is dropped; weights still come from the UNclamped
-// corner and only the indices are clamped (in byte space).  v_sqrt_f32 (1 ulp)
-// stands in for the correctly-rounded expansion: its argument lies in
-// [1e-8, 1 + 1e-8], nowhere near a denormal, and one ulp of a weight is 6e-8.
+// One pixel: slice the y-pre-lerped columns at (x, guide) and apply the affine
+// (bilateral_slice_apply.cc:50-80).
 template <int CIN, int COUT, bool OFFSET>
 __device__ __forceinline__ void slice_apply_pixel(const RowCtx& r, float xf, float g,
                                                   const float (&in)[CIN],
                                                   float (&out)[COUT]) {
   constexpr int CJ = CIN + (OFFSET ? 1 : 0);
   constexpr int C = COUT * CJ;
-  constexpr int kVecBytes = C * (int)sizeof(float);
-  const float gxf = xf * r.scale_x;  // xf = x + 0.5f, exact
-  const float fxl = floorf(gxf - 0.5f);
-  const float dx0 = (fxl + 0.5f) - gxf;
-  const float wx0 = 1.0f + dx0, wx1 = -dx0;
-  const float gzf = g * r.gd_f;
-  // floor of a wild guide is clamped in float before the int conversion so that the
-  // byte-space arithmetic below cannot overflow (v_med3_f32).
-  const float fzl = floorf(gzf - 0.5f);
-  const float dz0 = (fzl + 0.5f) - gzf;
-  const float dz1 = dz0 + 1.0f;
-  const float wz0 = 1.0f - __builtin_amdgcn_sqrtf(fmaf(dz0, dz0, kSmoothEps));
-  const float wz1 = 1.0f - __builtin_amdgcn_sqrtf(fmaf(dz1, dz1, kSmoothEps));
-  const int iz = (int)__builtin_amdgcn_fmed3f(fzl, -2.0f, r.gd_f + 1.0f);
-  const int zb = __mul24(iz, kVecBytes);  // |iz| <= GD + 1: 24-bit multiply is exact
-  const int zb0 = min(max(zb, 0), r.z_hi_b);
-  const int zb1 = min(max(zb + kVecBytes, 0), r.z_hi_b);
-  // x needs no guard: gxf in (0, GW) by construction, so gx0 in [-1, GW - 1].
-  const int xb = __mul24((int)fxl - r.gxlo, r.col_bytes);
-  const int xb0 = max(xb, r.x_lo_b);
-  const int xb1 = min(xb + r.col_bytes, r.x_hi_b);
-
+  const SliceTerms t = slice_terms<C, false>(r, xf, g);
   CoefVec<C> coef;
-  accum_vec<C, true>(coef, r.colY, xb0 + zb0, wx0 * wz0);
-  accum_vec<C, false>(coef, r.colY, xb0 + zb1, wx0 * wz1);
-  accum_vec<C, false>(coef, r.colY, xb1 + zb0, wx1 * wz0);
-  accum_vec<C, false>(coef, r.colY, xb1 + zb1, wx1 * wz1);
-
+  accum_vec<C, true>(coef, r.colY, t.a00, t.wx0 * t.wz0);
+  accum_vec<C, false>(coef, r.colY, t.a01, t.wx0 * t.wz1);
+  accum_vec<C, false>(coef, r.colY, t.a10, t.wx1 * t.wz0);
+  accum_vec<C, false>(coef, r.colY, t.a11, t.wx1 * t.wz1);
   // :72-80 -- per-pixel (Cout x Cj) . [in; 1]
 #pragma unroll
   for (int i = 0; i < COUT; ++i) {
@@ -141,66 +64,6 @@ __device__ __forceinline__ void slice_apply_pixel(const RowCtx& r, float xf, flo
     for (int j = 0; j < CIN; ++j) v = fmaf(coef.get(i * CJ + j), in[j], v);
     out[i] = v;
   }
-}
-
-// Blend the two grid rows this image row needs into LDS; returns the row context.
-// WAVE = false: the whole workgroup fills one image and meets at a barrier.
-// WAVE = true : each wavefront fills its own private image; LDS operations of one
-//               wave complete in order, so no s_barrier is needed -- waves never wait
-//               for each other.
-template <int C, bool WAVE>
-__device__ __forceinline__ RowCtx stage_row(float* __restrict__ colY,
-                                            const float* __restrict__ grid_b, int y, int xs,
-                                            int xe, int GH, int GW, int GD, float scale_x,
-                                            float scale_y) {
-  // Wave-uniform y terms (bilateral_slice_apply.cc:42,47,55-56).
-  const float gyf = (y + 0.5f) * scale_y;
-  const int gy0 = floor_to_int(gyf - 0.5f);
-  const float wy0 = tent_weight(gy0 + 0.5f, gyf);
-  const float wy1 = tent_weight(gy0 + 1 + 0.5f, gyf);
-  const int gy0c = clamp_index(gy0, 0, GH - 1);
-  const int gy1c = clamp_index(gy0 + 1, 0, GH - 1);
-  // Grid columns touched by pixels [xs, xe).
-  const int gxlo = clamp_index(floor_to_int((xs + 0.5f) * scale_x - 0.5f), 0, GW - 1);
-  const int gxhi =
-      clamp_index(floor_to_int((xe - 1 + 0.5f) * scale_x - 0.5f) + 1, 0, GW - 1);
-  const int n = (gxhi - gxlo + 1) * GD * C;  // floats; contiguous in the grid row
-  const float* r0 = grid_b + ((size_t)(gy0c * GW + gxlo) * GD) * C;
-  const float* r1 = grid_b + ((size_t)(gy1c * GW + gxlo) * GD) * C;
-  if constexpr (C % 4 == 0) {
-    const float4* a4 = reinterpret_cast<const float4*>(r0);
-    const float4* b4 = reinterpret_cast<const float4*>(r1);
-    float4* d4 = reinterpret_cast<float4*>(colY);
-    const int e0 = WAVE ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
-    const int estep = WAVE ? 64 : (int)blockDim.x;
-#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-    for (int e = e0; e < n / 4; e += estep) {
-      const float4 a = a4[e], b = b4[e];
-      d4[e] = make_float4(wy0 * a.x + wy1 * b.x, wy0 * a.y + wy1 * b.y,
-                          wy0 * a.z + wy1 * b.z, wy0 * a.w + wy1 * b.w);
-    }
-  } else {
-    const int e0 = WAVE ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
-    const int estep = WAVE ? 64 : (int)blockDim.x;
-#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-    for (int e = e0; e < n; e += estep) colY[e] = wy0 * r0[e] + wy1 * r1[e];
-  }
-  if constexpr (WAVE) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  } else {
-    __syncthreads();
-  }
-  const int col_bytes = GD * C * (int)sizeof(float);
-  return RowCtx{colY,
-                scale_x,
-                (float)GD,
-                gxlo,
-                col_bytes,
-                (0 - gxlo) * col_bytes,
-                (GW - 1 - gxlo) * col_bytes,
-                (GD - 1) * C * (int)sizeof(float)};
 }
 
 // ---- 4 consecutive pixels per thread, 16-byte global accesses -----------------------
@@ -552,55 +415,10 @@ __global__ __launch_bounds__(256) void apply_fwd_stream_vec4(
   (void)W;
 }
 
-struct Plan {
-  int threads, nseg, seg, max_cols;
-  bool vec4;
-};
-
-inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
-
-// Compute units of the current device (cached per device ordinal; benign race).
-int num_cus() {
-  static int cache[64] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (cache[dev] == 0) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    cache[dev] = n;
-  }
-  return cache[dev];
-}
-
 Plan make_plan(const ApplyArgs& a) {
   const bool aligned = (((uintptr_t)a.guide | (uintptr_t)a.input | (uintptr_t)a.out |
                          (uintptr_t)a.grid) & 15u) == 0;
-  Plan best{};
-  long long best_waste = -1;
-  const int cands[3] = {256, 192, 128};
-  for (int T : cands) {
-    const int span = T * kPxPerThread;
-    const int nseg = (a.W + span - 1) / span;
-    const long long waste = (long long)nseg * span - a.W;
-    if (best_waste < 0 || waste < best_waste) {
-      best_waste = waste;
-      best.threads = T;
-      best.nseg = nseg;
-    }
-  }
-  best.vec4 = aligned && (a.W % 4 == 0) && ((a.Cin * kPxPerThread) % 4 == 0) &&
-              ((a.Cout * kPxPerThread) % 4 == 0);
-  best.seg = round_up((a.W + best.nseg - 1) / best.nseg, 4);
-  // Threads actually needed for the (balanced) segment.
-  best.threads = round_up((best.seg + kPxPerThread - 1) / kPxPerThread, 64);
-  if (best.threads > 256) best.threads = 256;
-  // Upper bound of grid columns a segment can touch: floor differences of
-  // gx0 over seg-1 pixels (<= floor(d)+1), +1 for the upper neighbour, +1 for
-  // the count, +1 slack for float rounding of the coordinates.
-  const long long cols = ((long long)(best.seg - 1) * a.GW) / a.W + 4;
-  best.max_cols = (int)(cols < a.GW ? cols : a.GW);
-  return best;
+  return make_row_plan(a.W, a.GW, aligned);
 }
 
 template <int CIN, int COUT, bool OFFSET>

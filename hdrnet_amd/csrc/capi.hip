@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 
 #include "../../include/hdrnet_amd.h"
 #include "launch.hip.h"
@@ -13,7 +14,18 @@
 namespace {
 
 thread_local char g_error[512] = "";
-thread_local const char* g_kernel = "";
+
+// Introspection only (tests / benchmarks): name of the kernel(s) the most recent successful
+// call launched, process-wide -- autograd runs backward on a thread of its own, so a
+// thread-local would hide it from the caller.  Not used for any decision.
+std::mutex g_kernel_mu;
+char g_kernel_buf[128] = "";
+
+void set_kernel(const char* a, const char* b = "", const char* c = "") {
+  std::lock_guard<std::mutex> lock(g_kernel_mu);
+  snprintf(g_kernel_buf, sizeof(g_kernel_buf), "%s%s%s%s%s", a, (*a && *b) ? "+" : "", b,
+           ((*a || *b) && *c) ? "+" : "", c);
+}
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -66,7 +78,7 @@ int hdrnet_version(void) { return 100; /* 0.1.0 */ }
 
 const char* hdrnet_last_error(void) { return g_error; }
 
-const char* hdrnet_last_kernel(void) { return g_kernel; }
+const char* hdrnet_last_kernel(void) { return g_kernel_buf; }
 
 int hdrnet_bilateral_slice_apply_f32_ex(const float* grid, const float* guide,
                                         const float* input, float* out, int B, int H, int W,
@@ -81,7 +93,7 @@ int hdrnet_bilateral_slice_apply_f32_ex(const float* grid, const float* guide,
                 "(Cin=%d, Cout=%d)", has_offset ? " + 1" : "", Cin, Cout);
   const long long npix = (long long)B * H * W;
   if (npix == 0) {
-    g_kernel = "noop";
+    set_kernel("noop");
     g_error[0] = '\0';
     return HDRNET_OK;
   }
@@ -97,11 +109,11 @@ int hdrnet_bilateral_slice_apply_f32_ex(const float* grid, const float* guide,
     const char* name = "";
     const hipError_t e = launch_apply_fwd_rows(a, s, &name);
     const int rc = check_launch(e, "BilateralSliceApply");
-    if (rc == HDRNET_OK) g_kernel = name;
+    if (rc == HDRNET_OK) set_kernel(name);
     return rc;
   }
   const int rc = check_launch(launch_apply_fwd_generic(a, s), "BilateralSliceApply");
-  if (rc == HDRNET_OK) g_kernel = "apply_fwd_generic";
+  if (rc == HDRNET_OK) set_kernel("apply_fwd_generic");
   return rc;
 }
 
@@ -112,9 +124,11 @@ int hdrnet_bilateral_slice_apply_f32(const float* grid, const float* guide, cons
                                              Cout, has_offset, HDRNET_KERNEL_AUTO, stream);
 }
 
-size_t hdrnet_bilateral_slice_apply_grad_workspace_bytes(int, int, int, int, int, int, int, int,
-                                                         int) {
-  return 0;
+size_t hdrnet_bilateral_slice_apply_grad_workspace_bytes(int B, int H, int W, int GH, int GW,
+                                                         int GD, int Cin, int Cout,
+                                                         int has_offset) {
+  if (B <= 0 || H <= 0 || W <= 0 || GH <= 0 || GW <= 0 || GD <= 0 || Cin < 0 || Cout <= 0) return 0;
+  return hdrnet_amd::apply_grid_grad_mfma_workspace(B, H, W, GH, GW, GD, Cin, Cout, has_offset != 0);
 }
 
 int hdrnet_bilateral_slice_apply_grad_f32_ex(const float* grid, const float* guide,
@@ -130,7 +144,7 @@ int hdrnet_bilateral_slice_apply_grad_f32_ex(const float* grid, const float* gui
   if (Cin < 0 || Cout <= 0 || Cin + (has_offset ? 1 : 0) <= 0)
     return fail(HDRNET_INVALID_ARGUMENT, "bad channel counts (Cin=%d, Cout=%d)", Cin, Cout);
   if (!dgrid && !dguide && !dinput) {
-    g_kernel = "noop";
+    set_kernel("noop");
     g_error[0] = '\0';
     return HDRNET_OK;
   }
@@ -144,7 +158,7 @@ int hdrnet_bilateral_slice_apply_grad_f32_ex(const float* grid, const float* gui
           hipMemsetAsync(dgrid, 0, sizeof(float) * (size_t)B * GH * GW * GD * Cout * Cj, s);
       if (e != hipSuccess) return check_launch(e, "BilateralSliceApplyGrad");
     }
-    g_kernel = "noop";
+    set_kernel("noop");
     g_error[0] = '\0';
     return HDRNET_OK;
   }
@@ -152,11 +166,38 @@ int hdrnet_bilateral_slice_apply_grad_f32_ex(const float* grid, const float* gui
     return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
   ApplyGradArgs a{grid, guide, input, dout, dgrid, dguide, dinput, B, H, W, GH, GW, GD,
                   Cin, Cout, Cj, has_offset != 0, workspace, workspace_bytes};
-  if (family(flags) == HDRNET_KERNEL_FAST)
-    return fail(HDRNET_INVALID_ARGUMENT, "no fast BilateralSliceApplyGrad variant yet");
-  const int rc = check_launch(launch_apply_grad_generic(a, s), "BilateralSliceApplyGrad");
-  if (rc == HDRNET_OK) g_kernel = "apply_grad_generic";
-  return rc;
+  // dguide / dinput: one fused LDS-staged pass when a specialisation exists.
+  const bool pix_fast = family(flags) != HDRNET_KERNEL_GENERIC && (dguide || dinput) &&
+                        apply_vjp_rows_supported(a);
+  if (family(flags) == HDRNET_KERNEL_FAST && (dguide || dinput) && !pix_fast)
+    return fail(HDRNET_INVALID_ARGUMENT, "no fast BilateralSliceApplyGrad variant for this shape");
+  const char* pix_name = "";
+  ApplyGradArgs rest = a;
+  if (pix_fast) {
+    const int rc = check_launch(launch_apply_vjp_rows(a, s, &pix_name), "BilateralSliceApplyGrad");
+    if (rc != HDRNET_OK) return rc;
+    rest.dguide = nullptr;
+    rest.dinput = nullptr;
+  }
+  const char* gg_name = "";
+  if (dgrid && family(flags) != HDRNET_KERNEL_GENERIC) {
+    if (apply_grid_grad_mfma_supported(a)) {
+      const int rc = check_launch(launch_apply_grid_grad_mfma(a, s, &gg_name), "BilateralSliceApplyGrad");
+      if (rc != HDRNET_OK) return rc;
+      rest.dgrid = nullptr;
+    } else if (family(flags) == HDRNET_KERNEL_FAST) {
+      return fail(HDRNET_INVALID_ARGUMENT,
+                  "no fast grid-gradient variant for this shape (or workspace missing / too small)");
+    }
+  }
+  const char* rest_name = "";
+  if (rest.dgrid || rest.dguide || rest.dinput) {
+    const int rc = check_launch(launch_apply_grad_generic(rest, s), "BilateralSliceApplyGrad");
+    if (rc != HDRNET_OK) return rc;
+    rest_name = "apply_grad_generic";
+  }
+  set_kernel(pix_name, gg_name, rest_name);
+  return HDRNET_OK;
 }
 
 int hdrnet_bilateral_slice_apply_grad_f32(const float* grid, const float* guide,
@@ -179,7 +220,7 @@ int hdrnet_bilateral_slice_f32_ex(const float* grid, const float* guide, float* 
   if (int rc = check_flags(flags)) return rc;
   if (C <= 0) return fail(HDRNET_INVALID_ARGUMENT, "grid_channels must be positive (C=%d)", C);
   if ((long long)B * H * W == 0) {
-    g_kernel = "noop";
+    set_kernel("noop");
     g_error[0] = '\0';
     return HDRNET_OK;
   }
@@ -189,7 +230,7 @@ int hdrnet_bilateral_slice_f32_ex(const float* grid, const float* guide, float* 
   SliceArgs a{grid, guide, out, B, H, W, GH, GW, GD, C};
   const int rc =
       check_launch(launch_slice_fwd_generic(a, static_cast<hipStream_t>(stream)), "BilateralSlice");
-  if (rc == HDRNET_OK) g_kernel = "slice_fwd_generic";
+  if (rc == HDRNET_OK) set_kernel("slice_fwd_generic");
   return rc;
 }
 
@@ -199,7 +240,11 @@ int hdrnet_bilateral_slice_f32(const float* grid, const float* guide, float* out
                                        HDRNET_KERNEL_AUTO, stream);
 }
 
-size_t hdrnet_bilateral_slice_grad_workspace_bytes(int, int, int, int, int, int, int) { return 0; }
+size_t hdrnet_bilateral_slice_grad_workspace_bytes(int B, int H, int W, int GH, int GW, int GD,
+                                                   int C) {
+  if (B <= 0 || H <= 0 || W <= 0 || GH <= 0 || GW <= 0 || GD <= 0 || C <= 0) return 0;
+  return hdrnet_amd::slice_grid_grad_mfma_workspace(B, H, W, GH, GW, GD, C);
+}
 
 int hdrnet_bilateral_slice_grad_f32_ex(const float* grid, const float* guide, const float* dout,
                                        float* dgrid, float* dguide, int B, int H, int W, int GH,
@@ -210,7 +255,7 @@ int hdrnet_bilateral_slice_grad_f32_ex(const float* grid, const float* guide, co
   if (int rc = check_flags(flags)) return rc;
   if (C <= 0) return fail(HDRNET_INVALID_ARGUMENT, "grid_channels must be positive (C=%d)", C);
   if (!dgrid && !dguide) {
-    g_kernel = "noop";
+    set_kernel("noop");
     g_error[0] = '\0';
     return HDRNET_OK;
   }
@@ -220,18 +265,43 @@ int hdrnet_bilateral_slice_grad_f32_ex(const float* grid, const float* guide, co
       const hipError_t e = hipMemsetAsync(dgrid, 0, sizeof(float) * (size_t)B * GH * GW * GD * C, s);
       if (e != hipSuccess) return check_launch(e, "BilateralSliceGrad");
     }
-    g_kernel = "noop";
+    set_kernel("noop");
     g_error[0] = '\0';
     return HDRNET_OK;
   }
   if (!guide || !dout || (dguide && !grid)) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
-  if (family(flags) == HDRNET_KERNEL_FAST)
-    return fail(HDRNET_INVALID_ARGUMENT, "no fast BilateralSliceGrad variant yet");
   SliceGradArgs a{grid, guide, dout, dgrid, dguide, B, H, W, GH, GW, GD, C, workspace,
                   workspace_bytes};
-  const int rc = check_launch(launch_slice_grad_generic(a, s), "BilateralSliceGrad");
-  if (rc == HDRNET_OK) g_kernel = "slice_grad_generic";
-  return rc;
+  const bool pix_fast =
+      family(flags) != HDRNET_KERNEL_GENERIC && dguide && slice_vjp_rows_supported(a);
+  if (family(flags) == HDRNET_KERNEL_FAST && dguide && !pix_fast)
+    return fail(HDRNET_INVALID_ARGUMENT, "no fast BilateralSliceGrad variant for this shape");
+  const char* pix_name = "";
+  SliceGradArgs rest = a;
+  if (pix_fast) {
+    const int rc = check_launch(launch_slice_vjp_rows(a, s, &pix_name), "BilateralSliceGrad");
+    if (rc != HDRNET_OK) return rc;
+    rest.dguide = nullptr;
+  }
+  const char* gg_name = "";
+  if (dgrid && family(flags) != HDRNET_KERNEL_GENERIC) {
+    if (slice_grid_grad_mfma_supported(a)) {
+      const int rc = check_launch(launch_slice_grid_grad_mfma(a, s, &gg_name), "BilateralSliceGrad");
+      if (rc != HDRNET_OK) return rc;
+      rest.dgrid = nullptr;
+    } else if (family(flags) == HDRNET_KERNEL_FAST) {
+      return fail(HDRNET_INVALID_ARGUMENT,
+                  "no fast grid-gradient variant for this shape (or workspace missing / too small)");
+    }
+  }
+  const char* rest_name = "";
+  if (rest.dgrid || rest.dguide) {
+    const int rc = check_launch(launch_slice_grad_generic(rest, s), "BilateralSliceGrad");
+    if (rc != HDRNET_OK) return rc;
+    rest_name = "slice_grad_generic";
+  }
+  set_kernel(pix_name, gg_name, rest_name);
+  return HDRNET_OK;
 }
 
 int hdrnet_bilateral_slice_grad_f32(const float* grid, const float* guide, const float* dout,

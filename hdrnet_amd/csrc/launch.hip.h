@@ -63,4 +63,21 @@ hipError_t launch_slice_grad_generic(const SliceGradArgs& a, hipStream_t s);
 bool apply_fwd_rows_supported(const ApplyArgs& a);
 hipError_t launch_apply_fwd_rows(const ApplyArgs& a, hipStream_t s, const char** name);
 
+// apply_bwd_rows.hip -- LDS-staged per-pixel VJPs: dguide and dinput in one pass
+// (BilateralSliceApply), dguide (BilateralSlice).  dgrid is not their business.
+bool apply_vjp_rows_supported(const ApplyGradArgs& a);
+hipError_t launch_apply_vjp_rows(const ApplyGradArgs& a, hipStream_t s, const char** name);
+bool slice_vjp_rows_supported(const SliceGradArgs& a);
+hipError_t launch_slice_vjp_rows(const SliceGradArgs& a, hipStream_t s, const char** name);
+
+// grid_grad_mfma.hip -- deterministic two-stage dgrid: per-row-run fp32 MFMA contraction over
+// the pixels + fixed-order reduction of partial tiles held in the caller's workspace.
+size_t apply_grid_grad_mfma_workspace(int B, int H, int W, int GH, int GW, int GD, int Cin, int Cout,
+                                      bool has_offset);
+bool apply_grid_grad_mfma_supported(const ApplyGradArgs& a);  // shape AND workspace large enough
+hipError_t launch_apply_grid_grad_mfma(const ApplyGradArgs& a, hipStream_t s, const char** name);
+size_t slice_grid_grad_mfma_workspace(int B, int H, int W, int GH, int GW, int GD, int C);
+bool slice_grid_grad_mfma_supported(const SliceGradArgs& a);
+hipError_t launch_slice_grid_grad_mfma(const SliceGradArgs& a, hipStream_t s, const char** name);
+
 }  // namespace hdrnet_amd

@@ -1,0 +1,238 @@
+// Shared device code of the LDS-staged "row" kernels (forward: apply_fwd_rows.hip,
+// backward: apply_bwd_rows.hip): the y-pre-lerped column image, its staging, the
+// per-pixel slicing terms and the packed-FMA blend.  See apply_fwd_rows.hip for the
+// design notes and the reference line numbers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "numerics.hip.h"
+
+namespace hdrnet_amd {
+namespace rows {
+
+constexpr int kPxPerThread = 4;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int C>
+struct CoefVec {
+  static constexpr int kPairs = (C + 1) / 2;
+  f32x2 v[kPairs];  // coefficient c lives in v[c / 2][c % 2]
+  __device__ __forceinline__ float get(int c) const { return v[c >> 1][c & 1]; }
+};
+
+// coef (+)= w * vec, vec = the C floats at byte offset `off` of the LDS image.
+// Explicit 2-wide vectors: the blend maps onto v_pk_fma_f32 / v_pk_mul_f32 with the
+// weight broadcast through op_sel and the ds_read_b128 result consumed in place.
+template <int C, bool FIRST>
+__device__ __forceinline__ void accum_vec(CoefVec<C>& coef, const float* __restrict__ colY,
+                                          int off, float w) {
+  const f32x2 w2 = {w, w};
+  const char* base = reinterpret_cast<const char*>(colY) + off;
+  if constexpr (C % 4 == 0) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(base);
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q) {
+      const f32x4 t = p[q];
+      if constexpr (FIRST) {
+        coef.v[2 * q + 0] = w2 * t.xy;
+        coef.v[2 * q + 1] = w2 * t.zw;
+      } else {
+        coef.v[2 * q + 0] = __builtin_elementwise_fma(w2, t.xy, coef.v[2 * q + 0]);
+        coef.v[2 * q + 1] = __builtin_elementwise_fma(w2, t.zw, coef.v[2 * q + 1]);
+      }
+    }
+  } else {
+    const float* p = reinterpret_cast<const float*>(base);
+#pragma unroll
+    for (int q = 0; q < C; ++q)
+      coef.v[q >> 1][q & 1] = FIRST ? w * p[q] : fmaf(w, p[q], coef.v[q >> 1][q & 1]);
+  }
+}
+
+struct RowCtx {
+  const float* colY;  // LDS image, [ncol][GD][C]
+  float scale_x, gd_f;
+  // Byte-space addressing of the LDS image: column stride and the clamp windows of
+  // (gx - gxlo) * col_bytes and gz * vec_bytes.
+  int gxlo, col_bytes, x_lo_b, x_hi_b, z_hi_b;
+};
+
+// Blend the two grid rows this image row needs into LDS; returns the row context.
+// WAVE = false: the whole workgroup fills one image and meets at a barrier.
+// WAVE = true : each wavefront fills its own private image; LDS operations of one
+//               wave complete in order, so no s_barrier is needed -- waves never wait
+//               for each other.
+template <int C, bool WAVE>
+__device__ __forceinline__ RowCtx stage_row(float* __restrict__ colY,
+                                            const float* __restrict__ grid_b, int y, int xs,
+                                            int xe, int GH, int GW, int GD, float scale_x,
+                                            float scale_y) {
+  // Wave-uniform y terms (bilateral_slice_apply.cc:42,47,55-56).
+  const float gyf = __fmul_rn(y + 0.5f, scale_y);  // rounded product, as the reference
+  const int gy0 = floor_to_int(gyf - 0.5f);
+  const float wy0 = tent_weight(gy0 + 0.5f, gyf);
+  const float wy1 = tent_weight(gy0 + 1 + 0.5f, gyf);
+  const int gy0c = clamp_index(gy0, 0, GH - 1);
+  const int gy1c = clamp_index(gy0 + 1, 0, GH - 1);
+  // Grid columns touched by pixels [xs, xe).
+  const int gxlo = clamp_index(floor_to_int(__fmul_rn(xs + 0.5f, scale_x) - 0.5f), 0, GW - 1);
+  const int gxhi =
+      clamp_index(floor_to_int(__fmul_rn(xe - 1 + 0.5f, scale_x) - 0.5f) + 1, 0, GW - 1);
+  const int n = (gxhi - gxlo + 1) * GD * C;  // floats; contiguous in the grid row
+  const float* r0 = grid_b + ((size_t)(gy0c * GW + gxlo) * GD) * C;
+  const float* r1 = grid_b + ((size_t)(gy1c * GW + gxlo) * GD) * C;
+  if constexpr (C % 4 == 0) {
+    const float4* a4 = reinterpret_cast<const float4*>(r0);
+    const float4* b4 = reinterpret_cast<const float4*>(r1);
+    float4* d4 = reinterpret_cast<float4*>(colY);
+    const int e0 = WAVE ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
+    const int estep = WAVE ? 64 : (int)blockDim.x;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+    for (int e = e0; e < n / 4; e += estep) {
+      const float4 a = a4[e], b = b4[e];
+      d4[e] = make_float4(wy0 * a.x + wy1 * b.x, wy0 * a.y + wy1 * b.y,
+                          wy0 * a.z + wy1 * b.z, wy0 * a.w + wy1 * b.w);
+    }
+  } else {
+    const int e0 = WAVE ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
+    const int estep = WAVE ? 64 : (int)blockDim.x;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+    for (int e = e0; e < n; e += estep) colY[e] = wy0 * r0[e] + wy1 * r1[e];
+  }
+  if constexpr (WAVE) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+  const int col_bytes = GD * C * (int)sizeof(float);
+  return RowCtx{colY,
+                scale_x,
+                (float)GD,
+                gxlo,
+                col_bytes,
+                (0 - gxlo) * col_bytes,
+                (GW - 1 - gxlo) * col_bytes,
+                (GD - 1) * C * (int)sizeof(float)};
+}
+
+// Per-pixel slicing terms: the two x / z corner weights and the byte offsets of the four
+// (gx, gz) coefficient vectors in the LDS image.
+//
+// Coordinates and weights follow bilateral_slice_apply.cc:41-64:
+//   gxf = (x + .5) * scale_x, gx0 = floor(gxf - .5), dx0 = (gx0 + .5) - gxf  in (-1, 0]
+//   gzf = guide * GD,         gz0 = floor(gzf - .5), dz0 = (gz0 + .5) - gzf  in (-1, 0]
+//   wx0 = 1 - |dx0| = 1 + dx0,   wx1 = 1 - |dx0 + 1| = -dx0          (tent, numerics.h:53)
+//   wz0 = 1 - sqrt(dz0^2 + eps), wz1 = 1 - sqrt((dz0 + 1)^2 + eps)  (smoothed, :108)
+// floor() puts both corners within one cell of the sample, so the reference's
+// max(., 0) never binds and is dropped; weights still come from the UNclamped
+// corner and only the indices are clamped (in byte space).
+// EXACT_SQRT = false: v_sqrt_f32 (1 ulp) stands in for the correctly-rounded
+// expansion -- the argument lies in [1e-8, 1 + 1e-8], nowhere near a denormal, and one
+// ulp of a weight is 6e-8 (forward kernel).  EXACT_SQRT = true: IEEE sqrtf; the guide
+// VJP divides by it and compares it with 1 (numerics.h:116-126).
+struct SliceTerms {
+  float wx0, wx1, wz0, wz1;
+  float dz0, dz1, sz0, sz1;  // z offsets of the two corners and their smoothed |.|
+  int a00, a01, a10, a11;    // byte offsets: a<x><z>
+};
+
+template <int C, bool EXACT_SQRT>
+__device__ __forceinline__ SliceTerms slice_terms(const RowCtx& r, float xf, float g) {
+  constexpr int kVecBytes = C * (int)sizeof(float);
+  SliceTerms t;
+  // __fmul_rn: the products must be ROUNDED to f32 before use, as in the reference; letting
+  // the compiler contract them into the consumers (fma(xf, sx, -0.5), fma(-xf, sx, gx0+.5))
+  // shifts the weights by up to ulp(gxf)/2 -- 1e-5 at GW = 256.
+  const float gxf = __fmul_rn(xf, r.scale_x);  // xf = x + 0.5f, exact
+  const float fxl = floorf(gxf - 0.5f);
+  const float dx0 = (fxl + 0.5f) - gxf;
+  t.wx0 = 1.0f + dx0;
+  t.wx1 = -dx0;
+  const float gzf = __fmul_rn(g, r.gd_f);
+  const float fzl = floorf(gzf - 0.5f);
+  t.dz0 = (fzl + 0.5f) - gzf;
+  t.dz1 = (fzl + 1.5f) - gzf;  // NOT dz0 + 1: near a bin centre that loses the low bits of dz1,
+                               // and the guide VJP's d wz/d gz has slope 1e4 there
+  const float q0 = fmaf(t.dz0, t.dz0, kSmoothEps), q1 = fmaf(t.dz1, t.dz1, kSmoothEps);
+  t.sz0 = EXACT_SQRT ? sqrtf(q0) : __builtin_amdgcn_sqrtf(q0);
+  t.sz1 = EXACT_SQRT ? sqrtf(q1) : __builtin_amdgcn_sqrtf(q1);
+  t.wz0 = 1.0f - t.sz0;
+  t.wz1 = 1.0f - t.sz1;
+  // floor of a wild guide is clamped in float before the int conversion so that the
+  // byte-space arithmetic below cannot overflow (v_med3_f32).
+  const int iz = (int)__builtin_amdgcn_fmed3f(fzl, -2.0f, r.gd_f + 1.0f);
+  const int zb = __mul24(iz, kVecBytes);  // |iz| <= GD + 1: 24-bit multiply is exact
+  const int zb0 = min(max(zb, 0), r.z_hi_b);
+  const int zb1 = min(max(zb + kVecBytes, 0), r.z_hi_b);
+  // x needs no guard: gxf in (0, GW) by construction, so gx0 in [-1, GW - 1].
+  const int xb = __mul24((int)fxl - r.gxlo, r.col_bytes);
+  const int xb0 = max(xb, r.x_lo_b);
+  const int xb1 = min(xb + r.col_bytes, r.x_hi_b);
+  t.a00 = xb0 + zb0;
+  t.a01 = xb0 + zb1;
+  t.a10 = xb1 + zb0;
+  t.a11 = xb1 + zb1;
+  return t;
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Upper bound of grid columns `npx` consecutive pixels can touch: floor differences of gx0
+// over npx-1 pixels (<= floor(d)+1), +1 for the upper neighbour, +1 for the count, +1
+// slack for float rounding of the coordinates; never more than GW.
+inline int max_cols_for(int npx, int GW, int W) {
+  const long long cols = ((long long)(npx - 1) * GW) / W + 4;
+  return (int)(cols < GW ? cols : GW);
+}
+
+// How a row is cut into workgroup segments: `threads` lanes x 4 pixels per segment, the
+// segment width balanced over the row (e.g. W = 3840 -> 5 segments of 768 px / 192 threads;
+// W = 1920 -> 2 x 960 px / 256 threads with 16 idle lanes).
+struct Plan {
+  int threads, nseg, seg, max_cols;
+  bool vec4;  // 16-B accesses usable: W % 4 == 0 and 16-B aligned buffers
+};
+
+inline Plan make_row_plan(int W, int GW, bool aligned16) {
+  Plan best{};
+  long long best_waste = -1;
+  const int cands[3] = {256, 192, 128};
+  for (int T : cands) {
+    const int span = T * kPxPerThread;
+    const int nseg = (W + span - 1) / span;
+    const long long waste = (long long)nseg * span - W;
+    if (best_waste < 0 || waste < best_waste) {
+      best_waste = waste;
+      best.threads = T;
+      best.nseg = nseg;
+    }
+  }
+  best.vec4 = aligned16 && (W % 4 == 0);
+  best.seg = round_up((W + best.nseg - 1) / best.nseg, 4);
+  best.threads = round_up((best.seg + kPxPerThread - 1) / kPxPerThread, 64);
+  if (best.threads > 256) best.threads = 256;
+  best.max_cols = max_cols_for(best.seg, GW, W);
+  return best;
+}
+
+// Compute units of the current device (cached per device ordinal; benign race).
+inline int num_cus() {
+  static int cache[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (cache[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cache[dev] = n;
+  }
+  return cache[dev];
+}
+
+}  // namespace rows
+}  // namespace hdrnet_amd

@@ -153,7 +153,7 @@ def _apply_forward(grid, guide, inp, has_offset: bool) -> torch.Tensor:
     return out
 
 
-def _apply_backward(grid, guide, inp, dout, has_offset: bool, need):
+def _apply_backward(grid, guide, inp, dout, has_offset: bool, need, flags: Optional[int] = None):
     B, H, W, GH, GW, GD, Cin, Cout = _check_apply(grid, guide, inp, has_offset)
     if tuple(dout.shape) != (B, H, W, Cout):
         raise ValueError(f"backprop should have shape {(B, H, W, Cout)}, got {tuple(dout.shape)}")
@@ -173,7 +173,7 @@ def _apply_backward(grid, guide, inp, dout, has_offset: bool, need):
             grid.data_ptr(), guide.data_ptr(), inp.data_ptr(), dout.data_ptr(),
             _ptr(dgrid), _ptr(dguide), _ptr(dinput),
             B, H, W, GH, GW, GD, Cin, Cout, int(has_offset),
-            _ptr(ws), wbytes, _flags(), _stream(dev))
+            _ptr(ws), wbytes, _flags() if flags is None else flags, _stream(dev))
     _lib.check(rc, "BilateralSliceApplyGrad")
     return dgrid, dguide, dinput
 
@@ -191,7 +191,7 @@ def _slice_forward(grid, guide) -> torch.Tensor:
     return out
 
 
-def _slice_backward(grid, guide, dout, need):
+def _slice_backward(grid, guide, dout, need, flags: Optional[int] = None):
     B, H, W, GH, GW, GD, C = _check_slice(grid, guide)
     if dout.dim() != 4:
         raise ValueError("Codomain tangent should be 4D (batch, height, width, nchannels).")
@@ -209,7 +209,7 @@ def _slice_backward(grid, guide, dout, need):
     with torch.cuda.device(dev):
         rc = lib.hdrnet_bilateral_slice_grad_f32_ex(
             grid.data_ptr(), guide.data_ptr(), dout.data_ptr(), _ptr(dgrid), _ptr(dguide),
-            B, H, W, GH, GW, GD, C, _ptr(ws), wbytes, _flags(), _stream(dev))
+            B, H, W, GH, GW, GD, C, _ptr(ws), wbytes, _flags() if flags is None else flags, _stream(dev))
     _lib.check(rc, "BilateralSliceGrad")
     return dgrid, dguide
 
@@ -219,6 +219,9 @@ class _BilateralSlice(torch.autograd.Function):
     @staticmethod
     def forward(ctx, grid, guide):
         ctx.save_for_backward(grid, guide)
+        # autograd runs backward on its own thread: the (thread-local) kernel override in
+        # effect at forward time is carried along explicitly.
+        ctx.flags = _flags()
         return _slice_forward(grid, guide)
 
     @staticmethod
@@ -228,7 +231,7 @@ class _BilateralSlice(torch.autograd.Function):
         need = ctx.needs_input_grad
         if not (need[0] or need[1]):
             return None, None
-        return _slice_backward(grid, guide, grad, need)
+        return _slice_backward(grid, guide, grad, need, ctx.flags)
 
 
 class _BilateralSliceApply(torch.autograd.Function):
@@ -236,6 +239,7 @@ class _BilateralSliceApply(torch.autograd.Function):
     def forward(ctx, grid, guide, inp, has_offset):
         ctx.save_for_backward(grid, guide, inp)
         ctx.has_offset = bool(has_offset)
+        ctx.flags = _flags()
         return _apply_forward(grid, guide, inp, bool(has_offset))
 
     @staticmethod
@@ -245,7 +249,7 @@ class _BilateralSliceApply(torch.autograd.Function):
         need = ctx.needs_input_grad[:3]
         if not any(need):
             return None, None, None, None
-        dgrid, dguide, dinput = _apply_backward(grid, guide, inp, grad, ctx.has_offset, need)
+        dgrid, dguide, dinput = _apply_backward(grid, guide, inp, grad, ctx.has_offset, need, ctx.flags)
         return dgrid, dguide, dinput, None
 
 

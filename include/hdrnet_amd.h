@@ -76,8 +76,9 @@ int hdrnet_version(void);
 /* Text of the last error raised on the calling thread ("" if none). */
 const char* hdrnet_last_error(void);
 
-/* Name of the kernel variant the calling thread's last successful call
- * launched (e.g. "apply_fwd_rows<3,3,1>/vec4"); for tests and benchmarks. */
+/* Name of the kernel variant(s) the most recent successful call in this process launched
+ * (e.g. "apply_fwd_rows/vec4", "apply_vjp_rows/vec4+grid_grad_mfma"); introspection for
+ * tests and benchmarks only (process-wide: autograd calls the VJPs from its own thread). */
 const char* hdrnet_last_kernel(void);
 
 /* BilateralSliceApply forward.

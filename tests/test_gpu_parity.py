@@ -186,6 +186,64 @@ def test_apply_backward_random(dev, ops, port, shape):
             grads_close(N(ti.grad), wi, "dinput")
 
 
+def test_backward_uses_fast_kernels_and_is_deterministic(dev, ops):
+    """HDRNet's shape (Cin 3 -> Cout 3 + offset): dguide/dinput from the fused LDS-staged pass,
+    dgrid from the two-stage MFMA reduction; no atomics => bitwise repeatable."""
+    gen = torch.Generator(device=dev).manual_seed(77)
+    grid = torch.rand((2, 16, 16, 8, 12), device=dev, generator=gen)
+    guide = torch.rand((2, 270, 480), device=dev, generator=gen)
+    inp = torch.rand((2, 270, 480, 3), device=dev, generator=gen)
+    dout = torch.randn((2, 270, 480, 3), device=dev, generator=gen)
+    res = []
+    for _ in range(2):
+        tg, tgu, ti = (t.clone().requires_grad_(True) for t in (grid, guide, inp))
+        ops.bilateral_slice_apply(tg, tgu, ti, has_offset=True).backward(dout)
+        assert ops.last_kernel() == "apply_vjp_rows/vec4+grid_grad_mfma", ops.last_kernel()
+        res.append((tg.grad.clone(), tgu.grad.clone(), ti.grad.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("H,W", [(1080, 1920)])
+def test_full_frame_backward_fast_equals_generic(dev, ops, H, W):
+    """All three VJPs at 1080p: fast kernels vs the generic ones (which are bit-exact to the
+    reference CPU code; the gather-form dgrid takes ~0.1 s here, as slow as the reference's)."""
+    gen = torch.Generator(device=dev).manual_seed(2024)
+    grid = torch.rand((1, 16, 16, 8, 12), device=dev, generator=gen)
+    guide = torch.rand((1, H, W), device=dev, generator=gen) * 1.1 - 0.05
+    inp = torch.rand((1, H, W, 3), device=dev, generator=gen)
+    dout = torch.randn((1, H, W, 3), device=dev, generator=gen)
+    out = {}
+    for which in ("generic", "auto"):
+        tg, tgu, ti = (t.clone().requires_grad_(True) for t in (grid, guide, inp))
+        with ops.kernel_override(which):
+            ops.bilateral_slice_apply(tg, tgu, ti, has_offset=True).backward(dout)
+        out[which] = (tg.grad, tgu.grad, ti.grad)
+    for a, b, nm in zip(out["auto"], out["generic"], ("dgrid", "dguide", "dinput")):
+        scale = max(1.0, b.abs().max().item())
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * scale, msg=lambda m, nm=nm: nm + ": " + m)
+        print(f"{nm}: max|fast-generic| = {(a - b).abs().max().item():.3e} (scale {scale:.3g})")
+
+
+def test_full_frame_adjointness_4k(dev, ops):
+    """<dgrid, grid> == <dout, out> (the op is linear in the grid) and
+    <dinput, in> + <dout, out(in=0)> == <dout, out> (affine in the input), on a 4K frame."""
+    H, W = 2160, 3840
+    gen = torch.Generator(device=dev).manual_seed(5)
+    grid = torch.rand((1, 16, 16, 8, 12), device=dev, generator=gen).requires_grad_(True)
+    guide = torch.rand((1, H, W), device=dev, generator=gen)
+    inp = torch.rand((1, H, W, 3), device=dev, generator=gen).requires_grad_(True)
+    dout = torch.randn((1, H, W, 3), device=dev, generator=gen)
+    out = ops.bilateral_slice_apply(grid, guide, inp, has_offset=True)
+    out.backward(dout)
+    rhs = (dout.double() * out.detach().double()).sum().item()
+    lhs = (grid.grad.double() * grid.detach().double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-4 * abs(rhs) + 1e-2, (lhs, rhs)
+    off = ops.bilateral_slice_apply(grid.detach(), guide, torch.zeros_like(inp), has_offset=True)
+    lhs2 = (inp.grad.double() * inp.detach().double()).sum().item() + (dout.double() * off.double()).sum().item()
+    assert abs(lhs2 - rhs) <= 1e-4 * abs(rhs) + 1e-2, (lhs2, rhs)
+
+
 def test_partial_gradients(dev, ops, port):
     """A NULL output pointer skips that VJP (bilateral_slice_apply.cu.cc:393,401,409)."""
     rng = np.random.default_rng(5)
