@@ -32,6 +32,7 @@ SOURCES = [
     # (measured: 947 -> 646 ISA lines, 82 -> 55 VGPRs with it off).
     ("apply_fwd_rows.hip", ["-fno-slp-vectorize"]),
     ("apply_bwd_rows.hip", ["-fno-slp-vectorize"]),
+    ("slice_fwd_rows.hip", ["-fno-slp-vectorize"]),
     ("grid_grad_mfma.hip", []),
 ]
 

@@ -225,11 +225,18 @@ int hdrnet_bilateral_slice_f32_ex(const float* grid, const float* guide, float* 
     return HDRNET_OK;
   }
   if (!grid || !guide || !out) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
-  if (family(flags) == HDRNET_KERNEL_FAST)
-    return fail(HDRNET_INVALID_ARGUMENT, "no fast BilateralSlice variant yet");
   SliceArgs a{grid, guide, out, B, H, W, GH, GW, GD, C};
-  const int rc =
-      check_launch(launch_slice_fwd_generic(a, static_cast<hipStream_t>(stream)), "BilateralSlice");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool fast_ok = slice_fwd_rows_supported(a);
+  if (family(flags) == HDRNET_KERNEL_FAST && !fast_ok)
+    return fail(HDRNET_INVALID_ARGUMENT, "no fast BilateralSlice variant for this shape");
+  if (family(flags) != HDRNET_KERNEL_GENERIC && fast_ok) {
+    const char* name = "";
+    const int rc = check_launch(launch_slice_fwd_rows(a, s, &name), "BilateralSlice");
+    if (rc == HDRNET_OK) set_kernel(name);
+    return rc;
+  }
+  const int rc = check_launch(launch_slice_fwd_generic(a, s), "BilateralSlice");
   if (rc == HDRNET_OK) set_kernel("slice_fwd_generic");
   return rc;
 }

@@ -70,6 +70,10 @@ hipError_t launch_apply_vjp_rows(const ApplyGradArgs& a, hipStream_t s, const ch
 bool slice_vjp_rows_supported(const SliceGradArgs& a);
 hipError_t launch_slice_vjp_rows(const SliceGradArgs& a, hipStream_t s, const char** name);
 
+// slice_fwd_rows.hip -- LDS-staged BilateralSlice forward with lane-contiguous stores.
+bool slice_fwd_rows_supported(const SliceArgs& a);
+hipError_t launch_slice_fwd_rows(const SliceArgs& a, hipStream_t s, const char** name);
+
 // grid_grad_mfma.hip -- deterministic two-stage dgrid: per-row-run fp32 MFMA contraction over
 // the pixels + fixed-order reduction of partial tiles held in the caller's workspace.
 size_t apply_grid_grad_mfma_workspace(int B, int H, int W, int GH, int GW, int GD, int Cin, int Cout,

@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Times every entry point of the C-ABI on one MI355X (HIP events, rotating buffer sets).
+
+    python tools/op_bench.py [--workload 4k|1080p] [--steps 50] [--json out.json]
+
+Reports per-launch microseconds and algorithmic GB/s (SURVEY.md section 8d byte counts):
+  apply fwd   4*[HW(1+Cin+Cout) + grid]
+  apply bwd   reads grid, guide, input, dout; writes dgrid, dguide, dinput
+  slice fwd   4*[HW(1+C) + grid]
+  slice bwd   reads grid, guide, dout (C ch); writes dgrid, dguide
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from bench import CACHE_BYTES, WORKLOADS  # noqa: E402
+from hdrnet_amd import _lib  # noqa: E402
+
+
+def timeit(fn, steps, rounds=5):
+    out = []
+    for _ in range(rounds):
+        for k in range(3):
+            fn(k)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for k in range(steps):
+            fn(k)
+        e1.record()
+        torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) * 1e3 / steps)
+    return statistics.median(out), min(out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="4k")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--json", default=None)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    H, W, GH, GW, GD, desc = WORKLOADS[args.workload]
+    Cin, Cout, C = 3, 3, 12
+    npx = H * W
+    gridb = 4 * GH * GW * GD * C
+    nsets = max(3, -(-int(CACHE_BYTES * 1.5) // (4 * npx * 11)))
+    gen = torch.Generator(device=dev).manual_seed(1)
+    S = []
+    for _ in range(nsets):
+        S.append(dict(
+            grid=torch.rand((1, GH, GW, GD, C), device=dev, generator=gen),
+            guide=torch.rand((1, H, W), device=dev, generator=gen),
+            inp=torch.rand((1, H, W, Cin), device=dev, generator=gen),
+            dout=torch.randn((1, H, W, Cout), device=dev, generator=gen),
+            out=torch.empty((1, H, W, Cout), device=dev),
+            dgrid=torch.empty((1, GH, GW, GD, C), device=dev),
+            dguide=torch.empty((1, H, W), device=dev),
+            dinput=torch.empty((1, H, W, Cin), device=dev)))
+    # the un-fused slice moves 4*C B/px: two sets suffice to exceed the cache
+    sl = [dict(dout=torch.randn((1, H, W, C), device=dev, generator=gen),
+               out=torch.empty((1, H, W, C), device=dev)) for _ in range(2)]
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    wsb = lib.hdrnet_bilateral_slice_apply_grad_workspace_bytes(1, H, W, GH, GW, GD, Cin, Cout, 1)
+    ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
+    wsb2 = lib.hdrnet_bilateral_slice_grad_workspace_bytes(1, H, W, GH, GW, GD, C)
+    ws2 = torch.empty((max(wsb2, 16),), dtype=torch.uint8, device=dev)
+
+    def chk(rc):
+        if rc:
+            raise RuntimeError(lib.hdrnet_last_error().decode())
+
+    def apply_fwd(k):
+        s = S[k % nsets]
+        chk(lib.hdrnet_bilateral_slice_apply_f32(s["grid"].data_ptr(), s["guide"].data_ptr(), s["inp"].data_ptr(),
+                                                 s["out"].data_ptr(), 1, H, W, GH, GW, GD, Cin, Cout, 1, stream))
+
+    def apply_bwd(k, dg=True, dgu=True, di=True):
+        s = S[k % nsets]
+        chk(lib.hdrnet_bilateral_slice_apply_grad_f32(
+            s["grid"].data_ptr(), s["guide"].data_ptr(), s["inp"].data_ptr(), s["dout"].data_ptr(),
+            s["dgrid"].data_ptr() if dg else None, s["dguide"].data_ptr() if dgu else None,
+            s["dinput"].data_ptr() if di else None, 1, H, W, GH, GW, GD, Cin, Cout, 1,
+            ws.data_ptr(), wsb, stream))
+
+    def slice_fwd(k):
+        s, t = S[k % nsets], sl[k % 2]
+        chk(lib.hdrnet_bilateral_slice_f32(s["grid"].data_ptr(), s["guide"].data_ptr(), t["out"].data_ptr(),
+                                           1, H, W, GH, GW, GD, C, stream))
+
+    def slice_bwd(k):
+        s, t = S[k % nsets], sl[k % 2]
+        chk(lib.hdrnet_bilateral_slice_grad_f32(s["grid"].data_ptr(), s["guide"].data_ptr(), t["dout"].data_ptr(),
+                                                s["dgrid"].data_ptr(), s["dguide"].data_ptr(),
+                                                1, H, W, GH, GW, GD, C, ws2.data_ptr(), wsb2, stream))
+
+    rows = []
+
+    def run(name, fn, nbytes):
+        fn(0)
+        torch.cuda.synchronize()
+        kern = lib.hdrnet_last_kernel().decode()
+        med, mn = timeit(fn, args.steps)
+        rows.append(dict(op=name, kernel=kern, us=round(med, 2), us_min=round(mn, 2),
+                         algorithmic_MB=round(nbytes / 1e6, 1), GBps=round(nbytes / med / 1e3, 1),
+                         hbm_frac=round(nbytes / med / 1e3 / 8000, 4), MPps=round(npx / med, 0)))
+        print(f"{name:28s} {kern:40s} {med:8.2f} us (min {mn:7.2f})  {nbytes / 1e6:7.1f} MB  "
+              f"{nbytes / med / 1e3:7.1f} GB/s  {nbytes / med / 1e3 / 80:5.1f}% of 8 TB/s")
+
+    print(f"{desc}; {nsets} rotating sets; workspace apply-grad {wsb / 1e6:.1f} MB")
+    run("apply fwd", apply_fwd, 4 * npx * (1 + Cin + Cout) + gridb)
+    run("apply bwd (all three)", apply_bwd, 4 * npx * (1 + Cin + Cout) + 4 * npx * (1 + Cin) + 2 * gridb)
+    run("apply bwd dguide+dinput", lambda k: apply_bwd(k, dg=False), 4 * npx * (1 + Cin + Cout) + 4 * npx * (1 + Cin) + gridb)
+    run("apply bwd dgrid only", lambda k: apply_bwd(k, dgu=False, di=False), 4 * npx * (1 + Cin + Cout) + gridb)
+    run("slice fwd", slice_fwd, 4 * npx * (1 + C) + gridb)
+    run("slice bwd (both)", slice_bwd, 4 * npx * (1 + C) + 4 * npx + 2 * gridb)
+    if args.json:
+        json.dump(dict(workload=desc, rows=rows), open(args.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
