@@ -80,11 +80,11 @@ def run_steps(lib, sets, dims, stream, n, start=0):
 
 def timed(lib, sets, dims, stream, steps, dist_on, dev):
     """Barrier + sync, K launches bracketed by HIP events on the launch stream, sync + barrier."""
-    import torch.distributed as dist
+    from hdrnet_amd import dist as hd
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     if dist_on:
-        dist.barrier()
+        hd.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     ev0.record()
@@ -93,7 +93,7 @@ def timed(lib, sets, dims, stream, steps, dist_on, dev):
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
     if dist_on:
-        dist.barrier()
+        hd.barrier()
     return t1 - t0, ev0.elapsed_time(ev1) * 1e-3
 
 
@@ -151,10 +151,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     dist_on = world > 1
+    from hdrnet_amd import dist as hd
     if dist_on:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL; control plane only
+        hd.init(backend="nccl", device=dev)  # RCCL over xGMI; control plane only (barrier, max-time)
 
     from hdrnet_amd import _lib
     lib = _lib.load()  # raises loudly if the HIP library is missing
@@ -170,11 +169,7 @@ def main():
     wall, gpu_s = timed(lib, sets, dims, stream, args.steps, dist_on, dev)
     kernel = lib.hdrnet_last_kernel().decode()
 
-    elapsed = torch.tensor([wall, gpu_s], dtype=torch.float64, device=dev)
-    if dist_on:
-        import torch.distributed as dist
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    wall_max, gpu_max = float(elapsed[0]), float(elapsed[1])
+    wall_max, gpu_max = hd.max_over_ranks([wall, gpu_s], device=dev)
 
     mp_per_step = H * W / 1e6
     value = world * args.steps * mp_per_step / wall_max
@@ -227,7 +222,7 @@ def main():
         print(json.dumps(result), flush=True)
     if dist_on:
         import torch.distributed as dist
-        dist.barrier()
+        hd.barrier()
         dist.destroy_process_group()
 
 

@@ -1,0 +1,83 @@
+"""Multi-GPU plumbing for the bilateral-grid path: one process per GPU, images sharded
+across ranks, NO data-path collective.
+
+The path shards by image: every output pixel depends only on its own
+guide / input pixel and on its own image's grid, so rank r simply owns a contiguous block of
+the batch.  ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the MI355X node, "gloo"
+in the CPU tests) is used for the control plane only: the barrier around a timed region, the
+max-over-ranks of the elapsed time, and -- in tests -- gathering results to check them.
+The reference itself has no multi-device code at all (hdrnet/models.py:194 pins '/gpu:0').
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world() -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from the torch.distributed.run environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init(backend: Optional[str] = None, device: Optional[torch.device] = None) -> Tuple[int, int]:
+    """Join the process group described by the environment (no-op for world size 1)."""
+    rank, world, _ = env_rank_world()
+    if world == 1:
+        return 0, 1
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if not dist.is_initialized():
+        kw = {}
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        dist.init_process_group(backend=backend, **kw)
+    return dist.get_rank(), dist.get_world_size()
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced [start, stop) of `n_items` images for `rank` (first ranks get the
+    remainder).  Config #5: 8 images / 8 GPUs -> one each; config #4: 32 / 8 -> four each."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def barrier() -> None:
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(values: List[float], device: Optional[torch.device] = None) -> List[float]:
+    """Element-wise max of a few floats over all ranks (timings)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return list(values)
+    t = torch.tensor(values, dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t]
+
+
+def sharded_apply(fn: Callable[..., torch.Tensor], grid: torch.Tensor, guide: torch.Tensor,
+                  inp: torch.Tensor, rank: int, world: int, **kw) -> Tuple[torch.Tensor, Tuple[int, int]]:
+    """Run `fn(grid, guide, input, **kw)` on this rank's image shard of a full batch."""
+    lo, hi = shard_range(guide.shape[0], rank, world)
+    return fn(grid[lo:hi], guide[lo:hi], inp[lo:hi], **kw), (lo, hi)
+
+
+def gather_batch(local: torch.Tensor, n_items: int) -> torch.Tensor:
+    """All-gather variable-sized batch shards back into the full batch (tests / validation only;
+    the product path never needs it)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    world = dist.get_world_size()
+    parts: List[Optional[torch.Tensor]] = [None] * world
+    dist.all_gather_object(parts, local.cpu())
+    out = torch.cat([p for p in parts if p is not None and p.shape[0] > 0], dim=0)
+    assert out.shape[0] == n_items
+    return out
