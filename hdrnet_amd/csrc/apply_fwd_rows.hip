@@ -40,7 +40,7 @@ namespace {
 
 using namespace rows;
 
-constexpr int kVariantRows = 1, kVariantWave = 2, kVariantStream = 3;  // 3..6: 4/6/8/2 blocks per CU
+constexpr int kVariantRows = 1, kVariantWave = 2, kVariantStream = 3;  // 3..6: 4/5/6/3 blocks per CU
 
 // One pixel: slice the y-pre-lerped columns at (x, guide) and apply the affine
 // (bilateral_slice_apply.cc:50-80).
@@ -303,34 +303,118 @@ __global__ __launch_bounds__(256) void apply_fwd_wave_vec4(
   for (int q = 0; q < (COUT * kPxPerThread) / 4; ++q) op[q] = ov[q];
 }
 
-// ---- persistent, balanced streaming variant ------------------------------------------------
+// ---- persistent, balanced, software-pipelined streaming variant ---------------------------
 // The launch is sized to what the chip holds at once (CUs x blocks_per_cu workgroups of 4
-// waves) and every WAVE owns one contiguous, equal share of the image's pixel quads, which
-// it walks in chunks of <= 64 quads (256 pixels, never across a row end).  Per chunk it
-// stages its private y-pre-lerped columns, issues the NEXT chunk's guide/input loads, then
-// slices and stores the current chunk -- so each wave keeps a continuous stream of HBM
-// requests in flight, all waves finish together (no partially filled last round of
-// workgroups), and the only ramp left is one load latency at each end of the launch.
-template <int CIN, int COUT, bool OFFSET>
+// waves).  Every WAVE owns one contiguous, equal share of the image's pixel quads and walks
+// it in chunks of <= 64 quads (256 pixels, never across a row end).  The loop is software-
+// pipelined around the in-order vmcnt counter of CDNA (which counts stores as well): per
+// chunk i the wave
+//   a. waits for G_i, the two grid-row slices of chunk i (issued one iteration ago), blends
+//      them into its private LDS column image,
+//   b. waits for P_i, the chunk's guide/input quads (also issued one iteration ago),
+//   c. issues G_{i+1}, then d. P_{i+1}  -- BEFORE chunk i's stores, so that the waits of
+//      the next iteration never sit behind a store or a younger load,
+//   e. slices chunk i, f. transposes through LDS and stores.
+// Every wave therefore always has the next chunk's 4 KiB in flight while it computes, all
+// waves finish together (no partially filled last round of workgroups), and the only ramp
+// left is one load latency at the start and one chunk of compute at the end of the launch.
+// LDS traffic of ONE wave needs no fence: the LDS executes a wave's instructions in order, so
+// a ds_read issued after a ds_write of the same wave sees all 64 lanes' data.  (A
+// `fence(release, "wavefront")` would cost an s_waitcnt vmcnt(0), i.e. drain the prefetch.)
+// The scheduling barrier only keeps the compiler from moving LDS accesses across.
+__device__ __forceinline__ void wave_lds_order() {
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+
+constexpr int kStageRegs = 2;  // float4 per grid row per lane held in flight (<= 128 float4 / row)
+
+template <int CIN>
 struct QuadData {
   float4 g;
   float4 in[CIN];
 };
 
-template <int CIN, int COUT, bool OFFSET>
-__device__ __forceinline__ QuadData<CIN, COUT, OFFSET> load_quad(
-    const float* __restrict__ guide, const float* __restrict__ input, long long quad, bool on) {
-  QuadData<CIN, COUT, OFFSET> d;
-  d.g = make_float4(0.f, 0.f, 0.f, 0.f);
+// Unconditional: the caller clamps `quad` to a valid quad (idle lanes re-load the chunk's last
+// quad), so the loop body has no exec-masked branch around a VMEM instruction and the
+// compiler's s_waitcnt vmcnt(N) counts stay exact.
+template <int CIN>
+__device__ __forceinline__ QuadData<CIN> load_quad(const float* __restrict__ guide,
+                                                   const float* __restrict__ input,
+                                                   long long quad) {
+  QuadData<CIN> d;
+  d.g = reinterpret_cast<const float4*>(guide)[quad];
+  const float4* ip = reinterpret_cast<const float4*>(input) + quad * CIN;
 #pragma unroll
-  for (int q = 0; q < CIN; ++q) d.in[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (on) {
-    d.g = reinterpret_cast<const float4*>(guide)[quad];
-    const float4* ip = reinterpret_cast<const float4*>(input) + quad * CIN;
-#pragma unroll
-    for (int q = 0; q < CIN; ++q) d.in[q] = ip[q];
-  }
+  for (int q = 0; q < CIN; ++q) d.in[q] = ip[q];
   return d;
+}
+
+// Where a chunk sits and which grid data it needs (all wave-uniform).
+struct ChunkGeom {
+  int y, xs, len;        // image row, first pixel, quads
+  long long b;           // image
+  int gy0c, gy1c, gxlo, n4;  // clamped grid rows, first column, float4 count of the column image
+  float wy0, wy1;
+};
+
+template <int C>
+__device__ __forceinline__ ChunkGeom chunk_geom(long long b, int y, int xq, int len, int GH, int GW,
+                                                int GD, float scale_x, float scale_y) {
+  ChunkGeom c;
+  c.b = b;
+  c.y = y;
+  c.xs = xq * 4;
+  c.len = len;
+  const float gyf = mul_rn(y + 0.5f, scale_y);
+  const int gy0 = floor_to_int(gyf - 0.5f);
+  c.wy0 = tent_weight(gy0 + 0.5f, gyf);
+  c.wy1 = tent_weight(gy0 + 1 + 0.5f, gyf);
+  c.gy0c = clamp_index(gy0, 0, GH - 1);
+  c.gy1c = clamp_index(gy0 + 1, 0, GH - 1);
+  const int xe = c.xs + len * 4;
+  c.gxlo = clamp_index(floor_to_int(mul_rn(c.xs + 0.5f, scale_x) - 0.5f), 0, GW - 1);
+  const int gxhi = clamp_index(floor_to_int(mul_rn(xe - 1 + 0.5f, scale_x) - 0.5f) + 1, 0, GW - 1);
+  c.n4 = (gxhi - c.gxlo + 1) * GD * C / 4;
+  return c;
+}
+
+struct StageRegs {
+  float4 a[kStageRegs], b[kStageRegs];
+};
+
+template <int C>
+__device__ __forceinline__ StageRegs stage_issue(const float* __restrict__ grid, const ChunkGeom& c,
+                                                 int GH, int GW, int GD, int lane) {
+  StageRegs r;
+  const float* gb = grid + (size_t)c.b * GH * GW * GD * C;
+  const float4* a4 = reinterpret_cast<const float4*>(gb + ((size_t)(c.gy0c * GW + c.gxlo) * GD) * C);
+  const float4* b4 = reinterpret_cast<const float4*>(gb + ((size_t)(c.gy1c * GW + c.gxlo) * GD) * C);
+#pragma unroll
+  for (int k = 0; k < kStageRegs; ++k) {
+    const int e = min(lane + 64 * k, c.n4 - 1);  // clamped: idle lanes duplicate the last element
+    r.a[k] = a4[e];
+    r.b[k] = b4[e];
+  }
+  return r;
+}
+
+template <int C>
+__device__ __forceinline__ RowCtx stage_commit(float* __restrict__ colY, const StageRegs& r,
+                                               const ChunkGeom& c, int GW, int GD, float scale_x,
+                                               int lane) {
+  float4* d4 = reinterpret_cast<float4*>(colY);
+#pragma unroll
+  for (int k = 0; k < kStageRegs; ++k) {
+    const int e = min(lane + 64 * k, c.n4 - 1);  // duplicates write the same value
+    const float4 a = r.a[k], b = r.b[k];
+    d4[e] = make_float4(c.wy0 * a.x + c.wy1 * b.x, c.wy0 * a.y + c.wy1 * b.y,
+                        c.wy0 * a.z + c.wy1 * b.z, c.wy0 * a.w + c.wy1 * b.w);
+  }
+  wave_lds_order();
+  const int col_bytes = GD * C * (int)sizeof(float);
+  return RowCtx{colY, scale_x, (float)GD, c.gxlo, col_bytes, (0 - c.gxlo) * col_bytes,
+                (GW - 1 - c.gxlo) * col_bytes, (GD - 1) * C * (int)sizeof(float)};
 }
 
 template <int CIN, int COUT, bool OFFSET>
@@ -340,28 +424,35 @@ __global__ __launch_bounds__(256) void apply_fwd_stream_vec4(
     int GD, long long nquads, long long quads_per_wave, int lds_floats_per_wave, float scale_x,
     float scale_y) {
   constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
-  extern __shared__ __attribute__((aligned(16))) float colY_all[];
+  static_assert(C % 4 == 0, "float4 column image");
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  float* colY = colY_all + wave * lds_floats_per_wave;
+  float* colY = lds_all + wave * lds_floats_per_wave;
+  float4* slab = reinterpret_cast<float4*>(colY + (lds_floats_per_wave - 64 * kPxPerThread * COUT));
   const long long wid = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
   long long pos = wid * quads_per_wave;
   const long long end = min(pos + quads_per_wave, nquads);
   if (pos >= end) return;
-  const int W = Wq * 4;
-  // (b, y, xq) of `pos`, advanced incrementally afterwards; all wave-uniform.
+  // (b, y, xq) of `pos`, advanced incrementally; everything here is wave-uniform.
   long long row = pos / Wq;
   int xq = (int)(pos - row * Wq);
   int y = (int)(row % H);
   long long b = row / H;
-
   int len = (int)min((long long)min(64, Wq - xq), end - pos);
-  QuadData<CIN, COUT, OFFSET> cur = load_quad<CIN, COUT, OFFSET>(guide, input, pos + lane, lane < len);
+
+  ChunkGeom cg = chunk_geom<C>(b, y, xq, len, GH, GW, GD, scale_x, scale_y);
+  StageRegs sr = stage_issue<C>(grid, cg, GH, GW, GD, lane);                      // G_0
+  QuadData<CIN> cur = load_quad<CIN>(guide, input, pos + min(lane, len - 1));      // P_0
 
   while (true) {
+    // a. G_i -> this wave's LDS column image (frees the staging registers)
+    const RowCtx r = stage_commit<C>(colY, sr, cg, GW, GD, scale_x, lane);
+    // b./c. next chunk: geometry, then its grid rows and its guide / input quads go out NOW --
+    //       before chunk i is sliced and before its stores -- so they fly during the slicing
+    //       and no later wait sits behind a store.  (Past the end: re-load this chunk, unused.)
     const long long npos = pos + len;
-    int nxq = xq + len;
-    int ny = y;
+    int nxq = xq + len, ny = y;
     long long nb = b;
     if (nxq == Wq) {
       nxq = 0;
@@ -371,21 +462,17 @@ __global__ __launch_bounds__(256) void apply_fwd_stream_vec4(
       }
     }
     const int nlen = npos < end ? (int)min((long long)min(64, Wq - nxq), end - npos) : 0;
-
-    const float* grid_b = grid + (size_t)b * GH * GW * GD * C;
-    const int xs = xq * 4;
-    const RowCtx r =
-        stage_row<C, true>(colY, grid_b, y, xs, xs + len * 4, GH, GW, GD, scale_x, scale_y);
-
-    // Prefetch the next chunk while this one is being sliced.
-    const QuadData<CIN, COUT, OFFSET> nxt =
-        load_quad<CIN, COUT, OFFSET>(guide, input, npos + lane, lane < nlen);
-
-    if (lane < len) {
+    const bool more = nlen > 0;
+    const ChunkGeom ncg = more ? chunk_geom<C>(nb, ny, nxq, nlen, GH, GW, GD, scale_x, scale_y) : cg;
+    sr = stage_issue<C>(grid, ncg, GH, GW, GD, lane);
+    const QuadData<CIN> nxt =
+        load_quad<CIN>(guide, input, more ? npos + min(lane, nlen - 1) : pos + min(lane, len - 1));
+    // d. slice chunk i (idle lanes slice a duplicate of the last quad; their result is unused)
+    float4 ov[COUT];
+    {
       const float gs[4] = {cur.g.x, cur.g.y, cur.g.z, cur.g.w};
-      const float xf0 = (float)(xs + 4 * lane) + 0.5f;
+      const float xf0 = (float)(cg.xs + 4 * min(lane, len - 1)) + 0.5f;
       const float* inf = reinterpret_cast<const float*>(cur.in);
-      float4 ov[COUT];
       float* of = reinterpret_cast<float*>(ov);
 #pragma unroll
       for (int k = 0; k < kPxPerThread; ++k) {
@@ -396,23 +483,35 @@ __global__ __launch_bounds__(256) void apply_fwd_stream_vec4(
 #pragma unroll
         for (int i = 0; i < COUT; ++i) of[k * COUT + i] = o[i];
       }
-      float4* op = reinterpret_cast<float4*>(out) + (pos + lane) * COUT;
-#pragma unroll
-      for (int q = 0; q < COUT; ++q) op[q] = ov[q];
     }
-    if (nlen == 0) break;
-    // The next stage_row overwrites this wave's LDS image: its reads above are done
-    // (same wave, in order); keep the compiler from hoisting the writes.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    // e. transpose through the wave's slab; lane-contiguous 16-B stores.  Idle lanes write /
+    //    store a duplicate of the last valid element (same value, same address).
+    {
+      const int wl = min(lane, len - 1);
+#pragma unroll
+      for (int q = 0; q < COUT; ++q) slab[wl * COUT + q] = ov[q];
+      wave_lds_order();
+      const int nvalid = len * COUT;
+      float4* gp = reinterpret_cast<float4*>(out) + pos * COUT;
+      // all slab reads into distinct registers first: re-using one register quad for the three
+      // stores would make each store wait (vmcnt) for the previous one -- and, the counter
+      // being in-order, for the prefetch issued before it.
+      float4 tv[COUT];
+#pragma unroll
+      for (int k = 0; k < COUT; ++k) tv[k] = slab[min(lane + 64 * k, nvalid - 1)];
+#pragma unroll
+      for (int k = 0; k < COUT; ++k) gp[min(lane + 64 * k, nvalid - 1)] = tv[k];
+      wave_lds_order();
+    }
+    if (!more) break;
     cur = nxt;
+    cg = ncg;
     pos = npos;
     len = nlen;
     xq = nxq;
     y = ny;
     b = nb;
   }
-  (void)W;
 }
 
 Plan make_plan(const ApplyArgs& a) {
@@ -447,25 +546,28 @@ hipError_t launch_t(const ApplyArgs& a, hipStream_t s, const char** name) {
     *name = "apply_fwd_wave/vec4";
     return hipGetLastError();
   }
-  if (pl.vec4 && a.variant >= kVariantStream && a.variant < kVariantStream + 4) {
-    // Persistent balanced stream: CUs x blocks_per_cu workgroups of 4 waves.
-    const int bpc_table[4] = {4, 6, 8, 2};
-    const int blocks_per_cu = bpc_table[(a.variant - kVariantStream) & 3];
-    const int waves = 4;
-    const long long nquads = (long long)a.B * a.H * (a.W / 4);
-    long long nwaves = (long long)num_cus() * blocks_per_cu * waves;
-    if (nwaves > (nquads + 63) / 64) nwaves = (nquads + 63) / 64;  // small images: 1 chunk each
-    nwaves = (nwaves + waves - 1) / waves * waves;
-    const long long qpw = (nquads + nwaves - 1) / nwaves;
-    const long long ncol = ((long long)(64 * 4 - 1) * a.GW) / a.W + 4;
-    const int cols = (int)(ncol < a.GW ? ncol : a.GW);
-    const int lds_floats = round_up(cols * a.GD * C, 4);
-    apply_fwd_stream_vec4<CIN, COUT, OFFSET>
-        <<<(unsigned)(nwaves / waves), waves * 64, (size_t)waves * lds_floats * sizeof(float), s>>>(
-            a.grid, a.guide, a.input, a.out, a.H, a.W / 4, a.GH, a.GW, a.GD, nquads, qpw,
-            lds_floats, sx, sy);
-    *name = "apply_fwd_stream/vec4";
-    return hipGetLastError();
+  if constexpr (C % 4 == 0) {
+    if (pl.vec4 && a.variant >= kVariantStream && a.variant < kVariantStream + 4) {
+      // Persistent balanced stream: CUs x blocks_per_cu workgroups of 4 waves.
+      const int bpc_table[4] = {4, 5, 6, 3};
+      const int blocks_per_cu = bpc_table[(a.variant - kVariantStream) & 3];
+      const int waves = 4;
+      const long long nquads = (long long)a.B * a.H * (a.W / 4);
+      long long nwaves = (long long)num_cus() * blocks_per_cu * waves;
+      if (nwaves > (nquads + 63) / 64) nwaves = (nquads + 63) / 64;  // small images: 1 chunk each
+      nwaves = (nwaves + waves - 1) / waves * waves;
+      const long long qpw = (nquads + nwaves - 1) / nwaves;
+      const int cols = max_cols_for(64 * kPxPerThread, a.GW, a.W);
+      if (cols * a.GD * C / 4 <= 64 * kStageRegs) {
+        const int lds_floats = round_up(cols * a.GD * C, 4) + 64 * kPxPerThread * COUT;
+        apply_fwd_stream_vec4<CIN, COUT, OFFSET>
+            <<<(unsigned)(nwaves / waves), waves * 64, (size_t)waves * lds_floats * sizeof(float), s>>>(
+                a.grid, a.guide, a.input, a.out, a.H, a.W / 4, a.GH, a.GW, a.GD, nquads, qpw,
+                lds_floats, sx, sy);
+        *name = "apply_fwd_stream/vec4";
+        return hipGetLastError();
+      }
+    }
   }
   if constexpr (CIN == 3 && COUT == 3 && OFFSET) {
     if (pl.vec4 && a.variant >= 103 && a.variant <= 105) {

@@ -61,7 +61,7 @@ struct GGParams {
 };
 
 __device__ __forceinline__ int gx0_of(int x, float scale_x) {
-  return floor_to_int(__fmul_rn(x + 0.5f, scale_x) - 0.5f);
+  return floor_to_int(mul_rn(x + 0.5f, scale_x) - 0.5f);
 }
 
 // Smallest x in [0, W] with gx0_of(x) >= g (gx0_of is non-decreasing in x).
@@ -75,7 +75,7 @@ __device__ __forceinline__ int interval_start(int g, int W, float scale_x) {
 }
 
 __device__ __forceinline__ int gy_base_of(int y_first, float scale_y, int GH) {
-  return clamp_index(floor_to_int(__fmul_rn(y_first + 0.5f, scale_y) - 0.5f), 0, GH - 1);
+  return clamp_index(floor_to_int(mul_rn(y_first + 0.5f, scale_y) - 0.5f), 0, GH - 1);
 }
 
 // CIN/COUT/OFFSET as in the forward; APPLY = false: V = dout (C = COUT channels).
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   if (x_hi > x_lo) {
     for (int y = y_first; y < y_end; ++y) {
       // y terms of this row (bilateral_slice_apply.cc:42,47,55-56; weights un-clamped).
-      const float gyf = __fmul_rn(y + 0.5f, p.scale_y);
+      const float gyf = mul_rn(y + 0.5f, p.scale_y);
       const int gy0 = floor_to_int(gyf - 0.5f);
       const float wy0 = tent_weight(gy0 + 0.5f, gyf);
       const float wy1 = tent_weight(gy0 + 1 + 0.5f, gyf);
@@ -175,12 +175,12 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) v[c] = dq[cb][c];
               }
-              const float gxf = __fmul_rn((float)x + 0.5f, p.scale_x);
+              const float gxf = mul_rn((float)x + 0.5f, p.scale_x);
               const float wxa = tent_weight(gc0, gxf);
               const float wxb = tent_weight(gc1, gxf);
               const float w0 = fold_lo ? 0.0f : (fold_hi ? wxa + wxb : wxa);
               const float w1 = fold_lo ? wxa + wxb : (fold_hi ? 0.0f : wxb);
-              const float gzf = __fmul_rn(gq[cb], gd_f);  // gzf = guide * GD  (:120)
+              const float gzf = mul_rn(gq[cb], gd_f);  // gzf = guide * GD  (:120)
 #pragma unroll
               for (int z = 0; z < 8; ++z) {
                 if (z < p.GD) {

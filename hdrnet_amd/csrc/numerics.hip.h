@@ -52,6 +52,18 @@ __device__ __forceinline__ float smoothed_tent_grad(float x, float xs) {
   return (a > 1.0f) ? 0.0f : dx / a;
 }
 
+// a * b rounded to f32 and NOT available for FMA contraction into its consumers.  The
+// reference forms gxf = (x+.5)*scale_x, gyf, gzf as f32 values first; contracting them into
+// fma(x+.5, scale, -.5) or fma(-(x+.5), scale, g0+.5) shifts a weight by up to ulp(gxf)/2
+// (measured: 1.2e-5 output error at GH = 64).  Note __fmul_rn() does NOT stop the
+// contraction pass; the pragma (honoured under hipcc's -ffp-contract=fast-honor-pragmas)
+// drops the `contract` flag from this multiply.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  const float p = a * b;
+  return p;
+}
+
 // floor(v) as int with the conversion saturating (v_cvt_i32_f32 saturates and
 // maps NaN to 0), so a wild guide value cannot index out of bounds once clamped.
 __device__ __forceinline__ int floor_to_int(float v) { return (int)floorf(v); }

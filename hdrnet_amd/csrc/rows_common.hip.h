@@ -71,16 +71,16 @@ __device__ __forceinline__ RowCtx stage_row(float* __restrict__ colY,
                                             int xe, int GH, int GW, int GD, float scale_x,
                                             float scale_y) {
   // Wave-uniform y terms (bilateral_slice_apply.cc:42,47,55-56).
-  const float gyf = __fmul_rn(y + 0.5f, scale_y);  // rounded product, as the reference
+  const float gyf = mul_rn(y + 0.5f, scale_y);  // rounded product, as the reference
   const int gy0 = floor_to_int(gyf - 0.5f);
   const float wy0 = tent_weight(gy0 + 0.5f, gyf);
   const float wy1 = tent_weight(gy0 + 1 + 0.5f, gyf);
   const int gy0c = clamp_index(gy0, 0, GH - 1);
   const int gy1c = clamp_index(gy0 + 1, 0, GH - 1);
   // Grid columns touched by pixels [xs, xe).
-  const int gxlo = clamp_index(floor_to_int(__fmul_rn(xs + 0.5f, scale_x) - 0.5f), 0, GW - 1);
+  const int gxlo = clamp_index(floor_to_int(mul_rn(xs + 0.5f, scale_x) - 0.5f), 0, GW - 1);
   const int gxhi =
-      clamp_index(floor_to_int(__fmul_rn(xe - 1 + 0.5f, scale_x) - 0.5f) + 1, 0, GW - 1);
+      clamp_index(floor_to_int(mul_rn(xe - 1 + 0.5f, scale_x) - 0.5f) + 1, 0, GW - 1);
   const int n = (gxhi - gxlo + 1) * GD * C;  // floats; contiguous in the grid row
   const float* r0 = grid_b + ((size_t)(gy0c * GW + gxlo) * GD) * C;
   const float* r1 = grid_b + ((size_t)(gy1c * GW + gxlo) * GD) * C;
@@ -143,17 +143,20 @@ struct SliceTerms {
 
 template <int C, bool EXACT_SQRT>
 __device__ __forceinline__ SliceTerms slice_terms(const RowCtx& r, float xf, float g) {
+// No FMA contraction in the coordinate arithmetic: the reference rounds gxf / gzf to f32
+// before using them (__fmul_rn alone does not stop the contraction pass).
+#pragma clang fp contract(off)
   constexpr int kVecBytes = C * (int)sizeof(float);
   SliceTerms t;
   // __fmul_rn: the products must be ROUNDED to f32 before use, as in the reference; letting
   // the compiler contract them into the consumers (fma(xf, sx, -0.5), fma(-xf, sx, gx0+.5))
   // shifts the weights by up to ulp(gxf)/2 -- 1e-5 at GW = 256.
-  const float gxf = __fmul_rn(xf, r.scale_x);  // xf = x + 0.5f, exact
+  const float gxf = mul_rn(xf, r.scale_x);  // xf = x + 0.5f, exact
   const float fxl = floorf(gxf - 0.5f);
   const float dx0 = (fxl + 0.5f) - gxf;
   t.wx0 = 1.0f + dx0;
   t.wx1 = -dx0;
-  const float gzf = __fmul_rn(g, r.gd_f);
+  const float gzf = mul_rn(g, r.gd_f);
   const float fzl = floorf(gzf - 0.5f);
   t.dz0 = (fzl + 0.5f) - gzf;
   t.dz1 = (fzl + 1.5f) - gzf;  // NOT dz0 + 1: near a bin centre that loses the low bits of dz1,
