@@ -97,14 +97,14 @@ __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
   float4 iv[(CIN * kPxPerThread) / 4];
   if (active) {
     g4 = *reinterpret_cast<const float4*>(guide + p);
-    if constexpr (ABLATE < 3) {
+    if constexpr (!(ABLATE >= 3 && ABLATE <= 5)) {
       const float4* ip = reinterpret_cast<const float4*>(input + p * CIN);
 #pragma unroll
       for (int q = 0; q < (CIN * kPxPerThread) / 4; ++q) iv[q] = ip[q];
     }
   }
 
-  if constexpr (ABLATE >= 3) {
+  if constexpr (ABLATE >= 3 && ABLATE <= 5) {
     // (3: both contiguous; 4: contiguous loads, strided stores; 5: strided loads, contiguous stores)
     // memory skeleton with LANE-CONTIGUOUS 16-B accesses: thread t touches float4 number
     // t + k * blockDim of the segment's input / output (guide stays as is).
