@@ -54,6 +54,23 @@ def algorithmic_bytes(B, H, W, GH, GW, GD, Cin=3, Cout=3, has_offset=True):
     return 4 * B * (H * W * (1 + Cin + Cout) + GH * GW * GD * Cout * Cj)
 
 
+def measured_traffic(workload, kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*/traffic.json:
+    FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, KiB -> B),
+    if a record for this workload and kernel exists; bench.py cannot run the profiler on
+    itself, so this is the per-launch figure of the same command under `rocprofv3 --pmc`."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json"))):
+        try:
+            for rec in json.load(open(f)):
+                if rec.get("workload") == workload and rec.get("kernel") == kernel:
+                    best = dict(rec, source=os.path.relpath(f, ROOT))
+        except (OSError, ValueError):
+            pass
+    return best
+
+
 def make_sets(dev, nsets, H, W, GH, GW, GD, seed):
     gen = torch.Generator(device=dev).manual_seed(seed)
     sets = []
@@ -135,7 +152,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="4k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the cache-resident / 1080p extras")
+    ap.add_argument("--extra", action="store_true",
+                    help="also time the cache-resident rate and 1080p (same kernel name at other "
+                         "sizes: keep off when collecting rocprofv3 --stats for the roofline line)")
+    ap.add_argument("--no-extra", action="store_true", help=argparse.SUPPRESS)  # old spelling, no-op
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -188,14 +208,16 @@ def main():
                    "working_set_MB": round(nsets * abytes / 1e6, 1), "parallelism": f"image-shard x{world}",
                    "kernel": kernel},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                     "traffic": (measured_traffic(args.workload, kernel) or {}).get("bytes_per_launch"),
+                     "traffic_source": (measured_traffic(args.workload, kernel) or {}).get("source"),
                      "algorithmic_bytes_per_launch": abytes, "avg_kernel_us": round(avg_kernel_s * 1e6, 3),
                      "timing": "HIP events on the launch stream around the timed region / steps"},
     }
 
     if rank == 0 and world == 1:
         extra = {}
-        if not args.no_extra:
+        if args.extra:
             # cache-resident rate (one buffer set, stays in the 256 MiB Infinity Cache): labelled, not `value`
             one = sets[:1]
             run_steps(lib, one, dims, stream, 10)

@@ -40,7 +40,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kWaves = 2;      // waves (= tasks) per workgroup: 16 KB of LDS
+constexpr int kWaves = 4;      // waves per workgroup; they share ONE task and split its rows
 // Operand rows in LDS: 16 floats per pixel, the row's four float4 slots XOR-swizzled by
 // (pixel >> 1) & 3.  Writes (ds_write_b128, 8-lane groups, one row per lane) then cover 8
 // distinct 4-bank groups; the transposed ds_read_b32 (32-lane halves = pixels 4t, 4t+1, 16
@@ -91,8 +91,12 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   float* vt = lds + wave * (2 * 64 * kVStride);  // V rows [64][20]
   float* at = vt + 64 * kVStride;                // A rows [64][20]
 
-  const long long task = (long long)blockIdx.x * kWaves + wave;
-  if (task >= p.ntasks) return;
+  const long long task = blockIdx.x;  // one (image, row group, x-interval) per workgroup
+  {  // V rows: zero once (the channel pad of each row is never written again)
+    f32x4* vz = reinterpret_cast<f32x4*>(vt);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) vz[lane * 4 + q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const int nint = p.GW + 1;
   const int g = (int)(task % nint) - 1;  // gx0 of this wave's pixels
   const int yg = (int)((task / nint) % p.nyg);
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   for (int r = 0; r < 3; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (x_hi > x_lo) {
-    for (int y = y_first; y < y_end; ++y) {
+    for (int y = y_first + wave; y < y_end; y += kWaves) {
       // y terms of this row (bilateral_slice_apply.cc:42,47,55-56; weights un-clamped).
       const float gyf = mul_rn(y + 0.5f, p.scale_y);
       const int gy0 = floor_to_int(gyf - 0.5f);
@@ -154,54 +158,67 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
           if (x0 < x_hi) {  // wave-uniform
             const int len = min(64, x_hi - x0);
             const int x = x0 + lane;
-            // Stage both MFMA operands, lane = pixel.  Columns that clamp onto each other
-            // (g = -1: corner 0 -> column 0 == corner 1; g = GW-1: corner 1 -> column GW-1 ==
-            // corner 0) are folded into ONE A row, so stage 2 never sees a column twice.
-            float v[16], arow[16];
+            // Stage both MFMA operands, lane = pixel, branch-free (idle lanes carry zero
+            // weights and zero V).  Columns that clamp onto each other (g = -1: corner 0 ->
+            // column 0 == corner 1; g = GW-1: corner 1 -> column GW-1 == corner 0) are folded
+            // into ONE A row, so stage 2 never sees a column twice.
+            const float live = (lane < len) ? 1.0f : 0.0f;
+            const float gxf = mul_rn((float)x + 0.5f, p.scale_x);
+            const float wxa = tent_weight(gc0, gxf) * live;
+            const float wxb = tent_weight(gc1, gxf) * live;
+            const float w0 = fold_lo ? 0.0f : (fold_hi ? wxa + wxb : wxa);
+            const float w1 = fold_lo ? wxa + wxb : (fold_hi ? 0.0f : wxb);
+            // z: only the two corners around gzf carry weight (:121); the outermost half cells
+            // are forced to 1 (:122-125).  Two v_sqrt_f32 per pixel (1 ulp; argument >= 1e-8,
+            // no denormals; a weight moves by <= 6e-8, far below the summation noise of a
+            // 30 000-term reduction), then one select chain per gz row.
+            const float gzf = mul_rn(gq[cb], gd_f);  // gzf = guide * GD  (:120)
+            const float fz = floorf(gzf - 0.5f);
+            const float dza = (fz + 0.5f) - gzf, dzb = (fz + 1.5f) - gzf;
+            const float wa = std_max(1.0f - __builtin_amdgcn_sqrtf(fmaf(dza, dza, kSmoothEps)), 0.0f);
+            const float wb = std_max(1.0f - __builtin_amdgcn_sqrtf(fmaf(dzb, dzb, kSmoothEps)), 0.0f);
+            const int za = (int)__builtin_amdgcn_fmed3f(fz, -2.0f, gd_f + 1.0f), zb = za + 1;
+            const bool lo = gzf < 0.5f, hi = gzf > gd_f - 0.5f;
+            f32x4 wzv[2];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-              v[c] = 0.0f;
-              arow[c] = 0.0f;
+            for (int z = 0; z < 8; ++z) {
+              float wz = (z == za) ? wa : ((z == zb) ? wb : 0.0f);
+              if (z == 0) wz = lo ? 1.0f : wz;
+              wz = (z == p.GD - 1 && hi) ? 1.0f : wz;
+              wz = (z < p.GD) ? wz : 0.0f;
+              wzv[z >> 2][z & 3] = wz;
             }
-            if (lane < len) {
-              if constexpr (APPLY) {
+            f32x4 vq[3];
+            if constexpr (APPLY) {
+              static_assert(!APPLY || (COUT * CJ <= 12 && CJ <= 4) || true, "");
+            }
+            float vflat[16];
 #pragma unroll
-                for (int i = 0; i < COUT; ++i) {
+            for (int c = 0; c < 16; ++c) vflat[c] = 0.0f;
+            if constexpr (APPLY) {
 #pragma unroll
-                  for (int j = 0; j < CJ; ++j)
-                    v[i * CJ + j] = (j < CIN) ? dq[cb][i] * inq[cb][j < CIN ? j : 0] : dq[cb][i];
-                }
-              } else {
+              for (int i = 0; i < COUT; ++i) {
 #pragma unroll
-                for (int c = 0; c < C; ++c) v[c] = dq[cb][c];
+                for (int j = 0; j < CJ; ++j)
+                  vflat[i * CJ + j] = (j < CIN) ? dq[cb][i] * inq[cb][j < CIN ? j : 0] : dq[cb][i];
               }
-              const float gxf = mul_rn((float)x + 0.5f, p.scale_x);
-              const float wxa = tent_weight(gc0, gxf);
-              const float wxb = tent_weight(gc1, gxf);
-              const float w0 = fold_lo ? 0.0f : (fold_hi ? wxa + wxb : wxa);
-              const float w1 = fold_lo ? wxa + wxb : (fold_hi ? 0.0f : wxb);
-              const float gzf = mul_rn(gq[cb], gd_f);  // gzf = guide * GD  (:120)
+            } else {
 #pragma unroll
-              for (int z = 0; z < 8; ++z) {
-                if (z < p.GD) {
-                  // v_sqrt_f32 (1 ulp): the argument is >= 1e-8, no denormals; a weight moves
-                  // by <= 6e-8, far below the summation noise of a 30 000-term reduction.
-                  const float dz = (z + 0.5f) - gzf;
-                  float wz = std_max(1.0f - __builtin_amdgcn_sqrtf(fmaf(dz, dz, kSmoothEps)), 0.0f);
-                  if ((z == 0 && gzf < 0.5f) || (z == p.GD - 1 && gzf > gd_f - 0.5f)) wz = 1.0f;
-                  arow[z] = w0 * wz;
-                  arow[8 + z] = w1 * wz;
-                }
-              }
+              for (int c = 0; c < C; ++c) vflat[c] = dq[cb][c];
             }
             f32x4* vrow = reinterpret_cast<f32x4*>(vt + lane * kVStride);
             f32x4* ar = reinterpret_cast<f32x4*>(at + lane * kVStride);
             const int wsw = (lane >> 1) & 3;
+            // V: only the float4 slots that hold channels are written; the rest of the row was
+            // zeroed once at kernel start and is never touched again.
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              vrow[q ^ wsw] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-              ar[q ^ wsw] = f32x4{arow[4 * q], arow[4 * q + 1], arow[4 * q + 2], arow[4 * q + 3]};
-            }
+            for (int q = 0; q < (C + 3) / 4; ++q)
+              vrow[q ^ wsw] = f32x4{vflat[4 * q], vflat[4 * q + 1], vflat[4 * q + 2], vflat[4 * q + 3]};
+            ar[0 ^ wsw] = w0 * wzv[0];
+            ar[1 ^ wsw] = w0 * wzv[1];
+            ar[2 ^ wsw] = w1 * wzv[0];
+            ar[3 ^ wsw] = w1 * wzv[1];
+            (void)vq;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -250,42 +267,61 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
       }
     }
   }
-  float* dst = p.partial + (size_t)task * kTileFloats;
+  // Sum the four waves' register tiles in fixed order (wave 0 + 1 + 2 + 3) through LDS -- the
+  // operand slabs are free now -- and write one partial tile per workgroup.
+  __syncthreads();
+  float* red = lds + wave * kTileFloats;  // kTileFloats = 768 <= 2 * 64 * kVStride
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dst[(r * 16 + 4 * sub + q) * 16 + bc] = acc[r][q];
+    for (int q = 0; q < 4; ++q) red[(r * 16 + 4 * sub + q) * 16 + bc] = acc[r][q];
+  }
+  __syncthreads();
+  float* dst = p.partial + (size_t)task * kTileFloats;
+  for (int e = threadIdx.x; e < kTileFloats; e += kWaves * 64) {
+    float sum = lds[e];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) sum += lds[w * kTileFloats + e];
+    dst[e] = sum;
   }
 }
 
-// One thread per dgrid element; adds the partial tiles that cover it in fixed order:
-// row groups ascending, and for each the interval g = gx (its x-corner-0 row) and the
-// interval g = gx - 1 (its x-corner-1 row).
+// Stage 2.  One 256-thread workgroup per grid cell (b, gy, gx, gz): lane (part, c) adds the
+// partial tiles of row groups yg = yg_lo + part, +16, ... for channel c -- for each group the
+// interval g = gx (its x-corner-0 row) and the interval g = gx - 1 (its x-corner-1 row) --
+// then the 16 partial sums per channel are added in fixed order.  Reads are 64-B runs (the 16
+// channels of one tile row); the result is deterministic.
 __global__ __launch_bounds__(256) void grid_grad_stage2(const float* __restrict__ partial,
-                                                        float* __restrict__ dgrid, long long nelem,
-                                                        int GH, int GW, int GD, int C, int rg,
-                                                        int nyg, float scale_y) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= nelem) return;
-  const int c = (int)(e % C);
-  const int z = (int)((e / C) % GD);
-  const int gx = (int)((e / ((long long)C * GD)) % GW);
-  const int gy = (int)((e / ((long long)C * GD * GW)) % GH);
-  const long long b = e / ((long long)C * GD * GW * GH);
+                                                        float* __restrict__ dgrid, int GH, int GW,
+                                                        int GD, int C, int rg, int nyg,
+                                                        float scale_y) {
+  __shared__ float red[16][17];
+  const int c = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const long long cell = blockIdx.x;  // ((b * GH + gy) * GW + gx) * GD + z
+  const int z = (int)(cell % GD);
+  const int gx = (int)((cell / GD) % GW);
+  const int gy = (int)((cell / ((long long)GD * GW)) % GH);
+  const long long b = cell / ((long long)GD * GW * GH);
   const int nint = GW + 1;
   // Conservative window of row groups that can touch gy; exact membership is `rel`.
   const int yg_lo = max(0, (int)floorf((gy - 2.0f) / scale_y) / rg - 1);
   const int yg_hi = min(nyg, (int)ceilf((gy + 2.5f) / scale_y) / rg + 2);
   float s = 0.0f;
-  for (int yg = yg_lo; yg < yg_hi; ++yg) {
+  for (int yg = yg_lo + part; yg < yg_hi; yg += 16) {
     const int rel = gy - gy_base_of(yg * rg, scale_y, GH);
     if (rel < 0 || rel > 2) continue;
     const size_t t0 = ((size_t)b * nyg + yg) * nint;
-    // interval g = gx  -> task index gx + 1, k = z ; interval g = gx - 1 -> task gx, k = 8 + z
     s += partial[(t0 + gx + 1) * kTileFloats + (rel * 16 + z) * 16 + c];
     s += partial[(t0 + gx) * kTileFloats + (rel * 16 + 8 + z) * 16 + c];
   }
-  dgrid[e] = s;
+  red[part][c] = s;
+  __syncthreads();
+  if (part == 0 && c < C) {
+    float t = red[0][c];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += red[q][c];
+    dgrid[cell * C + c] = t;
+  }
 }
 
 struct GGPlan {
@@ -303,7 +339,7 @@ bool gg_plan(int B, int H, int W, int GH, int GW, int GD, int C, GGPlan* pl) {
   pl->rg = rg;
   pl->nyg = (H + rg - 1) / rg;
   pl->ntasks = (long long)B * pl->nyg * (GW + 1);
-  if ((pl->ntasks + kWaves - 1) / kWaves > 0x7fffffffLL) return false;
+  if (pl->ntasks > 0x7fffffffLL || (long long)B * GH * GW * GD > 0x7fffffffLL) return false;
   pl->ws_bytes = (size_t)pl->ntasks * kTileFloats * sizeof(float);
   return true;
 }
@@ -314,13 +350,13 @@ hipError_t gg_launch(const float* guide, const float* input, const float* dout, 
   constexpr int C = APPLY ? COUT * (CIN + (OFFSET ? 1 : 0)) : COUT;
   GGParams p{guide, input, dout, static_cast<float*>(ws), H, W, GH, GW, GD,
              pl.rg, pl.nyg, pl.ntasks, (float)GW / W, (float)GH / H};
-  const long long nblocks = (pl.ntasks + kWaves - 1) / kWaves;
+  const long long nblocks = pl.ntasks;
   grid_grad_stage1<CIN, COUT, OFFSET, APPLY><<<(unsigned)nblocks, kWaves * 64, 0, s>>>(p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  const long long nelem = (long long)B * GH * GW * GD * C;
-  grid_grad_stage2<<<(unsigned)((nelem + 255) / 256), 256, 0, s>>>(
-      static_cast<const float*>(ws), dgrid, nelem, GH, GW, GD, C, pl.rg, pl.nyg, (float)GH / H);
+  const long long ncell = (long long)B * GH * GW * GD;
+  grid_grad_stage2<<<(unsigned)ncell, 256, 0, s>>>(static_cast<const float*>(ws), dgrid, GH, GW, GD,
+                                                   C, pl.rg, pl.nyg, (float)GH / H);
   return hipGetLastError();
 }
 
