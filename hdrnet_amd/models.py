@@ -1,0 +1,248 @@
+"""The three HDRNet model graphs of the reference (``hdrnet/models.py``) as torch modules.
+
+SURVEY.md section 8f row 1 -- the direct CALLER of the hot path.  The low-resolution coefficient
+network and the point-wise guide are ordinary PyTorch-ROCm ops (stock convs / matmuls on the
+same stream); the full-resolution work is ``layers.bilateral_slice_apply`` = the HIP kernels.
+Nothing here is a kernel; it exists so that BASELINE.json's configs #3 (full inference at 4K)
+and #4 (training step) can be run end to end with the reference's graph.
+
+Conventions follow the reference so that weights could be ported one to one:
+
+* images are NHWC float32 (``lowres_input [B, 256, 256, 3]``, ``fullres_input [B, H, W, 3]``);
+* convs use TensorFlow ``padding='SAME'`` (asymmetric for stride 2: the extra row / column goes
+  at the END -- ``tf_same_pad``), ``tf.contrib.layers.batch_norm`` defaults (no scale,
+  ``center=True``, eps 1e-3, decay 0.999; ``hdrnet/layers.py:40-58``);
+* the prediction conv's channel ``(j * n_out + i) * gd + z`` is unrolled to
+  ``coeffs[b, gy, gx, z, i, j]`` exactly as ``models.py:134-138`` does;
+* fully connected layers see the ``(h, w, c)``-ordered flattening of ``models.py:92-93``.
+
+Parity status of this file: UNPINNED against TensorFlow (no TF1 here to run the reference graph);
+``tests/test_models.py`` pins the pieces that have closed forms (SAME padding, unroll order,
+guide formulas, the hot-path composition against the CPU oracle).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import layers
+
+__all__ = ["HDRNetCurves", "HDRNetPointwiseNNGuide", "HDRNetGaussianPyrNN", "default_params", "tf_same_pad"]
+
+
+def default_params(**overrides) -> Dict:
+    """Model hyper-parameters with the defaults of ``hdrnet/bin/train.py:227-236``."""
+    p = dict(batch_norm=False, net_input_size=256, luma_bins=8, spatial_bin=16,
+             channel_multiplier=1, guide_complexity=16)
+    p.update(overrides)
+    return p
+
+
+def tf_same_pad(x: torch.Tensor, kernel: int, stride: int) -> torch.Tensor:
+    """Pad an NCHW tensor the way TF's padding='SAME' does (total = max((ceil(n/s)-1)*s + k - n, 0),
+    floor(total/2) before, the rest after)."""
+    def pads(n):
+        total = max((math.ceil(n / stride) - 1) * stride + kernel - n, 0)
+        return total // 2, total - total // 2
+    (t, b), (l, r) = pads(x.shape[2]), pads(x.shape[3])
+    return F.pad(x, (l, r, t, b)) if (t or b or l or r) else x
+
+
+class _BN(nn.Module):
+    """tf.contrib.layers.batch_norm(center=True, scale=False): beta only, eps 1e-3, decay 0.999."""
+
+    def __init__(self, ch: int, dims: int):
+        super().__init__()
+        cls = nn.BatchNorm2d if dims == 2 else nn.BatchNorm1d
+        self.bn = cls(ch, eps=1e-3, momentum=1e-3, affine=True)
+        nn.init.ones_(self.bn.weight)
+        nn.init.zeros_(self.bn.bias)
+        self.bn.weight.requires_grad_(False)
+
+    def forward(self, x):
+        return self.bn(x)
+
+
+class _Conv(nn.Module):
+    """``layers.conv`` (hdrnet/layers.py:25-59): SAME conv, optional BN (then no conv bias), ReLU."""
+
+    def __init__(self, cin, cout, k, stride=1, use_bias=True, batch_norm=False, activation=F.relu):
+        super().__init__()
+        self.k, self.stride, self.activation = k, stride, activation
+        self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=0, bias=use_bias and not batch_norm)
+        nn.init.kaiming_normal_(self.conv.weight, mode="fan_in", nonlinearity="relu")  # variance_scaling(2, FAN_IN)
+        if self.conv.bias is not None:
+            nn.init.zeros_(self.conv.bias)
+        self.bn = _BN(cout, 2) if batch_norm else None
+
+    def forward(self, x):
+        x = self.conv(tf_same_pad(x, self.k, self.stride))
+        if self.bn is not None:
+            x = self.bn(x)
+        return self.activation(x) if self.activation is not None else x
+
+
+class _FC(nn.Module):
+    """``layers.fc`` (hdrnet/layers.py:62-93)."""
+
+    def __init__(self, cin, cout, use_bias=True, batch_norm=False, activation=F.relu):
+        super().__init__()
+        self.activation = activation
+        self.fc = nn.Linear(cin, cout, bias=use_bias and not batch_norm)
+        nn.init.kaiming_normal_(self.fc.weight, mode="fan_in", nonlinearity="relu")
+        if self.fc.bias is not None:
+            nn.init.zeros_(self.fc.bias)
+        self.bn = _BN(cout, 1) if batch_norm else None
+
+    def forward(self, x):
+        x = self.fc(x)
+        if self.bn is not None:
+            x = self.bn(x)
+        return self.activation(x) if self.activation is not None else x
+
+
+class _Coefficients(nn.Module):
+    """``HDRNetCurves._coefficients`` (hdrnet/models.py:62-142): splat -> global / local -> fusion ->
+    1x1 prediction -> unroll to ``[B, GH, GW, gd, n_out, n_in]``."""
+
+    def __init__(self, params: Dict, n_out: int, n_in: int):
+        super().__init__()
+        gd, cm, sb = params["luma_bins"], params["channel_multiplier"], params["spatial_bin"]
+        bn = params["batch_norm"]
+        self.gd, self.n_out, self.n_in = gd, n_out, n_in
+        n_ds = int(math.log2(params["net_input_size"] / sb))
+        splat, cin = [], 3
+        for i in range(n_ds):
+            splat.append(_Conv(cin, cm * (2 ** i) * gd, 3, stride=2, batch_norm=bn if i > 0 else False))
+            cin = cm * (2 ** i) * gd
+        self.splat = nn.Sequential(*splat)
+        self.global_conv = nn.Sequential(_Conv(cin, 8 * cm * gd, 3, stride=2, batch_norm=bn),
+                                         _Conv(8 * cm * gd, 8 * cm * gd, 3, stride=2, batch_norm=bn))
+        side = sb // 4  # grid is sb x sb after the splat; two stride-2 convs
+        self.fc1 = _FC(side * side * 8 * cm * gd, 32 * cm * gd, batch_norm=bn)
+        self.fc2 = _FC(32 * cm * gd, 16 * cm * gd, batch_norm=bn)
+        self.fc3 = _FC(16 * cm * gd, 8 * cm * gd, activation=None)
+        self.local1 = _Conv(cin, 8 * cm * gd, 3, batch_norm=bn)
+        self.local2 = _Conv(8 * cm * gd, 8 * cm * gd, 3, use_bias=False, activation=None)
+        self.pred = _Conv(8 * cm * gd, gd * n_out * n_in, 1, activation=None)
+
+    def forward(self, lowres_nhwc: torch.Tensor) -> torch.Tensor:
+        x = lowres_nhwc.permute(0, 3, 1, 2)  # the convs run NCHW; the tensor is 256 x 256
+        splat = self.splat(x)
+        g = self.global_conv(splat)
+        g = g.permute(0, 2, 3, 1).reshape(g.shape[0], -1)  # (h, w, c) flattening, models.py:92-93
+        g = self.fc3(self.fc2(self.fc1(g)))
+        loc = self.local2(self.local1(splat))
+        fusion = F.relu(loc + g[:, :, None, None])
+        pred = self.pred(fusion)  # [B, (j*n_out + i)*gd + z, GH, GW]
+        B, _, GH, GW = pred.shape
+        pred = pred.reshape(B, self.n_in, self.n_out, self.gd, GH, GW)
+        return pred.permute(0, 4, 5, 3, 2, 1).contiguous()  # [B, GH, GW, gd, n_out, n_in]
+
+
+class _CurvesGuide(nn.Module):
+    """``HDRNetCurves._guide`` (models.py:145-190): 3x3 colour matrix, 16-knot per-channel curves,
+    1x1 channel mixing, clip to [0, 1]."""
+
+    def __init__(self, nchans: int = 3, npts: int = 16):
+        super().__init__()
+        self.ccm = nn.Parameter(torch.eye(nchans) + torch.randn(1) * 1e-4)
+        self.ccm_bias = nn.Parameter(torch.zeros(nchans))
+        self.shifts = nn.Parameter(torch.linspace(0, 1, npts + 1)[:-1].repeat(nchans, 1))  # [c, k]
+        slopes = torch.zeros(nchans, npts)
+        slopes[:, 0] = 1.0
+        self.slopes = nn.Parameter(slopes)
+        self.mix_w = nn.Parameter(torch.full((nchans,), 1.0 / nchans))
+        self.mix_b = nn.Parameter(torch.zeros(()))
+
+    def forward(self, im: torch.Tensor) -> torch.Tensor:
+        g = im @ self.ccm + self.ccm_bias
+        g = (self.slopes * F.relu(g.unsqueeze(-1) - self.shifts)).sum(-1)
+        g = g @ self.mix_w + self.mix_b
+        return g.clamp(0.0, 1.0)
+
+
+class _PointwiseNNGuide(nn.Module):
+    """``HDRNetPointwiseNNGuide._guide`` (models.py:203-210): 1x1 conv 3 -> n (+BN, ReLU), 1x1 conv
+    n -> 1, sigmoid.  Point-wise, so it is written on the channel axis of the NHWC image."""
+
+    def __init__(self, n_feats: int, nchans: int = 3):
+        super().__init__()
+        self.w1 = nn.Parameter(torch.empty(nchans, n_feats))
+        nn.init.kaiming_normal_(self.w1.t(), mode="fan_in", nonlinearity="relu")
+        self.bn = nn.BatchNorm1d(n_feats, eps=1e-3, momentum=1e-3)
+        nn.init.ones_(self.bn.weight)
+        self.bn.weight.requires_grad_(False)
+        self.w2 = nn.Parameter(torch.empty(n_feats))
+        nn.init.normal_(self.w2, std=math.sqrt(2.0 / n_feats))
+        self.b2 = nn.Parameter(torch.zeros(()))
+
+    def forward(self, im: torch.Tensor) -> torch.Tensor:
+        h = im @ self.w1  # [B, H, W, n]
+        shape = h.shape
+        h = self.bn(h.reshape(-1, shape[-1])).reshape(shape)
+        return torch.sigmoid(F.relu(h) @ self.w2 + self.b2)
+
+
+class HDRNetCurves(nn.Module):
+    """``hdrnet/models.py:23-196``.  ``forward(lowres_input, fullres_input)`` = ``inference``."""
+
+    n_out, n_in = 3, 4
+
+    def __init__(self, params: Optional[Dict] = None):
+        super().__init__()
+        self.params = default_params(**(params or {}))
+        self.coefficients = _Coefficients(self.params, self.n_out, self.n_in)
+        self.guide = self._make_guide()
+
+    def _make_guide(self) -> nn.Module:
+        return _CurvesGuide()
+
+    def forward(self, lowres_input: torch.Tensor, fullres_input: torch.Tensor) -> torch.Tensor:
+        coeffs = self.coefficients(lowres_input)
+        guide = self.guide(fullres_input)
+        # models.py:193-196 -- the one call site of the hot path
+        return layers.bilateral_slice_apply(coeffs, guide, fullres_input, has_offset=True, name="slice")
+
+
+class HDRNetPointwiseNNGuide(HDRNetCurves):
+    """``hdrnet/models.py:199-210``."""
+
+    def _make_guide(self) -> nn.Module:
+        return _PointwiseNNGuide(self.params["guide_complexity"])
+
+
+class HDRNetGaussianPyrNN(HDRNetPointwiseNNGuide):
+    """``hdrnet/models.py:213-289``: three pyramid levels, one guide and one 3x4 slice-apply per
+    level (coefficient slices ``[:, :, :, :, 3*il:3*il+3, :]``), coarse-to-fine bilinear
+    (align_corners) up-adds."""
+
+    n_scales = 3
+    n_out, n_in = 9, 4
+
+    def _make_guide(self) -> nn.Module:
+        return nn.ModuleList([_PointwiseNNGuide(self.params["guide_complexity"]) for _ in range(self.n_scales)])
+
+    @staticmethod
+    def _resize(x_nhwc: torch.Tensor, h: int, w: int) -> torch.Tensor:
+        y = F.interpolate(x_nhwc.permute(0, 3, 1, 2), size=(h, w), mode="bilinear", align_corners=True)
+        return y.permute(0, 2, 3, 1).contiguous()
+
+    def forward(self, lowres_input: torch.Tensor, fullres_input: torch.Tensor) -> torch.Tensor:
+        coeffs = self.coefficients(lowres_input)
+        lvls: List[torch.Tensor] = [fullres_input]
+        h, w = fullres_input.shape[1:3]
+        for _ in range(self.n_scales - 1):
+            h, w = h // 2, w // 2
+            lvls.append(self._resize(lvls[-1], h, w))
+        guides = [g(lvl) for g, lvl in zip(self.guide, lvls)]
+        current = None
+        for il, (lvl, gd) in enumerate(reversed(list(zip(lvls, guides)))):  # models.py:278
+            c = coeffs[:, :, :, :, il * 3:(il + 1) * 3, :].contiguous()
+            out = layers.bilateral_slice_apply(c, gd, lvl, has_offset=True)
+            current = out if current is None else self._resize(current, out.shape[1], out.shape[2]) + out
+        return current

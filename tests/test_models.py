@@ -1,0 +1,186 @@
+"""hdrnet_amd/models.py: the closed-form pieces on CPU, the hot-path
+composition and the training step on the GPU (BASELINE.json configs #3 / #4 at test size)."""
+import math
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import ROOT
+from hdrnet_amd import models
+
+
+def test_tf_same_padding_matches_tensorflow_rule():
+    # TF SAME, k=3, s=2 on an even extent pads 0 before / 1 after; on an odd extent 1 / 1.
+    x = torch.arange(36.0).reshape(1, 1, 6, 6)
+    p = models.tf_same_pad(x, 3, 2)
+    assert p.shape == (1, 1, 7, 7) and torch.equal(p[0, 0, :6, :6], x[0, 0]) and p[0, 0, 6].abs().sum() == 0
+    x = torch.ones(1, 1, 5, 5)
+    assert models.tf_same_pad(x, 3, 2).shape == (1, 1, 7, 7)
+    assert models.tf_same_pad(x, 3, 1).shape == (1, 1, 7, 7)
+    assert models.tf_same_pad(x, 1, 1).shape == (1, 1, 5, 5)
+    # output extent = ceil(n / s)
+    conv = models._Conv(1, 1, 3, stride=2)
+    for n in (256, 255, 17, 16):
+        assert conv(torch.zeros(1, 1, n, n)).shape[-1] == math.ceil(n / 2)
+
+
+def test_coefficient_unroll_order():
+    """conv channel (j * n_out + i) * gd + z  ->  coeffs[b, gy, gx, z, i, j]  (models.py:134-138)."""
+    p = models.default_params()
+    net = models._Coefficients(p, n_out=3, n_in=4)
+    gd = p["luma_bins"]
+    with torch.no_grad():
+        net.pred.conv.weight.zero_()
+        net.pred.conv.bias.copy_(torch.arange(gd * 12, dtype=torch.float32))
+    with torch.no_grad():
+        out = net(torch.rand(2, 256, 256, 3))
+    assert out.shape == (2, 16, 16, 8, 3, 4)
+    for i in range(3):
+        for j in range(4):
+            for z in range(gd):
+                assert float(out[1, 5, 7, z, i, j]) == (j * 3 + i) * gd + z
+    # numpy restatement of tf.stack(tf.split(.., 12, 3), 4) then tf.stack(tf.split(.., 4, 4), 5)
+    t = np.arange(gd * 12, dtype=np.float32)[None, None, None, :]
+    a = np.stack(np.split(t, 12, axis=3), axis=4)
+    b = np.stack(np.split(a, 4, axis=4), axis=5)
+    assert np.array_equal(b[0, 0, 0], out[0, 0, 0].numpy())
+
+
+def test_parameter_count_and_shapes():
+    m = models.HDRNetPointwiseNNGuide()
+    n = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    assert 4.5e5 < n < 5.2e5, n  # ~482 k parameters at cm=1, gd=8
+    assert models.HDRNetGaussianPyrNN().coefficients.pred.conv.out_channels == 8 * 9 * 4
+
+
+def test_guides_match_their_formulas():
+    torch.manual_seed(0)
+    im = torch.rand(2, 5, 7, 3)
+    g = models._CurvesGuide()
+    out = g(im)
+    # at initialisation: ccm ~ I, curve = relu(x - 0) (slope 1 on the first knot only), mixing = mean
+    assert torch.allclose(out, im.mean(-1).clamp(0, 1), atol=2e-3)
+    pw = models._PointwiseNNGuide(16).eval()
+    with torch.no_grad():
+        pw.bn.running_mean.normal_()
+        pw.bn.running_var.uniform_(0.5, 2.0)
+        pw.bn.bias.normal_()
+    h = im.numpy() @ pw.w1.detach().numpy()
+    h = (h - pw.bn.running_mean.numpy()) / np.sqrt(pw.bn.running_var.numpy() + 1e-3) + pw.bn.bias.detach().numpy()
+    ref = 1.0 / (1.0 + np.exp(-(np.maximum(h, 0) @ pw.w2.detach().numpy() + float(pw.b2.detach()))))
+    assert np.allclose(pw(im).detach().numpy(), ref, atol=1e-5)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _grad_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from hdrnet_amd import dist as hd
+    from hdrnet_amd import models as M
+    hd.init(backend="gloo")
+    torch.manual_seed(0)  # same weights everywhere
+    net = M._Coefficients(M.default_params(), 3, 4)
+    torch.manual_seed(100 + rank)  # different data per rank
+    x = torch.rand(2, 256, 256, 3)
+    net(x).square().mean().backward()
+    local = [p.grad.clone() for p in net.parameters() if p.grad is not None]
+    n = hd.allreduce_gradients_flat(net.parameters(), world)
+    # reference: gather every rank's local grads and average
+    gathered = [None] * world
+    torch.distributed.all_gather_object(gathered, local)
+    ok = True
+    for k, p in enumerate([p for p in net.parameters() if p.grad is not None]):
+        want = sum(g[k] for g in gathered) / world
+        ok = ok and torch.allclose(p.grad, want, rtol=1e-5, atol=1e-7)
+    if rank == 0:
+        q.put((ok, n))
+    hd.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_flat_bucket_gradient_allreduce_gloo():
+    """The training step's one collective: a single flat fp32 bucket, 2 ranks, gloo."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    ok, n = q.get()
+    assert ok and 4.0e5 < n < 5.2e5
+
+
+# ---- GPU: the model drives the HIP hot path ---------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls", ["HDRNetCurves", "HDRNetPointwiseNNGuide", "HDRNetGaussianPyrNN"])
+def test_model_inference_composes_with_oracle(cls, port):
+    """coeffs / guide from the torch graph, slice-apply from the HIP kernel == the same coeffs /
+    guide pushed through the CPU oracle (pins the hot path inside each model graph)."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    m = getattr(models, cls)().to(dev).eval()
+    low = torch.rand(1, 256, 256, 3, device=dev)
+    full = torch.rand(1, 270, 480, 3, device=dev)
+    with torch.no_grad():
+        out = m(low, full)
+        coeffs = m.coefficients(low)
+    assert out.shape == (1, 270, 480, 3) and torch.isfinite(out).all()
+    if cls != "HDRNetGaussianPyrNN":
+        with torch.no_grad():
+            guide = m.guide(full)
+        g5 = coeffs.reshape(1, 16, 16, 8, 12).cpu().numpy()
+        want = port.bilateral_slice_apply(g5, guide.cpu().numpy(), full.cpu().numpy(), True)
+        np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_config3_full_inference_4k():
+    """BASELINE.json configs[2]: HDRNetPointwiseNNGuide, 3840x2160, batch 1, one MI355X."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = models.HDRNetPointwiseNNGuide().to(dev).eval()
+    low = torch.rand(1, 256, 256, 3, device=dev)
+    full = torch.rand(1, 2160, 3840, 3, device=dev)
+    with torch.no_grad():
+        out = m(low, full)
+    from hdrnet_amd import hdrnet_ops
+    assert hdrnet_ops.last_kernel() == "apply_fwd_rows/vec4"
+    assert out.shape == (1, 2160, 3840, 3) and torch.isfinite(out).all()
+
+
+@pytest.mark.gpu
+def test_config4_training_step_reduces_loss():
+    """BASELINE.json configs[3] at test size: fwd + bwd through the HIP VJPs + Adam; the L2 loss
+    (hdrnet/metrics.py:21-24) to a fixed target falls."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = models.HDRNetPointwiseNNGuide(dict(batch_norm=True)).to(dev).train()
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+    low = torch.rand(4, 256, 256, 3, device=dev)
+    full = F.interpolate(low.permute(0, 3, 1, 2), size=(270, 480), mode="bilinear").permute(0, 2, 3, 1).contiguous()
+    target = (full * 0.8 + 0.1).clamp(0, 1)
+    losses = []
+    for _ in range(30):
+        opt.zero_grad()
+        loss = (m(low, full) - target).square().mean()
+        loss.backward()
+        from hdrnet_amd import dist as hd
+        hd.allreduce_gradients_flat(m.parameters())  # no-op at world size 1
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < 0.5 * losses[0], losses[::5]

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""End-to-end timings of the reference's model graphs with the HIP hot path inside
+(BASELINE.json configs #3 and #4 on ONE MI355X; the 8-GPU runs are the driver's).
+
+    python tools/e2e_bench.py [--steps 20]
+
+config #3: HDRNetPointwiseNNGuide inference, 3840x2160, batch 1 (coefficient net + guide in
+           PyTorch-ROCm ops, slice-apply in the HIP kernel).
+config #4: training step (fwd + bwd + Adam) at 1920x1080, 4 images per GPU (= 32 / 8).
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from hdrnet_amd import dist as hd  # noqa: E402
+from hdrnet_amd import models  # noqa: E402
+
+
+def timeit(fn, steps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / steps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+
+    m = models.HDRNetPointwiseNNGuide().to(dev).eval()
+    low = torch.rand(1, 256, 256, 3, device=dev)
+    full = torch.rand(1, 2160, 3840, 3, device=dev)
+    with torch.no_grad():
+        t_all = timeit(lambda: m(low, full), args.steps)
+        t_coef = timeit(lambda: m.coefficients(low), args.steps)
+        t_guide = timeit(lambda: m.guide(full), args.steps)
+        coeffs, guide = m.coefficients(low), m.guide(full)
+        from hdrnet_amd import layers
+        t_slice = timeit(lambda: layers.bilateral_slice_apply(coeffs, guide, full, has_offset=True), args.steps)
+    mp = 2160 * 3840 / 1e6
+    print(f"config #3  HDRNetPointwiseNNGuide 3840x2160 b=1: {t_all * 1e3:.3f} ms/frame = {mp / t_all:.0f} MP/s "
+          f"(coefficients {t_coef * 1e3:.3f} ms, guide net {t_guide * 1e3:.3f} ms, slice-apply {t_slice * 1e3:.3f} ms)")
+
+    mt = models.HDRNetPointwiseNNGuide(dict(batch_norm=True)).to(dev).train()
+    opt = torch.optim.Adam([p for p in mt.parameters() if p.requires_grad], lr=1e-4)
+    B = 4
+    low = torch.rand(B, 256, 256, 3, device=dev)
+    full = torch.rand(B, 1080, 1920, 3, device=dev)
+    target = torch.rand(B, 1080, 1920, 3, device=dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = (mt(low, full) - target).square().mean()
+        loss.backward()
+        hd.allreduce_gradients_flat(mt.parameters())
+        opt.step()
+
+    t_step = timeit(step, max(5, args.steps // 2))
+    print(f"config #4  training step 1920x1080, {B} images/GPU: {t_step * 1e3:.2f} ms/step = "
+          f"{B * 1080 * 1920 / 1e6 / t_step:.0f} MP/s per GPU")
+
+
+if __name__ == "__main__":
+    main()
