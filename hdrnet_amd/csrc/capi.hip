@@ -124,6 +124,37 @@ int hdrnet_bilateral_slice_apply_f32(const float* grid, const float* guide, cons
                                              Cout, has_offset, HDRNET_KERNEL_AUTO, stream);
 }
 
+int hdrnet_bilateral_slice_apply_nnguide_f32(const float* grid, const float* input,
+                                             const float* guide_conv1, const float* guide_conv2,
+                                             float* out, float* guide_out, int B, int H, int W,
+                                             int GH, int GW, int GD, int Cin, int Cout,
+                                             int has_offset, int n_feats, void* stream) {
+  using namespace hdrnet_amd;
+  if (int rc = check_common(B, H, W, GH, GW, GD)) return rc;
+  if (Cin <= 0 || Cout <= 0 || n_feats <= 0 || n_feats > 4096)
+    return fail(HDRNET_INVALID_ARGUMENT, "bad channel / feature counts (Cin=%d, Cout=%d, n=%d)", Cin,
+                Cout, n_feats);
+  if ((long long)B * H * W == 0) {
+    set_kernel("noop");
+    g_error[0] = '\0';
+    return HDRNET_OK;
+  }
+  if (!grid || !input || !out || !guide_conv1 || !guide_conv2)
+    return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  ApplyArgs a{grid, nullptr, input, out, B, H, W, GH, GW, GD, Cin, Cout,
+              Cin + (has_offset ? 1 : 0), has_offset != 0, 0};
+  if (!apply_fwd_nnguide_supported(a, guide_out))
+    return fail(HDRNET_INVALID_ARGUMENT,
+                "fused guide + slice-apply needs (Cin, Cout) in {(3,3), (1,1)}, W %% 4 == 0 and 16-B "
+                "aligned buffers; run the guide network and hdrnet_bilateral_slice_apply_f32 instead");
+  const char* name = "";
+  const int rc = check_launch(launch_apply_fwd_nnguide(a, guide_conv1, guide_conv2, n_feats, guide_out,
+                                                      static_cast<hipStream_t>(stream), &name),
+                              "BilateralSliceApplyNNGuide");
+  if (rc == HDRNET_OK) set_kernel(name);
+  return rc;
+}
+
 size_t hdrnet_bilateral_slice_apply_grad_workspace_bytes(int B, int H, int W, int GH, int GW,
                                                          int GD, int Cin, int Cout,
                                                          int has_offset) {

@@ -63,6 +63,12 @@ hipError_t launch_slice_grad_generic(const SliceGradArgs& a, hipStream_t s);
 bool apply_fwd_rows_supported(const ApplyArgs& a);
 hipError_t launch_apply_fwd_rows(const ApplyArgs& a, hipStream_t s, const char** name);
 
+// Fused point-wise-NN guide + slice-apply forward (apply_fwd_rows.hip, GUIDE_NN).
+bool apply_fwd_nnguide_supported(const ApplyArgs& a, const float* guide_out);
+hipError_t launch_apply_fwd_nnguide(const ApplyArgs& a, const float* conv1, const float* conv2,
+                                    int n_feats, float* guide_out, hipStream_t s,
+                                    const char** name);
+
 // apply_bwd_rows.hip -- LDS-staged per-pixel VJPs: dguide and dinput in one pass
 // (BilateralSliceApply), dguide (BilateralSlice).  dgrid is not their business.
 bool apply_vjp_rows_supported(const ApplyGradArgs& a);

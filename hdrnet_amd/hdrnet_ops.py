@@ -34,7 +34,8 @@ import torch
 
 from . import _lib
 
-__all__ = ["bilateral_slice", "bilateral_slice_apply", "kernel_override", "last_kernel"]
+__all__ = ["bilateral_slice", "bilateral_slice_apply", "bilateral_slice_apply_nnguide",
+           "kernel_override", "last_kernel"]
 
 _tls = threading.local()
 
@@ -267,3 +268,43 @@ def bilateral_slice_apply(grid: torch.Tensor, guide: torch.Tensor, input: torch.
     (bilateral_slice_apply_op.cc:382-386)."""
     del name
     return _BilateralSliceApply.apply(grid, guide, input, has_offset)
+
+
+def bilateral_slice_apply_nnguide(grid: torch.Tensor, input: torch.Tensor,  # noqa: A002
+                                  guide_conv1: torch.Tensor, guide_conv2: torch.Tensor,
+                                  has_offset: bool = True, return_guide: bool = False):
+    """Inference-only fusion of ``HDRNetPointwiseNNGuide._guide`` (hdrnet/models.py:203-210, batch
+    norm folded) with ``bilateral_slice_apply``: the guide is computed in registers and never
+    written to memory (unless ``return_guide``).
+
+    ``guide_conv1`` is ``[n, Cin + 1]`` (weights then bias of feature k) and ``guide_conv2``
+    ``[n + 1]`` (mixing weights then bias) -- the layout ``hdrnet/bin/freeze_graph.py:170-184``
+    exports as ``guide_conv1.bin`` / ``guide_conv2.bin``.  No autograd (use the un-fused ops for
+    training).  Same shape rules as ``bilateral_slice_apply``; raises ``ValueError`` where the
+    fused kernel has no specialisation."""
+    _require_f32("guide_conv1", guide_conv1)
+    _require_f32("guide_conv2", guide_conv2)
+    if input.dim() != 4:
+        raise ValueError(f"Input image should be 4D (batch_size, height, width, input_channels), got {tuple(input.shape)}")
+    Cin = input.shape[3]
+    if guide_conv1.dim() != 2 or guide_conv1.shape[1] != Cin + 1:
+        raise ValueError(f"guide_conv1 should be [n, Cin + 1] = [n, {Cin + 1}], got {tuple(guide_conv1.shape)}")
+    n = guide_conv1.shape[0]
+    if tuple(guide_conv2.shape) != (n + 1,):
+        raise ValueError(f"guide_conv2 should be [n + 1] = [{n + 1}], got {tuple(guide_conv2.shape)}")
+    fake_guide = input[..., 0]  # shape carrier for the shared rule checks; never read
+    B, H, W, GH, GW, GD, Cin, Cout = _check_apply(grid, fake_guide, input, has_offset)
+    for nm, t in (("guide_conv1", guide_conv1), ("guide_conv2", guide_conv2)):
+        _require_gpu(nm, t)
+    grid, inp = grid.detach().contiguous(), input.detach().contiguous()
+    c1, c2 = guide_conv1.detach().contiguous(), guide_conv2.detach().contiguous()
+    dev = inp.device
+    out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
+    gout = torch.empty((B, H, W), dtype=torch.float32, device=dev) if return_guide else None
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        rc = lib.hdrnet_bilateral_slice_apply_nnguide_f32(
+            grid.data_ptr(), inp.data_ptr(), c1.data_ptr(), c2.data_ptr(), out.data_ptr(), _ptr(gout),
+            B, H, W, GH, GW, GD, Cin, Cout, int(bool(has_offset)), n, _stream(dev))
+    _lib.check(rc, "BilateralSliceApplyNNGuide")
+    return (out, gout) if return_guide else out

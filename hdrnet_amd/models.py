@@ -187,6 +187,16 @@ class _PointwiseNNGuide(nn.Module):
         h = self.bn(h.reshape(-1, shape[-1])).reshape(shape)
         return torch.sigmoid(F.relu(h) @ self.w2 + self.b2)
 
+    def folded(self):
+        """Batch-norm folded into the first layer, in the reference's export layout
+        (hdrnet/bin/freeze_graph.py:170-184): conv1 [n, Cin + 1], conv2 [n + 1]."""
+        inv = torch.rsqrt(self.bn.running_var + self.bn.eps) * self.bn.weight
+        w = self.w1 * inv  # [Cin, n]
+        b = self.bn.bias - self.bn.running_mean * inv
+        conv1 = torch.cat([w.t(), b[:, None]], dim=1).contiguous()
+        conv2 = torch.cat([self.w2, self.b2.reshape(1)]).contiguous()
+        return conv1.detach(), conv2.detach()
+
 
 class HDRNetCurves(nn.Module):
     """``hdrnet/models.py:23-196``.  ``forward(lowres_input, fullres_input)`` = ``inference``."""
@@ -210,10 +220,27 @@ class HDRNetCurves(nn.Module):
 
 
 class HDRNetPointwiseNNGuide(HDRNetCurves):
-    """``hdrnet/models.py:199-210``."""
+    """``hdrnet/models.py:199-210``.  In eval mode without autograd the guide network is FUSED
+    into the slice-apply kernel: the guide never touches HBM and the
+    16-channel full-resolution intermediate is never materialised."""
+
+    fuse_guide = True
 
     def _make_guide(self) -> nn.Module:
         return _PointwiseNNGuide(self.params["guide_complexity"])
+
+    def forward(self, lowres_input: torch.Tensor, fullres_input: torch.Tensor) -> torch.Tensor:
+        fusable = (self.fuse_guide and not self.training and not torch.is_grad_enabled()
+                   and fullres_input.is_cuda and fullres_input.shape[2] % 4 == 0)
+        if not fusable:
+            return super().forward(lowres_input, fullres_input)
+        from . import hdrnet_ops
+        coeffs = self.coefficients(lowres_input)
+        gs = coeffs.shape
+        conv1, conv2 = self.guide.folded()
+        return hdrnet_ops.bilateral_slice_apply_nnguide(
+            coeffs.reshape(gs[0], gs[1], gs[2], gs[3], gs[4] * gs[5]), fullres_input, conv1, conv2,
+            has_offset=True)
 
 
 class HDRNetGaussianPyrNN(HDRNetPointwiseNNGuide):

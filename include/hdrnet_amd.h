@@ -96,6 +96,22 @@ int hdrnet_bilateral_slice_apply_f32_ex(const float* grid, const float* guide,
                                         int Cin, int Cout, int has_offset,
                                         unsigned flags, void* stream);
 
+/* Fused point-wise guide network + BilateralSliceApply forward (inference).
+ * guide[b,y,x] = sigmoid(conv2[n] + sum_k conv2[k] * relu(conv1[k][Cin] + sum_j conv1[k][j] * input[b,y,x,j]))
+ * is computed in registers and sliced immediately; it is written to `guide_out` [B][H][W] only if
+ * that pointer is non-NULL.  This is HDRNetPointwiseNNGuide._guide (hdrnet/models.py:203-210) with
+ * batch-norm folded, in the parameter layout hdrnet/bin/freeze_graph.py:170-184 exports
+ * (guide_conv1.bin = [n][Cin+1], guide_conv2.bin = [n+1]) -- the fusion the reference's GL
+ * renderer performs (benchmark/assets/std.frag:36-52, benchmark/src/renderer.cc:119-171).
+ * Supported: (Cin, Cout) in {(3,3), (1,1)}, W % 4 == 0, 16-B aligned buffers; otherwise
+ * HDRNET_INVALID_ARGUMENT (run the guide network and the plain entry point instead). */
+int hdrnet_bilateral_slice_apply_nnguide_f32(const float* grid, const float* input,
+                                             const float* guide_conv1,
+                                             const float* guide_conv2, float* out,
+                                             float* guide_out, int B, int H, int W,
+                                             int GH, int GW, int GD, int Cin, int Cout,
+                                             int has_offset, int n_feats, void* stream);
+
 /* Scratch (bytes) the grad entry point wants for its deterministic two-stage
  * grid-gradient reduction; 0 is a legal answer.  The caller passes a device
  * buffer of at least this size as `workspace` (contents undefined on entry and

@@ -22,3 +22,16 @@ from .cpu_oracle import (  # noqa: F401
     port,
     ref,
 )
+
+
+def pointwise_nn_guide(inp, conv1, conv2):
+    """float32 numpy restatement of HDRNetPointwiseNNGuide._guide with batch-norm folded
+    (hdrnet/models.py:203-210; parameter layout of hdrnet/bin/freeze_graph.py:170-184):
+    guide = sigmoid(conv2[n] + sum_k conv2[k] * relu(conv1[k][Cin] + sum_j conv1[k][j] * in_j))."""
+    import numpy as np
+    inp = np.asarray(inp, np.float32)
+    conv1 = np.asarray(conv1, np.float32)
+    conv2 = np.asarray(conv2, np.float32)
+    h = inp @ conv1[:, :-1].T + conv1[:, -1]
+    t = (np.maximum(h, np.float32(0)) @ conv2[:-1] + conv2[-1]).astype(np.float32)
+    return (np.float32(1) / (np.float32(1) + np.exp(-t))).astype(np.float32)

@@ -281,6 +281,45 @@ def test_slice_random(dev, ops, port, shape):
     grads_close(N(tgu.grad), wgu, "dguide")
 
 
+# ---- fused point-wise guide network + slice-apply -------------------
+@pytest.mark.parametrize("shape", [(2, 36, 64, 16, 16, 8, 3, 16), (1, 128, 1024, 16, 16, 8, 3, 16),
+                                   (1, 40, 48, 8, 8, 4, 1, 5)])
+def test_nnguide_fused_matches_composed_oracle(dev, ops, port, shape):
+    """guide = folded point-wise NN (numpy, oracle.pointwise_nn_guide) -> oracle slice-apply, vs the
+    fused kernel.  The guide itself must agree to 1e-6; the output carries the guide's ulp-level
+    differences times d out / d guide = GD * (z-difference of the grid), hence 2e-5."""
+    import oracle
+    B, H, W, GH, GW, GD, Cin, n = shape
+    rng = np.random.default_rng(sum(shape))
+    grid = rng.random((B, GH, GW, GD, Cin * (Cin + 1))).astype(np.float32)
+    inp = rng.random((B, H, W, Cin)).astype(np.float32)
+    conv1 = (rng.standard_normal((n, Cin + 1)) * 0.8).astype(np.float32)
+    conv2 = (rng.standard_normal(n + 1) * 0.5).astype(np.float32)
+    guide = oracle.pointwise_nn_guide(inp, conv1, conv2)
+    want = port.bilateral_slice_apply(grid, guide, inp, True)
+    out, gout = ops.bilateral_slice_apply_nnguide(T(grid, dev), T(inp, dev), T(conv1, dev), T(conv2, dev),
+                                                  has_offset=True, return_guide=True)
+    assert ops.last_kernel() == "apply_fwd_rows/vec4+nnguide"
+    np.testing.assert_allclose(N(gout), guide, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(N(out), want, rtol=2e-5, atol=2e-5)
+    # and against the un-fused HIP path fed with the fused kernel's own guide: same slicing code
+    ref = ops.bilateral_slice_apply(T(grid, dev), gout, T(inp, dev), has_offset=True)
+    torch.testing.assert_close(out, ref, rtol=1e-6, atol=1e-6)
+    out2 = ops.bilateral_slice_apply_nnguide(T(grid, dev), T(inp, dev), T(conv1, dev), T(conv2, dev))
+    assert torch.equal(out2, out)
+
+
+def test_nnguide_rejects_unsupported(dev, ops):
+    from hdrnet_amd import _lib
+    g = torch.rand((1, 4, 4, 4, 12), device=dev)
+    with pytest.raises(_lib.HdrnetInvalidArgument):   # W % 4 != 0
+        ops.bilateral_slice_apply_nnguide(g, torch.rand((1, 8, 10, 3), device=dev), torch.rand((16, 4), device=dev),
+                                          torch.rand((17,), device=dev))
+    with pytest.raises(ValueError, match="guide_conv1"):
+        ops.bilateral_slice_apply_nnguide(g, torch.rand((1, 8, 8, 3), device=dev), torch.rand((16, 3), device=dev),
+                                          torch.rand((17,), device=dev))
+
+
 # ---- layers.py wrappers (6-D grids) -----------------------------------------------------------------
 def test_layers_6d(dev, ops, port):
     from hdrnet_amd import layers

@@ -159,8 +159,13 @@ def test_config3_full_inference_4k():
     with torch.no_grad():
         out = m(low, full)
     from hdrnet_amd import hdrnet_ops
-    assert hdrnet_ops.last_kernel() == "apply_fwd_rows/vec4"
+    assert hdrnet_ops.last_kernel() == "apply_fwd_rows/vec4+nnguide"  # guide net fused in eval mode
     assert out.shape == (1, 2160, 3840, 3) and torch.isfinite(out).all()
+    m.fuse_guide = False
+    with torch.no_grad():
+        ref = m(low, full)
+    assert hdrnet_ops.last_kernel() == "apply_fwd_rows/vec4"
+    torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-5)
 
 
 @pytest.mark.gpu

@@ -84,6 +84,15 @@ def main():
         chk(lib.hdrnet_bilateral_slice_apply_f32(s["grid"].data_ptr(), s["guide"].data_ptr(), s["inp"].data_ptr(),
                                                  s["out"].data_ptr(), 1, H, W, GH, GW, GD, Cin, Cout, 1, stream))
 
+    conv1 = (torch.randn((16, Cin + 1), device=dev, generator=gen) * 0.8).contiguous()
+    conv2 = (torch.randn((17,), device=dev, generator=gen) * 0.5).contiguous()
+
+    def apply_fwd_nnguide(k):
+        s = S[k % nsets]
+        chk(lib.hdrnet_bilateral_slice_apply_nnguide_f32(
+            s["grid"].data_ptr(), s["inp"].data_ptr(), conv1.data_ptr(), conv2.data_ptr(), s["out"].data_ptr(),
+            None, 1, H, W, GH, GW, GD, Cin, Cout, 1, 16, stream))
+
     def apply_bwd(k, dg=True, dgu=True, di=True):
         s = S[k % nsets]
         chk(lib.hdrnet_bilateral_slice_apply_grad_f32(
@@ -118,6 +127,7 @@ def main():
 
     print(f"{desc}; {nsets} rotating sets; workspace apply-grad {wsb / 1e6:.1f} MB")
     run("apply fwd", apply_fwd, 4 * npx * (1 + Cin + Cout) + gridb)
+    run("guide-NN(16) + apply fwd fused", apply_fwd_nnguide, 4 * npx * (Cin + Cout) + gridb)
     run("apply bwd (all three)", apply_bwd, 4 * npx * (1 + Cin + Cout) + 4 * npx * (1 + Cin) + 2 * gridb)
     run("apply bwd dguide+dinput", lambda k: apply_bwd(k, dg=False), 4 * npx * (1 + Cin + Cout) + 4 * npx * (1 + Cin) + gridb)
     run("apply bwd dgrid only", lambda k: apply_bwd(k, dgu=False, di=False), 4 * npx * (1 + Cin + Cout) + gridb)
