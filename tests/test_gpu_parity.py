@@ -345,7 +345,7 @@ def test_layers_6d(dev, ops, port):
 
 
 # ---- full-size frames: size-independent properties (the oracle takes seconds there) ----------------
-FULL = [(1080, 1920, 16, 16), (2160, 3840, 16, 16)]
+FULL = [(1080, 1920, 16, 16), (2160, 3840, 16, 16), (3000, 4000, 32, 32)]  # configs #2, #3, #5
 
 
 @pytest.mark.parametrize("H,W,GH,GW", FULL)

@@ -189,3 +189,24 @@ def test_config4_training_step_reduces_loss():
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < 0.5 * losses[0], losses[::5]
+
+
+@pytest.mark.gpu
+def test_graphed_inference_replays_exactly():
+    """hipGraph capture of the whole inference (torch ops + the HIP kernels through ctypes)."""
+    from hdrnet_amd.runtime import GraphedInference
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    m = models.HDRNetPointwiseNNGuide().to(dev).eval()
+    low = torch.rand(1, 256, 256, 3, device=dev)
+    full = torch.rand(1, 540, 960, 3, device=dev)
+    g = GraphedInference(m, [low, full])
+    for seed in (5, 6):
+        torch.manual_seed(seed)
+        low2, full2 = torch.rand_like(low), torch.rand_like(full)
+        with torch.no_grad():
+            want = m(low2, full2)
+        got = g(low2, full2).clone()
+        torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
+    with pytest.raises(ValueError):
+        g(low, torch.rand(1, 540, 964, 3, device=dev))

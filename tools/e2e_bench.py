@@ -52,21 +52,10 @@ def main():
         t_slice = timeit(lambda: layers.bilateral_slice_apply(coeffs, guide, full, has_offset=True), args.steps)
         # the whole inference captured in one hipGraph: the coefficient network is ~25 tiny
         # launches on a 256 x 256 tensor -- launch-bound in eager mode
-        static_low, static_full = low.clone(), full.clone()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                m(static_low, static_full)
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_out = m(static_low, static_full)
-        t_graph = timeit(graph.replay, args.steps)
-        ref = m(low, full)
-        graph.replay()
-        torch.cuda.synchronize()
-        assert torch.allclose(static_out, ref, rtol=1e-5, atol=1e-5)
+        from hdrnet_amd.runtime import GraphedInference
+        graphed = GraphedInference(m, [low, full])
+        t_graph = timeit(lambda: graphed(graphed.static_inputs[0], graphed.static_inputs[1]), args.steps)
+        assert torch.allclose(graphed(low, full), m(low, full), rtol=1e-5, atol=1e-5)
     mp = 2160 * 3840 / 1e6
     print(f"config #3  (hipGraph replay of the whole inference): {t_graph * 1e3:.3f} ms/frame = {mp / t_graph:.0f} MP/s")
     print(f"config #3  HDRNetPointwiseNNGuide 3840x2160 b=1: {t_all * 1e3:.3f} ms/frame = {mp / t_all:.0f} MP/s "
