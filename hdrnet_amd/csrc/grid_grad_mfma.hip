@@ -60,6 +60,14 @@ struct GGParams {
   float scale_x, scale_y;  // GW / W, GH / H  (forward's expressions)
 };
 
+// LDS traffic of ONE wave needs no fence: the LDS executes a wave's instructions in order, so
+// a ds_read issued after a ds_write of the same wave sees all 64 lanes' data.  (A
+// `fence(release, "wavefront")` costs an s_waitcnt vmcnt(0), i.e. would drain the prefetch.)
+__device__ __forceinline__ void wave_lds_order() {
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ int gx0_of(int x, float scale_x) {
   return floor_to_int(mul_rn(x + 0.5f, scale_x) - 0.5f);
 }
@@ -119,153 +127,162 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
 #pragma unroll
   for (int r = 0; r < 3; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (x_hi > x_lo) {
-    for (int y = y_first + wave; y < y_end; y += kWaves) {
-      // y terms of this row (bilateral_slice_apply.cc:42,47,55-56; weights un-clamped).
+  // Pixel batches of this wave, flattened over (row, batch-in-row): rows y_first + wave,
+  // + kWaves, ...; per row ceil(interval / 256) batches of <= 4 chunks of 64 pixels.  The loads
+  // of batch t+1 are issued before batch t is processed (two register sets), so a row's HBM
+  // latency hides behind the previous batch's ~6k cycles of staging + MFMA.
+  struct Batch {
+    float g[kBatch], in[kBatch][CIN_Q], d[kBatch][COUT];
+  };
+  const int span = x_hi - x_lo;
+  const int nbr = (span + 64 * kBatch - 1) / (64 * kBatch);  // batches per row
+  const int nrows = (y_end - (y_first + wave) + kWaves - 1) / kWaves;
+  const int nbt = (span > 0 && nrows > 0) ? nrows * nbr : 0;
+  auto load_batch = [&](int t, Batch& bt) {
+    const int r = t / nbr, bi = t - r * nbr;
+    const int y = y_first + wave + r * kWaves;
+    const size_t prow = ((size_t)b * p.H + y) * p.W;
+    const int xb = x_lo + bi * 64 * kBatch;
+#pragma unroll
+    for (int cb = 0; cb < kBatch; ++cb) {
+      // unconditional (clamped) loads: no exec-masked branch around VMEM keeps the compiler's
+      // vmcnt counts exact; pixels past the interval are zero-weighted below.
+      const size_t px = prow + min(xb + 64 * cb + lane, x_hi - 1);
+      bt.g[cb] = p.guide[px];
+      if constexpr (APPLY && CIN > 0) {
+#pragma unroll
+        for (int j = 0; j < CIN; ++j) bt.in[cb][j] = p.input[px * CIN + j];
+      }
+#pragma unroll
+      for (int i = 0; i < COUT; ++i) bt.d[cb][i] = p.dout[px * COUT + i];
+    }
+  };
+
+  Batch cur, nxt;
+  if (nbt > 0) load_batch(0, cur);
+  f32x4 dacc = {0.f, 0.f, 0.f, 0.f}, dacc2 = {0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < nbt; ++t) {
+    if (t + 1 < nbt) load_batch(t + 1, nxt);
+    const int r = t / nbr, bi = t - r * nbr;
+    const int y = y_first + wave + r * kWaves;
+    const int xb = x_lo + bi * 64 * kBatch;
+#pragma unroll
+    for (int cb = 0; cb < kBatch; ++cb) {
+      const int x0 = xb + 64 * cb;
+      if (x0 < x_hi) {  // wave-uniform
+        const int len = min(64, x_hi - x0);
+        const int x = x0 + lane;
+        // Stage both MFMA operands, lane = pixel, branch-free (idle lanes carry zero weights
+        // and zero V).  Columns that clamp onto each other (g = -1: corner 0 -> column 0 ==
+        // corner 1; g = GW-1: corner 1 -> column GW-1 == corner 0) are folded into ONE A row,
+        // so stage 2 never sees a column twice.
+        const float live = (lane < len) ? 1.0f : 0.0f;
+        const float gxf = mul_rn((float)x + 0.5f, p.scale_x);
+        const float wxa = tent_weight(gc0, gxf) * live;
+        const float wxb = tent_weight(gc1, gxf) * live;
+        const float w0 = fold_lo ? 0.0f : (fold_hi ? wxa + wxb : wxa);
+        const float w1 = fold_lo ? wxa + wxb : (fold_hi ? 0.0f : wxb);
+        // z: only the two corners around gzf carry weight (:121); the outermost half cells are
+        // forced to 1 (:122-125).  Two v_sqrt_f32 per pixel (1 ulp; argument >= 1e-8, no
+        // denormals; a weight moves by <= 6e-8, far below the summation noise of a 30 000-term
+        // reduction), then one select chain per gz row.
+        const float gzf = mul_rn(cur.g[cb], gd_f);  // gzf = guide * GD  (:120)
+        const float fz = floorf(gzf - 0.5f);
+        const float dza = (fz + 0.5f) - gzf, dzb = (fz + 1.5f) - gzf;
+        const float wa = std_max(1.0f - __builtin_amdgcn_sqrtf(fmaf(dza, dza, kSmoothEps)), 0.0f);
+        const float wb = std_max(1.0f - __builtin_amdgcn_sqrtf(fmaf(dzb, dzb, kSmoothEps)), 0.0f);
+        const int za = (int)__builtin_amdgcn_fmed3f(fz, -2.0f, gd_f + 1.0f), zb = za + 1;
+        const bool lo = gzf < 0.5f, hi = gzf > gd_f - 0.5f;
+        f32x4 wzv[2];
+#pragma unroll
+        for (int z = 0; z < 8; ++z) {
+          float wz = (z == za) ? wa : ((z == zb) ? wb : 0.0f);
+          if (z == 0) wz = lo ? 1.0f : wz;
+          wz = (z == p.GD - 1 && hi) ? 1.0f : wz;
+          wz = (z < p.GD) ? wz : 0.0f;
+          wzv[z >> 2][z & 3] = wz;
+        }
+        float vflat[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) vflat[c] = 0.0f;
+        if constexpr (APPLY) {
+#pragma unroll
+          for (int i = 0; i < COUT; ++i) {
+            const float di = cur.d[cb][i] * live;
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) vflat[i * CJ + j] = (j < CIN) ? di * cur.in[cb][j < CIN ? j : 0] : di;
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < C; ++c) vflat[c] = cur.d[cb][c] * live;
+        }
+        f32x4* vrow = reinterpret_cast<f32x4*>(vt + lane * kVStride);
+        f32x4* ar = reinterpret_cast<f32x4*>(at + lane * kVStride);
+        const int wsw = (lane >> 1) & 3;
+        // V: only the float4 slots that hold channels are written; the rest of the row was
+        // zeroed once at kernel start and is never touched again.
+#pragma unroll
+        for (int q = 0; q < (C + 3) / 4; ++q)
+          vrow[q ^ wsw] = f32x4{vflat[4 * q], vflat[4 * q + 1], vflat[4 * q + 2], vflat[4 * q + 3]};
+        ar[0 ^ wsw] = w0 * wzv[0];
+        ar[1 ^ wsw] = w0 * wzv[1];
+        ar[2 ^ wsw] = w1 * wzv[0];
+        ar[3 ^ wsw] = w1 * wzv[1];
+        wave_lds_order();
+        // D[k, c] += sum_px A[k, px] * V[px, c]; lane l reads A[px = 4t + (l >> 4)][l & 15]
+        // and V likewise.  Two accumulators break the dependent-issue chain.
+        if (len == 64) {  // full chunk: straight-line, all 32 LDS reads can run ahead
+          float av[16], bv[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            av[u] = at[rd_ofs(u)];
+            bv[u] = vt[rd_ofs(u)];
+          }
+#pragma unroll
+          for (int u = 0; u < 16; u += 2) {
+            dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], dacc, 0, 0, 0);
+            dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[u + 1], dacc2, 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int tg = 0; tg < 4; ++tg) {
+            if (16 * tg < len) {  // wave-uniform
+              float av[4], bv[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                av[u] = at[rd_ofs(4 * tg + u)];
+                bv[u] = vt[rd_ofs(4 * tg + u)];
+              }
+              dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], dacc, 0, 0, 0);
+              dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], dacc2, 0, 0, 0);
+              dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], dacc, 0, 0, 0);
+              dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], dacc2, 0, 0, 0);
+            }
+          }
+        }
+        wave_lds_order();
+      }
+    }
+    if (bi == nbr - 1) {
+      // last batch of the row: fold the row's 16x16 result, scaled by its two y weights
+      // (bilateral_slice_apply.cc:42,47,55-56; weights un-clamped, indices clamped), into the
+      // register tiles of the (<= 3) grid rows the group touches.
       const float gyf = mul_rn(y + 0.5f, p.scale_y);
       const int gy0 = floor_to_int(gyf - 0.5f);
       const float wy0 = tent_weight(gy0 + 0.5f, gyf);
       const float wy1 = tent_weight(gy0 + 1 + 0.5f, gyf);
       const int rel0 = clamp_index(gy0, 0, p.GH - 1) - gy_base;
       const int rel1 = clamp_index(gy0 + 1, 0, p.GH - 1) - gy_base;
-      const size_t prow = ((size_t)b * p.H + y) * p.W;
-      f32x4 dacc = {0.f, 0.f, 0.f, 0.f}, dacc2 = {0.f, 0.f, 0.f, 0.f};
-
-      for (int xb = x_lo; xb < x_hi; xb += 64 * kBatch) {
-        // all loads of the batch first (<= 4 x 28 B per lane in flight)
-        float gq[kBatch], inq[kBatch][CIN_Q], dq[kBatch][COUT];
-#pragma unroll
-        for (int cb = 0; cb < kBatch; ++cb) {
-          const int x = xb + 64 * cb + lane;
-          gq[cb] = 0.f;
-#pragma unroll
-          for (int j = 0; j < CIN_Q; ++j) inq[cb][j] = 0.f;
-#pragma unroll
-          for (int i = 0; i < COUT; ++i) dq[cb][i] = 0.f;
-          if (x < x_hi) {
-            gq[cb] = p.guide[prow + x];
-            if constexpr (APPLY && CIN > 0) {
-#pragma unroll
-              for (int j = 0; j < CIN; ++j) inq[cb][j] = p.input[(prow + x) * CIN + j];
-            }
-#pragma unroll
-            for (int i = 0; i < COUT; ++i) dq[cb][i] = p.dout[(prow + x) * COUT + i];
-          }
-        }
-#pragma unroll
-        for (int cb = 0; cb < kBatch; ++cb) {
-          const int x0 = xb + 64 * cb;
-          if (x0 < x_hi) {  // wave-uniform
-            const int len = min(64, x_hi - x0);
-            const int x = x0 + lane;
-            // Stage both MFMA operands, lane = pixel, branch-free (idle lanes carry zero
-            // weights and zero V).  Columns that clamp onto each other (g = -1: corner 0 ->
-            // column 0 == corner 1; g = GW-1: corner 1 -> column GW-1 == corner 0) are folded
-            // into ONE A row, so stage 2 never sees a column twice.
-            const float live = (lane < len) ? 1.0f : 0.0f;
-            const float gxf = mul_rn((float)x + 0.5f, p.scale_x);
-            const float wxa = tent_weight(gc0, gxf) * live;
-            const float wxb = tent_weight(gc1, gxf) * live;
-            const float w0 = fold_lo ? 0.0f : (fold_hi ? wxa + wxb : wxa);
-            const float w1 = fold_lo ? wxa + wxb : (fold_hi ? 0.0f : wxb);
-            // z: only the two corners around gzf carry weight (:121); the outermost half cells
-            // are forced to 1 (:122-125).  Two v_sqrt_f32 per pixel (1 ulp; argument >= 1e-8,
-            // no denormals; a weight moves by <= 6e-8, far below the summation noise of a
-            // 30 000-term reduction), then one select chain per gz row.
-            const float gzf = mul_rn(gq[cb], gd_f);  // gzf = guide * GD  (:120)
-            const float fz = floorf(gzf - 0.5f);
-            const float dza = (fz + 0.5f) - gzf, dzb = (fz + 1.5f) - gzf;
-            const float wa = std_max(1.0f - __builtin_amdgcn_sqrtf(fmaf(dza, dza, kSmoothEps)), 0.0f);
-            const float wb = std_max(1.0f - __builtin_amdgcn_sqrtf(fmaf(dzb, dzb, kSmoothEps)), 0.0f);
-            const int za = (int)__builtin_amdgcn_fmed3f(fz, -2.0f, gd_f + 1.0f), zb = za + 1;
-            const bool lo = gzf < 0.5f, hi = gzf > gd_f - 0.5f;
-            f32x4 wzv[2];
-#pragma unroll
-            for (int z = 0; z < 8; ++z) {
-              float wz = (z == za) ? wa : ((z == zb) ? wb : 0.0f);
-              if (z == 0) wz = lo ? 1.0f : wz;
-              wz = (z == p.GD - 1 && hi) ? 1.0f : wz;
-              wz = (z < p.GD) ? wz : 0.0f;
-              wzv[z >> 2][z & 3] = wz;
-            }
-            f32x4 vq[3];
-            if constexpr (APPLY) {
-              static_assert(!APPLY || (COUT * CJ <= 12 && CJ <= 4) || true, "");
-            }
-            float vflat[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) vflat[c] = 0.0f;
-            if constexpr (APPLY) {
-#pragma unroll
-              for (int i = 0; i < COUT; ++i) {
-#pragma unroll
-                for (int j = 0; j < CJ; ++j)
-                  vflat[i * CJ + j] = (j < CIN) ? dq[cb][i] * inq[cb][j < CIN ? j : 0] : dq[cb][i];
-              }
-            } else {
-#pragma unroll
-              for (int c = 0; c < C; ++c) vflat[c] = dq[cb][c];
-            }
-            f32x4* vrow = reinterpret_cast<f32x4*>(vt + lane * kVStride);
-            f32x4* ar = reinterpret_cast<f32x4*>(at + lane * kVStride);
-            const int wsw = (lane >> 1) & 3;
-            // V: only the float4 slots that hold channels are written; the rest of the row was
-            // zeroed once at kernel start and is never touched again.
-#pragma unroll
-            for (int q = 0; q < (C + 3) / 4; ++q)
-              vrow[q ^ wsw] = f32x4{vflat[4 * q], vflat[4 * q + 1], vflat[4 * q + 2], vflat[4 * q + 3]};
-            ar[0 ^ wsw] = w0 * wzv[0];
-            ar[1 ^ wsw] = w0 * wzv[1];
-            ar[2 ^ wsw] = w1 * wzv[0];
-            ar[3 ^ wsw] = w1 * wzv[1];
-            (void)vq;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // D[k, c] += sum_px A[k, px] * V[px, c]; lane l reads A[px = 4t + (l >> 4)][l & 15]
-            // and V likewise.  Two accumulators break the dependent-issue chain.
-            if (len == 64) {  // full chunk: straight-line, all 32 LDS reads can run ahead
-              float av[16], bv[16];
-#pragma unroll
-              for (int t = 0; t < 16; ++t) {
-                av[t] = at[rd_ofs(t)];
-                bv[t] = vt[rd_ofs(t)];
-              }
-#pragma unroll
-              for (int t = 0; t < 16; t += 2) {
-                dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[t], dacc, 0, 0, 0);
-                dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t + 1], bv[t + 1], dacc2, 0, 0, 0);
-              }
-            } else {
-#pragma unroll
-              for (int tg = 0; tg < 4; ++tg) {
-                if (16 * tg < len) {  // wave-uniform
-                  float av[4], bv[4];
-#pragma unroll
-                  for (int u = 0; u < 4; ++u) {
-                    av[u] = at[rd_ofs(4 * tg + u)];
-                    bv[u] = vt[rd_ofs(4 * tg + u)];
-                  }
-                  dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], dacc, 0, 0, 0);
-                  dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], dacc2, 0, 0, 0);
-                  dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], dacc, 0, 0, 0);
-                  dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], dacc2, 0, 0, 0);
-                }
-              }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-          }
-        }
-      }
-      // fold the row into the register tiles of the (<= 3) grid rows it touches
       dacc += dacc2;
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const float sr = (rel0 == r ? wy0 : 0.0f) + (rel1 == r ? wy1 : 0.0f);
-        acc[r] += sr * dacc;
+      for (int rr = 0; rr < 3; ++rr) {
+        const float sr = (rel0 == rr ? wy0 : 0.0f) + (rel1 == rr ? wy1 : 0.0f);
+        acc[rr] += sr * dacc;
       }
+      dacc = f32x4{0.f, 0.f, 0.f, 0.f};
+      dacc2 = dacc;
     }
+    cur = nxt;
   }
   // Sum the four waves' register tiles in fixed order (wave 0 + 1 + 2 + 3) through LDS -- the
   // operand slabs are free now -- and write one partial tile per workgroup.
