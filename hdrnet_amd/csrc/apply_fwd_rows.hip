@@ -559,7 +559,9 @@ __global__ __launch_bounds__(256) void apply_fwd_stream_vec4(
 Plan make_plan(const ApplyArgs& a) {
   const bool aligned = (((uintptr_t)a.guide | (uintptr_t)a.input | (uintptr_t)a.out |
                          (uintptr_t)a.grid) & 15u) == 0;
-  return make_row_plan(a.W, a.GW, aligned);
+  // benchmark variants 10 / 11 / 12 force 256 / 192 / 128 threads per workgroup
+  const int force = a.variant == 10 ? 256 : (a.variant == 11 ? 192 : (a.variant == 12 ? 128 : 0));
+  return make_row_plan(a.W, a.GW, aligned, force);
 }
 
 template <int CIN, int COUT, bool OFFSET>

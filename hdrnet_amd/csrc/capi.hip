@@ -155,6 +155,42 @@ int hdrnet_bilateral_slice_apply_nnguide_f32(const float* grid, const float* inp
   return rc;
 }
 
+int hdrnet_bilateral_slice_apply_io(const float* grid, const float* guide, const void* input,
+                                    void* out, int B, int H, int W, int GH, int GW, int GD, int Cin,
+                                    int Cout, int has_offset, int input_dtype,
+                                    float input_white_level, int output_dtype,
+                                    const float* guide_conv1, const float* guide_conv2, int n_feats,
+                                    float* guide_out, void* stream) {
+  using namespace hdrnet_amd;
+  if (int rc = check_common(B, H, W, GH, GW, GD)) return rc;
+  if (Cin <= 0 || Cout <= 0) return fail(HDRNET_INVALID_ARGUMENT, "bad channel counts");
+  if (input_dtype < 0 || input_dtype > 2 || output_dtype < 0 || output_dtype > 1)
+    return fail(HDRNET_INVALID_ARGUMENT, "unknown dtype code (input %d, output %d)", input_dtype,
+                output_dtype);
+  if (!(input_white_level > 0.0f))
+    return fail(HDRNET_INVALID_ARGUMENT, "input_white_level must be positive");
+  if ((long long)B * H * W == 0) {
+    set_kernel("noop");
+    g_error[0] = '\0';
+    return HDRNET_OK;
+  }
+  if (!grid || !input || !out) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  if (!guide && (!guide_conv1 || !guide_conv2 || n_feats <= 0 || n_feats > 4096))
+    return fail(HDRNET_INVALID_ARGUMENT, "either a guide map or the guide network must be given");
+  ApplyIoArgs a{grid, guide, input, out, B, H, W, GH, GW, GD, Cin, Cout, has_offset != 0,
+                input_dtype, output_dtype, input_white_level, guide_conv1, guide_conv2, n_feats,
+                guide_out};
+  if (!apply_fwd_io_supported(a))
+    return fail(HDRNET_INVALID_ARGUMENT,
+                "the wire-format forward supports Cin = Cout = 3 with offset, W %% 4 == 0, aligned "
+                "buffers; convert on the caller's side and use hdrnet_bilateral_slice_apply_f32");
+  const char* name = "";
+  const int rc = check_launch(launch_apply_fwd_io(a, static_cast<hipStream_t>(stream), &name),
+                              "BilateralSliceApplyIO");
+  if (rc == HDRNET_OK) set_kernel(name);
+  return rc;
+}
+
 size_t hdrnet_bilateral_slice_apply_grad_workspace_bytes(int B, int H, int W, int GH, int GW,
                                                          int GD, int Cin, int Cout,
                                                          int has_offset) {

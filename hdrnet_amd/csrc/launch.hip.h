@@ -19,6 +19,22 @@ struct ApplyArgs {
   int variant;  // 0 = library default; >0 selects a kernel variant (flags bits 8..15)
 };
 
+// Forward with wire-format conversion and / or the fused guide network (apply_fwd_io.hip).
+struct ApplyIoArgs {
+  const float* grid;
+  const float* guide;  // null => guide network (guide_conv1 / guide_conv2)
+  const void* input;   // input_dtype: 0 f32, 1 u8, 2 u16; value / white_level
+  void* out;           // output_dtype: 0 f32, 1 u8 = (uint8)(255 * clip(v, 0, 1))
+  int B, H, W, GH, GW, GD, Cin, Cout;
+  bool has_offset;
+  int input_dtype, output_dtype;
+  float white_level;
+  const float* guide_conv1;
+  const float* guide_conv2;
+  int n_feats;
+  float* guide_out;  // optional
+};
+
 struct ApplyGradArgs {
   const float* grid;
   const float* guide;
@@ -68,6 +84,9 @@ bool apply_fwd_nnguide_supported(const ApplyArgs& a, const float* guide_out);
 hipError_t launch_apply_fwd_nnguide(const ApplyArgs& a, const float* conv1, const float* conv2,
                                     int n_feats, float* guide_out, hipStream_t s,
                                     const char** name);
+
+bool apply_fwd_io_supported(const ApplyIoArgs& a);
+hipError_t launch_apply_fwd_io(const ApplyIoArgs& a, hipStream_t s, const char** name);
 
 // apply_bwd_rows.hip -- LDS-staged per-pixel VJPs: dguide and dinput in one pass
 // (BilateralSliceApply), dguide (BilateralSlice).  dgrid is not their business.

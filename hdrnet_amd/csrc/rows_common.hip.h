@@ -201,11 +201,12 @@ struct Plan {
   bool vec4;  // 16-B accesses usable: W % 4 == 0 and 16-B aligned buffers
 };
 
-inline Plan make_row_plan(int W, int GW, bool aligned16) {
+inline Plan make_row_plan(int W, int GW, bool aligned16, int force_threads = 0) {
   Plan best{};
   long long best_waste = -1;
   const int cands[3] = {256, 192, 128};
   for (int T : cands) {
+    if (force_threads && T != force_threads) continue;
     const int span = T * kPxPerThread;
     const int nseg = (W + span - 1) / span;
     const long long waste = (long long)nseg * span - W;

@@ -35,6 +35,7 @@ import torch
 from . import _lib
 
 __all__ = ["bilateral_slice", "bilateral_slice_apply", "bilateral_slice_apply_nnguide",
+           "bilateral_slice_apply_io",
            "kernel_override", "last_kernel"]
 
 _tls = threading.local()
@@ -308,3 +309,69 @@ def bilateral_slice_apply_nnguide(grid: torch.Tensor, input: torch.Tensor,  # no
             B, H, W, GH, GW, GD, Cin, Cout, int(bool(has_offset)), n, _stream(dev))
     _lib.check(rc, "BilateralSliceApplyNNGuide")
     return (out, gout) if return_guide else out
+
+
+_DTYPE_CODE = {torch.float32: 0, torch.uint8: 1, torch.uint16: 2}
+
+
+def bilateral_slice_apply_io(grid: torch.Tensor, input: torch.Tensor,  # noqa: A002
+                             guide: Optional[torch.Tensor] = None,
+                             guide_conv1: Optional[torch.Tensor] = None,
+                             guide_conv2: Optional[torch.Tensor] = None,
+                             input_white_level: Optional[float] = None,
+                             out_dtype: torch.dtype = torch.float32,
+                             has_offset: bool = True) -> torch.Tensor:
+    """Inference forward with the product's wire formats fused in: ``input`` may be uint8 / uint16
+    (``value / input_white_level``: 255, 65535, or 32767 for HDR+ -- hdrnet/data_pipeline.py:202-232,
+    :267-274) and the output may be uint8 ``= (uint8)(255 * clip(out, 0, 1))`` (hdrnet/bin/run.py:95).
+    Give either a ``guide`` map or the folded guide network (``guide_conv1``, ``guide_conv2``).
+    No autograd."""
+    if input.dim() != 4:
+        raise ValueError(f"Input image should be 4D (batch_size, height, width, input_channels), got {tuple(input.shape)}")
+    if input.dtype not in _DTYPE_CODE:
+        raise TypeError(f"input must be float32, uint8 or uint16, got {input.dtype}")
+    if out_dtype not in (torch.float32, torch.uint8):
+        raise TypeError(f"out_dtype must be float32 or uint8, got {out_dtype}")
+    if (guide is None) == (guide_conv1 is None or guide_conv2 is None):
+        raise ValueError("give either a guide map or both guide_conv1 and guide_conv2")
+    if input_white_level is None:
+        input_white_level = {torch.float32: 1.0, torch.uint8: 255.0, torch.uint16: 65535.0}[input.dtype]
+    _require_f32("grid", grid)
+    if grid.dim() != 5:
+        raise ValueError(f"Input grid should be 5D, got {tuple(grid.shape)}")
+    B, H, W, Cin = input.shape
+    if grid.shape[0] != B:
+        raise ValueError("Batch sizes should match.")
+    GH, GW, GD, C = grid.shape[1:]
+    Cj = Cin + (1 if has_offset else 0)
+    if C % Cj:
+        raise ValueError("Slicing with affine offset, grid should have output_channels * (input_channels + 1) channels.")
+    Cout = C // Cj
+    n = 0
+    if guide is not None:
+        _require_f32("guide", guide)
+        if tuple(guide.shape) != (B, H, W):
+            raise ValueError("Input and guide size should match.")
+        _require_gpu("guide", guide)
+        guide = guide.detach().contiguous()
+    else:
+        _require_f32("guide_conv1", guide_conv1)
+        _require_f32("guide_conv2", guide_conv2)
+        n = guide_conv1.shape[0]
+        if guide_conv1.dim() != 2 or guide_conv1.shape[1] != Cin + 1 or tuple(guide_conv2.shape) != (n + 1,):
+            raise ValueError("guide_conv1 should be [n, Cin + 1] and guide_conv2 [n + 1]")
+        guide_conv1, guide_conv2 = guide_conv1.detach().contiguous(), guide_conv2.detach().contiguous()
+    _require_gpu("grid", grid)
+    _require_gpu("input", input)
+    grid, inp = grid.detach().contiguous(), input.detach().contiguous()
+    dev = inp.device
+    out = torch.empty((B, H, W, Cout), dtype=out_dtype, device=dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        rc = lib.hdrnet_bilateral_slice_apply_io(
+            grid.data_ptr(), _ptr(guide), inp.data_ptr(), out.data_ptr(), B, H, W, GH, GW, GD, Cin, Cout,
+            int(bool(has_offset)), _DTYPE_CODE[input.dtype], float(input_white_level), _DTYPE_CODE[out_dtype],
+            _ptr(guide_conv1) if guide is None else None, _ptr(guide_conv2) if guide is None else None,
+            n, None, _stream(dev))
+    _lib.check(rc, "BilateralSliceApplyIO")
+    return out

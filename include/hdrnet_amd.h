@@ -112,6 +112,26 @@ int hdrnet_bilateral_slice_apply_nnguide_f32(const float* grid, const float* inp
                                              int GH, int GW, int GD, int Cin, int Cout,
                                              int has_offset, int n_feats, void* stream);
 
+/* BilateralSliceApply forward with the product's wire formats fused in (inference):
+ *   input  : HDRNET_F32, or HDRNET_U8 / HDRNET_U16 holding value / input_white_level --
+ *            tf.to_float(im) / white_level of hdrnet/data_pipeline.py:202-232 (255, 65535) and
+ *            :267-274 (HDR+: 32767);
+ *   output : HDRNET_F32, or HDRNET_U8 = (uint8)(255 * clip(out, 0, 1)), truncating --
+ *            hdrnet/bin/run.py:95;
+ *   guide  : a [B][H][W] float map, or NULL to evaluate the folded point-wise guide network
+ *            (guide_conv1 [n][Cin+1], guide_conv2 [n+1], see ..._nnguide_f32) in registers.
+ * Supported: Cin = Cout = 3 with offset, W % 4 == 0, 16-B aligned float buffers, 4-B aligned
+ * integer buffers; otherwise HDRNET_INVALID_ARGUMENT. */
+#define HDRNET_F32 0
+#define HDRNET_U8 1
+#define HDRNET_U16 2
+int hdrnet_bilateral_slice_apply_io(const float* grid, const float* guide, const void* input,
+                                    void* out, int B, int H, int W, int GH, int GW, int GD,
+                                    int Cin, int Cout, int has_offset, int input_dtype,
+                                    float input_white_level, int output_dtype,
+                                    const float* guide_conv1, const float* guide_conv2,
+                                    int n_feats, float* guide_out, void* stream);
+
 /* Scratch (bytes) the grad entry point wants for its deterministic two-stage
  * grid-gradient reduction; 0 is a legal answer.  The caller passes a device
  * buffer of at least this size as `workspace` (contents undefined on entry and

@@ -309,6 +309,56 @@ def test_nnguide_fused_matches_composed_oracle(dev, ops, port, shape):
     assert torch.equal(out2, out)
 
 
+@pytest.mark.parametrize("in_dtype,wl", [("uint8", 255.0), ("uint16", 65535.0), ("uint16", 32767.0), ("float32", 1.0)])
+@pytest.mark.parametrize("out_dtype", ["uint8", "float32"])
+@pytest.mark.parametrize("nn", [False, True])
+def test_wire_format_forward(dev, ops, port, in_dtype, wl, out_dtype, nn):
+    """uint8 / uint16 input (value / white level, data_pipeline.py:202-232,
+    :267-274) and uint8 output (cast(255 * clip(out, 0, 1)), run.py:95) fused into the kernel, with a
+    guide map or the fused guide network.  Oracle = the same conversions in float32 numpy around
+    the CPU slice-apply.  The uint8 output is compared exactly except where the float result sits
+    within 2e-5 * 255 of an integer boundary (at most 1 LSB, on < 0.05 % of the samples)."""
+    import oracle
+    B, H, W, GH, GW, GD = 2, 40, 96, 16, 16, 8
+    rng = np.random.default_rng(17)
+    # an affine close to identity so that the output spans [0, 1] and beyond (clip is exercised)
+    grid6 = np.zeros((B, GH, GW, GD, 3, 4), np.float32)
+    for i in range(3):
+        grid6[..., i, i] = 1.0
+    grid = (grid6 + 0.15 * rng.standard_normal(grid6.shape)).astype(np.float32).reshape(B, GH, GW, GD, 12)
+    if in_dtype == "float32":
+        raw = rng.random((B, H, W, 3)).astype(np.float32)
+        inp_f = raw
+    else:
+        hi = 256 if in_dtype == "uint8" else int(wl) + 1
+        raw = rng.integers(0, hi, (B, H, W, 3)).astype(in_dtype)
+        inp_f = (raw.astype(np.float32) / np.float32(wl)).astype(np.float32)
+    conv1 = (rng.standard_normal((16, 4)) * 0.8).astype(np.float32)
+    conv2 = (rng.standard_normal(17) * 0.5).astype(np.float32)
+    guide = oracle.pointwise_nn_guide(inp_f, conv1, conv2) if nn else rng.random((B, H, W)).astype(np.float32)
+    want_f = port.bilateral_slice_apply(grid, guide, inp_f, True)
+    t_in = torch.from_numpy(raw.view(np.uint16) if in_dtype == "uint16" else raw).to(dev)
+    if in_dtype == "uint16":
+        t_in = t_in.view(torch.uint16)
+    kw = dict(guide_conv1=T(conv1, dev), guide_conv2=T(conv2, dev)) if nn else dict(guide=T(guide, dev))
+    out = ops.bilateral_slice_apply_io(T(grid, dev), t_in, input_white_level=wl,
+                                       out_dtype=getattr(torch, out_dtype), **kw)
+    assert ops.last_kernel().startswith("apply_fwd_io/")
+    tol = 2e-5 if nn else 1e-5
+    if out_dtype == "float32":
+        np.testing.assert_allclose(N(out), want_f, rtol=tol, atol=tol)
+    else:
+        v = 255.0 * np.clip(want_f.astype(np.float64), 0, 1)
+        want_u8 = (np.float32(255.0) * np.clip(want_f, 0, 1)).astype(np.uint8)
+        got = N(out)
+        diff = np.abs(got.astype(np.int16) - want_u8.astype(np.int16))
+        near_edge = np.abs(v - np.round(v)) < 255.0 * 2 * tol
+        assert diff.max() <= 1
+        assert not np.any((diff > 0) & ~near_edge)
+        assert (diff > 0).mean() < 5e-4
+        assert got.min() == 0 and got.max() == 255  # the clip is exercised on both sides
+
+
 def test_nnguide_rejects_unsupported(dev, ops):
     from hdrnet_amd import _lib
     g = torch.rand((1, 4, 4, 4, 12), device=dev)

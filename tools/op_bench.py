@@ -93,6 +93,16 @@ def main():
             s["grid"].data_ptr(), s["inp"].data_ptr(), conv1.data_ptr(), conv2.data_ptr(), s["out"].data_ptr(),
             None, 1, H, W, GH, GW, GD, Cin, Cout, 1, 16, stream))
 
+    u8 = [dict(inp=torch.randint(0, 256, (1, H, W, 3), device=dev, dtype=torch.uint8),
+               out=torch.empty((1, H, W, 3), device=dev, dtype=torch.uint8)) for _ in range(nsets)]
+
+    def apply_io_u8(k, nn=True):
+        s, t = S[k % nsets], u8[k % nsets]
+        chk(lib.hdrnet_bilateral_slice_apply_io(
+            s["grid"].data_ptr(), None if nn else s["guide"].data_ptr(), t["inp"].data_ptr(), t["out"].data_ptr(),
+            1, H, W, GH, GW, GD, 3, 3, 1, 1, 255.0, 1, conv1.data_ptr() if nn else None,
+            conv2.data_ptr() if nn else None, 16 if nn else 0, None, stream))
+
     def apply_bwd(k, dg=True, dgu=True, di=True):
         s = S[k % nsets]
         chk(lib.hdrnet_bilateral_slice_apply_grad_f32(
@@ -128,6 +138,8 @@ def main():
     print(f"{desc}; {nsets} rotating sets; workspace apply-grad {wsb / 1e6:.1f} MB")
     run("apply fwd", apply_fwd, 4 * npx * (1 + Cin + Cout) + gridb)
     run("guide-NN(16) + apply fwd fused", apply_fwd_nnguide, 4 * npx * (Cin + Cout) + gridb)
+    run("u8 -> guide-NN + apply -> u8", apply_io_u8, npx * 6 + gridb)
+    run("u8 + guide map -> apply -> u8", lambda k: apply_io_u8(k, nn=False), npx * 10 + gridb)
     run("apply bwd (all three)", apply_bwd, 4 * npx * (1 + Cin + Cout) + 4 * npx * (1 + Cin) + 2 * gridb)
     run("apply bwd dguide+dinput", lambda k: apply_bwd(k, dg=False), 4 * npx * (1 + Cin + Cout) + 4 * npx * (1 + Cin) + gridb)
     run("apply bwd dgrid only", lambda k: apply_bwd(k, dgu=False, di=False), 4 * npx * (1 + Cin + Cout) + gridb)
