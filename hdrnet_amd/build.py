@@ -31,6 +31,7 @@ SOURCES = [
     # of that pairs unrelated scalars ACROSS pixels and pays for it in v_mov shuffles
     # (measured: 947 -> 646 ISA lines, 82 -> 55 VGPRs with it off).
     ("apply_fwd_rows.hip", ["-fno-slp-vectorize"]),
+    ("apply_fwd_variants.hip", ["-fno-slp-vectorize"]),
     ("apply_fwd_io.hip", ["-fno-slp-vectorize"]),
     ("apply_bwd_rows.hip", ["-fno-slp-vectorize"]),
     ("slice_fwd_rows.hip", ["-fno-slp-vectorize"]),

@@ -29,48 +29,21 @@
 // (wy0*g0 + wy1*g1)*(wx*wz) instead of sum((wx*wy)*wz*g).  Differences stay at the
 // 1e-7 relative level (tests/test_gpu_parity.py holds rtol=atol=1e-5 and reports
 // the reference's own 1e-6 bar).
+//
+// Benchmark-only alternatives (one wave per tile, persistent stream, memory skeletons) live
+// in apply_fwd_variants.hip; DESIGN.md section 4 records why they lost.
 #include <hip/hip_runtime.h>
 
 #include "launch.hip.h"
 #include "numerics.hip.h"
 #include "rows_common.hip.h"
-
 namespace hdrnet_amd {
 namespace {
 
 using namespace rows;
 
-constexpr int kVariantRows = 1, kVariantWave = 2, kVariantStream = 3;  // 3..6: 4/5/6/3 blocks per CU
-
-// One pixel: slice the y-pre-lerped columns at (x, guide) and apply the affine
-// (bilateral_slice_apply.cc:50-80).
-template <int CIN, int COUT, bool OFFSET>
-__device__ __forceinline__ void slice_apply_pixel(const RowCtx& r, float xf, float g,
-                                                  const float (&in)[CIN],
-                                                  float (&out)[COUT]) {
-  constexpr int CJ = CIN + (OFFSET ? 1 : 0);
-  constexpr int C = COUT * CJ;
-  const SliceTerms t = slice_terms<C, false>(r, xf, g);
-  CoefVec<C> coef;
-  accum_vec<C, true>(coef, r.colY, t.a00, t.wx0 * t.wz0);
-  accum_vec<C, false>(coef, r.colY, t.a01, t.wx0 * t.wz1);
-  accum_vec<C, false>(coef, r.colY, t.a10, t.wx1 * t.wz0);
-  accum_vec<C, false>(coef, r.colY, t.a11, t.wx1 * t.wz1);
-  // :72-80 -- per-pixel (Cout x Cj) . [in; 1]
-#pragma unroll
-  for (int i = 0; i < COUT; ++i) {
-    float v = OFFSET ? coef.get(i * CJ + CIN) : 0.0f;
-#pragma unroll
-    for (int j = 0; j < CIN; ++j) v = fmaf(coef.get(i * CJ + j), in[j], v);
-    out[i] = v;
-  }
-}
-
 // ---- 4 consecutive pixels per thread, 16-byte global accesses -----------------------
 // Requires W % 4 == 0, seg % 4 == 0 and 16-B aligned guide / input / out.
-// ABLATE (benchmark-only instantiations): 0 = the real kernel; 1 = same loads / stores
-// and launch shape but no staging and no slicing (memory skeleton); 2 = staging +
-// slicing of ONE pixel per quad (quarter of the VALU / LDS work, same memory traffic).
 //
 // GUIDE_NN: the guide is not read from memory but computed per pixel from the input by the
 // reference's point-wise guide network with batch-norm folded (HDRNetPointwiseNNGuide._guide,
@@ -79,6 +52,9 @@ __device__ __forceinline__ void slice_apply_pixel(const RowCtx& r, float xf, flo
 // -- the fusion the reference's own GL renderer performs (benchmark/assets/std.frag:36-52).
 // The guide never touches HBM (24 instead of 28 B/px) and the 16-channel full-resolution
 // intermediate of the un-fused graph disappears.
+//
+// LDS_STORES = false keeps the naive per-lane stores (16 B at a 16*COUT-byte lane stride); it
+// exists only to document the 6.5 us per 4K frame they cost (tools/ab_bench.py, variant 7).
 struct GuideNN {
   const float* conv1;  // [n][CIN + 1]: weights then bias of feature k
   const float* conv2;  // [n + 1]: mixing weights then bias
@@ -99,8 +75,7 @@ __device__ __forceinline__ float guide_nn_pixel(const GuideNN& gn, const float (
   }
   return 1.0f / (1.0f + expf(-acc));  // tf.nn.sigmoid
 }
-
-template <int CIN, int COUT, bool OFFSET, int ABLATE = 0, bool GUIDE_NN = false>
+template <int CIN, int COUT, bool OFFSET, bool GUIDE_NN = false, bool LDS_STORES = true>
 __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
     const float* __restrict__ grid, const float* __restrict__ guide,
     const float* __restrict__ input, float* __restrict__ out, int H, int W, int GH, int GW,
@@ -127,60 +102,20 @@ __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
   float4 iv[(CIN * kPxPerThread) / 4];
   if (active) {
     if constexpr (!GUIDE_NN) g4 = *reinterpret_cast<const float4*>(guide + p);
-    if constexpr (!(ABLATE >= 3 && ABLATE <= 5)) {
-      const float4* ip = reinterpret_cast<const float4*>(input + p * CIN);
+    const float4* ip = reinterpret_cast<const float4*>(input + p * CIN);
 #pragma unroll
-      for (int q = 0; q < (CIN * kPxPerThread) / 4; ++q) iv[q] = ip[q];
-    }
+    for (int q = 0; q < (CIN * kPxPerThread) / 4; ++q) iv[q] = ip[q];
   }
 
-  if constexpr (ABLATE >= 3 && ABLATE <= 5) {
-    // (3: both contiguous; 4: contiguous loads, strided stores; 5: strided loads, contiguous stores)
-    // memory skeleton with LANE-CONTIGUOUS 16-B accesses: thread t touches float4 number
-    // t + k * blockDim of the segment's input / output (guide stays as is).
-    const int nthreads = blockDim.x;
-    const size_t seg_p = (size_t)row * W + xs;
-    const int nq = (xe - xs) * CIN / 4;  // float4 count of the segment's input
-    const float4* ip = reinterpret_cast<const float4*>(input + seg_p * CIN);
-    float4* op = reinterpret_cast<float4*>(out + seg_p * COUT);
-    float4 v[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int e = (ABLATE == 5) ? (int)threadIdx.x * 3 + k : (int)threadIdx.x + k * nthreads;
-      if (e < nq) v[k] = ip[e];
-    }
-    float gq = 0.f;
-    if (active) gq = g4.x + g4.y + g4.z + g4.w;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int e = (ABLATE == 4) ? (int)threadIdx.x * 3 + k : (int)threadIdx.x + k * nthreads;
-      if (e < nq) {
-        v[k].x *= gq; v[k].y *= gq; v[k].z *= gq; v[k].w *= gq;
-        op[e] = v[k];
-      }
-    }
-    return;
-  }
-  if constexpr (ABLATE == 1) {
-    if (!active) return;
-    float4* op = reinterpret_cast<float4*>(out + p * COUT);
-    const float* gsf = reinterpret_cast<const float*>(&g4);
-#pragma unroll
-    for (int q = 0; q < (COUT * kPxPerThread) / 4; ++q) {
-      float4 v = iv[q % ((CIN * kPxPerThread) / 4)];
-      v.x *= gsf[0]; v.y *= gsf[1]; v.z *= gsf[2]; v.w *= gsf[3];
-      op[q] = v;
-    }
-    return;
-  }
   const RowCtx r = stage_row<C, false>(colY, grid_b, y, xs, xe, GH, GW, GD, scale_x, scale_y);
-  float* out_slabs = colY + slab_offset_floats;  // per-wave output transpose slabs
 
   float gs[4] = {g4.x, g4.y, g4.z, g4.w};
   const float xf0 = (float)x + 0.5f;  // (x + k) + 0.5f == xf0 + k exactly (x < 2^23)
   const float* inf = reinterpret_cast<const float*>(iv);
-  if constexpr (GUIDE_NN) {
-    if (active) {
+  float4 ov[(COUT * kPxPerThread) / 4];
+  float* of = reinterpret_cast<float*>(ov);
+  if (active) {
+    if constexpr (GUIDE_NN) {
 #pragma unroll
       for (int k = 0; k < kPxPerThread; ++k) {
         float in[CIN];
@@ -190,16 +125,8 @@ __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
       }
       if (gn.guide_out) *reinterpret_cast<float4*>(gn.guide_out + p) = make_float4(gs[0], gs[1], gs[2], gs[3]);
     }
-  }
-  float4 ov[(COUT * kPxPerThread) / 4];
-  float* of = reinterpret_cast<float*>(ov);
-  if constexpr (ABLATE == 2) {
 #pragma unroll
-    for (int q = 0; q < COUT * kPxPerThread; ++q) of[q] = inf[q % (CIN * kPxPerThread)] * gs[q & 3];
-  }
-  if (active) {
-#pragma unroll
-    for (int k = 0; k < (ABLATE == 2 ? 1 : kPxPerThread); ++k) {
+    for (int k = 0; k < kPxPerThread; ++k) {
       float in[CIN], o[COUT];
 #pragma unroll
       for (int j = 0; j < CIN; ++j) in[j] = inf[k * CIN + j];
@@ -208,7 +135,7 @@ __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
       for (int i = 0; i < COUT; ++i) of[k * COUT + i] = o[i];
     }
   }
-  if constexpr (ABLATE == 6) {  // direct per-lane stores: 16 B at a 16*COUT-byte lane stride
+  if constexpr (!LDS_STORES) {
     if (!active) return;
     float4* op = reinterpret_cast<float4*>(out + p * COUT);
 #pragma unroll
@@ -221,7 +148,7 @@ __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
   // through a private LDS slab: ds_write_b128 at the per-pixel stride (conflict-free:
   // 12-dword stride over 8-lane groups), then lane l reads float4 number l + 64k and
   // stores it -- every global_store_dwordx4 covers one dense 1 KiB run.
-  float4* slab = reinterpret_cast<float4*>(out_slabs) + (threadIdx.x >> 6) * (64 * COUT);
+  float4* slab = reinterpret_cast<float4*>(colY + slab_offset_floats) + (threadIdx.x >> 6) * (64 * COUT);
   const int lane = threadIdx.x & 63;
   if (active) {
 #pragma unroll
@@ -284,375 +211,39 @@ __global__ __launch_bounds__(256) void apply_fwd_rows_scalar(
   }
 }
 
-// ---- one wavefront per output tile ------------------------------------------------------
-// A tile is `tile_w` consecutive pixels of one image row (tile_w <= 256, 4 per lane).
-// Each wave stages its own y-pre-lerped columns (<= ~5 of them) in a private LDS
-// region and then slices its pixels: no workgroup barrier, waves are independent, and a
-// workgroup is just `waves_per_block` consecutive tiles.
-template <int CIN, int COUT, bool OFFSET>
-__global__ __launch_bounds__(256) void apply_fwd_wave_vec4(
-    const float* __restrict__ grid, const float* __restrict__ guide,
-    const float* __restrict__ input, float* __restrict__ out, int H, int W, int GH, int GW,
-    int GD, int tiles_per_row, int tile_w, long long ntiles, int lds_floats_per_wave,
-    float scale_x, float scale_y) {
-  constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
-  extern __shared__ __attribute__((aligned(16))) float colY_all[];
-  const int wave = threadIdx.x >> 6;
-  const int lane = threadIdx.x & 63;
-  const long long tile = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
-  if (tile >= ntiles) return;
-  float* colY = colY_all + wave * lds_floats_per_wave;
-  const int ti = (int)(tile % tiles_per_row);
-  const long long row = tile / tiles_per_row;  // = b * H + y
-  const int y = (int)(row % H);
-  const long long b = row / H;
-  const int xs = ti * tile_w;
-  const int xe = min(xs + tile_w, W);
-  const float* grid_b = grid + (size_t)b * GH * GW * GD * C;
-
-  const int x = xs + kPxPerThread * lane;
-  const bool active = x < xe;
-  const size_t p = (size_t)row * W + x;
-
-  float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 iv[(CIN * kPxPerThread) / 4];
-  if (active) {
-    g4 = *reinterpret_cast<const float4*>(guide + p);
-    const float4* ip = reinterpret_cast<const float4*>(input + p * CIN);
-#pragma unroll
-    for (int q = 0; q < (CIN * kPxPerThread) / 4; ++q) iv[q] = ip[q];
-  }
-
-  const RowCtx r = stage_row<C, true>(colY, grid_b, y, xs, xe, GH, GW, GD, scale_x, scale_y);
-  if (!active) return;
-
-  const float gs[4] = {g4.x, g4.y, g4.z, g4.w};
-  const float xf0 = (float)x + 0.5f;
-  const float* inf = reinterpret_cast<const float*>(iv);
-  float4 ov[(COUT * kPxPerThread) / 4];
-  float* of = reinterpret_cast<float*>(ov);
-#pragma unroll
-  for (int k = 0; k < kPxPerThread; ++k) {
-    float in[CIN], o[COUT];
-#pragma unroll
-    for (int j = 0; j < CIN; ++j) in[j] = inf[k * CIN + j];
-    slice_apply_pixel<CIN, COUT, OFFSET>(r, xf0 + (float)k, gs[k], in, o);
-#pragma unroll
-    for (int i = 0; i < COUT; ++i) of[k * COUT + i] = o[i];
-  }
-  float4* op = reinterpret_cast<float4*>(out + p * COUT);
-#pragma unroll
-  for (int q = 0; q < (COUT * kPxPerThread) / 4; ++q) op[q] = ov[q];
-}
-
-// ---- persistent, balanced, software-pipelined streaming variant ---------------------------
-// The launch is sized to what the chip holds at once (CUs x blocks_per_cu workgroups of 4
-// waves).  Every WAVE owns one contiguous, equal share of the image's pixel quads and walks
-// it in chunks of <= 64 quads (256 pixels, never across a row end).  The loop is software-
-// pipelined around the in-order vmcnt counter of CDNA (which counts stores as well): per
-// chunk i the wave
-//   a. waits for G_i, the two grid-row slices of chunk i (issued one iteration ago), blends
-//      them into its private LDS column image,
-//   b. waits for P_i, the chunk's guide/input quads (also issued one iteration ago),
-//   c. issues G_{i+1}, then d. P_{i+1}  -- BEFORE chunk i's stores, so that the waits of
-//      the next iteration never sit behind a store or a younger load,
-//   e. slices chunk i, f. transposes through LDS and stores.
-// Every wave therefore always has the next chunk's 4 KiB in flight while it computes, all
-// waves finish together (no partially filled last round of workgroups), and the only ramp
-// left is one load latency at the start and one chunk of compute at the end of the launch.
-// LDS traffic of ONE wave needs no fence: the LDS executes a wave's instructions in order, so
-// a ds_read issued after a ds_write of the same wave sees all 64 lanes' data.  (A
-// `fence(release, "wavefront")` would cost an s_waitcnt vmcnt(0), i.e. drain the prefetch.)
-// The scheduling barrier only keeps the compiler from moving LDS accesses across.
-__device__ __forceinline__ void wave_lds_order() {
-  __builtin_amdgcn_wave_barrier();
-  asm volatile("" ::: "memory");
-}
-
-constexpr int kStageRegs = 2;  // float4 per grid row per lane held in flight (<= 128 float4 / row)
-
-template <int CIN>
-struct QuadData {
-  float4 g;
-  float4 in[CIN];
+struct LaunchGeom {
+  Plan pl;
+  int slab_off;
+  size_t lds;
+  long long nblocks;
 };
 
-// Unconditional: the caller clamps `quad` to a valid quad (idle lanes re-load the chunk's last
-// quad), so the loop body has no exec-masked branch around a VMEM instruction and the
-// compiler's s_waitcnt vmcnt(N) counts stay exact.
-template <int CIN>
-__device__ __forceinline__ QuadData<CIN> load_quad(const float* __restrict__ guide,
-                                                   const float* __restrict__ input,
-                                                   long long quad) {
-  QuadData<CIN> d;
-  d.g = reinterpret_cast<const float4*>(guide)[quad];
-  const float4* ip = reinterpret_cast<const float4*>(input) + quad * CIN;
-#pragma unroll
-  for (int q = 0; q < CIN; ++q) d.in[q] = ip[q];
-  return d;
-}
-
-// Where a chunk sits and which grid data it needs (all wave-uniform).
-struct ChunkGeom {
-  int y, xs, len;        // image row, first pixel, quads
-  long long b;           // image
-  int gy0c, gy1c, gxlo, n4;  // clamped grid rows, first column, float4 count of the column image
-  float wy0, wy1;
-};
-
-template <int C>
-__device__ __forceinline__ ChunkGeom chunk_geom(long long b, int y, int xq, int len, int GH, int GW,
-                                                int GD, float scale_x, float scale_y) {
-  ChunkGeom c;
-  c.b = b;
-  c.y = y;
-  c.xs = xq * 4;
-  c.len = len;
-  const float gyf = mul_rn(y + 0.5f, scale_y);
-  const int gy0 = floor_to_int(gyf - 0.5f);
-  c.wy0 = tent_weight(gy0 + 0.5f, gyf);
-  c.wy1 = tent_weight(gy0 + 1 + 0.5f, gyf);
-  c.gy0c = clamp_index(gy0, 0, GH - 1);
-  c.gy1c = clamp_index(gy0 + 1, 0, GH - 1);
-  const int xe = c.xs + len * 4;
-  c.gxlo = clamp_index(floor_to_int(mul_rn(c.xs + 0.5f, scale_x) - 0.5f), 0, GW - 1);
-  const int gxhi = clamp_index(floor_to_int(mul_rn(xe - 1 + 0.5f, scale_x) - 0.5f) + 1, 0, GW - 1);
-  c.n4 = (gxhi - c.gxlo + 1) * GD * C / 4;
-  return c;
-}
-
-struct StageRegs {
-  float4 a[kStageRegs], b[kStageRegs];
-};
-
-template <int C>
-__device__ __forceinline__ StageRegs stage_issue(const float* __restrict__ grid, const ChunkGeom& c,
-                                                 int GH, int GW, int GD, int lane) {
-  StageRegs r;
-  const float* gb = grid + (size_t)c.b * GH * GW * GD * C;
-  const float4* a4 = reinterpret_cast<const float4*>(gb + ((size_t)(c.gy0c * GW + c.gxlo) * GD) * C);
-  const float4* b4 = reinterpret_cast<const float4*>(gb + ((size_t)(c.gy1c * GW + c.gxlo) * GD) * C);
-#pragma unroll
-  for (int k = 0; k < kStageRegs; ++k) {
-    const int e = min(lane + 64 * k, c.n4 - 1);  // clamped: idle lanes duplicate the last element
-    r.a[k] = a4[e];
-    r.b[k] = b4[e];
-  }
-  return r;
-}
-
-template <int C>
-__device__ __forceinline__ RowCtx stage_commit(float* __restrict__ colY, const StageRegs& r,
-                                               const ChunkGeom& c, int GW, int GD, float scale_x,
-                                               int lane) {
-  float4* d4 = reinterpret_cast<float4*>(colY);
-#pragma unroll
-  for (int k = 0; k < kStageRegs; ++k) {
-    const int e = min(lane + 64 * k, c.n4 - 1);  // duplicates write the same value
-    const float4 a = r.a[k], b = r.b[k];
-    d4[e] = make_float4(c.wy0 * a.x + c.wy1 * b.x, c.wy0 * a.y + c.wy1 * b.y,
-                        c.wy0 * a.z + c.wy1 * b.z, c.wy0 * a.w + c.wy1 * b.w);
-  }
-  wave_lds_order();
-  const int col_bytes = GD * C * (int)sizeof(float);
-  return RowCtx{colY, scale_x, (float)GD, c.gxlo, col_bytes, (0 - c.gxlo) * col_bytes,
-                (GW - 1 - c.gxlo) * col_bytes, (GD - 1) * C * (int)sizeof(float)};
-}
-
-template <int CIN, int COUT, bool OFFSET>
-__global__ __launch_bounds__(256) void apply_fwd_stream_vec4(
-    const float* __restrict__ grid, const float* __restrict__ guide,
-    const float* __restrict__ input, float* __restrict__ out, int H, int Wq, int GH, int GW,
-    int GD, long long nquads, long long quads_per_wave, int lds_floats_per_wave, float scale_x,
-    float scale_y) {
-  constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
-  static_assert(C % 4 == 0, "float4 column image");
-  extern __shared__ __attribute__((aligned(16))) float lds_all[];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  float* colY = lds_all + wave * lds_floats_per_wave;
-  float4* slab = reinterpret_cast<float4*>(colY + (lds_floats_per_wave - 64 * kPxPerThread * COUT));
-  const long long wid = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
-  long long pos = wid * quads_per_wave;
-  const long long end = min(pos + quads_per_wave, nquads);
-  if (pos >= end) return;
-  // (b, y, xq) of `pos`, advanced incrementally; everything here is wave-uniform.
-  long long row = pos / Wq;
-  int xq = (int)(pos - row * Wq);
-  int y = (int)(row % H);
-  long long b = row / H;
-  int len = (int)min((long long)min(64, Wq - xq), end - pos);
-
-  ChunkGeom cg = chunk_geom<C>(b, y, xq, len, GH, GW, GD, scale_x, scale_y);
-  StageRegs sr = stage_issue<C>(grid, cg, GH, GW, GD, lane);                      // G_0
-  QuadData<CIN> cur = load_quad<CIN>(guide, input, pos + min(lane, len - 1));      // P_0
-
-  while (true) {
-    // a. G_i -> this wave's LDS column image (frees the staging registers)
-    const RowCtx r = stage_commit<C>(colY, sr, cg, GW, GD, scale_x, lane);
-    // b./c. next chunk: geometry, then its grid rows and its guide / input quads go out NOW --
-    //       before chunk i is sliced and before its stores -- so they fly during the slicing
-    //       and no later wait sits behind a store.  (Past the end: re-load this chunk, unused.)
-    const long long npos = pos + len;
-    int nxq = xq + len, ny = y;
-    long long nb = b;
-    if (nxq == Wq) {
-      nxq = 0;
-      if (++ny == H) {
-        ny = 0;
-        ++nb;
-      }
-    }
-    const int nlen = npos < end ? (int)min((long long)min(64, Wq - nxq), end - npos) : 0;
-    const bool more = nlen > 0;
-    const ChunkGeom ncg = more ? chunk_geom<C>(nb, ny, nxq, nlen, GH, GW, GD, scale_x, scale_y) : cg;
-    sr = stage_issue<C>(grid, ncg, GH, GW, GD, lane);
-    const QuadData<CIN> nxt =
-        load_quad<CIN>(guide, input, more ? npos + min(lane, nlen - 1) : pos + min(lane, len - 1));
-    // d. slice chunk i (idle lanes slice a duplicate of the last quad; their result is unused)
-    float4 ov[COUT];
-    {
-      const float gs[4] = {cur.g.x, cur.g.y, cur.g.z, cur.g.w};
-      const float xf0 = (float)(cg.xs + 4 * min(lane, len - 1)) + 0.5f;
-      const float* inf = reinterpret_cast<const float*>(cur.in);
-      float* of = reinterpret_cast<float*>(ov);
-#pragma unroll
-      for (int k = 0; k < kPxPerThread; ++k) {
-        float in[CIN], o[COUT];
-#pragma unroll
-        for (int j = 0; j < CIN; ++j) in[j] = inf[k * CIN + j];
-        slice_apply_pixel<CIN, COUT, OFFSET>(r, xf0 + (float)k, gs[k], in, o);
-#pragma unroll
-        for (int i = 0; i < COUT; ++i) of[k * COUT + i] = o[i];
-      }
-    }
-    // e. transpose through the wave's slab; lane-contiguous 16-B stores.  Idle lanes write /
-    //    store a duplicate of the last valid element (same value, same address).
-    {
-      const int wl = min(lane, len - 1);
-#pragma unroll
-      for (int q = 0; q < COUT; ++q) slab[wl * COUT + q] = ov[q];
-      wave_lds_order();
-      const int nvalid = len * COUT;
-      float4* gp = reinterpret_cast<float4*>(out) + pos * COUT;
-      // all slab reads into distinct registers first: re-using one register quad for the three
-      // stores would make each store wait (vmcnt) for the previous one -- and, the counter
-      // being in-order, for the prefetch issued before it.
-      float4 tv[COUT];
-#pragma unroll
-      for (int k = 0; k < COUT; ++k) tv[k] = slab[min(lane + 64 * k, nvalid - 1)];
-#pragma unroll
-      for (int k = 0; k < COUT; ++k) gp[min(lane + 64 * k, nvalid - 1)] = tv[k];
-      wave_lds_order();
-    }
-    if (!more) break;
-    cur = nxt;
-    cg = ncg;
-    pos = npos;
-    len = nlen;
-    xq = nxq;
-    y = ny;
-    b = nb;
-  }
-}
-
-Plan make_plan(const ApplyArgs& a) {
+template <int C, int COUT>
+LaunchGeom geom_for(const ApplyArgs& a) {
+  LaunchGeom g;
   const bool aligned = (((uintptr_t)a.guide | (uintptr_t)a.input | (uintptr_t)a.out |
                          (uintptr_t)a.grid) & 15u) == 0;
-  // benchmark variants 10 / 11 / 12 force 256 / 192 / 128 threads per workgroup
-  const int force = a.variant == 10 ? 256 : (a.variant == 11 ? 192 : (a.variant == 12 ? 128 : 0));
-  return make_row_plan(a.W, a.GW, aligned, force);
+  g.pl = make_row_plan(a.W, a.GW, aligned);
+  // dynamic LDS: [colY image][one 64 x 4*COUT-float output slab per wave (vec4 kernel)]
+  g.slab_off = round_up(g.pl.max_cols * a.GD * C, 4);
+  g.lds = ((size_t)g.slab_off + (size_t)(g.pl.threads / 64) * 64 * kPxPerThread * COUT) * sizeof(float);
+  g.nblocks = (long long)a.B * a.H * g.pl.nseg;
+  return g;
 }
 
 template <int CIN, int COUT, bool OFFSET>
 hipError_t launch_t(const ApplyArgs& a, hipStream_t s, const char** name) {
   constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
-  const Plan pl = make_plan(a);
-  // dynamic LDS: [colY image][one 64 x 4*COUT-float output slab per wave (vec4 kernel)]
-  const int slab_off = round_up(pl.max_cols * a.GD * C, 4);
-  const size_t lds = ((size_t)slab_off + (size_t)(pl.threads / 64) * 64 * kPxPerThread * COUT) * sizeof(float);
-  const long long nblocks = (long long)a.B * a.H * pl.nseg;
+  const LaunchGeom g = geom_for<C, COUT>(a);
   const float sx = (float)a.GW / a.W, sy = (float)a.GH / a.H;
-  if (pl.vec4 && a.variant == kVariantWave) {
-    // One wavefront per tile of <= 256 pixels, balanced over the row.
-    const int tiles_per_row = (a.W + 64 * kPxPerThread - 1) / (64 * kPxPerThread);
-    const int tile_w = round_up((a.W + tiles_per_row - 1) / tiles_per_row, 4);
-    const long long ncol = ((long long)(tile_w - 1) * a.GW) / a.W + 4;
-    const int cols = (int)(ncol < a.GW ? ncol : a.GW);
-    const int lds_floats = round_up(cols * a.GD * C, 4);
-    const long long ntiles = (long long)a.B * a.H * tiles_per_row;
-    const int waves = 4;
-    apply_fwd_wave_vec4<CIN, COUT, OFFSET>
-        <<<(unsigned)((ntiles + waves - 1) / waves), waves * 64,
-           (size_t)waves * lds_floats * sizeof(float), s>>>(
-            a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, tiles_per_row, tile_w,
-            ntiles, lds_floats, sx, sy);
-    *name = "apply_fwd_wave/vec4";
-    return hipGetLastError();
-  }
-  if constexpr (C % 4 == 0) {
-    if (pl.vec4 && a.variant >= kVariantStream && a.variant < kVariantStream + 4) {
-      // Persistent balanced stream: CUs x blocks_per_cu workgroups of 4 waves.
-      const int bpc_table[4] = {4, 5, 6, 3};
-      const int blocks_per_cu = bpc_table[(a.variant - kVariantStream) & 3];
-      const int waves = 4;
-      const long long nquads = (long long)a.B * a.H * (a.W / 4);
-      long long nwaves = (long long)num_cus() * blocks_per_cu * waves;
-      if (nwaves > (nquads + 63) / 64) nwaves = (nquads + 63) / 64;  // small images: 1 chunk each
-      nwaves = (nwaves + waves - 1) / waves * waves;
-      const long long qpw = (nquads + nwaves - 1) / nwaves;
-      const int cols = max_cols_for(64 * kPxPerThread, a.GW, a.W);
-      if (cols * a.GD * C / 4 <= 64 * kStageRegs) {
-        const int lds_floats = round_up(cols * a.GD * C, 4) + 64 * kPxPerThread * COUT;
-        apply_fwd_stream_vec4<CIN, COUT, OFFSET>
-            <<<(unsigned)(nwaves / waves), waves * 64, (size_t)waves * lds_floats * sizeof(float), s>>>(
-                a.grid, a.guide, a.input, a.out, a.H, a.W / 4, a.GH, a.GW, a.GD, nquads, qpw,
-                lds_floats, sx, sy);
-        *name = "apply_fwd_stream/vec4";
-        return hipGetLastError();
-      }
-    }
-  }
-  if constexpr (CIN == 3 && COUT == 3 && OFFSET) {
-    if (pl.vec4 && a.variant >= 103 && a.variant <= 105) {
-      if (a.variant == 103)
-        apply_fwd_rows_vec4<CIN, COUT, OFFSET, 3><<<(unsigned)nblocks, pl.threads, lds, s>>>(
-            a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, pl.nseg, pl.seg, slab_off, sx, sy);
-      else if (a.variant == 104)
-        apply_fwd_rows_vec4<CIN, COUT, OFFSET, 4><<<(unsigned)nblocks, pl.threads, lds, s>>>(
-            a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, pl.nseg, pl.seg, slab_off, sx, sy);
-      else
-        apply_fwd_rows_vec4<CIN, COUT, OFFSET, 5><<<(unsigned)nblocks, pl.threads, lds, s>>>(
-            a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, pl.nseg, pl.seg, slab_off, sx, sy);
-      *name = a.variant == 103 ? "ABLATION/skeleton ld-contig st-contig"
-              : a.variant == 104 ? "ABLATION/skeleton ld-contig st-strided"
-                                 : "ABLATION/skeleton ld-strided st-contig";
-      return hipGetLastError();
-    }
-    if (pl.vec4 && (a.variant == 101 || a.variant == 102)) {  // benchmark-only ablations
-      if (a.variant == 101)
-        apply_fwd_rows_vec4<CIN, COUT, OFFSET, 1><<<(unsigned)nblocks, pl.threads, lds, s>>>(
-            a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, pl.nseg, pl.seg, slab_off, sx, sy);
-      else
-        apply_fwd_rows_vec4<CIN, COUT, OFFSET, 2><<<(unsigned)nblocks, pl.threads, lds, s>>>(
-            a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, pl.nseg, pl.seg, slab_off, sx, sy);
-      *name = a.variant == 101 ? "ABLATION/memory-skeleton" : "ABLATION/quarter-compute";
-      return hipGetLastError();
-    }
-  }
-  if (pl.vec4 && a.variant == 7) {
-    apply_fwd_rows_vec4<CIN, COUT, OFFSET, 6><<<(unsigned)nblocks, pl.threads, lds, s>>>(
-        a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, pl.nseg, pl.seg, slab_off, sx, sy);
-    *name = "apply_fwd_rows/vec4-direct-stores";
-    return hipGetLastError();
-  }
-  if (pl.vec4) {
-    apply_fwd_rows_vec4<CIN, COUT, OFFSET><<<(unsigned)nblocks, pl.threads, lds, s>>>(
-        a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, pl.nseg, pl.seg, slab_off, sx, sy);
+  if (g.pl.vec4) {
+    apply_fwd_rows_vec4<CIN, COUT, OFFSET><<<(unsigned)g.nblocks, g.pl.threads, g.lds, s>>>(
+        a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, g.pl.nseg, g.pl.seg, g.slab_off,
+        sx, sy);
     *name = "apply_fwd_rows/vec4";
   } else {
-    apply_fwd_rows_scalar<CIN, COUT, OFFSET><<<(unsigned)nblocks, pl.threads, lds, s>>>(
-        a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, pl.nseg, pl.seg, sx, sy);
+    apply_fwd_rows_scalar<CIN, COUT, OFFSET><<<(unsigned)g.nblocks, g.pl.threads, g.lds, s>>>(
+        a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, g.pl.nseg, g.pl.seg, sx, sy);
     *name = "apply_fwd_rows/scalar";
   }
   return hipGetLastError();
@@ -663,12 +254,9 @@ constexpr size_t kMaxLdsBytes = 64 * 1024;  // keep >= 2 workgroups per CU
 template <int CIN, int COUT, bool OFFSET>
 hipError_t launch_nnguide_t(const ApplyArgs& a, const GuideNN& gn, hipStream_t s) {
   constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
-  Plan pl = make_plan(a);
-  const int slab_off = round_up(pl.max_cols * a.GD * C, 4);
-  const size_t lds = ((size_t)slab_off + (size_t)(pl.threads / 64) * 64 * kPxPerThread * COUT) * sizeof(float);
-  const long long nblocks = (long long)a.B * a.H * pl.nseg;
-  apply_fwd_rows_vec4<CIN, COUT, OFFSET, 0, true><<<(unsigned)nblocks, pl.threads, lds, s>>>(
-      a.grid, nullptr, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, pl.nseg, pl.seg, slab_off,
+  const LaunchGeom g = geom_for<C, COUT>(a);
+  apply_fwd_rows_vec4<CIN, COUT, OFFSET, true><<<(unsigned)g.nblocks, g.pl.threads, g.lds, s>>>(
+      a.grid, nullptr, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, g.pl.nseg, g.pl.seg, g.slab_off,
       (float)a.GW / a.W, (float)a.GH / a.H, gn);
   return hipGetLastError();
 }
@@ -682,7 +270,7 @@ bool apply_fwd_nnguide_supported(const ApplyArgs& a, const float* guide_out) {
   t.guide = a.input;  // alignment check stand-in: no guide buffer is read
   if ((uintptr_t)guide_out & 15u) return false;
   if (!apply_fwd_rows_supported(t)) return false;
-  return make_plan(t).vec4;
+  return make_row_plan(t.W, t.GW, (((uintptr_t)t.input | (uintptr_t)t.out | (uintptr_t)t.grid) & 15u) == 0).vec4;
 }
 
 hipError_t launch_apply_fwd_nnguide(const ApplyArgs& a, const float* conv1, const float* conv2,
@@ -699,7 +287,6 @@ hipError_t launch_apply_fwd_nnguide(const ApplyArgs& a, const float* conv1, cons
   return hipErrorInvalidValue;
 }
 
-
 bool apply_fwd_rows_supported(const ApplyArgs& a) {
   const bool shape = (a.Cin == 3 && a.Cout == 3) || (a.Cin == 3 && a.Cout == 4 && a.has_offset) ||
                      (a.Cin == 1 && a.Cout == 1) || (a.Cin == 1 && a.Cout == 3 && a.has_offset) ||
@@ -708,13 +295,17 @@ bool apply_fwd_rows_supported(const ApplyArgs& a) {
   // stage_row reads the grid as float4 when C % 4 == 0.
   if ((a.Cout * a.Cj) % 4 == 0 && ((uintptr_t)a.grid & 15u)) return false;
   if ((long long)a.B * a.H * ((a.W + 511) / 512) > 0x7fffffffLL) return false;
-  const Plan pl = make_plan(a);
+  const Plan pl = make_row_plan(a.W, a.GW, true);
   const size_t lds = ((size_t)pl.max_cols * a.GD * a.Cout * a.Cj + 4 +
                       (size_t)(pl.threads / 64) * 64 * kPxPerThread * a.Cout) * sizeof(float);
   return lds <= kMaxLdsBytes;
 }
 
 hipError_t launch_apply_fwd_rows(const ApplyArgs& a, hipStream_t s, const char** name) {
+  if (a.variant != 0) {  // benchmark-only kernels, never selected by flags == 0
+    const hipError_t e = launch_apply_fwd_variant(a, s, name);
+    if (e != hipErrorNotSupported) return e;
+  }
 #define HDRNET_CASE(CI, CO, OFF) \
   if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF) return launch_t<CI, CO, OFF>(a, s, name)
   HDRNET_CASE(3, 3, true);
@@ -726,6 +317,18 @@ hipError_t launch_apply_fwd_rows(const ApplyArgs& a, hipStream_t s, const char**
   HDRNET_CASE(4, 4, true);
 #undef HDRNET_CASE
   return hipErrorInvalidValue;
+}
+
+// The direct-store instantiation, for tools/ab_bench.py only (apply_fwd_variants.hip routes here).
+hipError_t launch_apply_fwd_rows_direct_stores(const ApplyArgs& a, hipStream_t s, const char** name) {
+  if (!(a.Cin == 3 && a.Cout == 3 && a.has_offset)) return hipErrorInvalidValue;
+  const LaunchGeom g = geom_for<12, 3>(a);
+  if (!g.pl.vec4) return hipErrorInvalidValue;
+  apply_fwd_rows_vec4<3, 3, true, false, false><<<(unsigned)g.nblocks, g.pl.threads, g.lds, s>>>(
+      a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, g.pl.nseg, g.pl.seg, g.slab_off,
+      (float)a.GW / a.W, (float)a.GH / a.H);
+  *name = "apply_fwd_rows/vec4-direct-stores";
+  return hipGetLastError();
 }
 
 }  // namespace hdrnet_amd

@@ -183,6 +183,30 @@ __device__ __forceinline__ SliceTerms slice_terms(const RowCtx& r, float xf, flo
   return t;
 }
 
+// One pixel: slice the y-pre-lerped columns at (x, guide) and apply the affine
+// (bilateral_slice_apply.cc:50-80).
+template <int CIN, int COUT, bool OFFSET>
+__device__ __forceinline__ void slice_apply_pixel(const RowCtx& r, float xf, float g,
+                                                  const float (&in)[CIN],
+                                                  float (&out)[COUT]) {
+  constexpr int CJ = CIN + (OFFSET ? 1 : 0);
+  constexpr int C = COUT * CJ;
+  const SliceTerms t = slice_terms<C, false>(r, xf, g);
+  CoefVec<C> coef;
+  accum_vec<C, true>(coef, r.colY, t.a00, t.wx0 * t.wz0);
+  accum_vec<C, false>(coef, r.colY, t.a01, t.wx0 * t.wz1);
+  accum_vec<C, false>(coef, r.colY, t.a10, t.wx1 * t.wz0);
+  accum_vec<C, false>(coef, r.colY, t.a11, t.wx1 * t.wz1);
+  // :72-80 -- per-pixel (Cout x Cj) . [in; 1]
+#pragma unroll
+  for (int i = 0; i < COUT; ++i) {
+    float v = OFFSET ? coef.get(i * CJ + CIN) : 0.0f;
+#pragma unroll
+    for (int j = 0; j < CIN; ++j) v = fmaf(coef.get(i * CJ + j), in[j], v);
+    out[i] = v;
+  }
+}
+
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // Upper bound of grid columns `npx` consecutive pixels can touch: floor differences of gx0
@@ -201,12 +225,11 @@ struct Plan {
   bool vec4;  // 16-B accesses usable: W % 4 == 0 and 16-B aligned buffers
 };
 
-inline Plan make_row_plan(int W, int GW, bool aligned16, int force_threads = 0) {
+inline Plan make_row_plan(int W, int GW, bool aligned16) {
   Plan best{};
   long long best_waste = -1;
   const int cands[3] = {256, 192, 128};
   for (int T : cands) {
-    if (force_threads && T != force_threads) continue;
     const int span = T * kPxPerThread;
     const int nseg = (W + span - 1) / span;
     const long long waste = (long long)nseg * span - W;

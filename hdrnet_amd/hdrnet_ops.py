@@ -46,11 +46,13 @@ def _flags() -> int:
 
 
 @contextlib.contextmanager
-def kernel_override(which: str):
-    """Force a kernel family inside the block: 'auto' | 'generic' | 'fast' (tests/bench)."""
+def kernel_override(which: str, variant: int = 0):
+    """Force a kernel family inside the block: 'auto' | 'generic' | 'fast' (tests/bench).
+    `variant` > 0 additionally selects one of the benchmark-only forward kernels
+    (csrc/apply_fwd_variants.hip); it is ignored where no such variant exists."""
     table = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "fast": _lib.KERNEL_FAST}
     old = _flags()
-    _tls.flags = table[which]
+    _tls.flags = table[which] | ((int(variant) & 0xFF) << 8)
     try:
         yield
     finally:

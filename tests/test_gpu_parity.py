@@ -167,6 +167,24 @@ def test_apply_forward_random(dev, ops, port, shape):
     assert worst < 4.0, (kern, worst)
 
 
+# The benchmark-only forward kernels DESIGN.md quotes timings for (apply_fwd_variants.hip) must
+# compute the same op as the shipped one, or those timings compare nothing.
+@pytest.mark.parametrize("variant,expect", [(2, "apply_fwd_wave"), (3, "apply_fwd_stream"),
+                                            (5, "apply_fwd_stream"), (7, "direct-stores")])
+@pytest.mark.parametrize("shape", [(2, 48, 2048, 16, 16, 8, 3, 3, True, -0.2, 1.2),
+                                   (1, 37, 3076, 16, 16, 8, 3, 3, True, 0.0, 1.0)])
+def test_apply_forward_benchmark_variants(dev, ops, port, shape, variant, expect):
+    B, H, W, GH, GW, GD, Cin, Cout, ho, lo, hi = shape
+    rng = np.random.default_rng(variant * 1000 + W)
+    grid, guide, inp, _ = rand_case(rng, B, H, W, GH, GW, GD, Cin, Cout, ho, lo, hi)
+    want = port.bilateral_slice_apply(grid, guide, inp, ho)
+    with ops.kernel_override("fast", variant=variant):
+        got = N(ops.bilateral_slice_apply(T(grid, dev), T(guide, dev), T(inp, dev), has_offset=ho))
+        kern = ops.last_kernel()
+    assert expect in kern, kern
+    np.testing.assert_allclose(got, want, rtol=FWD_RTOL, atol=FWD_ATOL, err_msg=kern)
+
+
 @pytest.mark.parametrize("shape", APPLY_SHAPES[:10])
 def test_apply_backward_random(dev, ops, port, shape):
     B, H, W, GH, GW, GD, Cin, Cout, ho, lo, hi = shape
