@@ -35,7 +35,7 @@ SOURCES = [
     ("apply_fwd_io.hip", ["-fno-slp-vectorize"]),
     ("apply_bwd_rows.hip", ["-fno-slp-vectorize"]),
     ("slice_fwd_rows.hip", ["-fno-slp-vectorize"]),
-    ("grid_grad_mfma.hip", []),
+    ("grid_grad_mfma.hip", ["-fno-slp-vectorize"]),
 ]
 
 

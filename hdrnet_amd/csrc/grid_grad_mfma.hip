@@ -14,21 +14,26 @@
 // For the pixels of one image row that share gx0 (the lower x corner) this is a dense
 // contraction over the pixels:  D[k, c] += sum_px A[k, px] * V[px, c]  with 16 rows
 // k = (xcorner, gz) and A = wx * wz'.  That is exactly one v_mfma_f32_16x16x4_f32 per 4
-// pixels (f32 in, f32 accumulate, bit-equal to an fmaf chain), so the contraction runs on
-// the matrix pipe.  It is the one place in this library where MFMA is the right tool: a real
-// reduction over K = pixels, not a reshaped gather.
+// pixels (f32 in, f32 accumulate, bit-equal to an fmaf chain).  A real reduction over
+// K = pixels, not a reshaped gather -- the one place in this library where MFMA fits.  What it
+// buys is the data movement (the z scatter becomes dense rows; no atomics, deterministic), NOT
+// arithmetic rate: on gfx950 the f32-input MFMA runs at the VALU's own 32 FMA / cycle / SIMD and
+// does not overlap with VALU work of any wave on that SIMD (tools/debug/ubench/
+// mfma_valu_overlap.hip: MFMA-only 483 us + VALU-only 469 us -> 919 us interleaved), and the
+// tile is 19 % dense (4 live weights x 12 channels of 16 x 16).  Stage 1 is therefore bound by
+// FP32 issue: 16 MFMA (512 cycles) + ~115 VALU per 64-pixel chunk.
 //
-// Stage 1 (grid_grad_stage1): ONE WAVE owns one x-interval (all pixels with gx0 == g,
-//   g = -1 .. GW-1) of RG consecutive rows.  Per row it loads the interval's pixels
-//   (guide, input, dout: up to 4 chunks of 64 in flight), and per chunk each lane builds
-//   ITS pixel's two operand rows -- V (dout x [in; 1]) and A (16 weights, the two x corners
-//   folded into one row where they clamp onto the same column) -- writes them to a private
-//   LDS slab and the wave reads them back transposed into 16 MFMAs.  The row's 16x16 result
-//   is scaled by its two y weights into three REGISTER tiles (the <= 3 grid rows the group
-//   touches); after the last row the tiles go to the workspace.  No LDS accumulator, no
-//   atomics, no barrier: waves are independent and the result is deterministic.
-// Stage 2 (grid_grad_stage2): one thread per dgrid element adds, in fixed order, the
-//   partial tiles of the row groups and the two intervals that cover it.
+// Stage 1 (grid_grad_stage1): one workgroup of 4 waves owns one x-interval (all pixels with
+//   gx0 == g, g = -1 .. GW-1) of RG consecutive rows; its waves take alternate rows.  Per row a
+//   wave loads the interval's pixels (guide, input, dout: buffer loads, 2 chunks of 64 ahead),
+//   and per chunk each lane stages ITS pixel's operands -- V (dout x [in; 1]) and A (the two x
+//   corners folded into one row where they clamp onto the same column) -- in a private LDS
+//   slab; the wave reads them back as MFMA operands.  The row's 16x16 result is scaled by its
+//   two y weights into three REGISTER tiles (the <= 3 grid rows the group touches); after the
+//   last row the four waves' tiles are added in fixed order and go to the workspace.  No LDS
+//   accumulator, no atomics: the result is deterministic.
+// Stage 2 (grid_grad_stage2): one workgroup per grid cell adds, in fixed order, the partial
+//   tiles of the row groups and the two intervals that cover it.
 #include <hip/hip_runtime.h>
 
 #include "launch.hip.h"
@@ -41,12 +46,6 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWaves = 4;      // waves per workgroup; they share ONE task and split its rows
-// Operand rows in LDS: 16 floats per pixel, the row's four float4 slots XOR-swizzled by
-// (pixel >> 1) & 3.  Writes (ds_write_b128, 8-lane groups, one row per lane) then cover 8
-// distinct 4-bank groups; the transposed ds_read_b32 (32-lane halves = pixels 4t, 4t+1, 16
-// columns each) cover all 32 banks once.  (A 20-float padded row measured 33 % conflict cycles.)
-constexpr int kVStride = 16;
-constexpr int kBatch = 4;      // chunks of 64 pixels loaded ahead per row
 constexpr int kTileFloats = 3 * 16 * 16;  // partial tile: [rel 3][k 16][c 16]
 
 struct GGParams {
@@ -86,27 +85,70 @@ __device__ __forceinline__ int gy_base_of(int y_first, float scale_y, int GH) {
   return clamp_index(floor_to_int(mul_rn(y_first + 0.5f, scale_y) - 0.5f), 0, GH - 1);
 }
 
+// ---- stage 1 ---------------------------------------------------------------------------------
+// The operand slabs are stored k-major / channel-major ([16][kTStride] floats per wave):
+//   * the A operand is written as a SCATTER of its <= 4 live entries (2 x corners x 2 z corners)
+//     into a zeroed slab and re-zeroed after the MFMAs, instead of building 16 dense floats per
+//     pixel with a select chain (the z tent has two live taps; the forced-1 half cells one);
+//   * lane (sub, bc) of MFMA u takes pixel 16 * sub + u (any bijection of pixels onto (u, kk)
+//     computes the same sum), so its 16 operand values are CONTIGUOUS: 4 ds_read_b128 per
+//     operand instead of 16 ds_read_b32, bank-conflict-free with the 68-float row stride;
+//   * x weights depend on (chunk, lane) only, not on the row: computed once per wave.
 // CIN/COUT/OFFSET as in the forward; APPLY = false: V = dout (C = COUT channels).
+// Wave-uniform row base + 32-bit per-lane byte offset: buffer loads keep the addressing on the
+// scalar unit (global_load with 64-bit per-lane addresses cost ~2 extra VALU per load here) and
+// fetch a pixel's channels in one instruction (dword alignment is all a buffer load needs).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+}
+
+template <int N>
+__device__ __forceinline__ void buf_load(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, float* dst) {
+  if constexpr (N >= 4) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0);
+    dst[0] = __uint_as_float(v.x); dst[1] = __uint_as_float(v.y);
+    dst[2] = __uint_as_float(v.z); dst[3] = __uint_as_float(v.w);
+    if constexpr (N > 4) buf_load<N - 4>(rs, byte_off + 16, dst + 4);
+  } else if constexpr (N == 3) {
+    const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs, byte_off, 0, 0);
+    dst[0] = __uint_as_float(v.x); dst[1] = __uint_as_float(v.y); dst[2] = __uint_as_float(v.z);
+  } else if constexpr (N == 2) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 0);
+    dst[0] = __uint_as_float(v.x); dst[1] = __uint_as_float(v.y);
+  } else if constexpr (N == 1) {
+    dst[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 0));
+  }
+}
+
+constexpr int kTStride = 68;  // floats per operand row: 64 pixels + 4 (16-B aligned, 4-bank skew)
+
 template <int CIN, int COUT, bool OFFSET, bool APPLY>
 __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   constexpr int CJ = APPLY ? CIN + (OFFSET ? 1 : 0) : 1;
   constexpr int C = COUT * CJ;
   static_assert(C <= 16, "one 16-column MFMA tile");
   constexpr int CIN_Q = (APPLY && CIN > 0) ? CIN : 1;
-  __shared__ __attribute__((aligned(16))) float lds[kWaves * 2 * 64 * kVStride];
+  constexpr int kBatch = 2;  // chunks of 64 pixels loaded ahead (4: 132 VGPRs, 3 waves / SIMD, 6 % slower)
+  constexpr int kSlab = (16 + C) * kTStride;  // floats per wave: A^T [16][68] then V^T [C][68]
+  static_assert(kSlab >= kTileFloats, "the final reduction reuses the slabs");
+  __shared__ __attribute__((aligned(16))) float lds[kWaves * kSlab];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  float* vt = lds + wave * (2 * 64 * kVStride);  // V rows [64][20]
-  float* at = vt + 64 * kVStride;                // A rows [64][20]
-
-  const long long task = blockIdx.x;  // one (image, row group, x-interval) per workgroup
-  {  // V rows: zero once (the channel pad of each row is never written again)
-    f32x4* vz = reinterpret_cast<f32x4*>(vt);
+  float* at = lds + wave * kSlab;    // A^T[k][px]
+  float* vt = at + 16 * kTStride;    // V^T[c][px]
+  {  // zero the A slab once; afterwards every chunk restores the entries it wrote
+    f32x4* az = reinterpret_cast<f32x4*>(at);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) vz[lane * 4 + q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < (16 * kTStride / 4 + 63) / 64; ++q)
+      if (lane + 64 * q < 16 * kTStride / 4) az[lane + 64 * q] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  const long long task = blockIdx.x;  // one (image, row group, x-interval) per workgroup
   const int nint = p.GW + 1;
-  const int g = (int)(task % nint) - 1;  // gx0 of this wave's pixels
+  const int g = (int)(task % nint) - 1;  // gx0 of this workgroup's pixels
   const int yg = (int)((task / nint) % p.nyg);
   const long long b = task / ((long long)nint * p.nyg);
   const int x_lo = interval_start(g, p.W, p.scale_x);
@@ -117,44 +159,54 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   const bool fold_lo = g < 0, fold_hi = g >= p.GW - 1;
   const float gc0 = g + 0.5f, gc1 = g + 1 + 0.5f;
 
+  // Two x weights of pixel x; columns that clamp onto each other (g = -1: corner 0 -> column 0
+  // == corner 1; g = GW-1: corner 1 -> column GW-1 == corner 0) are folded into ONE A row, so
+  // stage 2 never sees a column twice.  Pixels past the interval get zero weights.
+  auto x_weights = [&](int x, float& w0, float& w1) {
+    const float live = (x < x_hi) ? 1.0f : 0.0f;
+    const float gxf = mul_rn((float)x + 0.5f, p.scale_x);
+    const float wxa = tent_weight(gc0, gxf) * live;
+    const float wxb = tent_weight(gc1, gxf) * live;
+    w0 = fold_lo ? 0.0f : (fold_hi ? wxa + wxb : wxa);
+    w1 = fold_lo ? wxa + wxb : (fold_hi ? 0.0f : wxb);
+  };
+  const int span = x_hi - x_lo;
+  const int nbr = (span + 64 * kBatch - 1) / (64 * kBatch);  // batches per row
+  float w0c[kBatch], w1c[kBatch];  // the common case nbr == 1: one batch per row, same x every row
+#pragma unroll
+  for (int cb = 0; cb < kBatch; ++cb) x_weights(x_lo + 64 * cb + lane, w0c[cb], w1c[cb]);
+
   // MFMA lane roles (v_mfma_f32_16x16x4_f32): A[k = lane & 15][kk = lane >> 4],
   // B[kk = lane >> 4][c = lane & 15], D[k = 4 * (lane >> 4) + r][c = lane & 15] in register r.
   const int sub = lane >> 4, bc = lane & 15;
-  // element (row r = 4t + sub, column bc) lives at r*16 + 4*((bc >> 2) ^ ((r >> 1) & 3)) + (bc & 3)
-  auto rd_ofs = [&](int t) { return (4 * t + sub) * kVStride + 4 * ((bc >> 2) ^ ((2 * t + (sub >> 1)) & 3)) + (bc & 3); };
+  const f32x4* a_rd = reinterpret_cast<const f32x4*>(at + bc * kTStride + 16 * sub);
+  const f32x4* v_rd = reinterpret_cast<const f32x4*>(vt + min(bc, C - 1) * kTStride + 16 * sub);
 
   f32x4 acc[3];
 #pragma unroll
   for (int r = 0; r < 3; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // Pixel batches of this wave, flattened over (row, batch-in-row): rows y_first + wave,
-  // + kWaves, ...; per row ceil(interval / 256) batches of <= 4 chunks of 64 pixels.  The loads
-  // of batch t+1 are issued before batch t is processed (two register sets), so a row's HBM
-  // latency hides behind the previous batch's ~6k cycles of staging + MFMA.
   struct Batch {
     float g[kBatch], in[kBatch][CIN_Q], d[kBatch][COUT];
   };
-  const int span = x_hi - x_lo;
-  const int nbr = (span + 64 * kBatch - 1) / (64 * kBatch);  // batches per row
   const int nrows = (y_end - (y_first + wave) + kWaves - 1) / kWaves;
   const int nbt = (span > 0 && nrows > 0) ? nrows * nbr : 0;
   auto load_batch = [&](int t, Batch& bt) {
     const int r = t / nbr, bi = t - r * nbr;
     const int y = y_first + wave + r * kWaves;
-    const size_t prow = ((size_t)b * p.H + y) * p.W;
+    const size_t prow = ((size_t)b * p.H + y) * p.W;  // wave-uniform
+    const __amdgpu_buffer_rsrc_t grs = row_rsrc(p.guide + prow);
+    const __amdgpu_buffer_rsrc_t irs = row_rsrc((APPLY && CIN > 0) ? p.input + prow * CIN : p.guide);
+    const __amdgpu_buffer_rsrc_t drs = row_rsrc(p.dout + prow * COUT);
     const int xb = x_lo + bi * 64 * kBatch;
 #pragma unroll
     for (int cb = 0; cb < kBatch; ++cb) {
       // unconditional (clamped) loads: no exec-masked branch around VMEM keeps the compiler's
-      // vmcnt counts exact; pixels past the interval are zero-weighted below.
-      const size_t px = prow + min(xb + 64 * cb + lane, x_hi - 1);
-      bt.g[cb] = p.guide[px];
-      if constexpr (APPLY && CIN > 0) {
-#pragma unroll
-        for (int j = 0; j < CIN; ++j) bt.in[cb][j] = p.input[px * CIN + j];
-      }
-#pragma unroll
-      for (int i = 0; i < COUT; ++i) bt.d[cb][i] = p.dout[px * COUT + i];
+      // vmcnt counts exact; pixels past the interval carry zero x weights.
+      const unsigned px = (unsigned)min(xb + 64 * cb + lane, x_hi - 1);
+      buf_load<1>(grs, px * 4u, &bt.g[cb]);
+      if constexpr (APPLY && CIN > 0) buf_load<CIN>(irs, px * (4u * CIN), bt.in[cb]);
+      buf_load<COUT>(drs, px * (4u * COUT), bt.d[cb]);
     }
   };
 
@@ -170,97 +222,61 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
     for (int cb = 0; cb < kBatch; ++cb) {
       const int x0 = xb + 64 * cb;
       if (x0 < x_hi) {  // wave-uniform
-        const int len = min(64, x_hi - x0);
-        const int x = x0 + lane;
-        // Stage both MFMA operands, lane = pixel, branch-free (idle lanes carry zero weights
-        // and zero V).  Columns that clamp onto each other (g = -1: corner 0 -> column 0 ==
-        // corner 1; g = GW-1: corner 1 -> column GW-1 == corner 0) are folded into ONE A row,
-        // so stage 2 never sees a column twice.
-        const float live = (lane < len) ? 1.0f : 0.0f;
-        const float gxf = mul_rn((float)x + 0.5f, p.scale_x);
-        const float wxa = tent_weight(gc0, gxf) * live;
-        const float wxb = tent_weight(gc1, gxf) * live;
-        const float w0 = fold_lo ? 0.0f : (fold_hi ? wxa + wxb : wxa);
-        const float w1 = fold_lo ? wxa + wxb : (fold_hi ? 0.0f : wxb);
+        float w0 = w0c[cb], w1 = w1c[cb];
+        if (nbr > 1) x_weights(x0 + lane, w0, w1);  // wave-uniform; only intervals wider than 256 px
         // z: only the two corners around gzf carry weight (:121); the outermost half cells are
         // forced to 1 (:122-125).  Two v_sqrt_f32 per pixel (1 ulp; argument >= 1e-8, no
         // denormals; a weight moves by <= 6e-8, far below the summation noise of a 30 000-term
-        // reduction), then one select chain per gz row.
+        // reduction).  P = (za, wa), Q = (za + 1, wb); Q is written first, so where it clamps onto
+        // P's slot (za == 7) P's value wins; there wb == 0 anyway.
         const float gzf = mul_rn(cur.g[cb], gd_f);  // gzf = guide * GD  (:120)
         const float fz = floorf(gzf - 0.5f);
         const float dza = (fz + 0.5f) - gzf, dzb = (fz + 1.5f) - gzf;
-        const float wa = std_max(1.0f - __builtin_amdgcn_sqrtf(fmaf(dza, dza, kSmoothEps)), 0.0f);
-        const float wb = std_max(1.0f - __builtin_amdgcn_sqrtf(fmaf(dzb, dzb, kSmoothEps)), 0.0f);
-        const int za = (int)__builtin_amdgcn_fmed3f(fz, -2.0f, gd_f + 1.0f), zb = za + 1;
+        float wP = std_max(1.0f - __builtin_amdgcn_sqrtf(fmaf(dza, dza, kSmoothEps)), 0.0f);
+        float wQ = std_max(1.0f - __builtin_amdgcn_sqrtf(fmaf(dzb, dzb, kSmoothEps)), 0.0f);
         const bool lo = gzf < 0.5f, hi = gzf > gd_f - 0.5f;
-        f32x4 wzv[2];
-#pragma unroll
-        for (int z = 0; z < 8; ++z) {
-          float wz = (z == za) ? wa : ((z == zb) ? wb : 0.0f);
-          if (z == 0) wz = lo ? 1.0f : wz;
-          wz = (z == p.GD - 1 && hi) ? 1.0f : wz;
-          wz = (z < p.GD) ? wz : 0.0f;
-          wzv[z >> 2][z & 3] = wz;
-        }
-        float vflat[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) vflat[c] = 0.0f;
+        int zP = min(max((int)__builtin_amdgcn_fmed3f(fz, -2.0f, 9.0f), 0), 7), zQ = min(zP + 1, 7);
+        if (lo) { zP = 0; zQ = 1; }
+        if (hi) { zP = p.GD - 1; zQ = (p.GD - 1) ^ 1; }
+        if (lo || hi) { wP = 1.0f; wQ = 0.0f; }
+        float* aP = at + zP * kTStride + lane;
+        float* aQ = at + zQ * kTStride + lane;
+        aQ[0] = w0 * wQ;
+        aQ[8 * kTStride] = w1 * wQ;
+        aP[0] = w0 * wP;
+        aP[8 * kTStride] = w1 * wP;
+        // V^T[c][px]: dout x [in; 1] (slice: dout)
         if constexpr (APPLY) {
 #pragma unroll
           for (int i = 0; i < COUT; ++i) {
-            const float di = cur.d[cb][i] * live;
 #pragma unroll
-            for (int j = 0; j < CJ; ++j) vflat[i * CJ + j] = (j < CIN) ? di * cur.in[cb][j < CIN ? j : 0] : di;
+            for (int j = 0; j < CJ; ++j)
+              vt[(i * CJ + j) * kTStride + lane] = (j < CIN) ? cur.d[cb][i] * cur.in[cb][j < CIN ? j : 0] : cur.d[cb][i];
           }
         } else {
 #pragma unroll
-          for (int c = 0; c < C; ++c) vflat[c] = cur.d[cb][c] * live;
-        }
-        f32x4* vrow = reinterpret_cast<f32x4*>(vt + lane * kVStride);
-        f32x4* ar = reinterpret_cast<f32x4*>(at + lane * kVStride);
-        const int wsw = (lane >> 1) & 3;
-        // V: only the float4 slots that hold channels are written; the rest of the row was
-        // zeroed once at kernel start and is never touched again.
-#pragma unroll
-        for (int q = 0; q < (C + 3) / 4; ++q)
-          vrow[q ^ wsw] = f32x4{vflat[4 * q], vflat[4 * q + 1], vflat[4 * q + 2], vflat[4 * q + 3]};
-        ar[0 ^ wsw] = w0 * wzv[0];
-        ar[1 ^ wsw] = w0 * wzv[1];
-        ar[2 ^ wsw] = w1 * wzv[0];
-        ar[3 ^ wsw] = w1 * wzv[1];
-        wave_lds_order();
-        // D[k, c] += sum_px A[k, px] * V[px, c]; lane l reads A[px = 4t + (l >> 4)][l & 15]
-        // and V likewise.  Two accumulators break the dependent-issue chain.
-        if (len == 64) {  // full chunk: straight-line, all 32 LDS reads can run ahead
-          float av[16], bv[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) {
-            av[u] = at[rd_ofs(u)];
-            bv[u] = vt[rd_ofs(u)];
-          }
-#pragma unroll
-          for (int u = 0; u < 16; u += 2) {
-            dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], dacc, 0, 0, 0);
-            dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[u + 1], dacc2, 0, 0, 0);
-          }
-        } else {
-#pragma unroll
-          for (int tg = 0; tg < 4; ++tg) {
-            if (16 * tg < len) {  // wave-uniform
-              float av[4], bv[4];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                av[u] = at[rd_ofs(4 * tg + u)];
-                bv[u] = vt[rd_ofs(4 * tg + u)];
-              }
-              dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], dacc, 0, 0, 0);
-              dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], dacc2, 0, 0, 0);
-              dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], dacc, 0, 0, 0);
-              dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], dacc2, 0, 0, 0);
-            }
-          }
+          for (int c = 0; c < C; ++c) vt[c * kTStride + lane] = cur.d[cb][c];
         }
         wave_lds_order();
+        // D[k, c] += sum_px A[k, px] * V[px, c]; two accumulators break the dependent-issue chain.
+        f32x4 av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          av[q] = a_rd[q];
+          bv[q] = v_rd[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][0], bv[q][0], dacc, 0, 0, 0);
+          dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][1], bv[q][1], dacc2, 0, 0, 0);
+          dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][2], bv[q][2], dacc, 0, 0, 0);
+          dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][3], bv[q][3], dacc2, 0, 0, 0);
+        }
+        wave_lds_order();
+        aQ[0] = 0.0f;
+        aQ[8 * kTStride] = 0.0f;
+        aP[0] = 0.0f;
+        aP[8 * kTStride] = 0.0f;
       }
     }
     if (bi == nbr - 1) {
@@ -287,7 +303,7 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   // Sum the four waves' register tiles in fixed order (wave 0 + 1 + 2 + 3) through LDS -- the
   // operand slabs are free now -- and write one partial tile per workgroup.
   __syncthreads();
-  float* red = lds + wave * kTileFloats;  // kTileFloats = 768 <= 2 * 64 * kVStride
+  float* red = lds + wave * kSlab;
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
 #pragma unroll
@@ -298,7 +314,7 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   for (int e = threadIdx.x; e < kTileFloats; e += kWaves * 64) {
     float sum = lds[e];
 #pragma unroll
-    for (int w = 1; w < kWaves; ++w) sum += lds[w * kTileFloats + e];
+    for (int w = 1; w < kWaves; ++w) sum += lds[w * kSlab + e];
     dst[e] = sum;
   }
 }
