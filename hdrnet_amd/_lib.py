@@ -34,6 +34,10 @@ SIGNATURES = {
     "hdrnet_bilateral_slice_apply_f32": (_I, [_FP] * 4 + [_I] * 9 + [_VP]),
     "hdrnet_bilateral_slice_apply_f32_ex": (_I, [_FP] * 4 + [_I] * 9 + [_U, _VP]),
     "hdrnet_bilateral_slice_apply_nnguide_f32": (_I, [_FP] * 6 + [_I] * 10 + [_VP]),
+    "hdrnet_pointwise_guide_grad_workspace_bytes": (_SZ, [ctypes.c_longlong, _I, _I]),
+    "hdrnet_pointwise_guide_grad_f32": (_I, [_FP] * 6 + [_I] + [_FP] * 2 + [ctypes.c_longlong, _I, _I, _VP, _SZ, _VP]),
+    "hdrnet_input_moments_workspace_bytes": (_SZ, [ctypes.c_longlong, _I]),
+    "hdrnet_input_moments_f32": (_I, [_FP, ctypes.c_longlong, _I, _FP, _FP, _VP, _SZ, _VP]),
     "hdrnet_bilateral_slice_apply_io": (_I, [_FP] * 4 + [_I] * 10 + [ctypes.c_float, _I] + [_FP] * 2 + [_I, _FP, _VP]),
     "hdrnet_bilateral_slice_apply_grad_workspace_bytes": (_SZ, [_I] * 9),
     "hdrnet_bilateral_slice_apply_grad_f32": (_I, [_FP] * 7 + [_I] * 9 + [_VP, _SZ, _VP]),

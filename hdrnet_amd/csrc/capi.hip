@@ -155,6 +155,74 @@ int hdrnet_bilateral_slice_apply_nnguide_f32(const float* grid, const float* inp
   return rc;
 }
 
+size_t hdrnet_pointwise_guide_grad_workspace_bytes(long long npx, int Cin, int n_feats) {
+  if (npx <= 0) return 0;
+  return hdrnet_amd::guide_grad_workspace_bytes(npx, Cin, n_feats);
+}
+
+int hdrnet_pointwise_guide_grad_f32(const float* input, const float* guide, const float* dguide,
+                                    const float* guide_conv1, const float* guide_conv2,
+                                    float* dinput, int accumulate_dinput, float* dconv1,
+                                    float* dconv2, long long npx, int Cin, int n_feats,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  using namespace hdrnet_amd;
+  if (npx < 0 || Cin <= 0 || n_feats <= 0)
+    return fail(HDRNET_INVALID_ARGUMENT, "bad sizes (npx=%lld, Cin=%d, n=%d)", npx, Cin, n_feats);
+  if (!dconv1 || !dconv2 || !guide_conv1 || !guide_conv2)
+    return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (npx == 0) {  // no pixels: zero parameter gradients
+    hipError_t e = hipMemsetAsync(dconv1, 0, sizeof(float) * (size_t)n_feats * (Cin + 1), s);
+    if (e == hipSuccess) e = hipMemsetAsync(dconv2, 0, sizeof(float) * (size_t)(n_feats + 1), s);
+    const int rc = check_launch(e, "PointwiseGuideGrad");
+    if (rc == HDRNET_OK) set_kernel("noop");
+    return rc;
+  }
+  if (!input || !guide || !dguide) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  GuideGradArgs a{input, guide, dguide, guide_conv1, guide_conv2, dinput, accumulate_dinput != 0,
+                  dconv1, dconv2, npx, Cin, n_feats, workspace, workspace_bytes};
+  if (!guide_grad_supported(a))
+    return fail(HDRNET_INVALID_ARGUMENT,
+                "guide-network gradient needs Cin in {1,3}, n_feats in {4,8,16}, 16-B aligned buffers "
+                "and a workspace of hdrnet_pointwise_guide_grad_workspace_bytes()");
+  const char* name = "";
+  const int rc = check_launch(launch_guide_grad(a, s, &name), "PointwiseGuideGrad");
+  if (rc == HDRNET_OK) set_kernel(name);
+  return rc;
+}
+
+size_t hdrnet_input_moments_workspace_bytes(long long npx, int Cin) {
+  if (npx <= 0) return 0;
+  return hdrnet_amd::input_moments_workspace_bytes(npx, Cin);
+}
+
+int hdrnet_input_moments_f32(const float* input, long long npx, int Cin, float* sums,
+                             float* moments, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+  using namespace hdrnet_amd;
+  if (npx < 0 || (Cin != 1 && Cin != 3))
+    return fail(HDRNET_INVALID_ARGUMENT, "input moments need npx >= 0 and Cin in {1,3} (npx=%lld, Cin=%d)",
+                npx, Cin);
+  if (!sums || !moments) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (npx == 0) {
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(float) * Cin, s);
+    if (e == hipSuccess) e = hipMemsetAsync(moments, 0, sizeof(float) * Cin * Cin, s);
+    const int rc = check_launch(e, "InputMoments");
+    if (rc == HDRNET_OK) set_kernel("noop");
+    return rc;
+  }
+  const size_t need = input_moments_workspace_bytes(npx, Cin);
+  if (!input || ((uintptr_t)input & 15u) || !workspace || workspace_bytes < need)
+    return fail(HDRNET_INVALID_ARGUMENT, "input moments need a 16-B aligned input and a workspace of "
+                                         "hdrnet_input_moments_workspace_bytes()");
+  const char* name = "";
+  const int rc = check_launch(launch_input_moments(input, npx, Cin, sums, moments, workspace, s, &name),
+                              "InputMoments");
+  if (rc == HDRNET_OK) set_kernel(name);
+  return rc;
+}
+
 int hdrnet_bilateral_slice_apply_io(const float* grid, const float* guide, const void* input,
                                     void* out, int B, int H, int W, int GH, int GW, int GD, int Cin,
                                     int Cout, int has_offset, int input_dtype,

@@ -1,0 +1,314 @@
+// Training side of the point-wise guide network (HDRNetPointwiseNNGuide._guide,
+// hdrnet/models.py:203-210: conv 1x1 Cin -> n with batch norm + ReLU, conv 1x1 n -> 1, sigmoid;
+// the conv / batch-norm wrappers are hdrnet/layers.py:23-58).  The forward is fused into the
+// slice-apply kernel (apply_fwd_rows.hip, GUIDE_NN) on the batch-norm-folded weights
+//
+//   guide = sigmoid(conv2[n] + sum_k conv2[k] * relu(conv1[k][Cin] + sum_j conv1[k][j] * in_j))
+//
+// and this file holds what a training step needs around it:
+//
+//   guide_nn_grad    the VJP of that expression: given dguide (from the slice-apply VJP) it
+//                    produces dconv1 [n][Cin+1], dconv2 [n+1] and adds the guide path's share to
+//                    dinput.  One pass over the pixels (40 B / px incl. the dinput read-modify-
+//                    write), parameter gradients accumulated in registers by persistent threads
+//                    and reduced in a fixed order (deterministic; no atomics).
+//   input_moments    sum_px in_j and sum_px in_i * in_j.  The conv is linear, so the batch
+//                    statistics batch norm needs in training mode (mean / biased variance of the
+//                    n-channel conv1 output over every pixel of the batch) follow from the Cin
+//                    means and the Cin x Cin second moments of the INPUT -- the n-channel
+//                    full-resolution intermediate never exists, in training either.
+//
+// In the un-fused graph these are ~20 full-resolution tensor passes, two of them rocBLAS gemv calls
+// on an [8.3 M x 16] matrix that take 75 ms of a 95 ms training step at 4 x 1080p.
+#include <hip/hip_runtime.h>
+
+#include "launch.hip.h"
+
+namespace hdrnet_amd {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kPx = 4;  // pixels per thread per iteration (float4 guide / dguide, CIN float4 of input)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// Adds the block's per-thread accumulators acc[0..NA) in a fixed order (lanes by butterfly,
+// then waves 0..3) and writes one row of partial sums per block.
+template <int NA>
+__device__ __forceinline__ void block_reduce_store(const float (&acc)[NA], float* partial_row) {
+  __shared__ float red[kThreads / 64][NA];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    const float s = wave_sum(acc[a]);
+    if (lane == 0) red[wave][a] = s;
+  }
+  __syncthreads();
+  for (int a = threadIdx.x; a < NA; a += kThreads) {
+    float s = red[0][a];
+#pragma unroll
+    for (int w = 1; w < kThreads / 64; ++w) s += red[w][a];
+    partial_row[a] = s;
+  }
+}
+
+// partial [nb][na] -> out[a] = sum_b partial[b][a], fixed order, accumulated in double.
+__global__ __launch_bounds__(256) void reduce_partials(const float* __restrict__ partial, int nb, int na,
+                                                       float* __restrict__ out0, int n0,
+                                                       float* __restrict__ out1) {
+  __shared__ double red[256];
+  const int a = blockIdx.x;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nb; b += 256) s += (double)partial[(size_t)b * na + a];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int m = 128; m >= 1; m >>= 1) {
+    if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (a < n0) out0[a] = (float)red[0];
+    else out1[a - n0] = (float)red[0];
+  }
+}
+
+// ---- VJP of the folded guide network ---------------------------------------------------------
+// guide (saved by the forward) gives the sigmoid's derivative without re-running the network's
+// second layer: dacc = dguide * g * (1 - g).
+template <int CIN, int NF, bool ACCUM>
+__global__ __launch_bounds__(kThreads, 2) void guide_nn_grad(
+    const float* __restrict__ input, const float* __restrict__ guide, const float* __restrict__ dguide,
+    const float* __restrict__ conv1, const float* __restrict__ conv2, float* __restrict__ dinput,
+    float* __restrict__ partial, long long npx) {
+  constexpr int CJ = CIN + 1;
+  constexpr int NA = NF * CJ + NF + 1;
+  float acc[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) acc[a] = 0.0f;
+
+  const long long nquads = (npx + kPx - 1) / kPx;
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long q = (long long)blockIdx.x * kThreads + threadIdx.x; q < nquads; q += stride) {
+    const long long p = q * kPx;
+    float g[kPx], dg[kPx], in[kPx][CIN], din[kPx][CIN];
+    if (p + kPx <= npx) {
+      const float4 g4 = *reinterpret_cast<const float4*>(guide + p);
+      const float4 d4 = *reinterpret_cast<const float4*>(dguide + p);
+      g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
+      dg[0] = d4.x; dg[1] = d4.y; dg[2] = d4.z; dg[3] = d4.w;
+      float4 iv[CIN];
+      const float4* ip = reinterpret_cast<const float4*>(input + p * CIN);
+#pragma unroll
+      for (int t = 0; t < CIN; ++t) iv[t] = ip[t];
+      const float* inf = reinterpret_cast<const float*>(iv);
+#pragma unroll
+      for (int k = 0; k < kPx; ++k) {
+#pragma unroll
+        for (int j = 0; j < CIN; ++j) in[k][j] = inf[k * CIN + j];
+      }
+    } else {  // ragged tail: pixels past the end contribute nothing
+#pragma unroll
+      for (int k = 0; k < kPx; ++k) {
+        const bool ok = p + k < npx;
+        g[k] = ok ? guide[p + k] : 0.0f;
+        dg[k] = ok ? dguide[p + k] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < CIN; ++j) in[k][j] = ok ? input[(p + k) * CIN + j] : 0.0f;
+      }
+    }
+    float da[kPx];
+#pragma unroll
+    for (int k = 0; k < kPx; ++k) {
+      da[k] = dg[k] * g[k] * (1.0f - g[k]);  // d sigmoid
+      acc[NF * CJ + NF] += da[k];            // d conv2 bias
+#pragma unroll
+      for (int j = 0; j < CIN; ++j) din[k][j] = 0.0f;
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      float w[CJ];
+#pragma unroll
+      for (int j = 0; j < CJ; ++j) w[j] = conv1[f * CJ + j];  // wave-uniform -> scalar loads
+      const float w2 = conv2[f];
+#pragma unroll
+      for (int k = 0; k < kPx; ++k) {
+        float h = w[CIN];
+#pragma unroll
+        for (int j = 0; j < CIN; ++j) h = fmaf(w[j], in[k][j], h);
+        acc[NF * CJ + f] = fmaf(da[k], fmaxf(h, 0.0f), acc[NF * CJ + f]);  // d conv2[f]
+        const float dh = (h > 0.0f) ? da[k] * w2 : 0.0f;                   // through the ReLU
+#pragma unroll
+        for (int j = 0; j < CIN; ++j) {
+          acc[f * CJ + j] = fmaf(dh, in[k][j], acc[f * CJ + j]);  // d conv1[f][j]
+          din[k][j] = fmaf(dh, w[j], din[k][j]);                  // d input_j
+        }
+        acc[f * CJ + CIN] += dh;  // d conv1 bias
+      }
+    }
+    if (dinput) {
+      if (p + kPx <= npx) {
+        float4* op = reinterpret_cast<float4*>(dinput + p * CIN);
+        float4 ov[CIN];
+        float* of = reinterpret_cast<float*>(ov);
+        if constexpr (ACCUM) {
+#pragma unroll
+          for (int t = 0; t < CIN; ++t) ov[t] = op[t];
+        } else {
+#pragma unroll
+          for (int t = 0; t < CIN * kPx; ++t) of[t] = 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < kPx; ++k) {
+#pragma unroll
+          for (int j = 0; j < CIN; ++j) of[k * CIN + j] += din[k][j];
+        }
+#pragma unroll
+        for (int t = 0; t < CIN; ++t) op[t] = ov[t];
+      } else {
+#pragma unroll
+        for (int k = 0; k < kPx; ++k) {
+          if (p + k < npx) {
+#pragma unroll
+            for (int j = 0; j < CIN; ++j) {
+              float* o = dinput + (p + k) * CIN + j;
+              *o = (ACCUM ? *o : 0.0f) + din[k][j];
+            }
+          }
+        }
+      }
+    }
+  }
+  block_reduce_store<NA>(acc, partial + (size_t)blockIdx.x * NA);
+}
+
+// ---- first and second moments of the input ------------------------------------------------------
+// acc layout: [CIN] sums, then [CIN][CIN] products (full matrix, symmetric).
+template <int CIN>
+__global__ __launch_bounds__(kThreads) void input_moments(const float* __restrict__ input,
+                                                          float* __restrict__ partial, long long npx) {
+  constexpr int NA = CIN + CIN * CIN;
+  float acc[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) acc[a] = 0.0f;
+  const long long nquads = (npx + kPx - 1) / kPx;
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long q = (long long)blockIdx.x * kThreads + threadIdx.x; q < nquads; q += stride) {
+    const long long p = q * kPx;
+    float in[kPx][CIN];
+    if (p + kPx <= npx) {
+      float4 iv[CIN];
+      const float4* ip = reinterpret_cast<const float4*>(input + p * CIN);
+#pragma unroll
+      for (int t = 0; t < CIN; ++t) iv[t] = ip[t];
+      const float* inf = reinterpret_cast<const float*>(iv);
+#pragma unroll
+      for (int k = 0; k < kPx; ++k) {
+#pragma unroll
+        for (int j = 0; j < CIN; ++j) in[k][j] = inf[k * CIN + j];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < kPx; ++k) {
+#pragma unroll
+        for (int j = 0; j < CIN; ++j) in[k][j] = (p + k < npx) ? input[(p + k) * CIN + j] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kPx; ++k) {
+#pragma unroll
+      for (int i = 0; i < CIN; ++i) {
+        acc[i] += in[k][i];
+#pragma unroll
+        for (int j = i; j < CIN; ++j) acc[CIN + i * CIN + j] = fmaf(in[k][i], in[k][j], acc[CIN + i * CIN + j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < CIN; ++i) {
+#pragma unroll
+    for (int j = 0; j < i; ++j) acc[CIN + i * CIN + j] = acc[CIN + j * CIN + i];
+  }
+  block_reduce_store<NA>(acc, partial + (size_t)blockIdx.x * NA);
+}
+
+int persistent_blocks(long long npx) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+  }
+  const long long want = (npx + (long long)kPx * kThreads - 1) / ((long long)kPx * kThreads);
+  const long long cap = (long long)cus * 4;
+  return (int)(want < cap ? (want > 0 ? want : 1) : cap);
+}
+
+bool guide_shape_ok(int Cin, int n) { return (Cin == 3 || Cin == 1) && (n == 16 || n == 8 || n == 4); }
+
+template <int CIN, int NF>
+hipError_t launch_grad_t(const GuideGradArgs& a, int nb, hipStream_t s) {
+  constexpr int NA = NF * (CIN + 1) + NF + 1;
+  float* partial = static_cast<float*>(a.workspace);
+  if (a.accumulate_dinput)
+    guide_nn_grad<CIN, NF, true><<<nb, kThreads, 0, s>>>(a.input, a.guide, a.dguide, a.conv1, a.conv2,
+                                                          a.dinput, partial, a.npx);
+  else
+    guide_nn_grad<CIN, NF, false><<<nb, kThreads, 0, s>>>(a.input, a.guide, a.dguide, a.conv1, a.conv2,
+                                                           a.dinput, partial, a.npx);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  reduce_partials<<<NA, 256, 0, s>>>(partial, nb, NA, a.dconv1, NF * (CIN + 1), a.dconv2);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+size_t guide_grad_workspace_bytes(long long npx, int Cin, int n) {
+  if (!guide_shape_ok(Cin, n)) return 0;
+  return (size_t)persistent_blocks(npx) * (size_t)(n * (Cin + 1) + n + 1) * sizeof(float);
+}
+
+bool guide_grad_supported(const GuideGradArgs& a) {
+  const size_t need = guide_grad_workspace_bytes(a.npx, a.Cin, a.n_feats);
+  const uintptr_t al = (uintptr_t)a.input | (uintptr_t)a.guide | (uintptr_t)a.dguide | (uintptr_t)a.dinput;
+  return need != 0 && a.workspace != nullptr && a.workspace_bytes >= need && (al & 15u) == 0;
+}
+
+hipError_t launch_guide_grad(const GuideGradArgs& a, hipStream_t s, const char** name) {
+  const int nb = persistent_blocks(a.npx);
+  *name = "guide_nn_grad";
+#define HDRNET_CASE(CI, NFEATS) \
+  if (a.Cin == CI && a.n_feats == NFEATS) return launch_grad_t<CI, NFEATS>(a, nb, s)
+  HDRNET_CASE(3, 16);
+  HDRNET_CASE(3, 8);
+  HDRNET_CASE(3, 4);
+  HDRNET_CASE(1, 16);
+  HDRNET_CASE(1, 8);
+  HDRNET_CASE(1, 4);
+#undef HDRNET_CASE
+  return hipErrorInvalidValue;
+}
+
+size_t input_moments_workspace_bytes(long long npx, int Cin) {
+  if (Cin != 1 && Cin != 3) return 0;
+  return (size_t)persistent_blocks(npx) * (size_t)(Cin + Cin * Cin) * sizeof(float);
+}
+
+hipError_t launch_input_moments(const float* input, long long npx, int Cin, float* sums, float* moments,
+                                void* workspace, hipStream_t s, const char** name) {
+  const int nb = persistent_blocks(npx);
+  float* partial = static_cast<float*>(workspace);
+  *name = "input_moments";
+  if (Cin == 3) input_moments<3><<<nb, kThreads, 0, s>>>(input, partial, npx);
+  else if (Cin == 1) input_moments<1><<<nb, kThreads, 0, s>>>(input, partial, npx);
+  else return hipErrorInvalidValue;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  reduce_partials<<<Cin + Cin * Cin, 256, 0, s>>>(partial, nb, Cin + Cin * Cin, sums, Cin, moments);
+  return hipGetLastError();
+}
+
+}  // namespace hdrnet_amd

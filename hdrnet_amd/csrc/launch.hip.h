@@ -50,6 +50,23 @@ struct ApplyGradArgs {
   int variant = 0;  // benchmark-only kernel variant (flags bits 8..15); 0 = library default
 };
 
+// Training side of the point-wise guide network (guide_nn_grad.hip).
+struct GuideGradArgs {
+  const float* input;   // [npx][Cin]
+  const float* guide;   // [npx] the forward's guide (sigmoid output)
+  const float* dguide;  // [npx]
+  const float* conv1;   // [n][Cin + 1]
+  const float* conv2;   // [n + 1]
+  float* dinput;        // [npx][Cin] or null
+  bool accumulate_dinput;  // true: dinput += guide path's share; false: dinput = it
+  float* dconv1;        // [n][Cin + 1]
+  float* dconv2;        // [n + 1]
+  long long npx;
+  int Cin, n_feats;
+  void* workspace;
+  size_t workspace_bytes;
+};
+
 struct SliceArgs {
   const float* grid;
   const float* guide;
@@ -113,5 +130,13 @@ hipError_t launch_apply_grid_grad_mfma(const ApplyGradArgs& a, hipStream_t s, co
 size_t slice_grid_grad_mfma_workspace(int B, int H, int W, int GH, int GW, int GD, int C);
 bool slice_grid_grad_mfma_supported(const SliceGradArgs& a);
 hipError_t launch_slice_grid_grad_mfma(const SliceGradArgs& a, hipStream_t s, const char** name);
+
+// guide_nn_grad.hip -- VJP of the folded point-wise guide network; input moments for batch norm.
+size_t guide_grad_workspace_bytes(long long npx, int Cin, int n);
+bool guide_grad_supported(const GuideGradArgs& a);
+hipError_t launch_guide_grad(const GuideGradArgs& a, hipStream_t s, const char** name);
+size_t input_moments_workspace_bytes(long long npx, int Cin);
+hipError_t launch_input_moments(const float* input, long long npx, int Cin, float* sums, float* moments,
+                                void* workspace, hipStream_t s, const char** name);
 
 }  // namespace hdrnet_amd

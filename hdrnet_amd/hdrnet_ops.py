@@ -273,18 +273,7 @@ def bilateral_slice_apply(grid: torch.Tensor, guide: torch.Tensor, input: torch.
     return _BilateralSliceApply.apply(grid, guide, input, has_offset)
 
 
-def bilateral_slice_apply_nnguide(grid: torch.Tensor, input: torch.Tensor,  # noqa: A002
-                                  guide_conv1: torch.Tensor, guide_conv2: torch.Tensor,
-                                  has_offset: bool = True, return_guide: bool = False):
-    """Inference-only fusion of ``HDRNetPointwiseNNGuide._guide`` (hdrnet/models.py:203-210, batch
-    norm folded) with ``bilateral_slice_apply``: the guide is computed in registers and never
-    written to memory (unless ``return_guide``).
-
-    ``guide_conv1`` is ``[n, Cin + 1]`` (weights then bias of feature k) and ``guide_conv2``
-    ``[n + 1]`` (mixing weights then bias) -- the layout ``hdrnet/bin/freeze_graph.py:170-184``
-    exports as ``guide_conv1.bin`` / ``guide_conv2.bin``.  No autograd (use the un-fused ops for
-    training).  Same shape rules as ``bilateral_slice_apply``; raises ``ValueError`` where the
-    fused kernel has no specialisation."""
+def _check_nnguide(grid, input, guide_conv1, guide_conv2, has_offset):  # noqa: A002
     _require_f32("guide_conv1", guide_conv1)
     _require_f32("guide_conv2", guide_conv2)
     if input.dim() != 4:
@@ -296,21 +285,122 @@ def bilateral_slice_apply_nnguide(grid: torch.Tensor, input: torch.Tensor,  # no
     if tuple(guide_conv2.shape) != (n + 1,):
         raise ValueError(f"guide_conv2 should be [n + 1] = [{n + 1}], got {tuple(guide_conv2.shape)}")
     fake_guide = input[..., 0]  # shape carrier for the shared rule checks; never read
-    B, H, W, GH, GW, GD, Cin, Cout = _check_apply(grid, fake_guide, input, has_offset)
+    dims = _check_apply(grid, fake_guide, input, has_offset)
     for nm, t in (("guide_conv1", guide_conv1), ("guide_conv2", guide_conv2)):
         _require_gpu(nm, t)
-    grid, inp = grid.detach().contiguous(), input.detach().contiguous()
-    c1, c2 = guide_conv1.detach().contiguous(), guide_conv2.detach().contiguous()
+    return dims + (n,)
+
+
+def _nnguide_forward(grid, inp, c1, c2, has_offset: bool, want_guide: bool):
+    B, H, W, GH, GW, GD, Cin, Cout, n = _check_nnguide(grid, inp, c1, c2, has_offset)
+    grid, inp, c1, c2 = grid.contiguous(), inp.contiguous(), c1.contiguous(), c2.contiguous()
     dev = inp.device
     out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
-    gout = torch.empty((B, H, W), dtype=torch.float32, device=dev) if return_guide else None
+    gout = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_guide else None
     lib = _lib.load()
     with torch.cuda.device(dev):
         rc = lib.hdrnet_bilateral_slice_apply_nnguide_f32(
             grid.data_ptr(), inp.data_ptr(), c1.data_ptr(), c2.data_ptr(), out.data_ptr(), _ptr(gout),
             B, H, W, GH, GW, GD, Cin, Cout, int(bool(has_offset)), n, _stream(dev))
     _lib.check(rc, "BilateralSliceApplyNNGuide")
-    return (out, gout) if return_guide else out
+    return out, gout
+
+
+def _guide_backward(inp, guide, dguide, c1, c2, dinput, accumulate: bool):
+    """VJP of the folded guide network: returns (dconv1, dconv2); adds the guide path's share to
+    ``dinput`` in place (or stores it, or skips it when ``dinput`` is None)."""
+    inp, guide, dguide = inp.contiguous(), guide.contiguous(), dguide.contiguous()
+    c1, c2 = c1.contiguous(), c2.contiguous()
+    dev = inp.device
+    npx, Cin, n = guide.numel(), inp.shape[-1], c1.shape[0]
+    dc1, dc2 = torch.empty_like(c1), torch.empty_like(c2)
+    lib = _lib.load()
+    wbytes = lib.hdrnet_pointwise_guide_grad_workspace_bytes(npx, Cin, n)
+    ws = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.hdrnet_pointwise_guide_grad_f32(
+            inp.data_ptr(), guide.data_ptr(), dguide.data_ptr(), c1.data_ptr(), c2.data_ptr(),
+            _ptr(dinput), int(bool(accumulate)), dc1.data_ptr(), dc2.data_ptr(), npx, Cin, n,
+            ws.data_ptr(), wbytes, _stream(dev))
+    _lib.check(rc, "PointwiseGuideGrad")
+    return dc1, dc2
+
+
+class _BilateralSliceApplyNNGuide(torch.autograd.Function):
+    """guide network + slice-apply as ONE differentiable op: forward = the fused kernel (the
+    guide is written once, for the backward); backward = slice-apply VJP, then the guide
+    network's VJP, which adds its share into the same dinput buffer."""
+
+    @staticmethod
+    def forward(ctx, grid, inp, c1, c2, has_offset):
+        out, guide = _nnguide_forward(grid, inp, c1, c2, bool(has_offset), want_guide=True)
+        ctx.save_for_backward(grid, inp, c1, c2, guide)
+        ctx.has_offset = bool(has_offset)
+        ctx.flags = _flags()
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad):
+        grid, inp, c1, c2, guide = ctx.saved_tensors
+        need_grid, need_inp, need_c1, need_c2 = ctx.needs_input_grad[:4]
+        need_net = need_c1 or need_c2
+        if not (need_grid or need_inp or need_net):
+            return None, None, None, None, None
+        dgrid, dguide, dinput = _apply_backward(grid, guide, inp, grad, ctx.has_offset,
+                                                (need_grid, need_net or need_inp, need_inp), ctx.flags)
+        dc1 = dc2 = None
+        if need_net or need_inp:
+            dc1, dc2 = _guide_backward(inp, guide, dguide, c1, c2, dinput, accumulate=True)
+        return dgrid, dinput, dc1 if need_c1 else None, dc2 if need_c2 else None, None
+
+
+def bilateral_slice_apply_nnguide(grid: torch.Tensor, input: torch.Tensor,  # noqa: A002
+                                  guide_conv1: torch.Tensor, guide_conv2: torch.Tensor,
+                                  has_offset: bool = True, return_guide: bool = False):
+    """Fusion of ``HDRNetPointwiseNNGuide._guide`` (hdrnet/models.py:203-210, batch norm folded)
+    with ``bilateral_slice_apply``: the guide is computed in registers and sliced immediately.
+
+    ``guide_conv1`` is ``[n, Cin + 1]`` (weights then bias of feature k) and ``guide_conv2``
+    ``[n + 1]`` (mixing weights then bias) -- the layout ``hdrnet/bin/freeze_graph.py:170-184``
+    exports as ``guide_conv1.bin`` / ``guide_conv2.bin``.
+
+    Differentiable in ``grid``, ``input``, ``guide_conv1`` and ``guide_conv2`` (the guide is then
+    written once for the backward, whose guide-network VJP exists for ``Cin`` in {1, 3} and ``n`` in
+    {4, 8, 16}).  ``return_guide=True`` returns ``(out, guide)`` without autograd.  Same shape rules
+    as ``bilateral_slice_apply``; raises ``ValueError`` where the fused kernel has no
+    specialisation."""
+    if return_guide:
+        return _nnguide_forward(grid.detach(), input.detach(), guide_conv1.detach(), guide_conv2.detach(),
+                                has_offset, want_guide=True)
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (grid, input, guide_conv1, guide_conv2)):
+        _check_nnguide(grid, input, guide_conv1, guide_conv2, has_offset)
+        return _BilateralSliceApplyNNGuide.apply(grid, input, guide_conv1, guide_conv2, has_offset)
+    return _nnguide_forward(grid.detach(), input.detach(), guide_conv1.detach(), guide_conv2.detach(),
+                            has_offset, want_guide=False)[0]
+
+
+def input_moments(input: torch.Tensor):  # noqa: A002
+    """``(sum_px in_j [Cin], sum_px in_i * in_j [Cin, Cin])`` over every pixel of ``input``
+    ``[..., Cin]`` in one pass.  The first guide convolution is linear, so these give the batch
+    statistics its batch norm needs in training mode (hdrnet/layers.py:40-58) without the
+    n-channel full-resolution tensor.  No autograd."""
+    _require_f32("input", input)
+    _require_gpu("input", input)
+    inp = input.detach().contiguous()
+    Cin = inp.shape[-1]
+    npx = inp.numel() // max(Cin, 1)
+    dev = inp.device
+    sums = torch.empty((Cin,), dtype=torch.float32, device=dev)
+    mom = torch.empty((Cin, Cin), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    wbytes = lib.hdrnet_input_moments_workspace_bytes(npx, Cin)
+    ws = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.hdrnet_input_moments_f32(inp.data_ptr(), npx, Cin, sums.data_ptr(), mom.data_ptr(),
+                                          ws.data_ptr(), wbytes, _stream(dev))
+    _lib.check(rc, "InputMoments")
+    return sums, mom
 
 
 _DTYPE_CODE = {torch.float32: 0, torch.uint8: 1, torch.uint16: 2}

@@ -187,15 +187,40 @@ class _PointwiseNNGuide(nn.Module):
         h = self.bn(h.reshape(-1, shape[-1])).reshape(shape)
         return torch.sigmoid(F.relu(h) @ self.w2 + self.b2)
 
-    def folded(self):
-        """Batch-norm folded into the first layer, in the reference's export layout
-        (hdrnet/bin/freeze_graph.py:170-184): conv1 [n, Cin + 1], conv2 [n + 1]."""
+    def folded(self, detach: bool = True):
+        """Batch-norm (running statistics) folded into the first layer, in the reference's export
+        layout (hdrnet/bin/freeze_graph.py:170-184): conv1 [n, Cin + 1], conv2 [n + 1]."""
         inv = torch.rsqrt(self.bn.running_var + self.bn.eps) * self.bn.weight
         w = self.w1 * inv  # [Cin, n]
         b = self.bn.bias - self.bn.running_mean * inv
         conv1 = torch.cat([w.t(), b[:, None]], dim=1).contiguous()
         conv2 = torch.cat([self.w2, self.b2.reshape(1)]).contiguous()
-        return conv1.detach(), conv2.detach()
+        return (conv1.detach(), conv2.detach()) if detach else (conv1, conv2)
+
+    def folded_batch(self, sums: torch.Tensor, moments: torch.Tensor, npx: int):
+        """Training-mode fold: batch norm normalises the conv output h = x . w1 with ITS mean and
+        biased variance over the batch (hdrnet/layers.py:40-58, is_training=True).  h is linear
+        in x, so  mean_h = w1^T mean_x  and  var_h[k] = w1[:,k]^T Cov_x w1[:,k]  -- computed here
+        from the input's first and second moments (``hdrnet_ops.input_moments``) in float64,
+        differentiable in w1 / beta / w2 / b2 (the moments are constants: the full-resolution image
+        is data).  Updates the running statistics exactly as ``nn.BatchNorm1d`` would."""
+        n = float(npx)
+        mean_x = sums.double() / n
+        cov_x = moments.double() / n - torch.outer(mean_x, mean_x)  # biased
+        w1 = self.w1.double()
+        mean_h = mean_x @ w1  # [n]
+        var_h = ((cov_x @ w1) * w1).sum(0).clamp_min(0.0)
+        with torch.no_grad():
+            m = self.bn.momentum
+            self.bn.running_mean.mul_(1 - m).add_(m * mean_h.float())
+            self.bn.running_var.mul_(1 - m).add_(m * (var_h * (n / max(n - 1.0, 1.0))).float())
+            self.bn.num_batches_tracked += 1
+        inv = torch.rsqrt(var_h + self.bn.eps) * self.bn.weight.double()
+        w = w1 * inv
+        b = self.bn.bias.double() - mean_h * inv
+        conv1 = torch.cat([w.t(), b[:, None]], dim=1).float().contiguous()
+        conv2 = torch.cat([self.w2, self.b2.reshape(1)]).contiguous()
+        return conv1, conv2
 
 
 class HDRNetCurves(nn.Module):
@@ -220,9 +245,11 @@ class HDRNetCurves(nn.Module):
 
 
 class HDRNetPointwiseNNGuide(HDRNetCurves):
-    """``hdrnet/models.py:199-210``.  In eval mode without autograd the guide network is FUSED
-    into the slice-apply kernel: the guide never touches HBM and the
-    16-channel full-resolution intermediate is never materialised."""
+    """``hdrnet/models.py:199-210``.  The guide network is FUSED into the slice-apply kernel
+    (SURVEY.md section 8f row 2): the 16-channel full-resolution intermediate is never
+    materialised, in inference (the guide never touches HBM) or in training (the guide is written
+    once for the backward; batch-norm statistics come from the input's moments; the network's VJP
+    is one more pass).  ``fuse_guide = False`` composes the un-fused ops instead."""
 
     fuse_guide = True
 
@@ -230,14 +257,25 @@ class HDRNetPointwiseNNGuide(HDRNetCurves):
         return _PointwiseNNGuide(self.params["guide_complexity"])
 
     def forward(self, lowres_input: torch.Tensor, fullres_input: torch.Tensor) -> torch.Tensor:
-        fusable = (self.fuse_guide and not self.training and not torch.is_grad_enabled()
-                   and fullres_input.is_cuda and fullres_input.shape[2] % 4 == 0)
+        n_feats = self.params["guide_complexity"]
+        fusable = (self.fuse_guide and fullres_input.is_cuda and fullres_input.shape[2] % 4 == 0
+                   and fullres_input.shape[3] in (1, 3))
+        differentiable = torch.is_grad_enabled() and (
+            fullres_input.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if differentiable and n_feats not in (4, 8, 16):
+            fusable = False  # no guide-network VJP kernel for this width: compose the ops
         if not fusable:
             return super().forward(lowres_input, fullres_input)
         from . import hdrnet_ops
         coeffs = self.coefficients(lowres_input)
         gs = coeffs.shape
-        conv1, conv2 = self.guide.folded()
+        if self.training:
+            # batch statistics of the (never materialised) conv1 output, from the input's moments
+            sums, moments = hdrnet_ops.input_moments(fullres_input)
+            npx = fullres_input.numel() // fullres_input.shape[3]
+            conv1, conv2 = self.guide.folded_batch(sums, moments, npx)
+        else:
+            conv1, conv2 = self.guide.folded(detach=not differentiable)
         return hdrnet_ops.bilateral_slice_apply_nnguide(
             coeffs.reshape(gs[0], gs[1], gs[2], gs[3], gs[4] * gs[5]), fullres_input, conv1, conv2,
             has_offset=True)

@@ -112,6 +112,34 @@ int hdrnet_bilateral_slice_apply_nnguide_f32(const float* grid, const float* inp
                                              int GH, int GW, int GD, int Cin, int Cout,
                                              int has_offset, int n_feats, void* stream);
 
+/* Training side of the point-wise guide network (HDRNetPointwiseNNGuide._guide,
+ * hdrnet/models.py:203-210; conv + batch norm wrappers hdrnet/layers.py:23-58).  These replace the
+ * TensorFlow-generated gradient sub-graph of the two 1x1 convolutions around the hot path; pixels
+ * are addressed flat (npx = B*H*W), buffers must be 16-B aligned.
+ *
+ * hdrnet_pointwise_guide_grad_f32: VJP of
+ *   guide = sigmoid(conv2[n] + sum_k conv2[k] * relu(conv1[k][Cin] + sum_j conv1[k][j] * in_j))
+ * given `guide` (as written by ..._nnguide_f32's guide_out) and `dguide` (from
+ * hdrnet_bilateral_slice_apply_grad_f32): writes dconv1 [n][Cin+1] and dconv2 [n+1]; if `dinput`
+ * is non-NULL the guide path's share of the input gradient is added to it
+ * (accumulate_dinput != 0: dinput already holds the slice path's share) or stored.
+ * Deterministic.  Supported: Cin in {1, 3}, n_feats in {4, 8, 16}; workspace from
+ * hdrnet_pointwise_guide_grad_workspace_bytes (0 = unsupported shape).
+ *
+ * hdrnet_input_moments_f32: sums[j] = sum_px in_j, moments[i][j] = sum_px in_i * in_j
+ * (Cin + Cin*Cin floats).  The first convolution is linear, so the training-mode batch-norm
+ * statistics of its n-channel output follow from these without materialising that tensor. */
+size_t hdrnet_pointwise_guide_grad_workspace_bytes(long long npx, int Cin, int n_feats);
+int hdrnet_pointwise_guide_grad_f32(const float* input, const float* guide, const float* dguide,
+                                    const float* guide_conv1, const float* guide_conv2,
+                                    float* dinput, int accumulate_dinput, float* dconv1,
+                                    float* dconv2, long long npx, int Cin, int n_feats,
+                                    void* workspace, size_t workspace_bytes, void* stream);
+size_t hdrnet_input_moments_workspace_bytes(long long npx, int Cin);
+int hdrnet_input_moments_f32(const float* input, long long npx, int Cin, float* sums,
+                             float* moments, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
 /* BilateralSliceApply forward with the product's wire formats fused in (inference):
  *   input  : HDRNET_F32, or HDRNET_U8 / HDRNET_U16 holding value / input_white_level --
  *            tf.to_float(im) / white_level of hdrnet/data_pipeline.py:202-232 (255, 65535) and

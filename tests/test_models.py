@@ -210,3 +210,105 @@ def test_graphed_inference_replays_exactly():
         torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6)
     with pytest.raises(ValueError):
         g(low, torch.rand(1, 540, 964, 3, device=dev))
+
+
+# ---- training side of the fused guide network (extended to training) ----
+def _torch_guide(inp, conv1, conv2):
+    """fp32 torch statement of the folded guide network (hdrnet/models.py:203-210)."""
+    h = inp @ conv1[:, :-1].t() + conv1[:, -1]
+    return torch.sigmoid(torch.relu(h) @ conv2[:-1] + conv2[-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 37, 52, 3, 16), (1, 64, 128, 3, 8), (1, 21, 36, 1, 4)])
+def test_input_moments(shape):
+    from hdrnet_amd import hdrnet_ops
+    B, H, W, Cin, _ = shape
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    x = torch.rand(B, H, W + 1, Cin, device=dev)[:, :, :W].contiguous()  # ragged pixel count
+    sums, mom = hdrnet_ops.input_moments(x)
+    assert hdrnet_ops.last_kernel() == "input_moments"
+    flat = x.reshape(-1, Cin).double()
+    torch.testing.assert_close(sums.double(), flat.sum(0), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(mom.double(), flat.t() @ flat, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 36, 52, 3, 16), (1, 64, 128, 3, 8), (1, 20, 36, 1, 4)])
+def test_fused_guide_apply_gradients_match_composition(shape):
+    """d(out)/d(grid, input, conv1, conv2) of the ONE fused differentiable op == autograd through
+    [torch guide network] -> [bilateral_slice_apply] (whose VJPs the parity tests pin to the oracle)."""
+    from hdrnet_amd import hdrnet_ops
+    B, H, W, Cin, n = shape
+    Cout = Cin
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    grid = torch.rand(B, 8, 8, 8, Cout * (Cin + 1), device=dev)
+    inp = torch.rand(B, H, W, Cin, device=dev)
+    conv1 = torch.randn(n, Cin + 1, device=dev) * 0.8
+    conv2 = torch.randn(n + 1, device=dev) * 0.5
+    dout = torch.randn(B, H, W, Cout, device=dev)
+
+    def run(fused):
+        leaves = [t.clone().requires_grad_(True) for t in (grid, inp, conv1, conv2)]
+        g, x, c1, c2 = leaves
+        if fused:
+            out = hdrnet_ops.bilateral_slice_apply_nnguide(g, x, c1, c2, has_offset=True)
+        else:
+            out = hdrnet_ops.bilateral_slice_apply(g, _torch_guide(x, c1, c2), x, has_offset=True)
+        out.backward(dout)
+        return out.detach(), [t.grad for t in leaves]
+
+    out_f, grads_f = run(True)
+    assert hdrnet_ops.last_kernel() == "guide_nn_grad"
+    out_r, grads_r = run(False)
+    torch.testing.assert_close(out_f, out_r, rtol=2e-5, atol=2e-5)
+    for name, a, b in zip(("dgrid", "dinput", "dconv1", "dconv2"), grads_f, grads_r):
+        scale = b.abs().max().item()
+        err = (a - b).abs().max().item()
+        assert err <= 2e-4 * scale + 1e-5, (name, err, scale)
+
+    # parameters only (the training case: the image needs no gradient): dinput is skipped
+    g = grid.clone().requires_grad_(True)
+    c1 = conv1.clone().requires_grad_(True)
+    out = hdrnet_ops.bilateral_slice_apply_nnguide(g, inp, c1, conv2, has_offset=True)
+    out.backward(dout)
+    torch.testing.assert_close(c1.grad, grads_f[2], rtol=1e-5, atol=1e-6)
+    # and the run is deterministic
+    _, again = run(True)
+    for a, b in zip(grads_f, again):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_training_fused_guide_matches_unfused_module():
+    """HDRNetPointwiseNNGuide.train(): the fused path (batch statistics from the input's moments,
+    fused forward, guide-network VJP kernel) == the composed torch graph: loss, every parameter
+    gradient, and the batch-norm running statistics."""
+    from hdrnet_amd import hdrnet_ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    m = models.HDRNetPointwiseNNGuide(dict(batch_norm=True)).to(dev).train()
+    ref = models.HDRNetPointwiseNNGuide(dict(batch_norm=True)).to(dev).train()
+    ref.load_state_dict(m.state_dict())
+    ref.fuse_guide = False
+    low = torch.rand(2, 256, 256, 3, device=dev)
+    full = torch.rand(2, 136, 240, 3, device=dev)
+    target = torch.rand(2, 136, 240, 3, device=dev)
+    loss = (m(low, full) - target).square().mean()
+    assert hdrnet_ops.last_kernel() == "apply_fwd_rows/vec4+nnguide"
+    loss.backward()
+    loss_ref = (ref(low, full) - target).square().mean()
+    loss_ref.backward()
+    torch.testing.assert_close(loss, loss_ref, rtol=1e-5, atol=1e-7)
+    for (name, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None, name
+        scale = q.grad.abs().max().item()
+        err = (p.grad - q.grad).abs().max().item()
+        assert err <= 1e-3 * scale + 1e-7, (name, err, scale)
+    torch.testing.assert_close(m.guide.bn.running_mean, ref.guide.bn.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(m.guide.bn.running_var, ref.guide.bn.running_var, rtol=1e-4, atol=1e-6)
+    assert int(m.guide.bn.num_batches_tracked) == int(ref.guide.bn.num_batches_tracked) == 1
