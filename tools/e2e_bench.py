@@ -79,6 +79,21 @@ def main():
     print(f"config #4  training step 1920x1080, {B} images/GPU: {t_step * 1e3:.2f} ms/step = "
           f"{B * 1080 * 1920 / 1e6 / t_step:.0f} MP/s per GPU")
 
+    # the same step with the guide network composed from torch ops (what round 1 first measured)
+    mt.fuse_guide = False
+    t_unfused = timeit(step, 3)
+    mt.fuse_guide = True
+    print(f"config #4  same step, guide network un-fused (torch ops): {t_unfused * 1e3:.2f} ms/step")
+
+    # the whole step (fwd + loss + bwd + Adam) as one hipGraph
+    from hdrnet_amd.runtime import GraphedTrainStep
+    mg = models.HDRNetPointwiseNNGuide(dict(batch_norm=True)).to(dev).train()
+    optg = torch.optim.Adam([p for p in mg.parameters() if p.requires_grad], lr=1e-4, capturable=True)
+    gstep = GraphedTrainStep(mg, lambda out, tgt: (out - tgt).square().mean(), optg, [low, full], [target])
+    t_graph = timeit(lambda: gstep([low, full], [target]), max(5, args.steps // 2))
+    print(f"config #4  the whole step as one hipGraph: {t_graph * 1e3:.2f} ms/step = "
+          f"{B * 1080 * 1920 / 1e6 / t_graph:.0f} MP/s per GPU")
+
 
 if __name__ == "__main__":
     main()
