@@ -1,0 +1,129 @@
+// How fast can ANY kernel move the forward's byte volume (4K frame: read 33.2 MB guide + 99.5 MB
+// input, write 99.5 MB) on this device, and does the block -> address mapping matter?
+// hipcc --offload-arch=gfx950 -O3
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+
+constexpr int H = 2160, W = 3840;
+constexpr long long NPX = (long long)H * W;
+
+// MODE 0: one block per 768-px row segment (the shipped geometry), lane-contiguous float4 accesses
+// MODE 1: same, blocks remapped so that each XCD (blockIdx % 8) streams its own contiguous eighth
+// MODE 2: persistent grid-stride, 1024 blocks x 256 threads, float4 per thread per stream per step
+// MODE 3: MODE 2 with two quads in flight per thread
+// MODE 4: one block per whole row (3840 px), 256 threads loop
+template <int MODE>
+__global__ __launch_bounds__(256) void k(const float4* __restrict__ g, const float4* __restrict__ in,
+                                         float4* __restrict__ out, int nblocks_logical) {
+  if constexpr (MODE == 0 || MODE == 1) {
+    int bid = blockIdx.x;
+    if constexpr (MODE == 1) {
+      const int per = nblocks_logical / 8;  // 10800 / 8 = 1350
+      bid = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    }
+    const long long q0 = (long long)bid * 192;  // quads (4 px) per segment: 768 / 4
+    const int t = threadIdx.x;
+    if (t < 192) {
+      const float4 gv = g[q0 + t];
+      float4 v[3];
+#pragma unroll
+      for (int k2 = 0; k2 < 3; ++k2) v[k2] = in[q0 * 3 + t + 192 * k2];
+      const float s = gv.x + gv.y + gv.z + gv.w;
+#pragma unroll
+      for (int k2 = 0; k2 < 3; ++k2) {
+        v[k2].x *= s; v[k2].y *= s; v[k2].z *= s; v[k2].w *= s;
+        out[q0 * 3 + t + 192 * k2] = v[k2];
+      }
+    }
+  } else if constexpr (MODE == 2 || MODE == 3) {
+    const long long nq = NPX / 4;
+    const long long stride = (long long)gridDim.x * 256;
+    constexpr int U = MODE == 3 ? 2 : 1;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nq; q += stride * U) {
+      float4 gv[U], v[U][3];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long qq = q + u * stride;
+        if (qq < nq) {
+          gv[u] = g[qq];
+          const long long base = (qq / 64) * 192 + (qq % 64);
+#pragma unroll
+          for (int k2 = 0; k2 < 3; ++k2) v[u][k2] = in[base + 64 * k2];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long long qq = q + u * stride;
+        if (qq < nq) {
+          const float s = gv[u].x + gv[u].y + gv[u].z + gv[u].w;
+          const long long base = (qq / 64) * 192 + (qq % 64);
+#pragma unroll
+          for (int k2 = 0; k2 < 3; ++k2) {
+            v[u][k2].x *= s; v[u][k2].y *= s; v[u][k2].z *= s; v[u][k2].w *= s;
+            out[base + 64 * k2] = v[u][k2];
+          }
+        }
+      }
+    }
+  } else {
+    const long long q0 = (long long)blockIdx.x * (W / 4);
+    for (int t = threadIdx.x; t < W / 4; t += 256) {
+      const float4 gv = g[q0 + t];
+      const long long base = q0 * 3 + (t / 64) * 192 + (t % 64);
+      float4 v[3];
+#pragma unroll
+      for (int k2 = 0; k2 < 3; ++k2) v[k2] = in[base + 64 * k2];
+      const float s = gv.x + gv.y + gv.z + gv.w;
+#pragma unroll
+      for (int k2 = 0; k2 < 3; ++k2) {
+        v[k2].x *= s; v[k2].y *= s; v[k2].z *= s; v[k2].w *= s;
+        out[base + 64 * k2] = v[k2];
+      }
+    }
+  }
+}
+
+int main() {
+  const int NSETS = 3;
+  float4 *g[NSETS], *in[NSETS], *out[NSETS];
+  for (int s = 0; s < NSETS; ++s) {
+    hipMalloc(&g[s], NPX * 4);
+    hipMalloc(&in[s], NPX * 12);
+    hipMalloc(&out[s], NPX * 12);
+    hipMemset(g[s], 0, NPX * 4);
+    hipMemset(in[s], 0, NPX * 12);
+  }
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const double bytes = NPX * 28.0;
+  auto time = [&](auto launch, const char* name) {
+    std::vector<float> ts;
+    for (int r = 0; r < 5; ++r) {
+      for (int i = 0; i < 5; ++i) launch(i % NSETS);
+      hipDeviceSynchronize();
+      hipEventRecord(e0);
+      for (int i = 0; i < 60; ++i) launch(i % NSETS);
+      hipEventRecord(e1);
+      hipDeviceSynchronize();
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      ts.push_back(ms * 1e3f / 60);
+    }
+    std::sort(ts.begin(), ts.end());
+    printf("%-52s median %6.2f us  min %6.2f us  -> %6.1f GB/s\n", name, ts[2], ts[0], bytes / ts[2] / 1e3);
+  };
+  for (int rep = 0; rep < 2; ++rep) {
+    time([&](int s) { k<0><<<10800, 256>>>(g[s], in[s], out[s], 10800); }, "0 block per 768-px segment (shipped geometry)");
+    time([&](int s) { k<0><<<10800, 192>>>(g[s], in[s], out[s], 10800); }, "0' same, 192-thread blocks");
+    time([&](int s) { k<1><<<10800, 192>>>(g[s], in[s], out[s], 10800); }, "1 XCD-contiguous remap");
+    time([&](int s) { k<2><<<1024, 256>>>(g[s], in[s], out[s], 0); }, "2 persistent 1024 blocks");
+    time([&](int s) { k<2><<<2048, 256>>>(g[s], in[s], out[s], 0); }, "2 persistent 2048 blocks");
+    time([&](int s) { k<3><<<1024, 256>>>(g[s], in[s], out[s], 0); }, "3 persistent 1024 blocks, 2 quads in flight");
+    time([&](int s) { k<3><<<2048, 256>>>(g[s], in[s], out[s], 0); }, "3 persistent 2048 blocks, 2 quads in flight");
+    time([&](int s) { k<4><<<2160, 256>>>(g[s], in[s], out[s], 0); }, "4 block per whole row");
+  }
+  return 0;
+}
