@@ -37,6 +37,7 @@ SOURCES = [
     ("slice_fwd_rows.hip", ["-fno-slp-vectorize"]),
     ("grid_grad_mfma.hip", ["-fno-slp-vectorize"]),
     ("guide_nn_grad.hip", ["-fno-slp-vectorize"]),
+    ("resize_bilinear.hip", []),
 ]
 
 

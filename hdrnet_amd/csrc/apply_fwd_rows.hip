@@ -75,12 +75,25 @@ __device__ __forceinline__ float guide_nn_pixel(const GuideNN& gn, const float (
   }
   return 1.0f / (1.0f + expf(-acc));  // tf.nn.sigmoid
 }
-template <int CIN, int COUT, bool OFFSET, bool GUIDE_NN = false, bool LDS_STORES = true>
+// UPADD: out += the coarser pyramid level's output, bilinearly up-sampled with align_corners = True
+// -- the `tf.image.resize_images(current, sz, BILINEAR, align_corners=True)` + `tf.add` of
+// HDRNetGaussianPyrNN._output (hdrnet/models.py:283-287).  TensorFlow (requirements.txt:
+// tensorflow_gpu==2.12.0; not vendored) computes, per axis, scale = (in - 1) / float(out - 1),
+// src = i * scale, lower = floor(src), upper = min(ceil(src), in - 1), lerp = src - lower, and
+// top + (bottom - top) * y_lerp with top = tl + (tr - tl) * x_lerp
+// (tensorflow/core/kernels/image/resize_bilinear_op.cc, legacy non-half-pixel path).
+struct UpAdd {
+  const float* coarse;  // [B][Hc][Wc][COUT]
+  int Hc, Wc;
+  float sh, sw;  // (Hc - 1) / float(H - 1), (Wc - 1) / float(W - 1)   (in / out when out == 1)
+};
+
+template <int CIN, int COUT, bool OFFSET, bool GUIDE_NN = false, bool LDS_STORES = true, bool UPADD = false>
 __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
     const float* __restrict__ grid, const float* __restrict__ guide,
     const float* __restrict__ input, float* __restrict__ out, int H, int W, int GH, int GW,
     int GD, int nseg, int seg, int slab_offset_floats, float scale_x, float scale_y,
-    GuideNN gn = GuideNN{nullptr, nullptr, nullptr, 0}) {
+    GuideNN gn = GuideNN{nullptr, nullptr, nullptr, 0}, UpAdd up = UpAdd{nullptr, 0, 0, 0.f, 0.f}) {
   constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
   extern __shared__ __attribute__((aligned(16))) float colY[];
   const int bid = blockIdx.x;
@@ -133,6 +146,30 @@ __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
       slice_apply_pixel<CIN, COUT, OFFSET>(r, xf0 + (float)k, gs[k], in, o);
 #pragma unroll
       for (int i = 0; i < COUT; ++i) of[k * COUT + i] = o[i];
+    }
+    if constexpr (UPADD) {
+      // row terms are workgroup-uniform; the 2 x 2 x COUT gathers hit the (small, cache-resident)
+      // coarse level
+      const float sy = mul_rn((float)y, up.sh);
+      const float fy = floorf(sy);
+      const float ly = sy - fy;
+      const int y0 = (int)fy, y1 = min((int)ceilf(sy), up.Hc - 1);
+      const float* r0 = up.coarse + ((size_t)b * up.Hc + y0) * up.Wc * COUT;
+      const float* r1 = up.coarse + ((size_t)b * up.Hc + y1) * up.Wc * COUT;
+#pragma unroll
+      for (int k = 0; k < kPxPerThread; ++k) {
+        const float sxf = mul_rn((float)(x + k), up.sw);
+        const float fx = floorf(sxf);
+        const float lx = sxf - fx;
+        const int x0 = (int)fx * COUT, x1 = min((int)ceilf(sxf), up.Wc - 1) * COUT;
+#pragma unroll
+        for (int i = 0; i < COUT; ++i) {
+          const float tl = r0[x0 + i], tr = r0[x1 + i], bl = r1[x0 + i], br = r1[x1 + i];
+          const float top = tl + (tr - tl) * lx;
+          const float bot = bl + (br - bl) * lx;
+          of[k * COUT + i] += top + (bot - top) * ly;
+        }
+      }
     }
   }
   if constexpr (!LDS_STORES) {
@@ -261,6 +298,22 @@ hipError_t launch_nnguide_t(const ApplyArgs& a, const GuideNN& gn, hipStream_t s
   return hipGetLastError();
 }
 
+float resize_scale(int in, int out) {  // TF CalculateResizeScale, align_corners = true
+  return out > 1 ? (float)(in - 1) / (float)(out - 1) : (float)in / (float)out;
+}
+
+template <bool GUIDE_NN>
+hipError_t launch_upadd_t(const ApplyArgs& a, const GuideNN& gn, const float* coarse, int Hc, int Wc,
+                          hipStream_t s) {
+  const LaunchGeom g = geom_for<12, 3>(a);
+  const UpAdd up{coarse, Hc, Wc, resize_scale(Hc, a.H), resize_scale(Wc, a.W)};
+  apply_fwd_rows_vec4<3, 3, true, GUIDE_NN, true, true>
+      <<<(unsigned)g.nblocks, g.pl.threads, g.lds, s>>>(
+          a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, g.pl.nseg, g.pl.seg, g.slab_off,
+          (float)a.GW / a.W, (float)a.GH / a.H, gn, up);
+  return hipGetLastError();
+}
+
 }  // namespace
 
 // Fused point-wise-NN guide + slice-apply.  Same shape support as the vec4 row kernel.
@@ -285,6 +338,31 @@ hipError_t launch_apply_fwd_nnguide(const ApplyArgs& a, const float* conv1, cons
   if (a.Cin == 1 && a.Cout == 1 && a.has_offset) return launch_nnguide_t<1, 1, true>(t, gn, s);
   if (a.Cin == 1 && a.Cout == 1 && !a.has_offset) return launch_nnguide_t<1, 1, false>(t, gn, s);
   return hipErrorInvalidValue;
+}
+
+// Slice-apply (+ optional fused guide network) + bilinear up-add of the coarser pyramid level.
+// One specialisation: Cin = Cout = 3 with offset (the reference's pyramid model), vec4 geometry.
+bool apply_fwd_upadd_supported(const ApplyArgs& a, const float* coarse, bool guide_nn) {
+  if (!(a.Cin == 3 && a.Cout == 3 && a.has_offset) || ((uintptr_t)coarse & 3u)) return false;
+  ApplyArgs t = a;
+  if (guide_nn) t.guide = a.input;
+  if (!apply_fwd_rows_supported(t)) return false;
+  const bool aligned = (((uintptr_t)t.guide | (uintptr_t)t.input | (uintptr_t)t.out | (uintptr_t)t.grid) & 15u) == 0;
+  return make_row_plan(t.W, t.GW, aligned).vec4;
+}
+
+hipError_t launch_apply_fwd_upadd(const ApplyArgs& a, const float* coarse, int Hc, int Wc,
+                                  const float* conv1, const float* conv2, int n_feats,
+                                  hipStream_t s, const char** name) {
+  if (conv1) {
+    const GuideNN gn{conv1, conv2, nullptr, n_feats};
+    ApplyArgs t = a;
+    t.guide = a.input;  // alignment stand-in: no guide buffer is read
+    *name = "apply_fwd_rows/vec4+nnguide+upadd";
+    return launch_upadd_t<true>(t, gn, coarse, Hc, Wc, s);
+  }
+  *name = "apply_fwd_rows/vec4+upadd";
+  return launch_upadd_t<false>(a, GuideNN{nullptr, nullptr, nullptr, 0}, coarse, Hc, Wc, s);
 }
 
 bool apply_fwd_rows_supported(const ApplyArgs& a) {

@@ -155,6 +155,59 @@ int hdrnet_bilateral_slice_apply_nnguide_f32(const float* grid, const float* inp
   return rc;
 }
 
+int hdrnet_bilateral_slice_apply_upadd_f32(const float* grid, const float* guide, const float* input,
+                                           const float* coarse, int Hc, int Wc, float* out, int B,
+                                           int H, int W, int GH, int GW, int GD, int Cin, int Cout,
+                                           int has_offset, const float* guide_conv1,
+                                           const float* guide_conv2, int n_feats, void* stream) {
+  using namespace hdrnet_amd;
+  if (int rc = check_common(B, H, W, GH, GW, GD)) return rc;
+  if (Cin <= 0 || Cout <= 0) return fail(HDRNET_INVALID_ARGUMENT, "bad channel counts");
+  if (Hc <= 0 || Wc <= 0) return fail(HDRNET_INVALID_ARGUMENT, "bad coarse extents (%d x %d)", Hc, Wc);
+  if ((guide != nullptr) == (guide_conv1 != nullptr))
+    return fail(HDRNET_INVALID_ARGUMENT, "give either a guide map or the guide network, not both / neither");
+  if (guide_conv1 && (!guide_conv2 || n_feats <= 0 || n_feats > 4096))
+    return fail(HDRNET_INVALID_ARGUMENT, "guide network needs conv1, conv2 and 0 < n_feats <= 4096");
+  if ((long long)B * H * W == 0) {
+    set_kernel("noop");
+    g_error[0] = '\0';
+    return HDRNET_OK;
+  }
+  if (!grid || !input || !out || !coarse) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  ApplyArgs a{grid, guide, input, out, B, H, W, GH, GW, GD, Cin, Cout,
+              Cin + (has_offset ? 1 : 0), has_offset != 0, 0};
+  if (!apply_fwd_upadd_supported(a, coarse, guide_conv1 != nullptr))
+    return fail(HDRNET_INVALID_ARGUMENT,
+                "slice-apply + up-add needs Cin = Cout = 3 with offset, W %% 4 == 0 and 16-B aligned "
+                "buffers; compose hdrnet_bilateral_slice_apply_f32 and hdrnet_resize_bilinear_f32 instead");
+  const char* name = "";
+  const int rc = check_launch(launch_apply_fwd_upadd(a, coarse, Hc, Wc, guide_conv1, guide_conv2, n_feats,
+                                                    static_cast<hipStream_t>(stream), &name),
+                              "BilateralSliceApplyUpAdd");
+  if (rc == HDRNET_OK) set_kernel(name);
+  return rc;
+}
+
+int hdrnet_resize_bilinear_f32(const float* in, float* out, int B, int Hin, int Win, int Hout, int Wout,
+                               int C, void* stream) {
+  using namespace hdrnet_amd;
+  if (B < 0 || Hin <= 0 || Win <= 0 || Hout < 0 || Wout < 0 || C <= 0)
+    return fail(HDRNET_INVALID_ARGUMENT, "bad extents (B=%d, in %dx%d, out %dx%d, C=%d)", B, Hin, Win, Hout,
+                Wout, C);
+  if ((long long)B * Hout * Wout == 0) {
+    set_kernel("noop");
+    g_error[0] = '\0';
+    return HDRNET_OK;
+  }
+  if (!in || !out) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  const char* name = "";
+  const int rc = check_launch(launch_resize_bilinear(in, out, B, Hin, Win, Hout, Wout, C,
+                                                    static_cast<hipStream_t>(stream), &name),
+                              "ResizeBilinear");
+  if (rc == HDRNET_OK) set_kernel(name);
+  return rc;
+}
+
 size_t hdrnet_pointwise_guide_grad_workspace_bytes(long long npx, int Cin, int n_feats) {
   if (npx <= 0) return 0;
   return hdrnet_amd::guide_grad_workspace_bytes(npx, Cin, n_feats);

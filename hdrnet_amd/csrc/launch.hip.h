@@ -107,6 +107,17 @@ hipError_t launch_apply_fwd_nnguide(const ApplyArgs& a, const float* conv1, cons
                                     int n_feats, float* guide_out, hipStream_t s,
                                     const char** name);
 
+// Slice-apply + bilinear (align_corners) up-add of the coarser pyramid level (apply_fwd_rows.hip,
+// UPADD); conv1 != null additionally fuses the guide network.
+bool apply_fwd_upadd_supported(const ApplyArgs& a, const float* coarse, bool guide_nn);
+hipError_t launch_apply_fwd_upadd(const ApplyArgs& a, const float* coarse, int Hc, int Wc,
+                                  const float* conv1, const float* conv2, int n_feats,
+                                  hipStream_t s, const char** name);
+
+// resize_bilinear.hip -- NHWC bilinear resize, align_corners = true (TF legacy semantics).
+hipError_t launch_resize_bilinear(const float* in, float* out, int B, int Hin, int Win, int Hout,
+                                  int Wout, int C, hipStream_t s, const char** name);
+
 bool apply_fwd_io_supported(const ApplyIoArgs& a);
 hipError_t launch_apply_fwd_io(const ApplyIoArgs& a, hipStream_t s, const char** name);
 

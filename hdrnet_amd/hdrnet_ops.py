@@ -35,7 +35,7 @@ import torch
 from . import _lib
 
 __all__ = ["bilateral_slice", "bilateral_slice_apply", "bilateral_slice_apply_nnguide",
-           "bilateral_slice_apply_io",
+           "bilateral_slice_apply_io", "bilateral_slice_apply_upadd", "resize_bilinear", "input_moments",
            "kernel_override", "last_kernel"]
 
 _tls = threading.local()
@@ -401,6 +401,63 @@ def input_moments(input: torch.Tensor):  # noqa: A002
                                           ws.data_ptr(), wbytes, _stream(dev))
     _lib.check(rc, "InputMoments")
     return sums, mom
+
+
+def resize_bilinear(input: torch.Tensor, height: int, width: int) -> torch.Tensor:  # noqa: A002
+    """NHWC ``tf.image.resize_images(input, (height, width), BILINEAR, align_corners=True)`` --
+    the resize that builds HDRNetGaussianPyrNN's multi-scale input (hdrnet/models.py:253-266).
+    No autograd."""
+    _require_f32("input", input)
+    if input.dim() != 4:
+        raise ValueError(f"input should be 4D (batch, height, width, channels), got {tuple(input.shape)}")
+    _require_gpu("input", input)
+    inp = input.detach().contiguous()
+    B, Hin, Win, C = inp.shape
+    out = torch.empty((B, int(height), int(width), C), dtype=torch.float32, device=inp.device)
+    lib = _lib.load()
+    with torch.cuda.device(inp.device):
+        rc = lib.hdrnet_resize_bilinear_f32(inp.data_ptr(), out.data_ptr(), B, Hin, Win, int(height),
+                                            int(width), C, _stream(inp.device))
+    _lib.check(rc, "ResizeBilinear")
+    return out
+
+
+def bilateral_slice_apply_upadd(grid: torch.Tensor, input: torch.Tensor, coarse: torch.Tensor,  # noqa: A002
+                                guide: Optional[torch.Tensor] = None,
+                                guide_conv1: Optional[torch.Tensor] = None,
+                                guide_conv2: Optional[torch.Tensor] = None,
+                                has_offset: bool = True) -> torch.Tensor:
+    """One level of ``HDRNetGaussianPyrNN._output`` (hdrnet/models.py:277-289) in one pass:
+    ``bilateral_slice_apply(grid, guide, input) + resize_bilinear(coarse -> H x W, align_corners)``.
+    Give either a ``guide`` map or the folded guide network (``guide_conv1``, ``guide_conv2``), which
+    is then evaluated in registers.  Inference only (no autograd)."""
+    if (guide is None) == (guide_conv1 is None):
+        raise ValueError("give either guide or (guide_conv1, guide_conv2)")
+    if input.dim() != 4:
+        raise ValueError(f"Input image should be 4D (batch_size, height, width, input_channels), got {tuple(input.shape)}")
+    if guide is None:
+        B, H, W, GH, GW, GD, Cin, Cout, n = _check_nnguide(grid, input, guide_conv1, guide_conv2, has_offset)
+    else:
+        B, H, W, GH, GW, GD, Cin, Cout = _check_apply(grid, guide, input, has_offset)
+        n = 0
+    _require_f32("coarse", coarse)
+    _require_gpu("coarse", coarse)
+    if coarse.dim() != 4 or coarse.shape[0] != B or coarse.shape[3] != Cout:
+        raise ValueError(f"coarse should be [B, Hc, Wc, Cout] = [{B}, *, *, {Cout}], got {tuple(coarse.shape)}")
+    grid, inp, coarse = grid.detach().contiguous(), input.detach().contiguous(), coarse.detach().contiguous()
+    gd = None if guide is None else guide.detach().contiguous()
+    c1 = None if guide_conv1 is None else guide_conv1.detach().contiguous()
+    c2 = None if guide_conv2 is None else guide_conv2.detach().contiguous()
+    dev = inp.device
+    out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        rc = lib.hdrnet_bilateral_slice_apply_upadd_f32(
+            grid.data_ptr(), _ptr(gd), inp.data_ptr(), coarse.data_ptr(), coarse.shape[1], coarse.shape[2],
+            out.data_ptr(), B, H, W, GH, GW, GD, Cin, Cout, int(bool(has_offset)), _ptr(c1), _ptr(c2), n,
+            _stream(dev))
+    _lib.check(rc, "BilateralSliceApplyUpAdd")
+    return out
 
 
 _DTYPE_CODE = {torch.float32: 0, torch.uint8: 1, torch.uint16: 2}

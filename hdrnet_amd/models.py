@@ -298,6 +298,9 @@ class HDRNetGaussianPyrNN(HDRNetPointwiseNNGuide):
         return y.permute(0, 2, 3, 1).contiguous()
 
     def forward(self, lowres_input: torch.Tensor, fullres_input: torch.Tensor) -> torch.Tensor:
+        if (self.fuse_guide and not self.training and not torch.is_grad_enabled() and fullres_input.is_cuda
+                and fullres_input.shape[3] == 3 and fullres_input.shape[2] % 16 == 0):
+            return self._forward_fused(lowres_input, fullres_input)
         coeffs = self.coefficients(lowres_input)
         lvls: List[torch.Tensor] = [fullres_input]
         h, w = fullres_input.shape[1:3]
@@ -310,4 +313,28 @@ class HDRNetGaussianPyrNN(HDRNetPointwiseNNGuide):
             c = coeffs[:, :, :, :, il * 3:(il + 1) * 3, :].contiguous()
             out = layers.bilateral_slice_apply(c, gd, lvl, has_offset=True)
             current = out if current is None else self._resize(current, out.shape[1], out.shape[2]) + out
+        return current
+
+    def _forward_fused(self, lowres_input: torch.Tensor, fullres_input: torch.Tensor) -> torch.Tensor:
+        """Inference with SURVEY.md section 8f rows 2 + 4 fused: per level ONE kernel evaluates the
+        level's guide network, slices, applies and adds the bilinearly up-sampled coarser result;
+        the multi-scale input comes from the NHWC resize kernel.  5 launches instead of ~40, and
+        no full-resolution intermediate besides the two down-sampled inputs."""
+        from . import hdrnet_ops
+        coeffs = self.coefficients(lowres_input)
+        gs = coeffs.shape
+        lvls: List[torch.Tensor] = [fullres_input]
+        h, w = fullres_input.shape[1:3]
+        for _ in range(self.n_scales - 1):
+            h, w = h // 2, w // 2
+            lvls.append(hdrnet_ops.resize_bilinear(lvls[-1], h, w))
+        current = None
+        for il, (lvl, gnet) in enumerate(reversed(list(zip(lvls, self.guide)))):  # models.py:278
+            c = coeffs[:, :, :, :, il * 3:(il + 1) * 3, :].reshape(gs[0], gs[1], gs[2], gs[3], 12)
+            conv1, conv2 = gnet.folded()
+            if current is None:
+                current = hdrnet_ops.bilateral_slice_apply_nnguide(c, lvl, conv1, conv2, has_offset=True)
+            else:
+                current = hdrnet_ops.bilateral_slice_apply_upadd(c, lvl, current, guide_conv1=conv1,
+                                                                 guide_conv2=conv2, has_offset=True)
         return current

@@ -112,6 +112,28 @@ int hdrnet_bilateral_slice_apply_nnguide_f32(const float* grid, const float* inp
                                              int GH, int GW, int GD, int Cin, int Cout,
                                              int has_offset, int n_feats, void* stream);
 
+/* Multi-scale output of HDRNetGaussianPyrNN (hdrnet/models.py:277-289): per pyramid level
+ *   out = BilateralSliceApply(grid_level, guide_level, input_level)
+ *         + resize_bilinear(coarser level's result -> H x W, align_corners = True)
+ * in ONE pass: the up-sampled coarse image and the un-added level output never exist.  The
+ * reference's GL renderer folds the levels in one shader too (benchmark/assets/gpyrnn.frag:65-86).
+ * `coarse` is [B][Hc][Wc][Cout].  Give either `guide` [B][H][W] or the folded guide network
+ * (guide_conv1 [n][Cin+1], guide_conv2 [n+1], evaluated in registers as in ..._nnguide_f32).
+ * Supported: Cin = Cout = 3 with offset, W % 4 == 0, 16-B aligned buffers.
+ *
+ * hdrnet_resize_bilinear_f32: NHWC bilinear resize, align_corners = True -- the
+ * tf.image.resize_images call that builds the multi-scale input (hdrnet/models.py:253-266).
+ * TensorFlow legacy semantics (tensorflow_gpu==2.12.0, resize_bilinear_op.cc): scale =
+ * (in-1)/float(out-1), src = i*scale, lower = floor, upper = min(ceil, in-1), lerp = src - lower. */
+int hdrnet_bilateral_slice_apply_upadd_f32(const float* grid, const float* guide,
+                                           const float* input, const float* coarse, int Hc,
+                                           int Wc, float* out, int B, int H, int W, int GH,
+                                           int GW, int GD, int Cin, int Cout, int has_offset,
+                                           const float* guide_conv1, const float* guide_conv2,
+                                           int n_feats, void* stream);
+int hdrnet_resize_bilinear_f32(const float* in, float* out, int B, int Hin, int Win, int Hout,
+                               int Wout, int C, void* stream);
+
 /* Training side of the point-wise guide network (HDRNetPointwiseNNGuide._guide,
  * hdrnet/models.py:203-210; conv + batch norm wrappers hdrnet/layers.py:23-58).  These replace the
  * TensorFlow-generated gradient sub-graph of the two 1x1 convolutions around the hot path; pixels

@@ -35,3 +35,33 @@ def pointwise_nn_guide(inp, conv1, conv2):
     h = inp @ conv1[:, :-1].T + conv1[:, -1]
     t = (np.maximum(h, np.float32(0)) @ conv2[:-1] + conv2[-1]).astype(np.float32)
     return (np.float32(1) / (np.float32(1) + np.exp(-t))).astype(np.float32)
+
+
+def resize_bilinear_align_corners(x, height, width):
+    """float32 numpy restatement of ``tf.image.resize_images(x, (height, width), BILINEAR,
+    align_corners=True)`` on NHWC arrays -- the resize of HDRNetGaussianPyrNN
+    (hdrnet/models.py:253-266, :283-286).  TensorFlow is a dependency of the reference that is not
+    under /root/reference (hdrnet/requirements.txt: tensorflow_gpu==2.12.0); its published legacy
+    algorithm (tensorflow/core/kernels/image/resize_bilinear_op.cc, half_pixel_centers = false):
+    scale = (in - 1) / float(out - 1) (in / float(out) if out == 1); src = i * scale;
+    lower = floor(src); upper = min(ceil(src), in - 1); lerp = src - lower;
+    out = top + (bottom - top) * y_lerp with top = tl + (tr - tl) * x_lerp."""
+    import numpy as np
+    x = np.asarray(x, np.float32)
+    B, Hin, Win, C = x.shape
+
+    def axis(n_in, n_out):
+        scale = np.float32(n_in - 1) / np.float32(n_out - 1) if n_out > 1 else np.float32(n_in) / np.float32(n_out)
+        src = (np.arange(n_out, dtype=np.float32) * scale).astype(np.float32)
+        lo = np.floor(src)
+        hi = np.minimum(np.ceil(src), n_in - 1)
+        return lo.astype(np.int64), hi.astype(np.int64), (src - lo).astype(np.float32)
+
+    y0, y1, ly = axis(Hin, int(height))
+    x0, x1, lx = axis(Win, int(width))
+    lx = lx[None, None, :, None]
+    ly = ly[None, :, None, None]
+    r0, r1 = x[:, y0], x[:, y1]
+    top = r0[:, :, x0] + (r0[:, :, x1] - r0[:, :, x0]) * lx
+    bot = r1[:, :, x0] + (r1[:, :, x1] - r1[:, :, x0]) * lx
+    return (top + (bot - top) * ly).astype(np.float32)

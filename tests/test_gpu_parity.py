@@ -327,6 +327,58 @@ def test_nnguide_fused_matches_composed_oracle(dev, ops, port, shape):
     assert torch.equal(out2, out)
 
 
+# ---- pyramid output: resize + slice-apply fused with the up-add -------
+@pytest.mark.parametrize("case", [(2, 37, 53, 3, 18, 26), (1, 64, 96, 3, 128, 192), (1, 9, 13, 1, 1, 1),
+                                  (1, 20, 30, 5, 20, 30)])
+def test_resize_bilinear_matches_oracle(dev, ops, case):
+    import oracle
+    B, Hin, Win, C, Hout, Wout = case
+    x = np.random.default_rng(sum(case)).random((B, Hin, Win, C)).astype(np.float32)
+    want = oracle.resize_bilinear_align_corners(x, Hout, Wout)
+    got = N(ops.resize_bilinear(T(x, dev), Hout, Wout))
+    assert ops.last_kernel() == "resize_bilinear_ac"
+    np.testing.assert_allclose(got, want, rtol=0, atol=5e-7)  # fma contraction of the three lerps
+    ref = torch.nn.functional.interpolate(T(x, dev).permute(0, 3, 1, 2), size=(Hout, Wout), mode="bilinear",
+                                          align_corners=True).permute(0, 2, 3, 1)
+    np.testing.assert_allclose(got, N(ref), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("fused_guide", [False, True])
+@pytest.mark.parametrize("case", [(2, 36, 64, 18, 32), (1, 45, 128, 22, 64), (1, 24, 256, 7, 100)])
+def test_upadd_matches_composed_oracle(dev, ops, port, case, fused_guide):
+    """One pyramid level: oracle slice-apply + oracle resize of the coarse level + add, vs the one
+    fused kernel (with the guide given as a map, or evaluated in registers from the folded net)."""
+    import oracle
+    B, H, W, Hc, Wc = case
+    rng = np.random.default_rng(sum(case) + int(fused_guide))
+    grid = rng.random((B, 16, 16, 8, 12)).astype(np.float32)
+    inp = rng.random((B, H, W, 3)).astype(np.float32)
+    coarse = rng.standard_normal((B, Hc, Wc, 3)).astype(np.float32)
+    conv1 = (rng.standard_normal((16, 4)) * 0.8).astype(np.float32)
+    conv2 = (rng.standard_normal(17) * 0.5).astype(np.float32)
+    guide = oracle.pointwise_nn_guide(inp, conv1, conv2) if fused_guide else rng.random((B, H, W)).astype(np.float32)
+    want = port.bilateral_slice_apply(grid, guide, inp, True) + oracle.resize_bilinear_align_corners(coarse, H, W)
+    if fused_guide:
+        got = ops.bilateral_slice_apply_upadd(T(grid, dev), T(inp, dev), T(coarse, dev), guide_conv1=T(conv1, dev),
+                                              guide_conv2=T(conv2, dev))
+        assert ops.last_kernel() == "apply_fwd_rows/vec4+nnguide+upadd"
+        tol = 2e-5
+    else:
+        got = ops.bilateral_slice_apply_upadd(T(grid, dev), T(inp, dev), T(coarse, dev), guide=T(guide, dev))
+        assert ops.last_kernel() == "apply_fwd_rows/vec4+upadd"
+        tol = 1e-5
+    np.testing.assert_allclose(N(got), want, rtol=tol, atol=tol)
+
+
+def test_upadd_rejects_unsupported(dev, ops):
+    g = torch.rand((1, 8, 8, 4, 12), device=dev)
+    x = torch.rand((1, 8, 10, 3), device=dev)  # W % 4 != 0
+    with pytest.raises(ValueError):
+        ops.bilateral_slice_apply_upadd(g, x, torch.rand((1, 4, 5, 3), device=dev), guide=torch.rand((1, 8, 10), device=dev))
+    with pytest.raises(ValueError):  # neither guide nor guide network
+        ops.bilateral_slice_apply_upadd(g, torch.rand((1, 8, 8, 3), device=dev), torch.rand((1, 4, 4, 3), device=dev))
+
+
 @pytest.mark.parametrize("in_dtype,wl", [("uint8", 255.0), ("uint16", 65535.0), ("uint16", 32767.0), ("float32", 1.0)])
 @pytest.mark.parametrize("out_dtype", ["uint8", "float32"])
 @pytest.mark.parametrize("nn", [False, True])

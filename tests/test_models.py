@@ -359,3 +359,22 @@ def test_graphed_train_step_matches_eager():
         scale = de.abs().max().item()
         assert scale > 0, name
         assert (dg - de).abs().max().item() <= 5e-2 * scale, (name, (dg - de).abs().max().item(), scale)
+
+
+@pytest.mark.gpu
+def test_pyramid_model_fused_matches_composed():
+    """HDRNetGaussianPyrNN inference: the fused path (resize kernel, per-level guide net + slice-apply
+    + up-add in one launch) == the composition of the un-fused ops (hdrnet/models.py:213-289)."""
+    from hdrnet_amd import hdrnet_ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(6)
+    m = models.HDRNetGaussianPyrNN().to(dev).eval()
+    low = torch.rand(1, 256, 256, 3, device=dev)
+    full = torch.rand(1, 272, 480, 3, device=dev)
+    with torch.no_grad():
+        out = m(low, full)
+        assert hdrnet_ops.last_kernel() == "apply_fwd_rows/vec4+nnguide+upadd"
+        m.fuse_guide = False
+        ref = m(low, full)
+        assert hdrnet_ops.last_kernel() == "apply_fwd_rows/vec4"
+    torch.testing.assert_close(out, ref, rtol=5e-5, atol=5e-5)

@@ -227,3 +227,37 @@ def test_grid_grad_is_adjoint_of_apply(port):
     off = port.bilateral_slice_apply(g["grid"], g["guide"], zero_in, ho).astype(np.float64)
     lhs2 = float((dinput.astype(np.float64) * g["input"]).sum() + (u * off).sum())
     assert abs(lhs2 - rhs) <= 2e-5 * abs(rhs)
+
+
+# ---- the TF bilinear resize (align_corners) restatement used by the pyramid tests ------------------
+@pytest.mark.parametrize("size", [(18, 26), (74, 106), (37, 53), (1, 1), (5, 200)])
+def test_resize_restatement_matches_torch_align_corners(size):
+    """tensorflow is not vendored by the reference (requirements.txt pins tensorflow_gpu==2.12.0);
+    the restatement of its legacy align_corners bilinear resize is pinned against the one
+    independent implementation available here, torch's F.interpolate(align_corners=True), and
+    against the closed forms below."""
+    import torch
+    import torch.nn.functional as F
+    import oracle
+    x = np.random.default_rng(7).random((2, 37, 53, 3), dtype=np.float32)
+    got = oracle.resize_bilinear_align_corners(x, *size)
+    want = F.interpolate(torch.from_numpy(x).permute(0, 3, 1, 2), size=size, mode="bilinear",
+                         align_corners=True).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=5e-7)
+
+
+def test_resize_restatement_closed_forms():
+    import oracle
+    rng = np.random.default_rng(8)
+    x = rng.random((1, 9, 13, 2), dtype=np.float32)
+    assert np.array_equal(oracle.resize_bilinear_align_corners(x, 9, 13), x)  # identity
+    # corners are preserved (align_corners) and a 2x up-sampling of size 2n-1 interleaves exactly
+    up = oracle.resize_bilinear_align_corners(x, 17, 25)
+    assert np.array_equal(up[:, ::2, ::2], x)
+    np.testing.assert_allclose(up[:, 1::2, ::2], 0.5 * (x[:, :-1] + x[:, 1:]), rtol=0, atol=1e-7)
+    # a linear ramp is reproduced by bilinear interpolation
+    yy, xx = np.meshgrid(np.linspace(0, 1, 9, dtype=np.float32), np.linspace(0, 2, 13, dtype=np.float32), indexing="ij")
+    ramp = (0.25 + 0.5 * yy + 0.125 * xx)[None, :, :, None].astype(np.float32)
+    y2, x2 = np.meshgrid(np.linspace(0, 1, 20, dtype=np.float32), np.linspace(0, 2, 31, dtype=np.float32), indexing="ij")
+    want = (0.25 + 0.5 * y2 + 0.125 * x2)[None, :, :, None]
+    np.testing.assert_allclose(oracle.resize_bilinear_align_corners(ramp, 20, 31), want, rtol=0, atol=2e-6)

@@ -61,6 +61,19 @@ def main():
     print(f"config #3  HDRNetPointwiseNNGuide 3840x2160 b=1: {t_all * 1e3:.3f} ms/frame = {mp / t_all:.0f} MP/s "
           f"(coefficients {t_coef * 1e3:.3f} ms, guide net {t_guide * 1e3:.3f} ms, slice-apply {t_slice * 1e3:.3f} ms)")
 
+    # HDRNetGaussianPyrNN inference at 4K: 3 levels, fused (resize kernel + one launch per level)
+    # vs composed from the un-fused ops
+    mp_ = models.HDRNetGaussianPyrNN().to(dev).eval()
+    with torch.no_grad():
+        t_pf = timeit(lambda: mp_(low, full), args.steps)
+        gp = GraphedInference(mp_, [low, full])
+        t_pg = timeit(lambda: gp(gp.static_inputs[0], gp.static_inputs[1]), args.steps)
+        mp_.fuse_guide = False
+        t_pu = timeit(lambda: mp_(low, full), 3)
+        mp_.fuse_guide = True
+    print(f"pyramid    HDRNetGaussianPyrNN 3840x2160 b=1: composed {t_pu * 1e3:.2f} ms/frame, fused "
+          f"{t_pf * 1e3:.3f} ms/frame, fused + hipGraph {t_pg * 1e3:.3f} ms/frame = {mp / t_pg:.0f} MP/s")
+
     mt = models.HDRNetPointwiseNNGuide(dict(batch_norm=True)).to(dev).train()
     opt = torch.optim.Adam([p for p in mt.parameters() if p.requires_grad], lr=1e-4)
     B = 4

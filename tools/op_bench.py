@@ -103,6 +103,20 @@ def main():
             1, H, W, GH, GW, GD, 3, 3, 1, 1, 255.0, 1, conv1.data_ptr() if nn else None,
             conv2.data_ptr() if nn else None, 16 if nn else 0, None, stream))
 
+    coarse = [torch.randn((1, H // 2, W // 2, 3), device=dev, generator=gen) for _ in range(nsets)]
+    half = [torch.empty((1, H // 2, W // 2, 3), device=dev) for _ in range(nsets)]
+
+    def apply_upadd(k, nn=True):
+        s = S[k % nsets]
+        chk(lib.hdrnet_bilateral_slice_apply_upadd_f32(
+            s["grid"].data_ptr(), None if nn else s["guide"].data_ptr(), s["inp"].data_ptr(),
+            coarse[k % nsets].data_ptr(), H // 2, W // 2, s["out"].data_ptr(), 1, H, W, GH, GW, GD, 3, 3, 1,
+            conv1.data_ptr() if nn else None, conv2.data_ptr() if nn else None, 16 if nn else 0, stream))
+
+    def resize_half(k):
+        chk(lib.hdrnet_resize_bilinear_f32(S[k % nsets]["inp"].data_ptr(), half[k % nsets].data_ptr(),
+                                           1, H, W, H // 2, W // 2, 3, stream))
+
     def apply_bwd(k, dg=True, dgu=True, di=True):
         s = S[k % nsets]
         chk(lib.hdrnet_bilateral_slice_apply_grad_f32(
@@ -140,6 +154,10 @@ def main():
     run("guide-NN(16) + apply fwd fused", apply_fwd_nnguide, 4 * npx * (Cin + Cout) + gridb)
     run("u8 -> guide-NN + apply -> u8", apply_io_u8, npx * 6 + gridb)
     run("u8 + guide map -> apply -> u8", lambda k: apply_io_u8(k, nn=False), npx * 10 + gridb)
+    run("apply + up-add of coarse level", lambda k: apply_upadd(k, nn=False),
+        4 * npx * (1 + Cin + Cout) + gridb + 4 * npx * 3 // 4)
+    run("guide-NN + apply + up-add", apply_upadd, 4 * npx * (Cin + Cout) + gridb + 4 * npx * 3 // 4)
+    run("resize bilinear 4K -> 1080p", resize_half, 4 * npx * 3 + 4 * npx * 3 // 4)
     run("apply bwd (all three)", apply_bwd, 4 * npx * (1 + Cin + Cout) + 4 * npx * (1 + Cin) + 2 * gridb)
     run("apply bwd dguide+dinput", lambda k: apply_bwd(k, dg=False), 4 * npx * (1 + Cin + Cout) + 4 * npx * (1 + Cin) + gridb)
     run("apply bwd dgrid only", lambda k: apply_bwd(k, dgu=False, di=False), 4 * npx * (1 + Cin + Cout) + gridb)
