@@ -115,7 +115,22 @@ int main() {
     std::sort(ts.begin(), ts.end());
     printf("%-52s median %6.2f us  min %6.2f us  -> %6.1f GB/s\n", name, ts[2], ts[0], bytes / ts[2] / 1e3);
   };
-  for (int rep = 0; rep < 2; ++rep) {
+  // (a) does the relative placement of the three streams matter (same HBM channel phase)?  No.
+  // (b) NOT the streaming case: `out` is ONE buffer re-written by every launch, so its 100 MB stay
+  //     in the 256 MB Infinity Cache -- 33 us = 7.06 TB/s apparent.  This is why bench.py rotates
+  //     over buffer sets larger than the cache.
+  {
+    float4* big;
+    hipMalloc(&big, NPX * 12 + (64 << 20));
+    for (size_t off : {(size_t)0, (size_t)256, (size_t)4096, (size_t)(64 << 10), (size_t)(1 << 20), (size_t)(3 << 20) + 8192}) {
+      float4* o = big + off / 16;
+      char name[96];
+      snprintf(name, sizeof name, "0' out = ONE re-used buffer (cache-resident), +%zu B", off);
+      time([&](int s) { k<0><<<10800, 192>>>(g[s], in[s], o, 10800); }, name);
+    }
+    printf("bases mod 2 MiB: g %zu in %zu out %zu\n", (size_t)g[0] % (2 << 20), (size_t)in[0] % (2 << 20), (size_t)out[0] % (2 << 20));
+  }
+  for (int rep = 0; rep < 1; ++rep) {
     time([&](int s) { k<0><<<10800, 256>>>(g[s], in[s], out[s], 10800); }, "0 block per 768-px segment (shipped geometry)");
     time([&](int s) { k<0><<<10800, 192>>>(g[s], in[s], out[s], 10800); }, "0' same, 192-thread blocks");
     time([&](int s) { k<1><<<10800, 192>>>(g[s], in[s], out[s], 10800); }, "1 XCD-contiguous remap");
