@@ -77,3 +77,39 @@ def test_version_and_error_text_without_gpu(libpath):
     assert rc == 1
     # Zero-sized image: legal no-op (the reference loops over an empty shape).
     assert lib.hdrnet_bilateral_slice_apply_f32(None, None, None, None, 0, 4, 4, 2, 2, 2, 3, 3, 1, None) == 0
+
+
+def test_new_entry_points_validate_without_gpu(libpath):
+    """Argument validation of the guide-network / pyramid / resize entry points happens before any
+    HIP call, like the four ops': error codes and messages are testable on a CPU box."""
+    lib = ctypes.CDLL(libpath)
+    lib.hdrnet_last_error.restype = ctypes.c_char_p
+    LL, I, P, SZ = ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+    lib.hdrnet_pointwise_guide_grad_workspace_bytes.restype = SZ
+    lib.hdrnet_pointwise_guide_grad_workspace_bytes.argtypes = [LL, I, I]
+    lib.hdrnet_input_moments_workspace_bytes.restype = SZ
+    lib.hdrnet_input_moments_workspace_bytes.argtypes = [LL, I]
+    # unsupported widths report "no workspace" = unsupported, never a bogus size
+    assert lib.hdrnet_pointwise_guide_grad_workspace_bytes(1000, 3, 5) == 0
+    assert lib.hdrnet_pointwise_guide_grad_workspace_bytes(1000, 2, 16) == 0
+    assert lib.hdrnet_input_moments_workspace_bytes(1000, 2) == 0
+    assert lib.hdrnet_input_moments_workspace_bytes(0, 3) == 0
+    lib.hdrnet_pointwise_guide_grad_f32.argtypes = [P] * 6 + [I] + [P] * 2 + [LL, I, I, P, SZ, P]
+    rc = lib.hdrnet_pointwise_guide_grad_f32(None, None, None, None, None, None, 0, None, None, 16, 3, 16, None, 0, None)
+    assert rc == 1 and b"null buffer" in lib.hdrnet_last_error()
+    rc = lib.hdrnet_pointwise_guide_grad_f32(None, None, None, None, None, None, 0, None, None, -1, 3, 16, None, 0, None)
+    assert rc == 1 and b"bad sizes" in lib.hdrnet_last_error()
+    lib.hdrnet_input_moments_f32.argtypes = [P, LL, I, P, P, P, SZ, P]
+    assert lib.hdrnet_input_moments_f32(None, 16, 2, None, None, None, 0, None) == 1
+    assert b"Cin in {1,3}" in lib.hdrnet_last_error()
+    lib.hdrnet_resize_bilinear_f32.argtypes = [P, P] + [I] * 6 + [P]
+    assert lib.hdrnet_resize_bilinear_f32(None, None, 1, 0, 4, 2, 2, 3, None) == 1
+    assert b"bad extents" in lib.hdrnet_last_error()
+    assert lib.hdrnet_resize_bilinear_f32(None, None, 1, 4, 4, 0, 2, 3, None) == 0  # empty output: no-op
+    lib.hdrnet_bilateral_slice_apply_upadd_f32.argtypes = [P] * 4 + [I, I, P] + [I] * 9 + [P, P, I, P]
+    rc = lib.hdrnet_bilateral_slice_apply_upadd_f32(None, None, None, None, 2, 2, None, 1, 4, 4, 2, 2, 2, 3, 3, 1,
+                                                    None, None, 0, None)
+    assert rc == 1 and b"either a guide map or the guide network" in lib.hdrnet_last_error()
+    rc = lib.hdrnet_bilateral_slice_apply_upadd_f32(None, None, None, None, 0, 2, None, 1, 4, 4, 2, 2, 2, 3, 3, 1,
+                                                    None, None, 0, None)
+    assert rc == 1 and b"coarse extents" in lib.hdrnet_last_error()

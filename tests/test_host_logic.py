@@ -80,3 +80,33 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(build, "build", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("no hipcc")))
     with pytest.raises(_lib.HdrnetLibraryError):
         _lib.load()
+
+
+def test_fused_ops_shape_rules_and_no_cpu_path():
+    """The guide-network / pyramid ops share the slice-apply shape rules and refuse CPU tensors."""
+    g, x = _t(1, 4, 4, 4, 12), _t(1, 8, 8, 3)
+    c1, c2 = _t(16, 4), _t(17)
+    with pytest.raises(ValueError, match=r"guide_conv1 should be \[n, Cin \+ 1\]"):
+        ops.bilateral_slice_apply_nnguide(g, x, _t(16, 3), c2)
+    with pytest.raises(ValueError, match=r"guide_conv2 should be \[n \+ 1\]"):
+        ops.bilateral_slice_apply_nnguide(g, x, c1, _t(16))
+    with pytest.raises(ValueError, match="with affine offset"):
+        ops.bilateral_slice_apply_nnguide(_t(1, 4, 4, 4, 13), x, c1, c2)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.bilateral_slice_apply_nnguide(g, x, c1, c2)
+    with pytest.raises(RuntimeError, match="no CPU path"):  # also through autograd
+        ops.bilateral_slice_apply_nnguide(g.requires_grad_(True), x, c1, c2)
+    with pytest.raises(ValueError, match="either guide or"):
+        ops.bilateral_slice_apply_upadd(g, x, _t(1, 4, 4, 3))
+    with pytest.raises(ValueError, match="either guide or"):
+        ops.bilateral_slice_apply_upadd(g, x, _t(1, 4, 4, 3), guide=_t(1, 8, 8), guide_conv1=c1, guide_conv2=c2)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.bilateral_slice_apply_upadd(g.detach(), x, _t(1, 4, 4, 3), guide=_t(1, 8, 8))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.resize_bilinear(x, 4, 4)
+    with pytest.raises(ValueError, match="4D"):
+        ops.resize_bilinear(_t(8, 8, 3), 4, 4)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.input_moments(x)
+    with pytest.raises(TypeError, match="float32"):
+        ops.input_moments(x.double())
