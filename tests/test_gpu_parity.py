@@ -565,6 +565,34 @@ def test_non_contiguous_inputs(dev, ops, port):
     np.testing.assert_allclose(got, want, rtol=FWD_RTOL, atol=FWD_ATOL)
 
 
+def test_misaligned_buffers_take_the_scalar_kernels(dev, ops, port):
+    """Dense tensors whose storage starts 4 B off a 16-B boundary (a view into a larger buffer):
+    the 16-byte-access kernels are not eligible; forward and backward must still be right."""
+    rng = np.random.default_rng(9)
+    B, H, W = 1, 24, 64
+    grid, guide, inp, dout = rand_case(rng, B, H, W, 8, 8, 8, 3, 3, True)
+    want = port.bilateral_slice_apply(grid, guide, inp, True)
+    wg, wgu, wi = port.bilateral_slice_apply_grad(grid, guide, inp, dout, True)
+
+    def off1(a):  # same values, data pointer = base + 4 bytes
+        buf = torch.empty(a.size + 1, dtype=torch.float32, device=dev)
+        v = buf[1:].view(*a.shape)
+        v.copy_(torch.from_numpy(a))
+        assert v.is_contiguous() and v.data_ptr() % 16 == 4
+        return v
+
+    tg = T(grid, dev).requires_grad_(True)
+    tgu = off1(guide).requires_grad_(True)
+    ti = off1(inp).requires_grad_(True)
+    out = ops.bilateral_slice_apply(tg, tgu, ti, has_offset=True)
+    assert ops.last_kernel() == "apply_fwd_rows/scalar"
+    np.testing.assert_allclose(N(out), want, rtol=FWD_RTOL, atol=FWD_ATOL)
+    out.backward(off1(dout))
+    grads_close(N(tg.grad), wg, "dgrid")
+    grads_close(N(tgu.grad), wgu, "dguide")
+    grads_close(N(ti.grad), wi, "dinput")
+
+
 def test_fast_flag_rejects_unsupported_shape(dev, ops):
     from hdrnet_amd import _lib
     with ops.kernel_override("fast"):
