@@ -353,7 +353,7 @@ int hdrnet_bilateral_slice_apply_grad_f32_ex(const float* grid, const float* gui
   if (!guide || !dout || (Cin > 0 && !input) || ((dguide || dinput) && !grid))
     return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
   ApplyGradArgs a{grid, guide, input, dout, dgrid, dguide, dinput, B, H, W, GH, GW, GD,
-                  Cin, Cout, Cj, has_offset != 0, workspace, workspace_bytes, variant(flags)};
+                  Cin, Cout, Cj, has_offset != 0, workspace, workspace_bytes};
   // dguide / dinput: one fused LDS-staged pass when a specialisation exists.
   const bool pix_fast = family(flags) != HDRNET_KERNEL_GENERIC && (dguide || dinput) &&
                         apply_vjp_rows_supported(a);

@@ -47,7 +47,6 @@ struct ApplyGradArgs {
   bool has_offset;
   void* workspace;
   size_t workspace_bytes;
-  int variant = 0;  // benchmark-only kernel variant (flags bits 8..15); 0 = library default
 };
 
 // Training side of the point-wise guide network (guide_nn_grad.hip).

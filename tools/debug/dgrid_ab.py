@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Interleaved A/B of grid-gradient stage-1 variants (flags bits 8..15), 4K, dgrid only."""
+"""Times the grid gradient (or, with --all3, the whole BilateralSliceApplyGrad) at 4K through the
+C-ABI, after checking it against the generic (bit-exact) kernels.  `--variants` passes flag bits
+8..15 through; the backward kernels currently define none, so 0 is the only meaningful value (the
+hook stays for the next round of stage-1 experiments)."""
 import argparse
 import os
 import statistics
