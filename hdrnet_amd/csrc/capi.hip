@@ -74,7 +74,7 @@ int variant(unsigned flags) { return (int)((flags >> 8) & 0xffu); }
 
 extern "C" {
 
-int hdrnet_version(void) { return 100; /* 0.1.0 */ }
+int hdrnet_version(void) { return 200; /* 0.2.0: + guide-network VJP, input moments, pyramid level, resize */ }
 
 const char* hdrnet_last_error(void) { return g_error; }
 
