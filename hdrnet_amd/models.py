@@ -298,9 +298,12 @@ class HDRNetGaussianPyrNN(HDRNetPointwiseNNGuide):
         return y.permute(0, 2, 3, 1).contiguous()
 
     def forward(self, lowres_input: torch.Tensor, fullres_input: torch.Tensor) -> torch.Tensor:
-        if (self.fuse_guide and not self.training and not torch.is_grad_enabled() and fullres_input.is_cuda
-                and fullres_input.shape[3] == 3 and fullres_input.shape[2] % 16 == 0):
+        fusable = (self.fuse_guide and fullres_input.is_cuda and fullres_input.shape[3] == 3
+                   and fullres_input.shape[2] % 16 == 0)
+        if fusable and not self.training and not torch.is_grad_enabled():
             return self._forward_fused(lowres_input, fullres_input)
+        if fusable and self.params["guide_complexity"] in (4, 8, 16):
+            return self._forward_fused_differentiable(lowres_input, fullres_input)
         coeffs = self.coefficients(lowres_input)
         lvls: List[torch.Tensor] = [fullres_input]
         h, w = fullres_input.shape[1:3]
@@ -312,6 +315,30 @@ class HDRNetGaussianPyrNN(HDRNetPointwiseNNGuide):
         for il, (lvl, gd) in enumerate(reversed(list(zip(lvls, guides)))):  # models.py:278
             c = coeffs[:, :, :, :, il * 3:(il + 1) * 3, :].contiguous()
             out = layers.bilateral_slice_apply(c, gd, lvl, has_offset=True)
+            current = out if current is None else self._resize(current, out.shape[1], out.shape[2]) + out
+        return current
+
+    def _forward_fused_differentiable(self, lowres_input: torch.Tensor, fullres_input: torch.Tensor) -> torch.Tensor:
+        """Training / autograd path: per level the differentiable fused op (guide network + slice-
+        apply, batch-norm statistics from the level's input moments); the up-adds stay torch ops."""
+        from . import hdrnet_ops
+        coeffs = self.coefficients(lowres_input)
+        gs = coeffs.shape
+        lvls: List[torch.Tensor] = [fullres_input]
+        h, w = fullres_input.shape[1:3]
+        for _ in range(self.n_scales - 1):
+            h, w = h // 2, w // 2
+            with torch.no_grad():
+                lvls.append(hdrnet_ops.resize_bilinear(lvls[-1], h, w))
+        current = None
+        for il, (lvl, gnet) in enumerate(reversed(list(zip(lvls, self.guide)))):  # models.py:278
+            c = coeffs[:, :, :, :, il * 3:(il + 1) * 3, :].reshape(gs[0], gs[1], gs[2], gs[3], 12)
+            if self.training:
+                sums, moments = hdrnet_ops.input_moments(lvl)
+                conv1, conv2 = gnet.folded_batch(sums, moments, lvl.numel() // lvl.shape[3])
+            else:
+                conv1, conv2 = gnet.folded(detach=False)
+            out = hdrnet_ops.bilateral_slice_apply_nnguide(c, lvl, conv1, conv2, has_offset=True)
             current = out if current is None else self._resize(current, out.shape[1], out.shape[2]) + out
         return current
 

@@ -378,3 +378,33 @@ def test_pyramid_model_fused_matches_composed():
         ref = m(low, full)
         assert hdrnet_ops.last_kernel() == "apply_fwd_rows/vec4"
     torch.testing.assert_close(out, ref, rtol=5e-5, atol=5e-5)
+
+
+@pytest.mark.gpu
+def test_pyramid_training_fused_matches_composed():
+    """HDRNetGaussianPyrNN.train(): per-level fused differentiable guide + slice-apply == the graph
+    composed from torch ops (loss and every parameter gradient)."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(9)
+    m = models.HDRNetGaussianPyrNN(dict(batch_norm=True)).to(dev).train()
+    ref = models.HDRNetGaussianPyrNN(dict(batch_norm=True)).to(dev).train()
+    ref.load_state_dict(m.state_dict())
+    ref.fuse_guide = False
+    low = torch.rand(2, 256, 256, 3, device=dev)
+    full = torch.rand(2, 144, 256, 3, device=dev)
+    target = torch.rand(2, 144, 256, 3, device=dev)
+    loss = (m(low, full) - target).square().mean()
+    loss.backward()
+    loss_ref = (ref(low, full) - target).square().mean()
+    loss_ref.backward()
+    torch.testing.assert_close(loss, loss_ref, rtol=2e-5, atol=1e-7)
+    checked = 0
+    for (name, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None, name
+        scale = q.grad.abs().max().item()
+        err = (p.grad - q.grad).abs().max().item()
+        assert err <= 2e-3 * scale + 1e-7, (name, err, scale)
+        checked += 1
+    assert checked > 20
