@@ -17,6 +17,8 @@
 
 #include <stdint.h>
 
+#include <cstdio>
+
 #include "launch.hip.h"
 #include "numerics.hip.h"
 #include "rows_common.hip.h"
@@ -26,11 +28,22 @@ namespace {
 
 using namespace rows;
 
+// Guide sources: 0 = a [B][H][W] map in memory; 1 = the folded point-wise guide network
+// (HDRNetPointwiseNNGuide._guide, hdrnet/models.py:203-210); 2 = the curves guide of the standard
+// model (HDRNetCurves._guide, hdrnet/models.py:145-190: 3x4 colour matrix, npts-knot ReLU curves per
+// channel, channel mixing, clip) -- the network the reference's standard GL shader evaluates in its
+// slicing pass (benchmark/assets/std.frag:36-45), in the parameter layout
+// hdrnet/bin/freeze_graph.py:107-127 exports (guide_ccm_f32_3x4.bin, guide_shifts_f32_16x3.bin,
+// guide_slopes_f32_16x3.bin, guide_mix_matrix_f32_1x4.bin).
+constexpr int kGuideMap = 0, kGuideNN = 1, kGuideCurves = 2;
+
 struct GuideNet {
-  const float* conv1;  // [n][CIN + 1]
-  const float* conv2;  // [n + 1]
+  const float* conv1;  // NN: [n][CIN + 1]            curves: ccm [CIN][CIN + 1] (row = output channel)
+  const float* conv2;  // NN: [n + 1]                 curves: mix [CIN + 1]
+  const float* shifts;  //                            curves: [n][CIN]
+  const float* slopes;  //                            curves: [n][CIN]
   float* guide_out;    // optional
-  int n;
+  int n;               // NN: features                curves: knots per channel
 };
 
 template <int CIN>
@@ -45,6 +58,32 @@ __device__ __forceinline__ float guide_net_pixel(const GuideNet& gn, const float
     acc = fmaf(gn.conv2[k], fmaxf(h, 0.0f), acc);
   }
   return 1.0f / (1.0f + expf(-acc));
+}
+
+// guide = clip(mix[CIN] + sum_c mix[c] * sum_k slopes[k][c] * relu(t_c - shifts[k][c]), 0, 1),
+// t_c = ccm[c][CIN] + sum_j ccm[c][j] * in_j     (models.py:157-188)
+template <int CIN>
+__device__ __forceinline__ float guide_curves_pixel(const GuideNet& gn, const float (&in)[CIN]) {
+  float t[CIN], cv[CIN];
+#pragma unroll
+  for (int c = 0; c < CIN; ++c) {
+    const float* w = gn.conv1 + c * (CIN + 1);  // wave-uniform -> scalar loads
+    float h = w[CIN];
+#pragma unroll
+    for (int j = 0; j < CIN; ++j) h = fmaf(w[j], in[j], h);
+    t[c] = h;
+    cv[c] = 0.0f;
+  }
+#pragma unroll 4
+  for (int k = 0; k < gn.n; ++k) {
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
+      cv[c] = fmaf(gn.slopes[k * CIN + c], fmaxf(t[c] - gn.shifts[k * CIN + c], 0.0f), cv[c]);
+  }
+  float g = gn.conv2[CIN];
+#pragma unroll
+  for (int c = 0; c < CIN; ++c) g = fmaf(gn.conv2[c], cv[c], g);
+  return fminf(fmaxf(g, 0.0f), 1.0f);  // tf.clip_by_value(guidemap, 0, 1)
 }
 
 // Load 4 pixels x CIN channels of TI starting at element index e0, as floats / white level.
@@ -71,7 +110,7 @@ __device__ __forceinline__ void load_pixels(const TI* __restrict__ src, size_t e
   }
 }
 
-template <int CIN, int COUT, bool OFFSET, bool GUIDE_NN, typename TI, typename TO>
+template <int CIN, int COUT, bool OFFSET, int GUIDE, typename TI, typename TO>
 __global__ __launch_bounds__(256) void apply_fwd_io_rows(
     const float* __restrict__ grid, const float* __restrict__ guide, const TI* __restrict__ input,
     TO* __restrict__ out, int H, int W, int GH, int GW, int GD, int nseg, int seg,
@@ -96,7 +135,7 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(
 #pragma unroll
   for (int q = 0; q < NI; ++q) inf[q] = 0.0f;
   if (active) {
-    if constexpr (!GUIDE_NN) {
+    if constexpr (GUIDE == kGuideMap) {
       const float4 g4 = *reinterpret_cast<const float4*>(guide + p);
       gs[0] = g4.x; gs[1] = g4.y; gs[2] = g4.z; gs[3] = g4.w;
     }
@@ -107,13 +146,13 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(
 
   float of[NO];
   if (active) {
-    if constexpr (GUIDE_NN) {
+    if constexpr (GUIDE != kGuideMap) {
 #pragma unroll
       for (int k = 0; k < kPxPerThread; ++k) {
         float in[CIN];
 #pragma unroll
         for (int j = 0; j < CIN; ++j) in[j] = inf[k * CIN + j];
-        gs[k] = guide_net_pixel<CIN>(gn, in);
+        gs[k] = GUIDE == kGuideNN ? guide_net_pixel<CIN>(gn, in) : guide_curves_pixel<CIN>(gn, in);
       }
       if (gn.guide_out) *reinterpret_cast<float4*>(gn.guide_out + p) = make_float4(gs[0], gs[1], gs[2], gs[3]);
     }
@@ -177,34 +216,34 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(
   }
 }
 
-template <int CIN, int COUT, bool OFFSET, bool GUIDE_NN, typename TI, typename TO>
+template <int CIN, int COUT, bool OFFSET, int GUIDE, typename TI, typename TO>
 hipError_t launch_io(const ApplyIoArgs& a, const Plan& pl, hipStream_t s) {
   constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
   const int slab_off = round_up(pl.max_cols * a.GD * C, 4);
   const size_t lds = ((size_t)slab_off + (size_t)(pl.threads / 64) * 64 * kPxPerThread * COUT) * sizeof(float);
   const long long nblocks = (long long)a.B * a.H * pl.nseg;
-  const GuideNet gn{a.guide_conv1, a.guide_conv2, a.guide_out, a.n_feats};
-  apply_fwd_io_rows<CIN, COUT, OFFSET, GUIDE_NN, TI, TO><<<(unsigned)nblocks, pl.threads, lds, s>>>(
+  const GuideNet gn{a.guide_conv1, a.guide_conv2, a.guide_shifts, a.guide_slopes, a.guide_out, a.n_feats};
+  apply_fwd_io_rows<CIN, COUT, OFFSET, GUIDE, TI, TO><<<(unsigned)nblocks, pl.threads, lds, s>>>(
       a.grid, a.guide, static_cast<const TI*>(a.input), static_cast<TO*>(a.out), a.H, a.W, a.GH, a.GW,
       a.GD, pl.nseg, pl.seg, slab_off, (float)a.GW / a.W, (float)a.GH / a.H, a.white_level, gn);
   return hipGetLastError();
 }
 
-template <bool GUIDE_NN, typename TI, typename TO>
+template <int GUIDE, typename TI, typename TO>
 hipError_t dispatch_shape(const ApplyIoArgs& a, const Plan& pl, hipStream_t s) {
-  if (a.Cin == 3 && a.Cout == 3 && a.has_offset) return launch_io<3, 3, true, GUIDE_NN, TI, TO>(a, pl, s);
+  if (a.Cin == 3 && a.Cout == 3 && a.has_offset) return launch_io<3, 3, true, GUIDE, TI, TO>(a, pl, s);
   return hipErrorInvalidValue;
 }
 
-template <bool GUIDE_NN>
+template <int GUIDE>
 hipError_t dispatch_types(const ApplyIoArgs& a, const Plan& pl, hipStream_t s) {
   const int in = a.input_dtype, out = a.output_dtype;
-  if (in == 1 && out == 1) return dispatch_shape<GUIDE_NN, uint8_t, uint8_t>(a, pl, s);
-  if (in == 1 && out == 0) return dispatch_shape<GUIDE_NN, uint8_t, float>(a, pl, s);
-  if (in == 2 && out == 1) return dispatch_shape<GUIDE_NN, uint16_t, uint8_t>(a, pl, s);
-  if (in == 2 && out == 0) return dispatch_shape<GUIDE_NN, uint16_t, float>(a, pl, s);
-  if (in == 0 && out == 1) return dispatch_shape<GUIDE_NN, float, uint8_t>(a, pl, s);
-  if (in == 0 && out == 0) return dispatch_shape<GUIDE_NN, float, float>(a, pl, s);
+  if (in == 1 && out == 1) return dispatch_shape<GUIDE, uint8_t, uint8_t>(a, pl, s);
+  if (in == 1 && out == 0) return dispatch_shape<GUIDE, uint8_t, float>(a, pl, s);
+  if (in == 2 && out == 1) return dispatch_shape<GUIDE, uint16_t, uint8_t>(a, pl, s);
+  if (in == 2 && out == 0) return dispatch_shape<GUIDE, uint16_t, float>(a, pl, s);
+  if (in == 0 && out == 1) return dispatch_shape<GUIDE, float, uint8_t>(a, pl, s);
+  if (in == 0 && out == 0) return dispatch_shape<GUIDE, float, float>(a, pl, s);
   return hipErrorInvalidValue;
 }
 
@@ -232,16 +271,14 @@ bool apply_fwd_io_supported(const ApplyIoArgs& a) {
 hipError_t launch_apply_fwd_io(const ApplyIoArgs& a, hipStream_t s, const char** name) {
   Plan pl;
   if (!plan_io(a, &pl)) return hipErrorInvalidValue;
-  static const char* const names[2][3][2] = {
-      {{"apply_fwd_io/f32->f32", "apply_fwd_io/f32->u8"},
-       {"apply_fwd_io/u8->f32", "apply_fwd_io/u8->u8"},
-       {"apply_fwd_io/u16->f32", "apply_fwd_io/u16->u8"}},
-      {{"apply_fwd_io/f32->f32+nnguide", "apply_fwd_io/f32->u8+nnguide"},
-       {"apply_fwd_io/u8->f32+nnguide", "apply_fwd_io/u8->u8+nnguide"},
-       {"apply_fwd_io/u16->f32+nnguide", "apply_fwd_io/u16->u8+nnguide"}}};
-  const bool nn = a.guide == nullptr;
-  *name = names[nn ? 1 : 0][a.input_dtype][a.output_dtype];
-  return nn ? dispatch_types<true>(a, pl, s) : dispatch_types<false>(a, pl, s);
+  static const char* const io[3][2] = {{"f32->f32", "f32->u8"}, {"u8->f32", "u8->u8"}, {"u16->f32", "u16->u8"}};
+  static const char* const suffix[3] = {"", "+nnguide", "+curvesguide"};
+  static thread_local char label[64];
+  const int kind = a.guide ? kGuideMap : (a.guide_shifts ? kGuideCurves : kGuideNN);
+  snprintf(label, sizeof label, "apply_fwd_io/%s%s", io[a.input_dtype][a.output_dtype], suffix[kind]);
+  *name = label;
+  if (kind == kGuideCurves) return dispatch_types<kGuideCurves>(a, pl, s);
+  return kind == kGuideNN ? dispatch_types<kGuideNN>(a, pl, s) : dispatch_types<kGuideMap>(a, pl, s);
 }
 
 }  // namespace hdrnet_amd

@@ -49,7 +49,7 @@ using namespace rows;
 // reference's point-wise guide network with batch-norm folded (HDRNetPointwiseNNGuide._guide,
 // hdrnet/models.py:203-210; parameters in the layout hdrnet/bin/freeze_graph.py:170-184 exports):
 //   guide = sigmoid(conv2[n] + sum_k conv2[k] * relu(conv1[k][CIN] + sum_j conv1[k][j] * in_j))
-// -- the fusion the reference's own GL renderer performs (benchmark/assets/std.frag:36-52).
+// -- the fusion the reference's own GL renderer performs (benchmark/assets/gpyrnn.frag:42-63).
 // The guide never touches HBM (24 instead of 28 B/px) and the 16-channel full-resolution
 // intermediate of the un-fused graph disappears.
 //

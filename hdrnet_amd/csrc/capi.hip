@@ -312,6 +312,43 @@ int hdrnet_bilateral_slice_apply_io(const float* grid, const float* guide, const
   return rc;
 }
 
+int hdrnet_bilateral_slice_apply_io_curves(const float* grid, const void* input, void* out, int B, int H,
+                                           int W, int GH, int GW, int GD, int Cin, int Cout,
+                                           int has_offset, int input_dtype, float input_white_level,
+                                           int output_dtype, const float* guide_ccm,
+                                           const float* guide_shifts, const float* guide_slopes,
+                                           const float* guide_mix, int npts, float* guide_out,
+                                           void* stream) {
+  using namespace hdrnet_amd;
+  if (int rc = check_common(B, H, W, GH, GW, GD)) return rc;
+  if (Cin <= 0 || Cout <= 0) return fail(HDRNET_INVALID_ARGUMENT, "bad channel counts");
+  if (input_dtype < 0 || input_dtype > 2 || output_dtype < 0 || output_dtype > 1)
+    return fail(HDRNET_INVALID_ARGUMENT, "unknown dtype code (input %d, output %d)", input_dtype,
+                output_dtype);
+  if (!(input_white_level > 0.0f))
+    return fail(HDRNET_INVALID_ARGUMENT, "input_white_level must be positive");
+  if (npts <= 0 || npts > 4096) return fail(HDRNET_INVALID_ARGUMENT, "bad number of curve knots (%d)", npts);
+  if ((long long)B * H * W == 0) {
+    set_kernel("noop");
+    g_error[0] = '\0';
+    return HDRNET_OK;
+  }
+  if (!grid || !input || !out || !guide_ccm || !guide_shifts || !guide_slopes || !guide_mix)
+    return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  ApplyIoArgs a{grid, nullptr, input, out, B, H, W, GH, GW, GD, Cin, Cout, has_offset != 0,
+                input_dtype, output_dtype, input_white_level, guide_ccm, guide_mix, npts,
+                guide_out, guide_shifts, guide_slopes};
+  if (!apply_fwd_io_supported(a))
+    return fail(HDRNET_INVALID_ARGUMENT,
+                "the fused curves-guide forward supports Cin = Cout = 3 with offset, W %% 4 == 0, aligned "
+                "buffers; evaluate the guide on the caller's side and use hdrnet_bilateral_slice_apply_f32");
+  const char* name = "";
+  const int rc = check_launch(launch_apply_fwd_io(a, static_cast<hipStream_t>(stream), &name),
+                              "BilateralSliceApplyIOCurves");
+  if (rc == HDRNET_OK) set_kernel(name);
+  return rc;
+}
+
 size_t hdrnet_bilateral_slice_apply_grad_workspace_bytes(int B, int H, int W, int GH, int GW,
                                                          int GD, int Cin, int Cout,
                                                          int has_offset) {

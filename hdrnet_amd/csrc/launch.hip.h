@@ -29,10 +29,12 @@ struct ApplyIoArgs {
   bool has_offset;
   int input_dtype, output_dtype;
   float white_level;
-  const float* guide_conv1;
-  const float* guide_conv2;
-  int n_feats;
+  const float* guide_conv1;  // NN: conv1 [n][Cin+1]; curves: ccm [Cin][Cin+1]
+  const float* guide_conv2;  // NN: conv2 [n+1];      curves: mix [Cin+1]
+  int n_feats;               // NN: features;         curves: knots per channel
   float* guide_out;  // optional
+  const float* guide_shifts = nullptr;  // non-null selects the curves guide: [n][Cin]
+  const float* guide_slopes = nullptr;  //                                    [n][Cin]
 };
 
 struct ApplyGradArgs {

@@ -463,24 +463,77 @@ def bilateral_slice_apply_upadd(grid: torch.Tensor, input: torch.Tensor, coarse:
 _DTYPE_CODE = {torch.float32: 0, torch.uint8: 1, torch.uint16: 2}
 
 
+def _apply_io_curves(grid, input, curves, input_white_level, out_dtype, has_offset, return_guide):  # noqa: A002
+    if len(curves) != 4:
+        raise ValueError("guide_curves should be (ccm, shifts, slopes, mix)")
+    ccm, shifts, slopes, mix = curves
+    B, H, W, Cin = input.shape
+    npts = shifts.shape[0] if shifts.dim() == 2 else -1
+    for nm, t, shape in (("ccm", ccm, (Cin, Cin + 1)), ("shifts", shifts, (npts, Cin)),
+                         ("slopes", slopes, (npts, Cin)), ("mix", mix, (Cin + 1,))):
+        _require_f32(f"guide_curves.{nm}", t)
+        if tuple(t.shape) != shape or npts <= 0:
+            raise ValueError(f"guide_curves.{nm} should be {list(shape)}, got {list(t.shape)}")
+    if input_white_level is None:
+        input_white_level = {torch.float32: 1.0, torch.uint8: 255.0, torch.uint16: 65535.0}[input.dtype]
+    _require_f32("grid", grid)
+    if grid.dim() != 5:
+        raise ValueError(f"Input grid should be 5D, got {tuple(grid.shape)}")
+    if grid.shape[0] != B:
+        raise ValueError("Batch sizes should match.")
+    GH, GW, GD, C = grid.shape[1:]
+    Cj = Cin + (1 if has_offset else 0)
+    if C % Cj:
+        raise ValueError("Slicing with affine offset, grid should have output_channels * (input_channels + 1) channels.")
+    Cout = C // Cj
+    for nm, t in (("grid", grid), ("input", input), ("guide_curves.ccm", ccm), ("guide_curves.shifts", shifts),
+                  ("guide_curves.slopes", slopes), ("guide_curves.mix", mix)):
+        _require_gpu(nm, t)
+    grid, inp = grid.detach().contiguous(), input.detach().contiguous()
+    ccm, shifts, slopes, mix = (t.detach().contiguous() for t in (ccm, shifts, slopes, mix))
+    dev = inp.device
+    out = torch.empty((B, H, W, Cout), dtype=out_dtype, device=dev)
+    gout = torch.empty((B, H, W), dtype=torch.float32, device=dev) if return_guide else None
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        rc = lib.hdrnet_bilateral_slice_apply_io_curves(
+            grid.data_ptr(), inp.data_ptr(), out.data_ptr(), B, H, W, GH, GW, GD, Cin, Cout,
+            int(bool(has_offset)), _DTYPE_CODE[input.dtype], float(input_white_level), _DTYPE_CODE[out_dtype],
+            ccm.data_ptr(), shifts.data_ptr(), slopes.data_ptr(), mix.data_ptr(), npts, _ptr(gout), _stream(dev))
+    _lib.check(rc, "BilateralSliceApplyIOCurves")
+    return (out, gout) if return_guide else out
+
+
 def bilateral_slice_apply_io(grid: torch.Tensor, input: torch.Tensor,  # noqa: A002
                              guide: Optional[torch.Tensor] = None,
                              guide_conv1: Optional[torch.Tensor] = None,
                              guide_conv2: Optional[torch.Tensor] = None,
                              input_white_level: Optional[float] = None,
                              out_dtype: torch.dtype = torch.float32,
-                             has_offset: bool = True) -> torch.Tensor:
+                             has_offset: bool = True,
+                             guide_curves: Optional[Tuple[torch.Tensor, ...]] = None,
+                             return_guide: bool = False):
     """Inference forward with the product's wire formats fused in: ``input`` may be uint8 / uint16
     (``value / input_white_level``: 255, 65535, or 32767 for HDR+ -- hdrnet/data_pipeline.py:202-232,
     :267-274) and the output may be uint8 ``= (uint8)(255 * clip(out, 0, 1))`` (hdrnet/bin/run.py:95).
-    Give either a ``guide`` map or the folded guide network (``guide_conv1``, ``guide_conv2``).
-    No autograd."""
+    The guide is ONE of: a ``guide`` map; the folded point-wise guide network (``guide_conv1``,
+    ``guide_conv2``); or ``guide_curves = (ccm [Cin, Cin+1], shifts [npts, Cin], slopes [npts, Cin],
+    mix [Cin+1])``, the standard model's curves guide (hdrnet/models.py:145-190) in the layout
+    hdrnet/bin/freeze_graph.py:107-127 exports -- then evaluated in registers, as the reference's
+    standard GL shader does (benchmark/assets/std.frag:36-45).  ``return_guide`` (curves only) also
+    returns the guide map.  No autograd."""
     if input.dim() != 4:
         raise ValueError(f"Input image should be 4D (batch_size, height, width, input_channels), got {tuple(input.shape)}")
     if input.dtype not in _DTYPE_CODE:
         raise TypeError(f"input must be float32, uint8 or uint16, got {input.dtype}")
     if out_dtype not in (torch.float32, torch.uint8):
         raise TypeError(f"out_dtype must be float32 or uint8, got {out_dtype}")
+    if guide_curves is not None:
+        if guide is not None or guide_conv1 is not None or guide_conv2 is not None:
+            raise ValueError("give exactly one of guide, (guide_conv1, guide_conv2), guide_curves")
+        return _apply_io_curves(grid, input, guide_curves, input_white_level, out_dtype, has_offset, return_guide)
+    if return_guide:
+        raise ValueError("return_guide is only available with guide_curves")
     if (guide is None) == (guide_conv1 is None or guide_conv2 is None):
         raise ValueError("give either a guide map or both guide_conv1 and guide_conv2")
     if input_white_level is None:

@@ -165,6 +165,15 @@ class _CurvesGuide(nn.Module):
         g = g @ self.mix_w + self.mix_b
         return g.clamp(0.0, 1.0)
 
+    def exported(self):
+        """The parameters in the layout hdrnet/bin/freeze_graph.py:107-127 writes (and the GL
+        renderer loads, benchmark/src/renderer.cc:197-225): ccm [3, 4] = (ccm; bias)^T, shifts /
+        slopes [npts, 3], mix [4] = (weights, bias)."""
+        ccm = torch.cat([self.ccm, self.ccm_bias[None, :]], dim=0).t().contiguous()
+        mix = torch.cat([self.mix_w, self.mix_b.reshape(1)]).contiguous()
+        return (ccm.detach(), self.shifts.detach().t().contiguous(), self.slopes.detach().t().contiguous(),
+                mix.detach())
+
 
 class _PointwiseNNGuide(nn.Module):
     """``HDRNetPointwiseNNGuide._guide`` (models.py:203-210): 1x1 conv 3 -> n (+BN, ReLU), 1x1 conv
@@ -237,8 +246,19 @@ class HDRNetCurves(nn.Module):
     def _make_guide(self) -> nn.Module:
         return _CurvesGuide()
 
+    fuse_guide = True
+
     def forward(self, lowres_input: torch.Tensor, fullres_input: torch.Tensor) -> torch.Tensor:
         coeffs = self.coefficients(lowres_input)
+        if (self.fuse_guide and isinstance(self.guide, _CurvesGuide) and not torch.is_grad_enabled()
+                and fullres_input.is_cuda and fullres_input.shape[3] == 3 and fullres_input.shape[2] % 4 == 0):
+            # inference: curves guide evaluated in registers inside the slice-apply kernel, as the
+            # reference's standard GL shader does (benchmark/assets/std.frag:32-53)
+            from . import hdrnet_ops
+            gs = coeffs.shape
+            return hdrnet_ops.bilateral_slice_apply_io(
+                coeffs.reshape(gs[0], gs[1], gs[2], gs[3], gs[4] * gs[5]), fullres_input,
+                guide_curves=self.guide.exported(), has_offset=True)
         guide = self.guide(fullres_input)
         # models.py:193-196 -- the one call site of the hot path
         return layers.bilateral_slice_apply(coeffs, guide, fullres_input, has_offset=True, name="slice")
@@ -250,8 +270,6 @@ class HDRNetPointwiseNNGuide(HDRNetCurves):
     materialised, in inference (the guide never touches HBM) or in training (the guide is written
     once for the backward; batch-norm statistics come from the input's moments; the network's VJP
     is one more pass).  ``fuse_guide = False`` composes the un-fused ops instead."""
-
-    fuse_guide = True
 
     def _make_guide(self) -> nn.Module:
         return _PointwiseNNGuide(self.params["guide_complexity"])

@@ -102,7 +102,7 @@ int hdrnet_bilateral_slice_apply_f32_ex(const float* grid, const float* guide,
  * that pointer is non-NULL.  This is HDRNetPointwiseNNGuide._guide (hdrnet/models.py:203-210) with
  * batch-norm folded, in the parameter layout hdrnet/bin/freeze_graph.py:170-184 exports
  * (guide_conv1.bin = [n][Cin+1], guide_conv2.bin = [n+1]) -- the fusion the reference's GL
- * renderer performs (benchmark/assets/std.frag:36-52, benchmark/src/renderer.cc:119-171).
+ * renderer performs (benchmark/assets/gpyrnn.frag:42-63, benchmark/src/renderer.cc:119-171).
  * Supported: (Cin, Cout) in {(3,3), (1,1)}, W % 4 == 0, 16-B aligned buffers; otherwise
  * HDRNET_INVALID_ARGUMENT (run the guide network and the plain entry point instead). */
 int hdrnet_bilateral_slice_apply_nnguide_f32(const float* grid, const float* input,
@@ -111,6 +111,24 @@ int hdrnet_bilateral_slice_apply_nnguide_f32(const float* grid, const float* inp
                                              float* guide_out, int B, int H, int W,
                                              int GH, int GW, int GD, int Cin, int Cout,
                                              int has_offset, int n_feats, void* stream);
+
+/* The standard model's one-pass inference: HDRNetCurves._guide (hdrnet/models.py:145-190) evaluated
+ * in registers, then BilateralSliceApply, with the wire-format conversions of
+ * hdrnet_bilateral_slice_apply_io -- what the reference's standard GL shader does
+ * (benchmark/assets/std.frag:32-53; uniforms loaded by benchmark/src/renderer.cc:197-225).
+ *   t_c   = ccm[c][Cin] + sum_j ccm[c][j] * in_j
+ *   guide = clip(mix[Cin] + sum_c mix[c] * sum_k slopes[k][c] * relu(t_c - shifts[k][c]), 0, 1)
+ * Parameters in the layout hdrnet/bin/freeze_graph.py:107-127 exports: guide_ccm [Cin][Cin+1]
+ * (guide_ccm_f32_3x4.bin), guide_shifts / guide_slopes [npts][Cin] (guide_shifts_f32_16x3.bin,
+ * guide_slopes_f32_16x3.bin), guide_mix [Cin+1] (guide_mix_matrix_f32_1x4.bin).  `guide_out`
+ * [B][H][W] is written only if non-NULL.  Same support as hdrnet_bilateral_slice_apply_io. */
+int hdrnet_bilateral_slice_apply_io_curves(const float* grid, const void* input, void* out, int B,
+                                           int H, int W, int GH, int GW, int GD, int Cin,
+                                           int Cout, int has_offset, int input_dtype,
+                                           float input_white_level, int output_dtype,
+                                           const float* guide_ccm, const float* guide_shifts,
+                                           const float* guide_slopes, const float* guide_mix,
+                                           int npts, float* guide_out, void* stream);
 
 /* Multi-scale output of HDRNetGaussianPyrNN (hdrnet/models.py:277-289): per pyramid level
  *   out = BilateralSliceApply(grid_level, guide_level, input_level)

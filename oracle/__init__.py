@@ -37,6 +37,20 @@ def pointwise_nn_guide(inp, conv1, conv2):
     return (np.float32(1) / (np.float32(1) + np.exp(-t))).astype(np.float32)
 
 
+def curves_guide(inp, ccm34, shifts, slopes, mix):
+    """float32 numpy restatement of HDRNetCurves._guide (hdrnet/models.py:145-190) on the exported
+    parameters (hdrnet/bin/freeze_graph.py:107-127): ccm34 [3, 4] (row = output channel: 3 weights
+    + bias), shifts / slopes [npts, 3], mix [4] (3 weights + bias):
+    t = in @ ccm + bias; c = sum_k slopes_k * relu(t - shifts_k); guide = clip(c @ mix_w + mix_b, 0, 1)."""
+    import numpy as np
+    inp = np.asarray(inp, np.float32)
+    ccm34, shifts, slopes, mix = (np.asarray(a, np.float32) for a in (ccm34, shifts, slopes, mix))
+    t = (inp @ ccm34[:, :-1].T + ccm34[:, -1]).astype(np.float32)            # [..., 3]
+    c = (slopes * np.maximum(t[..., None, :] - shifts, np.float32(0))).sum(-2, dtype=np.float32)
+    g = (c @ mix[:-1] + mix[-1]).astype(np.float32)
+    return np.clip(g, np.float32(0), np.float32(1))
+
+
 def resize_bilinear_align_corners(x, height, width):
     """float32 numpy restatement of ``tf.image.resize_images(x, (height, width), BILINEAR,
     align_corners=True)`` on NHWC arrays -- the resize of HDRNetGaussianPyrNN

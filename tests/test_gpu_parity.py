@@ -327,6 +327,46 @@ def test_nnguide_fused_matches_composed_oracle(dev, ops, port, shape):
     assert torch.equal(out2, out)
 
 
+# ---- curves guide (the standard model) fused into slice-apply --------------------------------------
+@pytest.mark.parametrize("in_dtype,out_dtype", [("float32", "float32"), ("uint8", "uint8"), ("uint16", "float32")])
+def test_curves_guide_fused_matches_composed_oracle(dev, ops, port, in_dtype, out_dtype):
+    """guide = oracle.curves_guide (numpy restatement of HDRNetCurves._guide) -> oracle slice-apply,
+    vs the one fused kernel, fp32 and in the wire formats of the reference's GL renderer."""
+    import oracle
+    B, H, W = 2, 40, 96
+    rng = np.random.default_rng(21)
+    grid = rng.random((B, 16, 16, 8, 12)).astype(np.float32)
+    ccm = (np.concatenate([np.eye(3), np.zeros((3, 1))], 1) + 0.2 * rng.standard_normal((3, 4))).astype(np.float32)
+    shifts = (np.tile(np.linspace(0, 1, 16, endpoint=False)[:, None], (1, 3)) + 0.01 * rng.standard_normal((16, 3))).astype(np.float32)
+    slopes = (0.3 * rng.standard_normal((16, 3))).astype(np.float32)
+    slopes[0] += 1.0
+    mix = np.array([0.4, 0.35, 0.25, 0.02], np.float32)
+    if in_dtype == "float32":
+        raw = rng.random((B, H, W, 3)).astype(np.float32)
+        x, wl = raw, 1.0
+    else:
+        hi = 255 if in_dtype == "uint8" else 65535
+        raw = rng.integers(0, hi + 1, (B, H, W, 3)).astype(in_dtype)
+        x, wl = raw.astype(np.float32) / np.float32(hi), float(hi)
+    guide = oracle.curves_guide(x, ccm, shifts, slopes, mix)
+    want = port.bilateral_slice_apply(grid, guide, x, True)
+    traw = torch.from_numpy(raw.astype(np.int32)).to(dev).to(getattr(torch, in_dtype)) if in_dtype != "float32" else T(raw, dev)
+    out, gout = ops.bilateral_slice_apply_io(
+        T(grid, dev), traw, guide_curves=tuple(T(a, dev) for a in (ccm, shifts, slopes, mix)),
+        input_white_level=wl, out_dtype=getattr(torch, out_dtype), return_guide=True)
+    assert ops.last_kernel() == f"apply_fwd_io/{ {'float32': 'f32', 'uint8': 'u8', 'uint16': 'u16'}[in_dtype]}->" \
+                                f"{ {'float32': 'f32', 'uint8': 'u8'}[out_dtype]}+curvesguide"
+    np.testing.assert_allclose(N(gout), guide, rtol=0, atol=2e-6)
+    if out_dtype == "float32":
+        np.testing.assert_allclose(N(out), want, rtol=3e-5, atol=3e-5)
+    else:
+        q = np.clip(want, 0, 1) * np.float32(255)
+        got = N(out).astype(np.int32)
+        exact = q.astype(np.uint8).astype(np.int32)
+        near_edge = np.abs(q - np.round(q)) < 3e-5 * 255
+        assert np.all((got == exact) | (near_edge & (np.abs(got - exact) <= 1)))
+
+
 # ---- pyramid output (SURVEY.md section 8f row 4): resize + slice-apply fused with the up-add -------
 @pytest.mark.parametrize("case", [(2, 37, 53, 3, 18, 26), (1, 64, 96, 3, 128, 192), (1, 9, 13, 1, 1, 1),
                                   (1, 20, 30, 5, 20, 30)])

@@ -408,3 +408,26 @@ def test_pyramid_training_fused_matches_composed():
         assert err <= 2e-3 * scale + 1e-7, (name, err, scale)
         checked += 1
     assert checked > 20
+
+
+@pytest.mark.gpu
+def test_curves_model_fused_matches_composed():
+    """HDRNetCurves inference (the reference's default model): curves guide evaluated inside the
+    slice-apply kernel == guide module + slice-apply op."""
+    from hdrnet_amd import hdrnet_ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(12)
+    m = models.HDRNetCurves().to(dev).eval()
+    with torch.no_grad():  # move the guide away from its (trivial) initial state
+        m.guide.ccm.add_(torch.randn(3, 3, device=dev) * 0.2)
+        m.guide.slopes.add_(torch.randn(3, 16, device=dev) * 0.2)
+        m.guide.mix_b.add_(0.03)
+    low = torch.rand(1, 256, 256, 3, device=dev)
+    full = torch.rand(1, 270, 480, 3, device=dev)
+    with torch.no_grad():
+        out = m(low, full)
+        assert hdrnet_ops.last_kernel() == "apply_fwd_io/f32->f32+curvesguide"
+        m.fuse_guide = False
+        ref = m(low, full)
+        assert hdrnet_ops.last_kernel() == "apply_fwd_rows/vec4"
+    torch.testing.assert_close(out, ref, rtol=3e-5, atol=3e-5)

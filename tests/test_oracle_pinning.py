@@ -261,3 +261,28 @@ def test_resize_restatement_closed_forms():
     y2, x2 = np.meshgrid(np.linspace(0, 1, 20, dtype=np.float32), np.linspace(0, 2, 31, dtype=np.float32), indexing="ij")
     want = (0.25 + 0.5 * y2 + 0.125 * x2)[None, :, :, None]
     np.testing.assert_allclose(oracle.resize_bilinear_align_corners(ramp, 20, 31), want, rtol=0, atol=2e-6)
+
+
+def test_curves_guide_restatement_closed_forms():
+    """oracle.curves_guide (HDRNetCurves._guide, hdrnet/models.py:145-190): with the reference's
+    initial parameters (identity ccm, slope 1 on the first knot only, mix = 1/3) the guide is the
+    channel mean of the input; and it is piecewise linear with kinks exactly at the shifts."""
+    import oracle
+    rng = np.random.default_rng(3)
+    x = rng.random((2, 6, 7, 3), dtype=np.float32)
+    ccm = np.concatenate([np.eye(3, dtype=np.float32), np.zeros((3, 1), np.float32)], axis=1)
+    shifts = np.tile(np.linspace(0, 1, 16, endpoint=False, dtype=np.float32)[:, None], (1, 3))
+    slopes = np.zeros((16, 3), np.float32)
+    slopes[0] = 1.0
+    mix = np.array([1 / 3, 1 / 3, 1 / 3, 0.0], np.float32)
+    np.testing.assert_allclose(oracle.curves_guide(x, ccm, shifts, slopes, mix), x.mean(-1), rtol=0, atol=1e-6)
+    # one active channel, slopes (1, -1 at shift 0.5): a tent rising to 0.5 then flat
+    slopes2 = np.zeros((16, 3), np.float32)
+    slopes2[0, 0], slopes2[8, 0] = 1.0, -1.0
+    mix2 = np.array([1.0, 0.0, 0.0, 0.0], np.float32)
+    g = oracle.curves_guide(x, ccm, shifts, slopes2, mix2)
+    np.testing.assert_allclose(g, np.minimum(x[..., 0], 0.5), rtol=0, atol=1e-6)
+    # clip
+    mix3 = np.array([4.0, 0.0, 0.0, -1.0], np.float32)
+    g = oracle.curves_guide(x, ccm, shifts, slopes, mix3)
+    np.testing.assert_allclose(g, np.clip(4 * x[..., 0] - 1, 0, 1), rtol=0, atol=1e-6)

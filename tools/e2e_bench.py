@@ -61,6 +61,18 @@ def main():
     print(f"config #3  HDRNetPointwiseNNGuide 3840x2160 b=1: {t_all * 1e3:.3f} ms/frame = {mp / t_all:.0f} MP/s "
           f"(coefficients {t_coef * 1e3:.3f} ms, guide net {t_guide * 1e3:.3f} ms, slice-apply {t_slice * 1e3:.3f} ms)")
 
+    # HDRNetCurves (the reference's default model) inference at 4K: curves guide fused vs composed
+    mc = models.HDRNetCurves().to(dev).eval()
+    with torch.no_grad():
+        t_cf = timeit(lambda: mc(low, full), args.steps)
+        gc = GraphedInference(mc, [low, full])
+        t_cg = timeit(lambda: gc(gc.static_inputs[0], gc.static_inputs[1]), args.steps)
+        mc.fuse_guide = False
+        t_cu = timeit(lambda: mc(low, full), 3)
+        mc.fuse_guide = True
+    print(f"curves     HDRNetCurves 3840x2160 b=1: composed {t_cu * 1e3:.2f} ms/frame, fused {t_cf * 1e3:.3f} ms/frame, "
+          f"fused + hipGraph {t_cg * 1e3:.3f} ms/frame = {mp / t_cg:.0f} MP/s")
+
     # HDRNetGaussianPyrNN inference at 4K: 3 levels, fused (resize kernel + one launch per level)
     # vs composed from the un-fused ops
     mp_ = models.HDRNetGaussianPyrNN().to(dev).eval()

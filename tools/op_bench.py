@@ -103,6 +103,18 @@ def main():
             1, H, W, GH, GW, GD, 3, 3, 1, 1, 255.0, 1, conv1.data_ptr() if nn else None,
             conv2.data_ptr() if nn else None, 16 if nn else 0, None, stream))
 
+    ccm = torch.cat([torch.eye(3, device=dev), torch.zeros((3, 1), device=dev)], 1) + 0.1 * torch.randn((3, 4), device=dev, generator=gen)
+    shifts = torch.linspace(0, 1, 17, device=dev)[:-1, None].repeat(1, 3).contiguous()
+    slopes = (0.2 * torch.randn((16, 3), device=dev, generator=gen)).contiguous()
+    mixv = torch.tensor([0.4, 0.35, 0.25, 0.0], device=dev)
+
+    def apply_io_curves(k, u8io=True):
+        s, t = S[k % nsets], u8[k % nsets]
+        chk(lib.hdrnet_bilateral_slice_apply_io_curves(
+            s["grid"].data_ptr(), (t["inp"] if u8io else s["inp"]).data_ptr(), (t["out"] if u8io else s["out"]).data_ptr(),
+            1, H, W, GH, GW, GD, 3, 3, 1, 1 if u8io else 0, 255.0 if u8io else 1.0, 1 if u8io else 0,
+            ccm.data_ptr(), shifts.data_ptr(), slopes.data_ptr(), mixv.data_ptr(), 16, None, stream))
+
     coarse = [torch.randn((1, H // 2, W // 2, 3), device=dev, generator=gen) for _ in range(nsets)]
     half = [torch.empty((1, H // 2, W // 2, 3), device=dev) for _ in range(nsets)]
 
@@ -154,6 +166,8 @@ def main():
     run("guide-NN(16) + apply fwd fused", apply_fwd_nnguide, 4 * npx * (Cin + Cout) + gridb)
     run("u8 -> guide-NN + apply -> u8", apply_io_u8, npx * 6 + gridb)
     run("u8 + guide map -> apply -> u8", lambda k: apply_io_u8(k, nn=False), npx * 10 + gridb)
+    run("curves guide + apply fwd fused", lambda k: apply_io_curves(k, u8io=False), 4 * npx * (Cin + Cout) + gridb)
+    run("u8 -> curves guide + apply -> u8", apply_io_curves, npx * 6 + gridb)
     run("apply + up-add of coarse level", lambda k: apply_upadd(k, nn=False),
         4 * npx * (1 + Cin + Cout) + gridb + 4 * npx * 3 // 4)
     run("guide-NN + apply + up-add", apply_upadd, 4 * npx * (Cin + Cout) + gridb + 4 * npx * 3 // 4)
