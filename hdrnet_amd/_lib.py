@@ -39,6 +39,8 @@ SIGNATURES = {
     "hdrnet_resize_bilinear_f32": (_I, [_FP, _FP] + [_I] * 6 + [_VP]),
     "hdrnet_pointwise_guide_grad_workspace_bytes": (_SZ, [ctypes.c_longlong, _I, _I]),
     "hdrnet_pointwise_guide_grad_f32": (_I, [_FP] * 6 + [_I] + [_FP] * 2 + [ctypes.c_longlong, _I, _I, _VP, _SZ, _VP]),
+    "hdrnet_curves_guide_grad_workspace_bytes": (_SZ, [ctypes.c_longlong, _I, _I]),
+    "hdrnet_curves_guide_grad_f32": (_I, [_FP] * 7 + [_I] + [_FP] * 4 + [ctypes.c_longlong, _I, _I, _VP, _SZ, _VP]),
     "hdrnet_input_moments_workspace_bytes": (_SZ, [ctypes.c_longlong, _I]),
     "hdrnet_input_moments_f32": (_I, [_FP, ctypes.c_longlong, _I, _FP, _FP, _VP, _SZ, _VP]),
     "hdrnet_bilateral_slice_apply_io": (_I, [_FP] * 4 + [_I] * 10 + [ctypes.c_float, _I] + [_FP] * 2 + [_I, _FP, _VP]),

@@ -244,6 +244,46 @@ int hdrnet_pointwise_guide_grad_f32(const float* input, const float* guide, cons
   return rc;
 }
 
+size_t hdrnet_curves_guide_grad_workspace_bytes(long long npx, int Cin, int npts) {
+  if (npx <= 0) return 0;
+  return hdrnet_amd::curves_grad_workspace_bytes(npx, Cin, npts);
+}
+
+int hdrnet_curves_guide_grad_f32(const float* input, const float* dguide, const float* guide_ccm,
+                                 const float* guide_shifts, const float* guide_slopes,
+                                 const float* guide_mix, float* dinput, int accumulate_dinput,
+                                 float* dccm, float* dshifts, float* dslopes, float* dmix, long long npx,
+                                 int Cin, int npts, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  using namespace hdrnet_amd;
+  if (npx < 0 || Cin <= 0 || npts <= 0)
+    return fail(HDRNET_INVALID_ARGUMENT, "bad sizes (npx=%lld, Cin=%d, npts=%d)", npx, Cin, npts);
+  if (!dccm || !dshifts || !dslopes || !dmix || !guide_ccm || !guide_shifts || !guide_slopes || !guide_mix)
+    return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (npx == 0) {  // no pixels: zero parameter gradients
+    hipError_t e = hipMemsetAsync(dccm, 0, sizeof(float) * (size_t)Cin * (Cin + 1), s);
+    if (e == hipSuccess) e = hipMemsetAsync(dshifts, 0, sizeof(float) * (size_t)npts * Cin, s);
+    if (e == hipSuccess) e = hipMemsetAsync(dslopes, 0, sizeof(float) * (size_t)npts * Cin, s);
+    if (e == hipSuccess) e = hipMemsetAsync(dmix, 0, sizeof(float) * (size_t)(Cin + 1), s);
+    const int rc = check_launch(e, "CurvesGuideGrad");
+    if (rc == HDRNET_OK) set_kernel("noop");
+    return rc;
+  }
+  if (!input || !dguide) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  CurvesGradArgs a{input, dguide, guide_ccm, guide_shifts, guide_slopes, guide_mix, dinput,
+                   accumulate_dinput != 0, dccm, dshifts, dslopes, dmix, npx, Cin, npts, workspace,
+                   workspace_bytes};
+  if (!curves_grad_supported(a))
+    return fail(HDRNET_INVALID_ARGUMENT,
+                "curves-guide gradient needs Cin = 3, npts = 16 and a workspace of "
+                "hdrnet_curves_guide_grad_workspace_bytes()");
+  const char* name = "";
+  const int rc = check_launch(launch_curves_grad(a, s, &name), "CurvesGuideGrad");
+  if (rc == HDRNET_OK) set_kernel(name);
+  return rc;
+}
+
 size_t hdrnet_input_moments_workspace_bytes(long long npx, int Cin) {
   if (npx <= 0) return 0;
   return hdrnet_amd::input_moments_workspace_bytes(npx, Cin);

@@ -56,10 +56,15 @@ __device__ __forceinline__ void block_reduce_store(const float (&acc)[NA], float
   }
 }
 
-// partial [nb][na] -> out[a] = sum_b partial[b][a], fixed order, accumulated in double.
+// partial [nb][na] -> sum_b partial[b][a], fixed order, accumulated in double; accumulator a goes to
+// the destination segment that contains it (segments are consecutive ranges of a).
+struct Segments {
+  float* dst[4];
+  int n[4];
+};
+
 __global__ __launch_bounds__(256) void reduce_partials(const float* __restrict__ partial, int nb, int na,
-                                                       float* __restrict__ out0, int n0,
-                                                       float* __restrict__ out1) {
+                                                       Segments seg) {
   __shared__ double red[256];
   const int a = blockIdx.x;
   double s = 0.0;
@@ -71,8 +76,15 @@ __global__ __launch_bounds__(256) void reduce_partials(const float* __restrict__
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    if (a < n0) out0[a] = (float)red[0];
-    else out1[a - n0] = (float)red[0];
+    int off = a;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (off < seg.n[q]) {
+        seg.dst[q][off] = (float)red[0];
+        break;
+      }
+      off -= seg.n[q];
+    }
   }
 }
 
@@ -185,6 +197,100 @@ __global__ __launch_bounds__(kThreads, 2) void guide_nn_grad(
   block_reduce_store<NA>(acc, partial + (size_t)blockIdx.x * NA);
 }
 
+// ---- VJP of the curves guide (HDRNetCurves._guide, hdrnet/models.py:145-190) -------------------------
+//   t_c = ccm[c][3] + sum_j ccm[c][j] in_j;  cv_c = sum_k slopes[k][c] relu(t_c - shifts[k][c]);
+//   guide = clip(mix[3] + sum_c mix[c] cv_c, 0, 1)
+// 112 parameter gradients (ccm 12, shifts 48, slopes 48, mix 4) are too many register accumulators
+// for one pass, so the knots are split: pass FIRST handles knots [0, 8) plus ccm, mix and dinput,
+// the second pass knots [8, 16).  Both recompute the (cheap) forward.  The clip passes the gradient
+// where 0 <= pre-clip value <= 1 (tf.clip_by_value / torch.clamp).
+constexpr int kKnots = 16, kKnotsPerPass = 8;
+
+template <bool FIRST, bool ACCUM>
+__global__ __launch_bounds__(kThreads, 2) void curves_guide_grad(
+    const float* __restrict__ input, const float* __restrict__ dguide, const float* __restrict__ ccm,
+    const float* __restrict__ shifts, const float* __restrict__ slopes, const float* __restrict__ mix,
+    float* __restrict__ dinput, float* __restrict__ partial, long long npx) {
+  constexpr int CIN = 3;
+  constexpr int K0 = FIRST ? 0 : kKnotsPerPass;
+  // accumulators: [dshift 8x3][dslope 8x3] (+ FIRST: [dccm 3x4][dmix 4])
+  constexpr int NA = 2 * kKnotsPerPass * CIN + (FIRST ? CIN * (CIN + 1) + CIN + 1 : 0);
+  constexpr int O_SL = kKnotsPerPass * CIN, O_CCM = 2 * kKnotsPerPass * CIN, O_MIX = O_CCM + CIN * (CIN + 1);
+  float acc[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) acc[a] = 0.0f;
+
+  // One pixel per thread per iteration (a 12-B and a 4-B load, dense across the wave): with the 64
+  // accumulators, four pixels unrolled (as in guide_nn_grad) spill.
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long p = (long long)blockIdx.x * kThreads + threadIdx.x; p < npx; p += stride) {
+    const float dgp = dguide[p];
+    float in[CIN];
+#pragma unroll
+    for (int j = 0; j < CIN; ++j) in[j] = input[p * CIN + j];
+    // forward: t, curve values, pre-clip guide
+    float t[CIN], cv[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+      float h = ccm[c * (CIN + 1) + CIN];
+#pragma unroll
+      for (int j = 0; j < CIN; ++j) h = fmaf(ccm[c * (CIN + 1) + j], in[j], h);
+      t[c] = h;
+      cv[c] = 0.0f;
+    }
+#pragma unroll
+    for (int kk = 0; kk < kKnots; ++kk) {
+#pragma unroll
+      for (int c = 0; c < CIN; ++c)
+        cv[c] = fmaf(slopes[kk * CIN + c], fmaxf(t[c] - shifts[kk * CIN + c], 0.0f), cv[c]);
+    }
+    float g = mix[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) g = fmaf(mix[c], cv[c], g);
+    const float dgk = (g >= 0.0f && g <= 1.0f) ? dgp : 0.0f;  // through the clip
+    float dt[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+      const float dcv = dgk * mix[c];
+      if constexpr (FIRST) acc[O_MIX + c] = fmaf(dgk, cv[c], acc[O_MIX + c]);
+      float dtc = 0.0f;
+#pragma unroll
+      for (int kk = 0; kk < kKnots; ++kk) {
+        if (FIRST || (kk >= K0 && kk < K0 + kKnotsPerPass)) {
+          const float a = t[c] - shifts[kk * CIN + c];
+          const float w = (a > 0.0f) ? dcv * slopes[kk * CIN + c] : 0.0f;  // d / d t_c through knot kk
+          if constexpr (FIRST) dtc += w;
+          if (kk >= K0 && kk < K0 + kKnotsPerPass) {
+            acc[(kk - K0) * CIN + c] -= w;                                                               // d shifts
+            acc[O_SL + (kk - K0) * CIN + c] = fmaf(dcv, fmaxf(a, 0.0f), acc[O_SL + (kk - K0) * CIN + c]);  // d slopes
+          }
+        }
+      }
+      dt[c] = dtc;
+    }
+    if constexpr (FIRST) {
+      acc[O_MIX + CIN] += dgk;
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) {
+#pragma unroll
+        for (int j = 0; j < CIN; ++j) acc[O_CCM + c * (CIN + 1) + j] = fmaf(dt[c], in[j], acc[O_CCM + c * (CIN + 1) + j]);
+        acc[O_CCM + c * (CIN + 1) + CIN] += dt[c];
+      }
+      if (dinput) {
+#pragma unroll
+        for (int j = 0; j < CIN; ++j) {
+          float v = 0.0f;
+#pragma unroll
+          for (int c = 0; c < CIN; ++c) v = fmaf(dt[c], ccm[c * (CIN + 1) + j], v);
+          float* o = dinput + p * CIN + j;
+          *o = (ACCUM ? *o : 0.0f) + v;
+        }
+      }
+    }
+  }
+  block_reduce_store<NA>(acc, partial + (size_t)blockIdx.x * NA);
+}
+
 // ---- first and second moments of the input ------------------------------------------------------
 // acc layout: [CIN] sums, then [CIN][CIN] products (full matrix, symmetric).
 template <int CIN>
@@ -260,7 +366,8 @@ hipError_t launch_grad_t(const GuideGradArgs& a, int nb, hipStream_t s) {
                                                            a.dinput, partial, a.npx);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  reduce_partials<<<NA, 256, 0, s>>>(partial, nb, NA, a.dconv1, NF * (CIN + 1), a.dconv2);
+  reduce_partials<<<NA, 256, 0, s>>>(partial, nb, NA,
+                                     Segments{{a.dconv1, a.dconv2, nullptr, nullptr}, {NF * (CIN + 1), NF + 1, 0, 0}});
   return hipGetLastError();
 }
 
@@ -307,7 +414,45 @@ hipError_t launch_input_moments(const float* input, long long npx, int Cin, floa
   else return hipErrorInvalidValue;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  reduce_partials<<<Cin + Cin * Cin, 256, 0, s>>>(partial, nb, Cin + Cin * Cin, sums, Cin, moments);
+  reduce_partials<<<Cin + Cin * Cin, 256, 0, s>>>(partial, nb, Cin + Cin * Cin,
+                                                  Segments{{sums, moments, nullptr, nullptr}, {Cin, Cin * Cin, 0, 0}});
+  return hipGetLastError();
+}
+
+size_t curves_grad_workspace_bytes(long long npx, int Cin, int npts) {
+  if (Cin != 3 || npts != 16) return 0;
+  // two passes: 64 and 48 accumulators per workgroup
+  return (size_t)persistent_blocks(npx) * (size_t)(64 + 48) * sizeof(float);
+}
+
+bool curves_grad_supported(const CurvesGradArgs& a) {
+  const size_t need = curves_grad_workspace_bytes(a.npx, a.Cin, a.npts);
+  const uintptr_t al = (uintptr_t)a.input | (uintptr_t)a.dguide | (uintptr_t)a.dinput;
+  return need != 0 && a.workspace != nullptr && a.workspace_bytes >= need && (al & 3u) == 0;
+}
+
+hipError_t launch_curves_grad(const CurvesGradArgs& a, hipStream_t s, const char** name) {
+  const int nb = persistent_blocks(a.npx);
+  float* pa = static_cast<float*>(a.workspace);
+  float* pb = pa + (size_t)nb * 64;
+  *name = "curves_guide_grad";
+  if (a.accumulate_dinput)
+    curves_guide_grad<true, true><<<nb, kThreads, 0, s>>>(a.input, a.dguide, a.ccm, a.shifts, a.slopes, a.mix,
+                                                           a.dinput, pa, a.npx);
+  else
+    curves_guide_grad<true, false><<<nb, kThreads, 0, s>>>(a.input, a.dguide, a.ccm, a.shifts, a.slopes, a.mix,
+                                                            a.dinput, pa, a.npx);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  curves_guide_grad<false, false><<<nb, kThreads, 0, s>>>(a.input, a.dguide, a.ccm, a.shifts, a.slopes, a.mix,
+                                                           nullptr, pb, a.npx);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  // pass A: [dshift k 0..7][dslope k 0..7][dccm 12][dmix 4]; pass B: [dshift k 8..15][dslope k 8..15]
+  reduce_partials<<<64, 256, 0, s>>>(pa, nb, 64, Segments{{a.dshifts, a.dslopes, a.dccm, a.dmix}, {24, 24, 12, 4}});
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  reduce_partials<<<48, 256, 0, s>>>(pb, nb, 48, Segments{{a.dshifts + 24, a.dslopes + 24, nullptr, nullptr}, {24, 24, 0, 0}});
   return hipGetLastError();
 }
 

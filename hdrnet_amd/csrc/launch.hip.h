@@ -68,6 +68,20 @@ struct GuideGradArgs {
   size_t workspace_bytes;
 };
 
+// VJP of the curves guide (guide_nn_grad.hip).  Parameter layouts as exported by the reference.
+struct CurvesGradArgs {
+  const float* input;   // [npx][3]
+  const float* dguide;  // [npx]
+  const float *ccm, *shifts, *slopes, *mix;  // [3][4], [16][3], [16][3], [4]
+  float* dinput;        // [npx][3] or null
+  bool accumulate_dinput;
+  float *dccm, *dshifts, *dslopes, *dmix;
+  long long npx;
+  int Cin, npts;
+  void* workspace;
+  size_t workspace_bytes;
+};
+
 struct SliceArgs {
   const float* grid;
   const float* guide;
@@ -147,6 +161,9 @@ hipError_t launch_slice_grid_grad_mfma(const SliceGradArgs& a, hipStream_t s, co
 size_t guide_grad_workspace_bytes(long long npx, int Cin, int n);
 bool guide_grad_supported(const GuideGradArgs& a);
 hipError_t launch_guide_grad(const GuideGradArgs& a, hipStream_t s, const char** name);
+size_t curves_grad_workspace_bytes(long long npx, int Cin, int npts);
+bool curves_grad_supported(const CurvesGradArgs& a);
+hipError_t launch_curves_grad(const CurvesGradArgs& a, hipStream_t s, const char** name);
 size_t input_moments_workspace_bytes(long long npx, int Cin);
 hipError_t launch_input_moments(const float* input, long long npx, int Cin, float* sums, float* moments,
                                 void* workspace, hipStream_t s, const char** name);

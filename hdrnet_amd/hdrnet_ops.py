@@ -35,7 +35,7 @@ import torch
 from . import _lib
 
 __all__ = ["bilateral_slice", "bilateral_slice_apply", "bilateral_slice_apply_nnguide",
-           "bilateral_slice_apply_io", "bilateral_slice_apply_upadd", "resize_bilinear", "input_moments",
+           "bilateral_slice_apply_io", "bilateral_slice_apply_curves", "bilateral_slice_apply_upadd", "resize_bilinear", "input_moments",
            "kernel_override", "last_kernel"]
 
 _tls = threading.local()
@@ -378,6 +378,62 @@ def bilateral_slice_apply_nnguide(grid: torch.Tensor, input: torch.Tensor,  # no
         return _BilateralSliceApplyNNGuide.apply(grid, input, guide_conv1, guide_conv2, has_offset)
     return _nnguide_forward(grid.detach(), input.detach(), guide_conv1.detach(), guide_conv2.detach(),
                             has_offset, want_guide=False)[0]
+
+
+class _BilateralSliceApplyCurves(torch.autograd.Function):
+    """curves guide + slice-apply as ONE differentiable op (the standard model's training path):
+    forward = the fused kernel (guide written once for the backward); backward = slice-apply VJP,
+    then the curves guide's VJP, which adds its share into the same dinput buffer."""
+
+    @staticmethod
+    def forward(ctx, grid, inp, ccm, shifts, slopes, mix, has_offset):
+        out, guide = _apply_io_curves(grid, inp, (ccm, shifts, slopes, mix), None, torch.float32,
+                                      bool(has_offset), True)
+        ctx.save_for_backward(grid, inp, ccm, shifts, slopes, mix, guide)
+        ctx.has_offset = bool(has_offset)
+        ctx.flags = _flags()
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad):
+        grid, inp, ccm, shifts, slopes, mix, guide = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        need_net = any(need[2:6])
+        if not (need[0] or need[1] or need_net):
+            return (None,) * 7
+        dgrid, dguide, dinput = _apply_backward(grid, guide, inp, grad, ctx.has_offset,
+                                                (need[0], need_net or need[1], need[1]), ctx.flags)
+        grads = [None] * 4
+        if need_net or need[1]:
+            inp_c, dguide = inp.contiguous(), dguide.contiguous()
+            params = [t.contiguous() for t in (ccm, shifts, slopes, mix)]
+            outs = [torch.empty_like(t) for t in params]
+            npx, npts = dguide.numel(), shifts.shape[0]
+            lib = _lib.load()
+            wbytes = lib.hdrnet_curves_guide_grad_workspace_bytes(npx, 3, npts)
+            ws = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=inp.device)
+            with torch.cuda.device(inp.device):
+                rc = lib.hdrnet_curves_guide_grad_f32(
+                    inp_c.data_ptr(), dguide.data_ptr(), *[t.data_ptr() for t in params], _ptr(dinput), 1,
+                    *[t.data_ptr() for t in outs], npx, 3, npts, ws.data_ptr(), wbytes, _stream(inp.device))
+            _lib.check(rc, "CurvesGuideGrad")
+            grads = [g if n else None for g, n in zip(outs, need[2:6])]
+        return (dgrid, dinput, *grads, None)
+
+
+def bilateral_slice_apply_curves(grid: torch.Tensor, input: torch.Tensor, ccm: torch.Tensor,  # noqa: A002
+                                 shifts: torch.Tensor, slopes: torch.Tensor, mix: torch.Tensor,
+                                 has_offset: bool = True) -> torch.Tensor:
+    """``HDRNetCurves._guide`` (hdrnet/models.py:145-190) fused with ``bilateral_slice_apply``, fp32,
+    differentiable in ``grid``, ``input`` and the four guide parameter arrays (layouts of
+    hdrnet/bin/freeze_graph.py:107-127: ccm [3, 4], shifts / slopes [16, 3], mix [4]).  The wire-format
+    inference variant is ``bilateral_slice_apply_io(..., guide_curves=...)``."""
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (grid, input, ccm, shifts, slopes, mix)):
+        if input.dim() != 4 or input.shape[3] != 3 or shifts.dim() != 2 or shifts.shape[0] != 16:
+            raise ValueError("the differentiable curves-guide op needs Cin = 3 and 16 knots per channel")
+        return _BilateralSliceApplyCurves.apply(grid, input, ccm, shifts, slopes, mix, has_offset)
+    return _apply_io_curves(grid, input, (ccm, shifts, slopes, mix), None, torch.float32, has_offset, False)
 
 
 def input_moments(input: torch.Tensor):  # noqa: A002

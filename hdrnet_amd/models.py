@@ -160,19 +160,24 @@ class _CurvesGuide(nn.Module):
         self.mix_b = nn.Parameter(torch.zeros(()))
 
     def forward(self, im: torch.Tensor) -> torch.Tensor:
-        g = im @ self.ccm + self.ccm_bias
+        # Written with broadcasts + reductions rather than `@`: on a [8.3 M, 3] activation rocBLAS
+        # turns `x @ w` / its backward into gemv calls that take 70 ms of a 100 ms training step.
+        g = (im.unsqueeze(-1) * self.ccm).sum(-2) + self.ccm_bias
         g = (self.slopes * F.relu(g.unsqueeze(-1) - self.shifts)).sum(-1)
-        g = g @ self.mix_w + self.mix_b
+        g = (g * self.mix_w).sum(-1) + self.mix_b
         return g.clamp(0.0, 1.0)
 
     def exported(self):
         """The parameters in the layout hdrnet/bin/freeze_graph.py:107-127 writes (and the GL
         renderer loads, benchmark/src/renderer.cc:197-225): ccm [3, 4] = (ccm; bias)^T, shifts /
         slopes [npts, 3], mix [4] = (weights, bias)."""
+        return tuple(t.detach() for t in self.exported_differentiable())
+
+    def exported_differentiable(self):
+        """Same arrays, attached to the autograd graph (training through the fused op)."""
         ccm = torch.cat([self.ccm, self.ccm_bias[None, :]], dim=0).t().contiguous()
         mix = torch.cat([self.mix_w, self.mix_b.reshape(1)]).contiguous()
-        return (ccm.detach(), self.shifts.detach().t().contiguous(), self.slopes.detach().t().contiguous(),
-                mix.detach())
+        return ccm, self.shifts.t().contiguous(), self.slopes.t().contiguous(), mix
 
 
 class _PointwiseNNGuide(nn.Module):
@@ -194,7 +199,10 @@ class _PointwiseNNGuide(nn.Module):
         h = im @ self.w1  # [B, H, W, n]
         shape = h.shape
         h = self.bn(h.reshape(-1, shape[-1])).reshape(shape)
-        return torch.sigmoid(F.relu(h) @ self.w2 + self.b2)
+        # (relu(h) * w2).sum(-1), not `relu(h) @ w2`: the backward of the latter is a rocBLAS gemv on
+        # an [8.3 M, 16] matrix that takes 75 ms (this is only the un-fused composition; the model
+        # normally runs the fused kernels)
+        return torch.sigmoid((F.relu(h) * self.w2).sum(-1) + self.b2)
 
     def folded(self, detach: bool = True):
         """Batch-norm (running statistics) folded into the first layer, in the reference's export
@@ -250,15 +258,16 @@ class HDRNetCurves(nn.Module):
 
     def forward(self, lowres_input: torch.Tensor, fullres_input: torch.Tensor) -> torch.Tensor:
         coeffs = self.coefficients(lowres_input)
-        if (self.fuse_guide and isinstance(self.guide, _CurvesGuide) and not torch.is_grad_enabled()
-                and fullres_input.is_cuda and fullres_input.shape[3] == 3 and fullres_input.shape[2] % 4 == 0):
-            # inference: curves guide evaluated in registers inside the slice-apply kernel, as the
-            # reference's standard GL shader does (benchmark/assets/std.frag:32-53)
+        if (self.fuse_guide and isinstance(self.guide, _CurvesGuide) and fullres_input.is_cuda
+                and fullres_input.shape[3] == 3 and fullres_input.shape[2] % 4 == 0):
+            # curves guide evaluated in registers inside the slice-apply kernel, as the reference's
+            # standard GL shader does (benchmark/assets/std.frag:32-53); with autograd on, the
+            # backward is the slice-apply VJP + the curves guide's VJP kernel
             from . import hdrnet_ops
             gs = coeffs.shape
-            return hdrnet_ops.bilateral_slice_apply_io(
+            return hdrnet_ops.bilateral_slice_apply_curves(
                 coeffs.reshape(gs[0], gs[1], gs[2], gs[3], gs[4] * gs[5]), fullres_input,
-                guide_curves=self.guide.exported(), has_offset=True)
+                *self.guide.exported_differentiable(), has_offset=True)
         guide = self.guide(fullres_input)
         # models.py:193-196 -- the one call site of the hot path
         return layers.bilateral_slice_apply(coeffs, guide, fullres_input, has_offset=True, name="slice")

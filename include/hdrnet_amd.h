@@ -175,6 +175,18 @@ int hdrnet_pointwise_guide_grad_f32(const float* input, const float* guide, cons
                                     float* dinput, int accumulate_dinput, float* dconv1,
                                     float* dconv2, long long npx, int Cin, int n_feats,
                                     void* workspace, size_t workspace_bytes, void* stream);
+/* VJP of the curves guide (HDRNetCurves._guide, hdrnet/models.py:145-190; formula and parameter
+ * layouts at hdrnet_bilateral_slice_apply_io_curves): given dguide it writes dccm [Cin][Cin+1],
+ * dshifts / dslopes [npts][Cin], dmix [Cin+1] and adds (accumulate_dinput != 0) or stores the guide
+ * path's share of dinput (NULL: skipped).  The clip passes the gradient where the pre-clip value lies
+ * in [0, 1].  Deterministic.  Supported: Cin = 3, npts = 16 (the reference hard-codes 16 knots). */
+size_t hdrnet_curves_guide_grad_workspace_bytes(long long npx, int Cin, int npts);
+int hdrnet_curves_guide_grad_f32(const float* input, const float* dguide, const float* guide_ccm,
+                                 const float* guide_shifts, const float* guide_slopes,
+                                 const float* guide_mix, float* dinput, int accumulate_dinput,
+                                 float* dccm, float* dshifts, float* dslopes, float* dmix,
+                                 long long npx, int Cin, int npts, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 size_t hdrnet_input_moments_workspace_bytes(long long npx, int Cin);
 int hdrnet_input_moments_f32(const float* input, long long npx, int Cin, float* sums,
                              float* moments, void* workspace, size_t workspace_bytes,

@@ -431,3 +431,83 @@ def test_curves_model_fused_matches_composed():
         ref = m(low, full)
         assert hdrnet_ops.last_kernel() == "apply_fwd_rows/vec4"
     torch.testing.assert_close(out, ref, rtol=3e-5, atol=3e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 36, 52), (1, 31, 64)])
+def test_fused_curves_apply_gradients_match_composition(shape):
+    """All six gradients of the ONE fused differentiable curves-guide + slice-apply op == autograd
+    through [torch curves guide] -> [bilateral_slice_apply] (ragged pixel count, guide values that
+    hit the clip on both sides)."""
+    from hdrnet_amd import hdrnet_ops
+    B, H, W = shape
+    dev = torch.device("cuda:0")
+    torch.manual_seed(13)
+    grid = torch.rand(B, 8, 8, 8, 12, device=dev)
+    inp = torch.rand(B, H, W, 3, device=dev)
+    ccm = torch.cat([torch.eye(3, device=dev), torch.zeros(3, 1, device=dev)], 1) + 0.3 * torch.randn(3, 4, device=dev)
+    shifts = torch.linspace(0, 1, 17, device=dev)[:-1, None].repeat(1, 3) + 0.013 * torch.randn(16, 3, device=dev)
+    slopes = 0.4 * torch.randn(16, 3, device=dev)
+    slopes[0] += 1.0
+    mix = torch.tensor([0.9, 0.8, 0.7, -0.4], device=dev)  # pre-clip range ~[-0.4, 2]: clips on both sides
+    dout = torch.randn(B, H, W, 3, device=dev)
+
+    def torch_guide(x, c, sh, sl, mx):
+        t = (x.unsqueeze(-2) * c[:, :3]).sum(-1) + c[:, 3]
+        cv = (sl.t() * torch.relu(t.unsqueeze(-1) - sh.t())).sum(-1)
+        return ((cv * mx[:3]).sum(-1) + mx[3]).clamp(0.0, 1.0)
+
+    def run(fused):
+        leaves = [t.clone().requires_grad_(True) for t in (grid, inp, ccm, shifts, slopes, mix)]
+        g, x, c, sh, sl, mx = leaves
+        if fused:
+            out = hdrnet_ops.bilateral_slice_apply_curves(g, x, c, sh, sl, mx, has_offset=True)
+        else:
+            out = hdrnet_ops.bilateral_slice_apply(g, torch_guide(x, c, sh, sl, mx), x, has_offset=True)
+        out.backward(dout)
+        return out.detach(), [t.grad for t in leaves]
+
+    out_f, grads_f = run(True)
+    assert hdrnet_ops.last_kernel() == "curves_guide_grad"
+    out_r, grads_r = run(False)
+    frac_clipped = float(((torch_guide(inp, ccm, shifts, slopes, mix) <= 0) |
+                          (torch_guide(inp, ccm, shifts, slopes, mix) >= 1)).float().mean())
+    assert 0.02 < frac_clipped < 0.9, frac_clipped
+    torch.testing.assert_close(out_f, out_r, rtol=3e-5, atol=3e-5)
+    for name, a, b in zip(("dgrid", "dinput", "dccm", "dshifts", "dslopes", "dmix"), grads_f, grads_r):
+        scale = b.abs().max().item()
+        err = (a - b).abs().max().item()
+        assert err <= 3e-4 * scale + 1e-5, (name, err, scale)
+    _, again = run(True)
+    for a, b in zip(grads_f, again):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_training_fused_curves_matches_unfused_module():
+    """HDRNetCurves.train() (the reference's default model): fused forward + curves VJP kernel == the
+    composed torch graph: loss and every parameter gradient."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(14)
+    m = models.HDRNetCurves(dict(batch_norm=True)).to(dev).train()
+    with torch.no_grad():
+        m.guide.ccm.add_(torch.randn(3, 3, device=dev) * 0.2)
+        m.guide.slopes.add_(torch.randn(3, 16, device=dev) * 0.2)
+    ref = models.HDRNetCurves(dict(batch_norm=True)).to(dev).train()
+    ref.load_state_dict(m.state_dict())
+    ref.fuse_guide = False
+    low = torch.rand(2, 256, 256, 3, device=dev)
+    full = torch.rand(2, 136, 240, 3, device=dev)
+    target = torch.rand(2, 136, 240, 3, device=dev)
+    loss = (m(low, full) - target).square().mean()
+    loss.backward()
+    loss_ref = (ref(low, full) - target).square().mean()
+    loss_ref.backward()
+    torch.testing.assert_close(loss, loss_ref, rtol=2e-5, atol=1e-7)
+    for (name, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None, name
+        scale = q.grad.abs().max().item()
+        err = (p.grad - q.grad).abs().max().item()
+        assert err <= 2e-3 * scale + 1e-7, (name, err, scale)
