@@ -113,3 +113,26 @@ def test_new_entry_points_validate_without_gpu(libpath):
     rc = lib.hdrnet_bilateral_slice_apply_upadd_f32(None, None, None, None, 0, 2, None, 1, 4, 4, 2, 2, 2, 3, 3, 1,
                                                     None, None, 0, None)
     assert rc == 1 and b"coarse extents" in lib.hdrnet_last_error()
+
+
+def test_curves_entry_points_validate_without_gpu(libpath):
+    lib = ctypes.CDLL(libpath)
+    lib.hdrnet_last_error.restype = ctypes.c_char_p
+    LL, I, P, SZ, F = ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_float
+    lib.hdrnet_curves_guide_grad_workspace_bytes.restype = SZ
+    lib.hdrnet_curves_guide_grad_workspace_bytes.argtypes = [LL, I, I]
+    assert lib.hdrnet_curves_guide_grad_workspace_bytes(1000, 3, 8) == 0   # the reference has 16 knots
+    assert lib.hdrnet_curves_guide_grad_workspace_bytes(1000, 1, 16) == 0
+    lib.hdrnet_curves_guide_grad_f32.argtypes = [P] * 7 + [I] + [P] * 4 + [LL, I, I, P, SZ, P]
+    rc = lib.hdrnet_curves_guide_grad_f32(*([None] * 7), 0, *([None] * 4), 10, 3, 16, None, 0, None)
+    assert rc == 1 and b"null buffer" in lib.hdrnet_last_error()
+    lib.hdrnet_bilateral_slice_apply_io_curves.argtypes = [P] * 3 + [I] * 10 + [F, I] + [P] * 4 + [I, P, P]
+    rc = lib.hdrnet_bilateral_slice_apply_io_curves(None, None, None, 1, 4, 4, 2, 2, 2, 3, 3, 1, 0, 1.0, 0,
+                                                    None, None, None, None, 0, None, None)
+    assert rc == 1 and b"curve knots" in lib.hdrnet_last_error()
+    rc = lib.hdrnet_bilateral_slice_apply_io_curves(None, None, None, 1, 4, 4, 2, 2, 2, 3, 3, 1, 5, 1.0, 0,
+                                                    None, None, None, None, 16, None, None)
+    assert rc == 1 and b"dtype" in lib.hdrnet_last_error()
+    rc = lib.hdrnet_bilateral_slice_apply_io_curves(None, None, None, 1, 4, 4, 2, 2, 2, 3, 3, 1, 0, 1.0, 0,
+                                                    None, None, None, None, 16, None, None)
+    assert rc == 1 and b"null buffer" in lib.hdrnet_last_error()
