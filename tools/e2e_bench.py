@@ -110,6 +110,22 @@ def main():
     mt.fuse_guide = True
     print(f"config #4  same step, guide network un-fused (torch ops): {t_unfused * 1e3:.2f} ms/step")
 
+    # the reference's default model (HDRNetCurves), same step: fused curves guide vs composed
+    mcv = models.HDRNetCurves(dict(batch_norm=True)).to(dev).train()
+    optc = torch.optim.Adam([p for p in mcv.parameters() if p.requires_grad], lr=1e-4)
+
+    def step_curves():
+        optc.zero_grad(set_to_none=True)
+        (mcv(low, full) - target).square().mean().backward()
+        optc.step()
+
+    t_cs = timeit(step_curves, max(5, args.steps // 2))
+    mcv.fuse_guide = False
+    t_csu = timeit(step_curves, 3)
+    mcv.fuse_guide = True
+    print(f"curves     HDRNetCurves training step 1920x1080, {B} images/GPU: composed {t_csu * 1e3:.2f} ms/step, "
+          f"fused {t_cs * 1e3:.2f} ms/step")
+
     # the whole step (fwd + loss + bwd + Adam) as one hipGraph
     from hdrnet_amd.runtime import GraphedTrainStep
     mg = models.HDRNetPointwiseNNGuide(dict(batch_norm=True)).to(dev).train()
