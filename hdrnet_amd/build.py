@@ -36,7 +36,7 @@ SOURCES = [
     ("apply_bwd_rows.hip", ["-fno-slp-vectorize"]),
     ("slice_fwd_rows.hip", ["-fno-slp-vectorize"]),
     ("grid_grad_mfma.hip", ["-fno-slp-vectorize"]),
-    ("guide_nn_grad.hip", ["-fno-slp-vectorize"]),
+    ("guide_grad.hip", ["-fno-slp-vectorize"]),
     ("resize_bilinear.hip", []),
 ]
 

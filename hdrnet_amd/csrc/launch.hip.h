@@ -51,7 +51,7 @@ struct ApplyGradArgs {
   size_t workspace_bytes;
 };
 
-// Training side of the point-wise guide network (guide_nn_grad.hip).
+// Training side of the point-wise guide network (guide_grad.hip).
 struct GuideGradArgs {
   const float* input;   // [npx][Cin]
   const float* guide;   // [npx] the forward's guide (sigmoid output)
@@ -68,7 +68,7 @@ struct GuideGradArgs {
   size_t workspace_bytes;
 };
 
-// VJP of the curves guide (guide_nn_grad.hip).  Parameter layouts as exported by the reference.
+// VJP of the curves guide (guide_grad.hip).  Parameter layouts as exported by the reference.
 struct CurvesGradArgs {
   const float* input;   // [npx][3]
   const float* dguide;  // [npx]
@@ -157,7 +157,7 @@ size_t slice_grid_grad_mfma_workspace(int B, int H, int W, int GH, int GW, int G
 bool slice_grid_grad_mfma_supported(const SliceGradArgs& a);
 hipError_t launch_slice_grid_grad_mfma(const SliceGradArgs& a, hipStream_t s, const char** name);
 
-// guide_nn_grad.hip -- VJP of the folded point-wise guide network; input moments for batch norm.
+// guide_grad.hip -- VJP of the folded point-wise guide network; input moments for batch norm.
 size_t guide_grad_workspace_bytes(long long npx, int Cin, int n);
 bool guide_grad_supported(const GuideGradArgs& a);
 hipError_t launch_guide_grad(const GuideGradArgs& a, hipStream_t s, const char** name);
