@@ -129,6 +129,10 @@ class _Coefficients(nn.Module):
         self.local1 = _Conv(cin, 8 * cm * gd, 3, batch_norm=bn)
         self.local2 = _Conv(8 * cm * gd, 8 * cm * gd, 3, use_bias=False, activation=None)
         self.pred = _Conv(8 * cm * gd, gd * n_out * n_in, 1, activation=None)
+        # MIOpen picks NHWC implicit-GEMM kernels for these shapes and the activations already are
+        # channels-last (an NHWC tensor viewed as NCHW): keep the weights in that format too, or every
+        # call converts them (8 extra launches of 67 per inference)
+        self.to(memory_format=torch.channels_last)
 
     def forward(self, lowres_nhwc: torch.Tensor) -> torch.Tensor:
         x = lowres_nhwc.permute(0, 3, 1, 2)  # the convs run NCHW; the tensor is 256 x 256
