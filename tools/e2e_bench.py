@@ -129,7 +129,7 @@ def main():
     # the whole step (fwd + loss + bwd + Adam) as one hipGraph
     from hdrnet_amd.runtime import GraphedTrainStep
     mg = models.HDRNetPointwiseNNGuide(dict(batch_norm=True)).to(dev).train()
-    optg = torch.optim.Adam([p for p in mg.parameters() if p.requires_grad], lr=1e-4, capturable=True)
+    optg = torch.optim.Adam([p for p in mg.parameters() if p.requires_grad], lr=1e-4, capturable=True, fused=True)
     gstep = GraphedTrainStep(mg, lambda out, tgt: (out - tgt).square().mean(), optg, [low, full], [target])
     t_graph = timeit(lambda: gstep([low, full], [target]), max(5, args.steps // 2))
     print(f"config #4  the whole step as one hipGraph: {t_graph * 1e3:.2f} ms/step = "
