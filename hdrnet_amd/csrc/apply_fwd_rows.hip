@@ -88,7 +88,8 @@ struct UpAdd {
   float sh, sw;  // (Hc - 1) / float(H - 1), (Wc - 1) / float(W - 1)   (in / out when out == 1)
 };
 
-template <int CIN, int COUT, bool OFFSET, bool GUIDE_NN = false, bool LDS_STORES = true, bool UPADD = false>
+template <int CIN, int COUT, bool OFFSET, bool GUIDE_NN = false, bool LDS_STORES = true, bool UPADD = false,
+          bool NT_LOADS = false>
 __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
     const float* __restrict__ grid, const float* __restrict__ guide,
     const float* __restrict__ input, float* __restrict__ out, int H, int W, int GH, int GW,
@@ -111,9 +112,31 @@ __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
 
   // Issue this thread's streaming loads before the staging pass so their HBM
   // latency overlaps the (L2-resident) grid reads and the barrier.
+  // NT_LOADS (benchmark variant 8): nontemporal, LANE-CONTIGUOUS loads (lane l takes float4 number
+  // l + 64k of the wave's input run) + an LDS transpose.  Nontemporal loads lower the no-compute
+  // floor of this geometry from 41.2 to 39.0 us (36.2 us stand-alone), but only lane-contiguous:
+  // an nt line is not kept for the next instruction, so the per-pixel pattern (three loads that
+  // each touch every line of the run) re-fetches and loses 5 us.  The full kernel does not
+  // cash it in (44.5 vs 43.6 us): it is bound by bytes in flight -- 10 workgroups per CU cover
+  // latency + compute -- not by the memory system's peak.  DESIGN.md section 4.
+  const int lane = threadIdx.x & 63;
+  const int wave_x0 = xs + kPxPerThread * (int)(threadIdx.x & ~63u);
+  const int wave_px = min(xe, wave_x0 + 64 * kPxPerThread) - wave_x0;  // <= 0 for an idle wave
+  float4* slab = reinterpret_cast<float4*>(colY + slab_offset_floats) +
+                 (threadIdx.x >> 6) * (64 * (CIN > COUT ? CIN : COUT));
   float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 iv[(CIN * kPxPerThread) / 4];
-  if (active) {
+  if constexpr (LDS_STORES && NT_LOADS) {
+    if constexpr (!GUIDE_NN) {
+      if (active) g4 = load_stream4(guide + p);
+    }
+    const float* ibase = input + ((size_t)row * W + wave_x0) * CIN;
+#pragma unroll
+    for (int k = 0; k < CIN; ++k) {
+      const int e = lane + 64 * k;
+      if (e < wave_px * CIN / 4) iv[k] = load_stream4(ibase + 4 * e);
+    }
+  } else if (active) {
     if constexpr (!GUIDE_NN) g4 = *reinterpret_cast<const float4*>(guide + p);
     const float4* ip = reinterpret_cast<const float4*>(input + p * CIN);
 #pragma unroll
@@ -121,6 +144,22 @@ __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
   }
 
   const RowCtx r = stage_row<C, false>(colY, grid_b, y, xs, xe, GH, GW, GD, scale_x, scale_y);
+
+  if constexpr (LDS_STORES && NT_LOADS) {  // transpose the input run: lane-contiguous -> this lane's 4 pixels
+#pragma unroll
+    for (int k = 0; k < CIN; ++k) {
+      const int e = lane + 64 * k;
+      if (e < wave_px * CIN / 4) slab[e] = iv[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (active) {
+#pragma unroll
+      for (int q = 0; q < CIN; ++q) iv[q] = slab[lane * CIN + q];
+    }
+    __builtin_amdgcn_wave_barrier();  // the slab is reused for the output below
+  }
 
   float gs[4] = {g4.x, g4.y, g4.z, g4.w};
   const float xf0 = (float)x + 0.5f;  // (x + k) + 0.5f == xf0 + k exactly (x < 2^23)
@@ -185,8 +224,6 @@ __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
   // through a private LDS slab: ds_write_b128 at the per-pixel stride (conflict-free:
   // 12-dword stride over 8-lane groups), then lane l reads float4 number l + 64k and
   // stores it -- every global_store_dwordx4 covers one dense 1 KiB run.
-  float4* slab = reinterpret_cast<float4*>(colY + slab_offset_floats) + (threadIdx.x >> 6) * (64 * COUT);
-  const int lane = threadIdx.x & 63;
   if (active) {
 #pragma unroll
     for (int q = 0; q < COUT; ++q) slab[lane * COUT + q] = ov[q];
@@ -194,8 +231,7 @@ __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const int wave_x0 = xs + kPxPerThread * (int)(threadIdx.x & ~63u);
-  const int nvalid = (min(xe, wave_x0 + 64 * kPxPerThread) - wave_x0) * COUT / 4;  // float4s
+  const int nvalid = wave_px * COUT / 4;  // float4s
   float4* gp = reinterpret_cast<float4*>(out + ((size_t)row * W + wave_x0) * COUT);
 #pragma unroll
   for (int k = 0; k < COUT; ++k) {
@@ -257,13 +293,14 @@ struct LaunchGeom {
 
 template <int C, int COUT>
 LaunchGeom geom_for(const ApplyArgs& a) {
+  const int slab_ch = a.Cin > COUT ? a.Cin : COUT;  // the slab transposes the input run, then the output
   LaunchGeom g;
   const bool aligned = (((uintptr_t)a.guide | (uintptr_t)a.input | (uintptr_t)a.out |
                          (uintptr_t)a.grid) & 15u) == 0;
   g.pl = make_row_plan(a.W, a.GW, aligned);
   // dynamic LDS: [colY image][one 64 x 4*COUT-float output slab per wave (vec4 kernel)]
   g.slab_off = round_up(g.pl.max_cols * a.GD * C, 4);
-  g.lds = ((size_t)g.slab_off + (size_t)(g.pl.threads / 64) * 64 * kPxPerThread * COUT) * sizeof(float);
+  g.lds = ((size_t)g.slab_off + (size_t)(g.pl.threads / 64) * 64 * kPxPerThread * slab_ch) * sizeof(float);
   g.nblocks = (long long)a.B * a.H * g.pl.nseg;
   return g;
 }
@@ -375,7 +412,8 @@ bool apply_fwd_rows_supported(const ApplyArgs& a) {
   if ((long long)a.B * a.H * ((a.W + 511) / 512) > 0x7fffffffLL) return false;
   const Plan pl = make_row_plan(a.W, a.GW, true);
   const size_t lds = ((size_t)pl.max_cols * a.GD * a.Cout * a.Cj + 4 +
-                      (size_t)(pl.threads / 64) * 64 * kPxPerThread * a.Cout) * sizeof(float);
+                      (size_t)(pl.threads / 64) * 64 * kPxPerThread * (a.Cin > a.Cout ? a.Cin : a.Cout)) *
+                     sizeof(float);
   return lds <= kMaxLdsBytes;
 }
 
@@ -397,15 +435,21 @@ hipError_t launch_apply_fwd_rows(const ApplyArgs& a, hipStream_t s, const char**
   return hipErrorInvalidValue;
 }
 
-// The direct-store instantiation, for tools/ab_bench.py only (apply_fwd_variants.hip routes here).
-hipError_t launch_apply_fwd_rows_direct_stores(const ApplyArgs& a, hipStream_t s, const char** name) {
+// The direct-store / plain-load instantiations, for tools/ab_bench.py only (apply_fwd_variants.hip
+// routes here): which = 0 per-lane stores, 1 = nontemporal lane-contiguous input loads.
+hipError_t launch_apply_fwd_rows_direct_stores(const ApplyArgs& a, hipStream_t s, const char** name, int which) {
   if (!(a.Cin == 3 && a.Cout == 3 && a.has_offset)) return hipErrorInvalidValue;
   const LaunchGeom g = geom_for<12, 3>(a);
   if (!g.pl.vec4) return hipErrorInvalidValue;
-  apply_fwd_rows_vec4<3, 3, true, false, false><<<(unsigned)g.nblocks, g.pl.threads, g.lds, s>>>(
-      a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, g.pl.nseg, g.pl.seg, g.slab_off,
-      (float)a.GW / a.W, (float)a.GH / a.H);
-  *name = "apply_fwd_rows/vec4-direct-stores";
+  if (which == 0)
+    apply_fwd_rows_vec4<3, 3, true, false, false><<<(unsigned)g.nblocks, g.pl.threads, g.lds, s>>>(
+        a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, g.pl.nseg, g.pl.seg, g.slab_off,
+        (float)a.GW / a.W, (float)a.GH / a.H);
+  else
+    apply_fwd_rows_vec4<3, 3, true, false, true, false, true><<<(unsigned)g.nblocks, g.pl.threads, g.lds, s>>>(
+        a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, g.pl.nseg, g.pl.seg, g.slab_off,
+        (float)a.GW / a.W, (float)a.GH / a.H);
+  *name = which == 0 ? "apply_fwd_rows/vec4-direct-stores" : "apply_fwd_rows/vec4-nt-loads";
   return hipGetLastError();
 }
 

@@ -8,8 +8,11 @@
 //   2        one wavefront per tile (no workgroup barrier, per-wave LDS image)
 //   3..6     persistent software-pipelined stream, {4,5,6,3} workgroups per CU
 //   7        product kernel with naive per-lane strided stores (no LDS transpose)
+//   8        product kernel with nontemporal lane-contiguous input loads + LDS transpose
+//   9-11     Q = 2, 3, 4 quads per thread, all loads issued first (more bytes in flight per wave)
 //   101      memory skeleton: the product kernel's loads / stores / launch shape, no slicing
 //   103-105  memory skeletons with lane-contiguous accesses on {both, loads only, stores only}
+//   106      103 with nontemporal input loads (the shipped kernel's access pattern)
 //
 // Skeletons do NOT compute the op (their name says ABLATION); the others are checked for
 // parity by tests/test_gpu_parity.py like the product kernel.
@@ -27,6 +30,7 @@ using namespace rows;
 constexpr int kVariantWave = 2;
 constexpr int kVariantStream = 3;  // .. 6
 constexpr int kVariantDirectStores = 7;
+constexpr int kVariantNtLoads = 8;
 
 // ---- memory skeletons ---------------------------------------------------------------------
 // MODE 1: thread = 4 consecutive pixels, exactly the product kernel's global accesses.
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(256) void apply_fwd_skeleton(
   const bool active = x < xe;
   const size_t p = (size_t)row * W + x;
   float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (active) g4 = *reinterpret_cast<const float4*>(guide + p);
+  if (active) g4 = (MODE == 6) ? load_stream4(guide + p) : *reinterpret_cast<const float4*>(guide + p);
   if constexpr (MODE == 1) {
     if (!active) return;
     const float4* ip = reinterpret_cast<const float4*>(input + p * CIN);
@@ -70,7 +74,10 @@ __global__ __launch_bounds__(256) void apply_fwd_skeleton(
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int e = (MODE == 5) ? (int)threadIdx.x * 3 + k : (int)threadIdx.x + k * nthreads;
-      if (e < nq) v[k] = ip[e];
+      if (e < nq) {
+        if constexpr (MODE == 6) v[k] = load_stream4(reinterpret_cast<const float*>(ip + e));
+        else v[k] = ip[e];
+      }
     }
     const float gq = g4.x + g4.y + g4.z + g4.w;
 #pragma unroll
@@ -82,6 +89,114 @@ __global__ __launch_bounds__(256) void apply_fwd_skeleton(
       }
     }
   }
+}
+
+// ---- Q quads per thread: more bytes in flight per wave ---------------------------------------------
+// The shipped kernel holds 4 KB of loads per wave and is bound by bytes in flight (10 workgroups per
+// CU have to cover HBM latency + their own compute).  Here a thread owns Q quads -- quad q of thread t
+// is pixels xs + 4 (q * blockDim + t) .. +3, so quad q of a wave is still one dense 256-pixel run --
+// issues ALL its loads first and then slices / stores quad by quad through the wave's slab.
+template <int CIN, int COUT, bool OFFSET, int Q>
+__global__ __launch_bounds__(256) void apply_fwd_rows_multiquad(
+    const float* __restrict__ grid, const float* __restrict__ guide, const float* __restrict__ input,
+    float* __restrict__ out, int H, int W, int GH, int GW, int GD, int nseg, int seg,
+    int slab_offset_floats, float scale_x, float scale_y) {
+  constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
+  extern __shared__ __attribute__((aligned(16))) float colY[];
+  const int bid = blockIdx.x;
+  const int segi = bid % nseg;
+  const int row = bid / nseg;  // = b * H + y
+  const int y = row % H;
+  const int b = row / H;
+  const int xs = segi * seg;
+  const int xe = min(xs + seg, W);
+  const float* grid_b = grid + (size_t)b * GH * GW * GD * C;
+  const int nthreads = blockDim.x;
+
+  float4 g4[Q], iv[Q][CIN];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int x = xs + kPxPerThread * (q * nthreads + (int)threadIdx.x);
+    g4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (x < xe) {
+      const size_t p = (size_t)row * W + x;
+      g4[q] = *reinterpret_cast<const float4*>(guide + p);
+      const float4* ip = reinterpret_cast<const float4*>(input + p * CIN);
+#pragma unroll
+      for (int k = 0; k < CIN; ++k) iv[q][k] = ip[k];
+    }
+  }
+
+  const RowCtx r = stage_row<C, false>(colY, grid_b, y, xs, xe, GH, GW, GD, scale_x, scale_y);
+
+  float4* slab = reinterpret_cast<float4*>(colY + slab_offset_floats) + (threadIdx.x >> 6) * (64 * COUT);
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int x = xs + kPxPerThread * (q * nthreads + (int)threadIdx.x);
+    const bool active = x < xe;
+    const float gs[4] = {g4[q].x, g4[q].y, g4[q].z, g4[q].w};
+    const float xf0 = (float)x + 0.5f;
+    const float* inf = reinterpret_cast<const float*>(iv[q]);
+    float4 ov[COUT];
+    float* of = reinterpret_cast<float*>(ov);
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < kPxPerThread; ++k) {
+        float in[CIN], o[COUT];
+#pragma unroll
+        for (int j = 0; j < CIN; ++j) in[j] = inf[k * CIN + j];
+        slice_apply_pixel<CIN, COUT, OFFSET>(r, xf0 + (float)k, gs[k], in, o);
+#pragma unroll
+        for (int i = 0; i < COUT; ++i) of[k * COUT + i] = o[i];
+      }
+#pragma unroll
+      for (int k = 0; k < COUT; ++k) slab[lane * COUT + k] = ov[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    const int wave_x0 = xs + kPxPerThread * (q * nthreads + (int)(threadIdx.x & ~63u));
+    const int nvalid = (min(xe, wave_x0 + 64 * kPxPerThread) - wave_x0) * COUT / 4;  // float4s
+    float4* gp = reinterpret_cast<float4*>(out + ((size_t)row * W + wave_x0) * COUT);
+#pragma unroll
+    for (int k = 0; k < COUT; ++k) {
+      const int e = lane + 64 * k;
+      if (e < nvalid) gp[e] = slab[e];
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  }
+}
+
+template <int Q>
+hipError_t launch_multiquad(const ApplyArgs& a, hipStream_t s, const char** name) {
+  // segments of T * 4 * Q pixels, balanced over the row like make_row_plan
+  int best_T = 0, best_nseg = 0;
+  long long best_waste = -1;
+  for (int T : {256, 192, 128, 64}) {
+    const int span = T * kPxPerThread * Q;
+    const int nseg = (a.W + span - 1) / span;
+    const long long waste = (long long)nseg * span - a.W;
+    if (best_waste < 0 || waste < best_waste) {
+      best_waste = waste;
+      best_T = T;
+      best_nseg = nseg;
+    }
+  }
+  const int seg = round_up((a.W + best_nseg - 1) / best_nseg, 4);
+  int threads = round_up((seg + kPxPerThread * Q - 1) / (kPxPerThread * Q), 64);
+  if (threads > 256) threads = 256;
+  (void)best_T;
+  const int max_cols = max_cols_for(seg, a.GW, a.W);
+  const int slab_off = round_up(max_cols * a.GD * 12, 4);
+  const size_t lds = ((size_t)slab_off + (size_t)(threads / 64) * 64 * kPxPerThread * 3) * sizeof(float);
+  if (lds > 64 * 1024) return hipErrorNotSupported;
+  const long long nblocks = (long long)a.B * a.H * best_nseg;
+  apply_fwd_rows_multiquad<3, 3, true, Q><<<(unsigned)nblocks, threads, lds, s>>>(
+      a.grid, a.guide, a.input, a.out, a.H, a.W, a.GH, a.GW, a.GD, best_nseg, seg, slab_off,
+      (float)a.GW / a.W, (float)a.GH / a.H);
+  *name = Q == 2 ? "apply_fwd_rows/multiquad2" : (Q == 3 ? "apply_fwd_rows/multiquad3" : "apply_fwd_rows/multiquad4");
+  return hipGetLastError();
 }
 
 // ---- one wavefront per output tile ------------------------------------------------------
@@ -419,6 +534,10 @@ hipError_t launch_variant_t(const ApplyArgs& a, const Plan& pl, hipStream_t s, c
         apply_fwd_skeleton<5><<<nblocks, pl.threads, 0, s>>>(a.guide, a.input, a.out, a.H, a.W, pl.nseg, pl.seg);
         *name = "ABLATION/skeleton ld-strided st-contig";
         return hipGetLastError();
+      case 106:
+        apply_fwd_skeleton<6><<<nblocks, pl.threads, 0, s>>>(a.guide, a.input, a.out, a.H, a.W, pl.nseg, pl.seg);
+        *name = "ABLATION/skeleton nt-ld-contig st-contig";
+        return hipGetLastError();
       default:
         break;
     }
@@ -434,7 +553,13 @@ hipError_t launch_apply_fwd_variant(const ApplyArgs& a, hipStream_t s, const cha
                          (uintptr_t)a.grid) & 15u) == 0;
   const Plan pl = make_row_plan(a.W, a.GW, aligned);
   if (!pl.vec4) return hipErrorNotSupported;
-  if (a.variant == kVariantDirectStores) return launch_apply_fwd_rows_direct_stores(a, s, name);
+  if (a.variant == kVariantDirectStores) return launch_apply_fwd_rows_direct_stores(a, s, name, 0);
+  if (a.variant == kVariantNtLoads) return launch_apply_fwd_rows_direct_stores(a, s, name, 1);
+  if (a.Cin == 3 && a.Cout == 3 && a.has_offset) {
+    if (a.variant == 9) return launch_multiquad<2>(a, s, name);
+    if (a.variant == 10) return launch_multiquad<3>(a, s, name);
+    if (a.variant == 11) return launch_multiquad<4>(a, s, name);
+  }
 #define HDRNET_CASE(CI, CO, OFF) \
   if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF) return launch_variant_t<CI, CO, OFF>(a, pl, s, name)
   HDRNET_CASE(3, 3, true);

@@ -114,7 +114,7 @@ hipError_t launch_apply_fwd_rows(const ApplyArgs& a, hipStream_t s, const char**
 // apply_fwd_variants.hip -- benchmark-only alternatives, reached only with a non-zero variant
 // number; hipErrorNotSupported = no such variant for the shape.
 hipError_t launch_apply_fwd_variant(const ApplyArgs& a, hipStream_t s, const char** name);
-hipError_t launch_apply_fwd_rows_direct_stores(const ApplyArgs& a, hipStream_t s, const char** name);
+hipError_t launch_apply_fwd_rows_direct_stores(const ApplyArgs& a, hipStream_t s, const char** name, int which);
 
 // Fused point-wise-NN guide + slice-apply forward (apply_fwd_rows.hip, GUIDE_NN).
 bool apply_fwd_nnguide_supported(const ApplyArgs& a, const float* guide_out);

@@ -207,6 +207,17 @@ __device__ __forceinline__ void slice_apply_pixel(const RowCtx& r, float xf, flo
   }
 }
 
+// Streaming 16-B load of pixel data that is read exactly once (guide / input / dout): the `nt`
+// policy.  Measured with the forward's byte volume and launch geometry and no compute
+// (tools/debug/ubench/stream_cache_policy.hip): plain loads + plain stores 41.2 us, nontemporal
+// loads + plain stores 36.2 us (6.4 TB/s = 80 % of 8 TB/s), nontemporal stores on top 36.9 us.  The
+// builtin needs an ext-vector pointee to stay ONE global_load_dwordx4 (through a float4 struct it
+// is scalarised into four dword loads -- the variant round 1 first measured as 8 % slower).
+__device__ __forceinline__ float4 load_stream4(const float* __restrict__ p) {
+  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // Upper bound of grid columns `npx` consecutive pixels can touch: floor differences of gx0
