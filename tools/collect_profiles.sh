@@ -20,7 +20,7 @@ python $R/tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_sq --match apply
 cd $R
 python tools/op_bench.py --workload 4k --json $O/ops_4k.json > $O/ops_4k.txt 2>&1
 python tools/op_bench.py --workload 1080p --json $O/ops_1080p.json > $O/ops_1080p.txt 2>&1
-python tools/ab_bench.py --variants 0,2,3,7,101,103,104,105 --rounds 5 --steps 100 > $O/ab_variants_4k.txt 2>&1
+python tools/ab_bench.py --variants 0,2,3,7,8,9,11,101,103,104,105,106 --rounds 5 --steps 100 > $O/ab_variants_4k.txt 2>&1
 python tools/e2e_bench.py > $O/e2e.txt 2>&1
 # 4. device micro-benchmarks
 for b in stream_patterns valu_rates mfma_valu_overlap; do
