@@ -170,7 +170,8 @@ def test_apply_forward_random(dev, ops, port, shape):
 # The benchmark-only forward kernels DESIGN.md quotes timings for (apply_fwd_variants.hip) must
 # compute the same op as the shipped one, or those timings compare nothing.
 @pytest.mark.parametrize("variant,expect", [(2, "apply_fwd_wave"), (3, "apply_fwd_stream"),
-                                            (5, "apply_fwd_stream"), (7, "direct-stores")])
+                                            (5, "apply_fwd_stream"), (7, "direct-stores"),
+                                            (8, "nt-loads"), (9, "multiquad2"), (11, "multiquad4")])
 @pytest.mark.parametrize("shape", [(2, 48, 2048, 16, 16, 8, 3, 3, True, -0.2, 1.2),
                                    (1, 37, 3076, 16, 16, 8, 3, 3, True, 0.0, 1.0)])
 def test_apply_forward_benchmark_variants(dev, ops, port, shape, variant, expect):
