@@ -31,6 +31,7 @@ SIGNATURES = {
     "hdrnet_version": (_I, []),
     "hdrnet_last_error": (ctypes.c_char_p, []),
     "hdrnet_last_kernel": (ctypes.c_char_p, []),
+    "hdrnet_enable_kernel_names": (None, [_I]),
     "hdrnet_bilateral_slice_apply_f32": (_I, [_FP] * 4 + [_I] * 9 + [_VP]),
     "hdrnet_bilateral_slice_apply_f32_ex": (_I, [_FP] * 4 + [_I] * 9 + [_U, _VP]),
     "hdrnet_bilateral_slice_apply_nnguide_f32": (_I, [_FP] * 6 + [_I] * 10 + [_VP]),
@@ -69,6 +70,12 @@ class HdrnetRuntimeError(RuntimeError):
 
 _lock = threading.Lock()
 _lib: Optional[ctypes.CDLL] = None
+_tools_lib: Optional[ctypes.CDLL] = None
+
+# Symbols only the tools build exports (include/hdrnet_amd_tools.h).
+TOOLS_SIGNATURES = {
+    "hdrnet_tools_set_trace": (None, [_VP]),
+}
 
 
 def lib_path() -> str:
@@ -77,41 +84,75 @@ def lib_path() -> str:
     return _build.LIB_PATH
 
 
+def _open(tools: bool) -> ctypes.CDLL:
+    # torch must be imported first so that its bundled libamdhip64.so.7 is the
+    # HIP runtime both sides share (same SONAME => the loader reuses it).
+    import torch  # noqa: F401
+
+    from . import build as _build
+
+    target = _build.TOOLS_LIB_PATH if tools else _build.LIB_PATH
+    try:
+        path = _build.build(tools=tools)
+    except Exception as e:  # noqa: BLE001
+        # A library that is older than its sources is NOT silently acceptable: tests passing on a
+        # stale binary is exactly what the "which .so was loaded" check cannot see.  Refuse unless
+        # the caller explicitly allows it (a host without hipcc that was handed a prebuilt tree).
+        if os.path.exists(target) and os.environ.get("HDRNET_AMD_ALLOW_STALE_LIB") == "1":
+            import warnings
+
+            warnings.warn(f"hdrnet_amd: rebuilding {os.path.basename(target)} FAILED ({e}); loading the "
+                          "existing, possibly STALE library because HDRNET_AMD_ALLOW_STALE_LIB=1",
+                          RuntimeWarning, stacklevel=3)
+            path = target
+        else:
+            hint = (" (an older library exists; set HDRNET_AMD_ALLOW_STALE_LIB=1 to load it anyway)"
+                    if os.path.exists(target) else "")
+            raise HdrnetLibraryError(
+                f"cannot build {os.path.basename(target)} (hipcc for gfx950 required): {e}{hint}") from e
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:
+        raise HdrnetLibraryError(f"cannot load {path}: {e}") from e
+    table = dict(SIGNATURES)
+    if tools:
+        table.update(TOOLS_SIGNATURES)
+    for name, (res, args) in table.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HdrnetLibraryError(f"{path} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
 def load() -> ctypes.CDLL:
-    """Load (building first if the in-tree library is missing or stale)."""
+    """Load the product library (building first if the in-tree library is missing or stale)."""
     global _lib
     if _lib is not None:
         return _lib
     with _lock:
-        if _lib is not None:
-            return _lib
-        # torch must be imported first so that its bundled libamdhip64.so.7 is the
-        # HIP runtime both sides share (same SONAME => the loader reuses it).
-        import torch  # noqa: F401
-
-        from . import build as _build
-
-        try:
-            path = _build.build()
-        except Exception as e:  # noqa: BLE001
-            if os.path.exists(_build.LIB_PATH):
-                path = _build.LIB_PATH  # stale but usable (e.g. no hipcc on this host)
-            else:
-                raise HdrnetLibraryError(
-                    f"cannot build libhdrnet_amd.so (hipcc for gfx950 required): {e}") from e
-        try:
-            lib = ctypes.CDLL(path)
-        except OSError as e:
-            raise HdrnetLibraryError(f"cannot load {path}: {e}") from e
-        for name, (res, args) in SIGNATURES.items():
-            try:
-                fn = getattr(lib, name)
-            except AttributeError as e:
-                raise HdrnetLibraryError(f"{path} does not export {name}") from e
-            fn.restype = res
-            fn.argtypes = args
-        _lib = lib
+        if _lib is None:
+            _lib = _open(tools=False)
     return _lib
+
+
+def load_tools() -> ctypes.CDLL:
+    """Load the TOOLS build (benchmark variants, memory skeletons, timeline trace); used by
+    tools/*.py and the variant tests only -- never by the ops."""
+    global _tools_lib
+    if _tools_lib is not None:
+        return _tools_lib
+    with _lock:
+        if _tools_lib is None:
+            _tools_lib = _open(tools=True)
+    return _tools_lib
+
+
+def enable_kernel_names(on: bool = True) -> None:
+    """Switch the hdrnet_last_kernel() bookkeeping on / off (off by default)."""
+    load().hdrnet_enable_kernel_names(1 if on else 0)
 
 
 def last_error() -> str:

@@ -4,7 +4,7 @@ hipcc cross-compiles without a GPU.  The library is built IN-TREE
 (hdrnet_amd/lib/libhdrnet_amd.so) so that it travels with the repository snapshot to
 the GPU box and shows up as a loaded in-tree .so of the test processes.
 
-    python -m hdrnet_amd.build [--force] [--verbose]
+    python -m hdrnet_amd.build [--force] [--verbose] [--tools]
 """
 from __future__ import annotations
 
@@ -18,6 +18,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libhdrnet_amd.so")
+# Tools build (include/hdrnet_amd_tools.h): the same sources with -DHDRNET_TOOLS_BUILD plus the
+# benchmark-only kernel variants / memory skeletons.  Never loaded by the product path.
+TOOLS_LIB_PATH = os.path.join(LIB_DIR, "libhdrnet_amd_tools.so")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 ARCH = "gfx950"
@@ -31,13 +34,16 @@ SOURCES = [
     # of that pairs unrelated scalars ACROSS pixels and pays for it in v_mov shuffles
     # (measured: 947 -> 646 ISA lines, 82 -> 55 VGPRs with it off).
     ("apply_fwd_rows.hip", ["-fno-slp-vectorize"]),
-    ("apply_fwd_variants.hip", ["-fno-slp-vectorize"]),
+    ("apply_fwd_seg.hip", ["-fno-slp-vectorize"]),
     ("apply_fwd_io.hip", ["-fno-slp-vectorize"]),
     ("apply_bwd_rows.hip", ["-fno-slp-vectorize"]),
     ("slice_fwd_rows.hip", ["-fno-slp-vectorize"]),
     ("grid_grad_mfma.hip", ["-fno-slp-vectorize"]),
     ("guide_grad.hip", ["-fno-slp-vectorize"]),
     ("resize_bilinear.hip", []),
+]
+TOOLS_ONLY_SOURCES = [
+    ("apply_fwd_variants.hip", ["-fno-slp-vectorize"]),
 ]
 
 
@@ -56,10 +62,11 @@ def _deps() -> List[str]:
     return out
 
 
-def is_stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+def is_stale(tools: bool = False) -> bool:
+    path = TOOLS_LIB_PATH if tools else LIB_PATH
+    if not os.path.exists(path):
         return True
-    t = os.path.getmtime(LIB_PATH)
+    t = os.path.getmtime(path)
     return any(os.path.getmtime(d) > t for d in _deps())
 
 
@@ -73,35 +80,58 @@ def _run(cmd: List[str], verbose: bool) -> None:
         print(res.stdout + res.stderr, flush=True)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 and link libhdrnet_amd.so.  Returns its path."""
-    if not force and not is_stale():
-        return LIB_PATH
+def build(force: bool = False, verbose: bool = False, tools: bool = False) -> str:
+    """Compile every HIP source for gfx950 and link libhdrnet_amd.so (tools=True:
+    libhdrnet_amd_tools.so).  Returns its path.
+
+    Safe against concurrent callers (every rank of `bench.py --gpus N` loads the library): the
+    build runs under an exclusive file lock, staleness is re-checked once the lock is held, and
+    objects / the link output go to per-process temporary names before an atomic rename."""
+    lib_path = TOOLS_LIB_PATH if tools else LIB_PATH
+    if not force and not is_stale(tools):
+        return lib_path
     cc = hipcc()
     os.makedirs(LIB_DIR, exist_ok=True)
-    objdir = os.path.join(LIB_DIR, "obj")
-    os.makedirs(objdir, exist_ok=True)
-    objs = []
-    procs = []
-    for src, extra in SOURCES:
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [cc, *COMMON, *extra, "-I", CSRC, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-        objs.append(obj)
-    for cmd, p in procs:
-        out, _ = p.communicate()
-        if p.returncode != 0:
-            raise RuntimeError("command failed: %s\n%s" % (" ".join(cmd), out))
-        if verbose and out:
-            print(out, flush=True)
-    tmp = LIB_PATH + ".tmp"
-    _run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", tmp, *objs], verbose)
-    os.replace(tmp, LIB_PATH)
-    return LIB_PATH
+    import fcntl
+
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale(tools):  # another process built it while we waited
+                return lib_path
+            objdir = os.path.join(LIB_DIR, "obj_tools" if tools else "obj")
+            os.makedirs(objdir, exist_ok=True)
+            tag = ".%d" % os.getpid()
+            define = ["-DHDRNET_TOOLS_BUILD"] if tools else []
+            objs = []
+            procs = []
+            for src, extra in SOURCES + (TOOLS_ONLY_SOURCES if tools else []):
+                obj = os.path.join(objdir, src.replace(".hip", ".o") + tag)
+                cmd = [cc, *COMMON, *define, *extra, "-I", CSRC, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+                objs.append(obj)
+            try:
+                for cmd, p in procs:
+                    out, _ = p.communicate()
+                    if p.returncode != 0:
+                        raise RuntimeError("command failed: %s\n%s" % (" ".join(cmd), out))
+                    if verbose and out:
+                        print(out, flush=True)
+                tmp = lib_path + tag + ".tmp"
+                _run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", tmp, *objs], verbose)
+                os.replace(tmp, lib_path)
+            finally:
+                for o in objs:
+                    if os.path.exists(o):
+                        os.remove(o)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return lib_path
 
 
 if __name__ == "__main__":
-    path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)
-    print(path)
+    for _tools in ([False, True] if "--tools" in sys.argv else [False]):
+        print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv,
+                    tools=_tools))

@@ -418,10 +418,12 @@ bool apply_fwd_rows_supported(const ApplyArgs& a) {
 }
 
 hipError_t launch_apply_fwd_rows(const ApplyArgs& a, hipStream_t s, const char** name) {
-  if (a.variant != 0) {  // benchmark-only kernels, never selected by flags == 0
+#ifdef HDRNET_TOOLS_BUILD
+  if (a.variant != 0) {  // benchmark-only kernels (tools build), never selected by flags == 0
     const hipError_t e = launch_apply_fwd_variant(a, s, name);
     if (e != hipErrorNotSupported) return e;
   }
+#endif
 #define HDRNET_CASE(CI, CO, OFF) \
   if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF) return launch_t<CI, CO, OFF>(a, s, name)
   HDRNET_CASE(3, 3, true);
@@ -435,6 +437,7 @@ hipError_t launch_apply_fwd_rows(const ApplyArgs& a, hipStream_t s, const char**
   return hipErrorInvalidValue;
 }
 
+#ifdef HDRNET_TOOLS_BUILD
 // The direct-store / plain-load instantiations, for tools/ab_bench.py only (apply_fwd_variants.hip
 // routes here): which = 0 per-lane stores, 1 = nontemporal lane-contiguous input loads.
 hipError_t launch_apply_fwd_rows_direct_stores(const ApplyArgs& a, hipStream_t s, const char** name, int which) {
@@ -452,5 +455,7 @@ hipError_t launch_apply_fwd_rows_direct_stores(const ApplyArgs& a, hipStream_t s
   *name = which == 0 ? "apply_fwd_rows/vec4-direct-stores" : "apply_fwd_rows/vec4-nt-loads";
   return hipGetLastError();
 }
+
+#endif  // HDRNET_TOOLS_BUILD
 
 }  // namespace hdrnet_amd

@@ -4,8 +4,10 @@
 // caller's stream.  See include/hdrnet_amd.h for the contract.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 
 #include "../../include/hdrnet_amd.h"
@@ -16,12 +18,26 @@ namespace {
 thread_local char g_error[512] = "";
 
 // Introspection only (tests / benchmarks): name of the kernel(s) the most recent successful
-// call launched, process-wide -- autograd runs backward on a thread of its own, so a
-// thread-local would hide it from the caller.  Not used for any decision.
+// call launched.  OFF by default -- a launch then does no bookkeeping at all (no lock, no
+// formatting); hdrnet_enable_kernel_names(1), or HDRNET_AMD_KERNEL_NAMES=1 in the environment at
+// load time, switches it on.  Process-wide rather than thread-local because autograd runs
+// backward on a thread of its own.  Not used for any decision.
+std::atomic<int> g_kernel_names{-1};  // -1: consult the environment on first use
 std::mutex g_kernel_mu;
 char g_kernel_buf[128] = "";
 
+bool kernel_names_on() {
+  int v = g_kernel_names.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("HDRNET_AMD_KERNEL_NAMES");
+    v = (e && *e && *e != '0') ? 1 : 0;
+    g_kernel_names.store(v, std::memory_order_relaxed);
+  }
+  return v != 0;
+}
+
 void set_kernel(const char* a, const char* b = "", const char* c = "") {
+  if (!kernel_names_on()) return;
   std::lock_guard<std::mutex> lock(g_kernel_mu);
   snprintf(g_kernel_buf, sizeof(g_kernel_buf), "%s%s%s%s%s", a, (*a && *b) ? "+" : "", b,
            ((*a || *b) && *c) ? "+" : "", c);
@@ -65,6 +81,12 @@ int check_common(int B, int H, int W, int GH, int GW, int GD) {
 int check_flags(unsigned flags) {
   if ((flags & 0xffu) > HDRNET_KERNEL_FAST || (flags >> 16) != 0)
     return fail(HDRNET_INVALID_ARGUMENT, "unknown flags 0x%x", flags);
+#ifndef HDRNET_TOOLS_BUILD
+  if ((flags >> 8) != 0)
+    return fail(HDRNET_INVALID_ARGUMENT,
+                "kernel variants (flags bits 8..15) exist only in the tools build "
+                "(libhdrnet_amd_tools.so), flags 0x%x", flags);
+#endif
   return HDRNET_OK;
 }
 unsigned family(unsigned flags) { return flags & 0xffu; }
@@ -79,6 +101,15 @@ int hdrnet_version(void) { return 200; /* 0.2.0: + guide-network VJP, input mome
 const char* hdrnet_last_error(void) { return g_error; }
 
 const char* hdrnet_last_kernel(void) { return g_kernel_buf; }
+
+void hdrnet_enable_kernel_names(int on) { g_kernel_names.store(on ? 1 : 0, std::memory_order_relaxed); }
+
+#ifdef HDRNET_TOOLS_BUILD
+// tools build only (include/hdrnet_amd_tools.h)
+void hdrnet_tools_set_trace(void* device_buf) {
+  hdrnet_amd::apply_fwd_seg_set_trace(static_cast<long long*>(device_buf));
+}
+#endif
 
 int hdrnet_bilateral_slice_apply_f32_ex(const float* grid, const float* guide,
                                         const float* input, float* out, int B, int H, int W,

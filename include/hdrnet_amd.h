@@ -66,8 +66,10 @@ extern "C" {
 #define HDRNET_KERNEL_FAST 2u    /* LDS-staged specialisations; INVALID_ARGUMENT \
                                     if the shape has none */
 
-/* Bits 8..15 of `flags` select a variant inside the family (0 = library default);
- * benchmarks use it for in-process A/B runs.  Variants are not part of the stable ABI. */
+/* Bits 8..15 of `flags` select a benchmark variant inside the family (0 = library default).
+ * Variants exist only in the TOOLS build of the library (libhdrnet_amd_tools.so,
+ * include/hdrnet_amd_tools.h); the product library answers HDRNET_INVALID_ARGUMENT to any
+ * non-zero variant. */
 #define HDRNET_VARIANT(n) (((unsigned)(n) & 0xffu) << 8)
 
 /* ABI version: major*10000 + minor*100 + patch. */
@@ -80,6 +82,11 @@ const char* hdrnet_last_error(void);
  * (e.g. "apply_fwd_rows/vec4", "apply_vjp_rows/vec4+grid_grad_mfma"); introspection for
  * tests and benchmarks only (process-wide: autograd calls the VJPs from its own thread). */
 const char* hdrnet_last_kernel(void);
+
+/* hdrnet_last_kernel() bookkeeping is OFF by default, so that a launch takes no lock and formats
+ * no string; tests and benchmarks switch it on (non-zero) / off here, or with
+ * HDRNET_AMD_KERNEL_NAMES=1 in the environment when the library is loaded. */
+void hdrnet_enable_kernel_names(int on);
 
 /* BilateralSliceApply forward.
  * out[b,y,x,i] = sum_j trilerp(grid[.., i, j]; x, y, guide[b,y,x]) * (j < Cin ? input[b,y,x,j] : 1)

@@ -1,0 +1,38 @@
+/* Tools build of the C-ABI library: libhdrnet_amd_tools.so.
+ *
+ * Same sources and the same entry points as libhdrnet_amd.so (include/hdrnet_amd.h), compiled with
+ * -DHDRNET_TOOLS_BUILD, plus what only benchmarks and experiments need:
+ *
+ *   - kernel VARIANTS of BilateralSliceApply forward, selected with HDRNET_VARIANT(n) in the
+ *     `flags` of hdrnet_bilateral_slice_apply_f32_ex (tools/ab_bench.py times them interleaved
+ *     with the product kernel).  Variants 101-106 are memory skeletons that do NOT compute the op
+ *     (their kernel name starts with "ABLATION"); they are the reason this is a separate library.
+ *       2        one wavefront per tile            3..6   persistent software-pipelined stream
+ *       7        per-lane strided stores           8      round-1 kernel + nontemporal loads
+ *       9..11    2 / 3 / 4 quads per thread        19     the round-1 product kernel (apply_fwd_rows)
+ *       20..31   apply_fwd_seg knobs: (v - 20) bits 0..1 pixel loads {per-lane, nontemporal
+ *                lane-contiguous, LDS-DMA, LDS-DMA nontemporal}, bits 2..3 log2(rows per workgroup)
+ *       36..47   the same with a per-workgroup timeline trace (hdrnet_tools_set_trace)
+ *       101, 103..106  memory skeletons
+ *   - hdrnet_tools_set_trace: device buffer that the trace variants fill with
+ *     [workgroup][2] = {start, end} in wall_clock64() ticks (100 MHz).
+ *
+ * Nothing in the product path links or loads this library.
+ */
+#ifndef HDRNET_AMD_TOOLS_H_
+#define HDRNET_AMD_TOOLS_H_
+
+#include "hdrnet_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* device_buf: at least 2 * (number of workgroups of the traced launch) int64; NULL disables. */
+void hdrnet_tools_set_trace(void* device_buf);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* HDRNET_AMD_TOOLS_H_ */

@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The tests assert on hdrnet_last_kernel(); its bookkeeping is off by default (include/hdrnet_amd.h).
+os.environ.setdefault("HDRNET_AMD_KERNEL_NAMES", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -167,23 +167,52 @@ def test_apply_forward_random(dev, ops, port, shape):
     assert worst < 4.0, (kern, worst)
 
 
-# The benchmark-only forward kernels DESIGN.md quotes timings for (apply_fwd_variants.hip) must
-# compute the same op as the shipped one, or those timings compare nothing.
+# The benchmark-only forward kernels DESIGN.md quotes timings for (tools build of the library:
+# apply_fwd_variants.hip, the apply_fwd_seg knobs) must compute the same op as the shipped one, or
+# those timings compare nothing.  They are reached through the TOOLS library's C-ABI only.
 @pytest.mark.parametrize("variant,expect", [(2, "apply_fwd_wave"), (3, "apply_fwd_stream"),
                                             (5, "apply_fwd_stream"), (7, "direct-stores"),
-                                            (8, "nt-loads"), (9, "multiquad2"), (11, "multiquad4")])
+                                            (8, "nt-loads"), (9, "multiquad2"), (11, "multiquad4"),
+                                            (19, "apply_fwd_rows/vec4"),
+                                            (20, "seg/R1-lane"), (21, "seg/R1-ntcontig"),
+                                            (22, "seg/R1-dma"), (23, "seg/R1-dma-nt"),
+                                            (24, "seg/R2-lane"), (25, "seg/R2-ntcontig"),
+                                            (28, "seg/R4-lane"), (29, "seg/R4-ntcontig")])
 @pytest.mark.parametrize("shape", [(2, 48, 2048, 16, 16, 8, 3, 3, True, -0.2, 1.2),
-                                   (1, 37, 3076, 16, 16, 8, 3, 3, True, 0.0, 1.0)])
-def test_apply_forward_benchmark_variants(dev, ops, port, shape, variant, expect):
+                                   (1, 37, 3076, 16, 16, 8, 3, 3, True, 0.0, 1.0),
+                                   (1, 21, 1920, 16, 16, 8, 3, 3, True, -0.1, 1.1)])
+def test_apply_forward_benchmark_variants(dev, port, shape, variant, expect):
+    import torch
+    from hdrnet_amd import _lib
+    tools = _lib.load_tools()
+    tools.hdrnet_enable_kernel_names(1)
     B, H, W, GH, GW, GD, Cin, Cout, ho, lo, hi = shape
     rng = np.random.default_rng(variant * 1000 + W)
     grid, guide, inp, _ = rand_case(rng, B, H, W, GH, GW, GD, Cin, Cout, ho, lo, hi)
     want = port.bilateral_slice_apply(grid, guide, inp, ho)
-    with ops.kernel_override("fast", variant=variant):
-        got = N(ops.bilateral_slice_apply(T(grid, dev), T(guide, dev), T(inp, dev), has_offset=ho))
-        kern = ops.last_kernel()
+    tg, tgu, ti = T(grid, dev), T(guide, dev), T(inp, dev)
+    out = torch.full((B, H, W, Cout), float("nan"), device=dev)
+    rc = tools.hdrnet_bilateral_slice_apply_f32_ex(
+        tg.data_ptr(), tgu.data_ptr(), ti.data_ptr(), out.data_ptr(), B, H, W, GH, GW, GD, Cin, Cout,
+        int(ho), _lib.KERNEL_FAST | (variant << 8), torch.cuda.current_stream(dev).cuda_stream)
+    assert rc == 0, tools.hdrnet_last_error().decode()
+    torch.cuda.synchronize()
+    kern = tools.hdrnet_last_kernel().decode()
     assert expect in kern, kern
-    np.testing.assert_allclose(got, want, rtol=FWD_RTOL, atol=FWD_ATOL, err_msg=kern)
+    np.testing.assert_allclose(N(out), want, rtol=FWD_RTOL, atol=FWD_ATOL, err_msg=kern)
+
+
+def test_product_library_has_no_benchmark_variants(dev):
+    """The product library refuses variant numbers (skeletons that write garbage live only in the
+    tools build)."""
+    import torch
+    from hdrnet_amd import _lib
+    lib = _lib.load()
+    t = torch.zeros(64, device=dev)
+    rc = lib.hdrnet_bilateral_slice_apply_f32_ex(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(),
+                                                 1, 1, 4, 1, 1, 1, 3, 3, 1, _lib.KERNEL_FAST | (101 << 8), None)
+    assert rc == _lib.HDRNET_INVALID_ARGUMENT
+    assert "tools build" in lib.hdrnet_last_error().decode()
 
 
 @pytest.mark.parametrize("shape", APPLY_SHAPES[:10])

@@ -34,7 +34,9 @@ def main():
                 k = row["Kernel_Name"]
                 if match and match not in k:
                     continue
-                short = k.split("(")[0][-60:]
+                short = k.replace("(anonymous namespace)::", "").replace("hdrnet_amd::", "")
+                short = short[:short.rfind("(")] if "(" in short else short
+                short = short.replace("void ", "")[-80:]
                 acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
                 acc[short]["_vgpr"] = [float(row.get("VGPR_Count", 0) or 0)]
                 acc[short]["_lds"] = [float(row.get("LDS_Block_Size", 0) or 0)]
