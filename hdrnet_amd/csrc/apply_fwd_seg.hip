@@ -366,7 +366,9 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
 #pragma unroll
           for (int i = 0; i < COUT; ++i) of[k * COUT + i] = o[i];
         }
-        // a lane reads and writes only ITS slab entries here: in place, no cross-lane hazard
+        // CIN == COUT: a lane reads and writes only ITS slab entries here -- in place, no cross-lane
+        // hazard; otherwise the input reads of all lanes must precede the output writes.
+        if constexpr (LOADS != kLoadsLane && CIN != COUT) __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int q = 0; q < COUT; ++q) slab[lane * COUT + q] = ov[q];
       }
