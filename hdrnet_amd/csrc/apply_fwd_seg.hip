@@ -26,6 +26,8 @@
 // coordinates and weights; only the index clamps moved into the image.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+
 #include "launch.hip.h"
 #include "numerics.hip.h"
 #include "rows_common.hip.h"
@@ -40,6 +42,13 @@ constexpr int kLoadsNtContig = 1;  // nontemporal, lane-contiguous, transposed t
 constexpr int kLoadsDma = 2;       // LDS-DMA (global_load_lds_dwordx4), default cache policy
 constexpr int kLoadsDmaNt = 3;     // LDS-DMA, nontemporal
 
+// Output stores (all lane-contiguous 16 B after the per-wave LDS transpose):
+constexpr int kStoresGlobal = 0;  // global_store_dwordx4, predicated on the run length
+constexpr int kStoresBuf = 1;     // buffer_store_dwordx4 on a per-row-segment descriptor (out-of-range lanes dropped by the bounds check)
+constexpr int kStoresBufNt = 2;   // ... nt
+constexpr int kStoresBufSc1 = 3;  // ... sc1 (write-through: the line does not stay dirty in the XCD's L2)
+constexpr int kStoresBufSc01 = 4; // ... sc0 sc1
+
 constexpr int kStageMax = 2;  // staging elements (16 B or 4 B) a thread may hold in registers
 
 struct SegParams {
@@ -53,8 +62,22 @@ struct SegParams {
   int slab_off;    // float offset of the per-wave slabs in dynamic LDS
   float scale_x, scale_y;
   float inv_col;   // 1 / (GD * C / VEC): column of a staging element by float multiply
-  long long* trace;  // TRACE: [nblocks][2] wall-clock ticks (start, end); else unused
+  long long* trace;  // TRACE: [nblocks][3] wall-clock ticks (start, end), XCC id; else unused
 };
+
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+// Raw buffer descriptor over `bytes` bytes at `base` (gfx9 family: dword 3 = 0x00020000).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+template <int STORES>
+__device__ __forceinline__ void buf_store16(float4 v, __amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  constexpr int aux = STORES == kStoresBufNt ? 2 : STORES == kStoresBufSc1 ? 16 : STORES == kStoresBufSc01 ? 17 : 0;
+  const v4i32 d = {__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)byte_off, 0, aux);
+}
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -212,7 +235,7 @@ struct PixLoads {
   float4 iv[CIN];
 };
 
-template <int CIN, int COUT, bool OFFSET, int R, int LOADS, bool TRACE>
+template <int CIN, int COUT, bool OFFSET, int R, int LOADS, int STORES, bool TRACE>
 __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
   constexpr int CJ = CIN + (OFFSET ? 1 : 0);
   constexpr int C = COUT * CJ;
@@ -377,17 +400,25 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       {
         float* oseg = p.out + (row * p.W + xs) * COUT;  // uniform
-        if (wave_px >= 64 * kPxPerThread) {             // full wave (uniform): unpredicated stores
+        if constexpr (STORES == kStoresGlobal) {
+          if (wave_px >= 64 * kPxPerThread) {  // full wave (uniform): unpredicated stores
+#pragma unroll
+            for (int k = 0; k < COUT; ++k)
+              *reinterpret_cast<float4*>(oseg + (wpx * COUT + 4u * (unsigned)(lane + 64 * k))) = slab[lane + 64 * k];
+          } else {
+            const int nvalid = wave_px * COUT / 4;  // float4s
+#pragma unroll
+            for (int k = 0; k < COUT; ++k) {
+              const int e = lane + 64 * k;
+              if (e < nvalid) *reinterpret_cast<float4*>(oseg + (wpx * COUT + 4u * (unsigned)e)) = slab[e];
+            }
+          }
+        } else {
+          // descriptor over exactly this row segment: lanes past the run are dropped by the bounds check
+          const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(oseg, (unsigned)(xe - xs) * COUT * 4u);
 #pragma unroll
           for (int k = 0; k < COUT; ++k)
-            *reinterpret_cast<float4*>(oseg + (wpx * COUT + 4u * (unsigned)(lane + 64 * k))) = slab[lane + 64 * k];
-        } else {
-          const int nvalid = wave_px * COUT / 4;  // float4s
-#pragma unroll
-          for (int k = 0; k < COUT; ++k) {
-            const int e = lane + 64 * k;
-            if (e < nvalid) *reinterpret_cast<float4*>(oseg + (wpx * COUT + 4u * (unsigned)e)) = slab[e];
-          }
+            buf_store16<STORES>(slab[lane + 64 * k], orsrc, (wpx * COUT + 4u * (unsigned)(lane + 64 * k)) * 4u);
         }
       }
 
@@ -404,8 +435,9 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
   if constexpr (TRACE) {
     if (tid == 0) {
       const size_t bid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-      p.trace[2 * bid] = t_start;
-      p.trace[2 * bid + 1] = wall_clock64();
+      p.trace[3 * bid] = t_start;
+      p.trace[3 * bid + 1] = wall_clock64();
+      p.trace[3 * bid + 2] = __builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0xf;  // HW_REG_XCC_ID
     }
   }
 }
@@ -438,7 +470,7 @@ SegGeom seg_geom(const ApplyArgs& a, int R, int loads) {
   return g;
 }
 
-template <int CIN, int COUT, bool OFFSET, int R, int LOADS, bool TRACE>
+template <int CIN, int COUT, bool OFFSET, int R, int LOADS, int STORES, bool TRACE>
 hipError_t launch_seg_t(const ApplyArgs& a, hipStream_t s, long long* trace) {
   constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
   constexpr int VEC = (C % 4 == 0) ? 4 : 1;
@@ -462,40 +494,57 @@ hipError_t launch_seg_t(const ApplyArgs& a, hipStream_t s, long long* trace) {
   p.inv_col = 1.0f / (float)(a.GD * (C / VEC));
   p.trace = trace;
   const dim3 grid3((unsigned)g.pl.nseg, (unsigned)((a.H + R - 1) / R), (unsigned)a.B);
-  apply_fwd_seg<CIN, COUT, OFFSET, R, LOADS, TRACE><<<grid3, g.pl.threads, g.lds, s>>>(p);
+  apply_fwd_seg<CIN, COUT, OFFSET, R, LOADS, STORES, TRACE><<<grid3, g.pl.threads, g.lds, s>>>(p);
   return hipGetLastError();
 }
 
-long long* g_trace = nullptr;  // tools only: device buffer of [nblocks][2] ticks
+long long* g_trace = nullptr;  // tools only: device buffer of [nblocks][3]
 
 }  // namespace
 
 void apply_fwd_seg_set_trace(long long* device_buf) { g_trace = device_buf; }
 
-// knob = variant - 20: bits 0..1 LOADS, bits 2..3 log2 R (R = 1, 2, 4); +16: timeline trace.
+// Tools build: knob = variant - 20.
+//   0..19  R = 1: loads = knob % 4 {lane, nt-contig, dma, dma-nt}, stores = knob / 4 {global, buf, buf-nt, buf-sc1, buf-sc0sc1}
+//   20..39 the same with the timeline trace
+//   40..43 R = 2 {lane, nt-contig}, R = 4 {lane, nt-contig}; 44..47 traced
 hipError_t launch_apply_fwd_seg(const ApplyArgs& a, int knob, hipStream_t s, const char** name) {
   if (!(a.Cin == 3 && a.Cout == 3 && a.has_offset)) return hipErrorNotSupported;
-  static const char* const names[] = {
-      "apply_fwd_seg/R1-lane", "apply_fwd_seg/R1-ntcontig", "apply_fwd_seg/R1-dma", "apply_fwd_seg/R1-dma-nt",
-      "apply_fwd_seg/R2-lane", "apply_fwd_seg/R2-ntcontig", "", "",
-      "apply_fwd_seg/R4-lane", "apply_fwd_seg/R4-ntcontig", "", ""};
-  const bool trace = (knob & 16) != 0;
-  const int k = knob & 15;
-  if (k >= 12 || !*names[k]) return hipErrorNotSupported;
+  static char namebuf[64];
+  static const char* const lname[] = {"lane", "ntcontig", "dma", "dma-nt"};
+  static const char* const sname[] = {"", "+bufst", "+bufst-nt", "+bufst-sc1", "+bufst-sc0sc1"};
+  if (knob < 0 || knob >= 48) return hipErrorNotSupported;
+  if (knob < 40) {
+    const bool trace = knob >= 20;
+    const int k = knob % 20, L = k % 4, S = k / 4;
+    if (trace && !g_trace) return hipErrorInvalidValue;
+    snprintf(namebuf, sizeof namebuf, "apply_fwd_seg/R1-%s%s", lname[L], sname[S]);
+    *name = namebuf;
+#define SEG_CASE(LL, SS)                                                              \
+  if (L == LL && S == SS)                                                             \
+    return trace ? launch_seg_t<3, 3, true, 1, LL, SS, true>(a, s, g_trace)           \
+                 : launch_seg_t<3, 3, true, 1, LL, SS, false>(a, s, nullptr)
+    SEG_CASE(0, 0); SEG_CASE(1, 0); SEG_CASE(2, 0); SEG_CASE(3, 0);
+    SEG_CASE(0, 1); SEG_CASE(1, 1); SEG_CASE(2, 1); SEG_CASE(3, 1);
+    SEG_CASE(0, 2); SEG_CASE(1, 2); SEG_CASE(2, 2); SEG_CASE(3, 2);
+    SEG_CASE(0, 3); SEG_CASE(1, 3); SEG_CASE(2, 3); SEG_CASE(3, 3);
+    SEG_CASE(0, 4); SEG_CASE(1, 4); SEG_CASE(2, 4); SEG_CASE(3, 4);
+#undef SEG_CASE
+    return hipErrorNotSupported;
+  }
+  const bool trace = knob >= 44;
+  const int k = (knob - 40) % 4;
   if (trace && !g_trace) return hipErrorInvalidValue;
-  *name = names[k];
-#define SEG_CASE(K, RR, LL)                                                            \
-  if (k == K)                                                                          \
-    return trace ? launch_seg_t<3, 3, true, RR, LL, true>(a, s, g_trace)               \
-                 : launch_seg_t<3, 3, true, RR, LL, false>(a, s, nullptr)
-  SEG_CASE(0, 1, 0);
-  SEG_CASE(1, 1, 1);
-  SEG_CASE(2, 1, 2);
-  SEG_CASE(3, 1, 3);
-  SEG_CASE(4, 2, 0);
-  SEG_CASE(5, 2, 1);
-  SEG_CASE(8, 4, 0);
-  SEG_CASE(9, 4, 1);
+  snprintf(namebuf, sizeof namebuf, "apply_fwd_seg/R%d-%s", k < 2 ? 2 : 4, lname[k & 1]);
+  *name = namebuf;
+#define SEG_CASE(K, RR, LL)                                                           \
+  if (k == K)                                                                         \
+    return trace ? launch_seg_t<3, 3, true, RR, LL, 0, true>(a, s, g_trace)           \
+                 : launch_seg_t<3, 3, true, RR, LL, 0, false>(a, s, nullptr)
+  SEG_CASE(0, 2, 0);
+  SEG_CASE(1, 2, 1);
+  SEG_CASE(2, 4, 0);
+  SEG_CASE(3, 4, 1);
 #undef SEG_CASE
   return hipErrorNotSupported;
 }

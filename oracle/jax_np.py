@@ -57,10 +57,18 @@ def smoothed_lerp_weight_grad(x, xs, eps=_EPS):
 
 
 # ---- shared coordinate / weight set-up (bilateral_slice.py:316-355 == :41-81) ----
-def _corners(grid_shape, guide):
+def _corners(grid_shape, guide, rows=None):
+    """rows = (r0, r1, H): `guide` holds only image rows r0..r1-1 of an H-row image (the
+    CPU-baseline leg of bench.py evaluates a bounded row window of a full-size frame; the
+    reference evaluates whole images, rows=None)."""
     gh, gw, gd = grid_shape[:3]
     h, w = guide.shape
-    ii, jj = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    r0 = 0
+    if rows is not None:
+        r0, r1, h_full = rows
+        assert r1 - r0 == h
+        h = h_full
+    ii, jj = np.meshgrid(np.arange(r0, r0 + guide.shape[0]), np.arange(w), indexing="ij")
     scale_i = F(gh / h)  # python-float scale applied in f32, as jnp weak typing does
     scale_j = F(gw / w)
     gif = (ii.astype(F) + F(0.5)) * scale_i
@@ -92,11 +100,12 @@ def _weighted_sum(vals, wi, wj, wk):
     return acc
 
 
-def bilateral_slice(grid, guide):
-    """grid (gh,gw,gd,gc), guide (h,w) -> (h,w,gc).  jax/bilateral_slice.py:299-380."""
+def bilateral_slice(grid, guide, rows=None):
+    """grid (gh,gw,gd,gc), guide (h,w) -> (h,w,gc).  jax/bilateral_slice.py:299-380.
+    rows: see _corners (row window of a taller image; not part of the reference API)."""
     grid = np.asarray(grid, F)
     guide = np.asarray(guide, F)
-    gif, gjf, gkf, gi0, gj0, gk0 = _corners(grid.shape, guide)
+    gif, gjf, gkf, gi0, gj0, gk0 = _corners(grid.shape, guide, rows)
     wi = (lerp_weight(gi0.astype(F) + F(0.5), gif), lerp_weight(gi0.astype(F) + F(1.5), gif))
     wj = (lerp_weight(gj0.astype(F) + F(0.5), gjf), lerp_weight(gj0.astype(F) + F(1.5), gjf))
     wk = (smoothed_lerp_weight(gk0.astype(F) + F(0.5), gkf),

@@ -176,8 +176,11 @@ def test_apply_forward_random(dev, ops, port, shape):
                                             (19, "apply_fwd_rows/vec4"),
                                             (20, "seg/R1-lane"), (21, "seg/R1-ntcontig"),
                                             (22, "seg/R1-dma"), (23, "seg/R1-dma-nt"),
-                                            (24, "seg/R2-lane"), (25, "seg/R2-ntcontig"),
-                                            (28, "seg/R4-lane"), (29, "seg/R4-ntcontig")])
+                                            (25, "seg/R1-ntcontig+bufst"), (29, "seg/R1-ntcontig+bufst-nt"),
+                                            (33, "seg/R1-ntcontig+bufst-sc1"), (35, "seg/R1-dma-nt+bufst-sc1"),
+                                            (37, "seg/R1-ntcontig+bufst-sc0sc1"),
+                                            (60, "seg/R2-lane"), (61, "seg/R2-ntcontig"),
+                                            (62, "seg/R4-lane"), (63, "seg/R4-ntcontig")])
 @pytest.mark.parametrize("shape", [(2, 48, 2048, 16, 16, 8, 3, 3, True, -0.2, 1.2),
                                    (1, 37, 3076, 16, 16, 8, 3, 3, True, 0.0, 1.0),
                                    (1, 21, 1920, 16, 16, 8, 3, 3, True, -0.1, 1.1)])
@@ -198,7 +201,8 @@ def test_apply_forward_benchmark_variants(dev, port, shape, variant, expect):
     assert rc == 0, tools.hdrnet_last_error().decode()
     torch.cuda.synchronize()
     kern = tools.hdrnet_last_kernel().decode()
-    assert expect in kern, kern
+    # a variant without a specialisation for the shape falls back to the product kernel
+    assert expect in kern or (variant in (3, 5) and kern == "apply_fwd_rows/vec4"), kern
     np.testing.assert_allclose(N(out), want, rtol=FWD_RTOL, atol=FWD_ATOL, err_msg=kern)
 
 

@@ -11,9 +11,10 @@ Infinity Cache), variants interleaved, and the table reports median / min of the
 Each variant is first checked against the generic (bit-exact-to-reference) kernel; a variant that
 fails the check or the launch is reported and dropped, the others still run.
 
---trace: for the listed TRACE variants (36..47), one launch per frame writes every workgroup's
-{start, end} wall-clock ticks (100 MHz); the summary printed is the launch's timeline: dispatch
-ramp, workgroup lifetimes, resident-workgroup and retirement profiles in 1-us buckets, tail.
+--trace: for the listed apply_fwd_seg variants, one launch of the variant's traced twin writes every
+workgroup's {start, end} wall-clock ticks (100 MHz) and XCC id; the summary printed is the
+launch's timeline: dispatch ramp, workgroup lifetimes, resident-workgroup and retirement profiles
+in 1-us buckets, tail.
 """
 import argparse
 import json
@@ -42,12 +43,25 @@ def time_launches(fn, steps):
     return e0.elapsed_time(e1) * 1e3 / steps  # us per launch
 
 
-def trace_summary(tr, name, px_per_wg):
-    """tr: [nwg, 2] int64 ticks of 10 ns."""
+def trace_summary(tr, name):
+    """tr: [nwg, 3] int64: start, end (ticks of 10 ns), XCC id.  The 100 MHz counters of the XCDs
+    are not guaranteed to be aligned; the per-XCC lines show each XCD's own first start / last
+    end relative to the global first start, and the summary below them is computed AFTER shifting
+    every XCD's timeline to a common first start (assumes the XCDs begin within ~0.3 us of each
+    other, which is what the dispatcher does)."""
     import numpy as np
+    xcc = tr[:, 2]
     t0 = tr[:, 0].min()
-    st = (tr[:, 0] - t0) * 0.01  # us
-    en = (tr[:, 1] - t0) * 0.01
+    print(f"  trace [{name}]: {len(tr)} workgroups")
+    st = np.zeros(len(tr))
+    en = np.zeros(len(tr))
+    for x in sorted(set(xcc.tolist())):
+        m = xcc == x
+        s0 = tr[m, 0].min()
+        print(f"    xcc {x}: {int(m.sum())} wgs, first start {(s0 - t0) * 0.01:+.2f} us, span "
+              f"{(tr[m, 1].max() - s0) * 0.01:.2f} us")
+        st[m] = (tr[m, 0] - s0) * 0.01
+        en[m] = (tr[m, 1] - s0) * 0.01
     life = en - st
     total = en.max()
     nb = int(total) + 1
@@ -55,7 +69,7 @@ def trace_summary(tr, name, px_per_wg):
     retired = np.bincount(en.astype(int), minlength=nb)
     resident = np.cumsum(started) - np.cumsum(retired) + retired  # resident at some point in the bucket
     q = lambda a, p: float(np.percentile(a, p))
-    print(f"  trace [{name}]: {len(tr)} workgroups, span {total:.2f} us (first start -> last end)")
+    print(f"    span {total:.2f} us (first start -> last end, per-XCD clocks aligned)")
     print(f"    starts: 50% by {q(st, 50):.2f} us, 90% by {q(st, 90):.2f}, last {st.max():.2f}")
     print(f"    lifetime us: p10 {q(life, 10):.2f}  p50 {q(life, 50):.2f}  p90 {q(life, 90):.2f}  max {life.max():.2f}")
     print(f"    ends: first {en.min():.2f} us, 10% by {q(en, 10):.2f}, 90% by {q(en, 90):.2f}, 99% by {q(en, 99):.2f}, last {total:.2f}")
@@ -159,11 +173,12 @@ def main():
 
     traces = []
     for v in [int(x) for x in args.trace.split(",") if x != ""]:
+        vt = v + 20 if 20 <= v < 40 else v + 4  # traced twin of the plain variant (hdrnet_amd_tools.h)
         try:
-            buf = torch.zeros((1 << 16, 2), dtype=torch.int64, device=dev)
+            buf = torch.zeros((1 << 16, 3), dtype=torch.int64, device=dev)
             lib.hdrnet_tools_set_trace(buf.data_ptr())
-            fn = launcher(_lib.KERNEL_FAST | (v << 8))
-            plain = launcher(_lib.KERNEL_FAST | ((v - 16) << 8))
+            fn = launcher(_lib.KERNEL_FAST | (vt << 8))
+            plain = launcher(_lib.KERNEL_FAST | (v << 8))
             time_launches(plain, 50)  # warm clocks, queue is busy right up to the traced launch
             fn(1)
             plain(2)
@@ -171,7 +186,7 @@ def main():
             tr = buf.cpu().numpy()
             tr = tr[tr[:, 0] != 0]
             nm = lib.hdrnet_last_kernel().decode()
-            traces.append(dict(trace_summary(tr, f"variant {v} {nm}", 0), variant=v))
+            traces.append(dict(trace_summary(tr, f"variant {v} {nm}"), variant=v))
         except Exception as e:  # noqa: BLE001
             print(f"trace variant {v}: FAILED ({e})", flush=True)
         finally:
