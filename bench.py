@@ -3,6 +3,10 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 4k|1080p|hdrp]
 
+`--gpus N` with N > 1 from a bare shell re-launches itself as N ranks under
+torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1); launched by the driver under
+torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.
+
 Metric (BASELINE.json): megapixels/s of BilateralSliceApply forward @4K (3840x2160 fp32 NHWC,
 grid 16x16x8x12, batch 1), reported with the fraction of the MI355X HBM roofline; for N > 1
 each rank (one process per GPU, launched by torch.distributed.run) processes its OWN frames
@@ -16,11 +20,20 @@ working set exceeds the 256 MiB Infinity Cache + L2 (232 MB per 4K frame x 3 set
 number is an HBM number, not a cache number; the cache-resident rate is reported separately
 under "extra".
 
+Before the W counted warm-up steps an untimed, disclosed PRE-ROLL (>= 60 ms of launches,
+`preroll_launches` in the JSON) takes the device out of the idle power state, in which the same
+kernel runs ~8 % slower; and when the timed region is shorter than 10 ms (`--steps 20`), where
+the host-side synchronisation latency would be a visible fraction of the wall clock, `value` is
+computed from the HIP-event time of the region instead (`"clock": "events"`).
+
 Adds to the JSON line:
   roofline     -- algorithmic bytes / average kernel duration (HIP events on the launch
-                  stream around the timed region) vs the 8 TB/s HBM3E peak
-  cpu_baseline -- the reference's own CPU op (oracle/_ref, kind "reference") or the C port,
-                  timed on this host on a bounded sample (rank 0, N = 1 only)
+                  stream around the timed region) vs the 8 TB/s HBM3E peak; `traffic` = HBM bytes
+                  per launch from the committed rocprofv3 PMC passes, only if they were collected
+                  on the SAME kernel sources (digest of hdrnet_amd/csrc), else null
+  cpu_baseline -- the reference's own CPU op (oracle/_ref, kind "reference") on ONE core (value),
+                  plus legs: nproc whole-image processes of it, and the numpy restatement of
+                  jax/bilateral_slice.py; bounded samples, rank 0, N = 1 only
 """
 from __future__ import annotations
 
@@ -54,21 +67,40 @@ def algorithmic_bytes(B, H, W, GH, GW, GD, Cin=3, Cout=3, has_offset=True):
     return 4 * B * (H * W * (1 + Cin + Cout) + GH * GW * GD * Cout * Cj)
 
 
+def source_digest():
+    """sha256 over the kernel sources (hdrnet_amd/csrc/*, sorted): stamps a PMC record with the
+    code it was measured on (the GPU box has no .git)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "hdrnet_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(workload, kernel):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*/traffic.json:
-    FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, KiB -> B),
-    if a record for this workload and kernel exists; bench.py cannot run the profiler on
-    itself, so this is the per-launch figure of the same command under `rocprofv3 --pmc`."""
+    FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md section HBM, calibrated on this access
+    pattern in profiles/r02/README.md) + WRITE_SIZE, KiB -> B).  bench.py cannot run the profiler
+    on itself, so this is the per-launch figure of the same command under `rocprofv3 --pmc`
+    (tools/collect_profiles.sh) -- accepted ONLY if the record's source digest equals the digest
+    of the kernel sources being benched; otherwise (None, reason)."""
     import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json"))):
+    digest = source_digest()
+    stale = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")), reverse=True):
         try:
             for rec in json.load(open(f)):
                 if rec.get("workload") == workload and rec.get("kernel") == kernel:
-                    best = dict(rec, source=os.path.relpath(f, ROOT))
+                    if rec.get("source_digest") == digest:
+                        return dict(rec, source=os.path.relpath(f, ROOT)), None
+                    stale = os.path.relpath(f, ROOT)
         except (OSError, ValueError):
             pass
-    return best
+    return None, (f"PMC record in {stale} was measured on other kernel sources" if stale
+                  else "no PMC record for this workload / kernel")
 
 
 def make_sets(dev, nsets, H, W, GH, GW, GD, seed, smooth_guide=False):
@@ -123,35 +155,38 @@ def timed(lib, sets, dims, stream, steps, dist_on, dev):
     return t1 - t0, ev0.elapsed_time(ev1) * 1e-3
 
 
-def cpu_baseline(H, W, GH, GW, GD, budget_s=20.0):
-    """The reference's CPU op timed on this host's cores, bounded sample (whole frames)."""
-    import oracle
-    rng = np.random.default_rng(1234)
-    grid = rng.random((1, GH, GW, GD, 12), dtype=np.float32)
-    guide = rng.random((1, H, W), dtype=np.float32)
-    inp = rng.random((1, H, W, 3), dtype=np.float32)
-    if oracle.have_ref():
-        impl, kind, cores = oracle.ref(), "reference", 1
-    else:
-        impl, kind = oracle.port(), "port"
-        cores = impl.set_threads(os.cpu_count() or 1)
-    # one short probe to size the sample
-    hp = max(8, H // 16)
-    t = time.perf_counter()
-    impl.bilateral_slice_apply(grid, guide[:, :hp], inp[:, :hp], True)
-    per_px = (time.perf_counter() - t) / (hp * W)
-    frames = int(max(1, min(8, budget_s / max(per_px * H * W, 1e-9))))
-    t = time.perf_counter()
-    for _ in range(frames):
-        impl.bilateral_slice_apply(grid, guide, inp, True)
-    dt = time.perf_counter() - t
-    return {
-        "value": round(frames * H * W / 1e6 / dt, 4), "unit": "MP/s", "cores": cores, "kind": kind,
-        "sample": f"{frames} frame(s) of {W}x{H}, grid {GH}x{GW}x{GD}x12, "
-                  + ("oracle/_ref (reference bilateral_slice_apply.cc compiled unchanged, -O2, serial)"
-                     if kind == "reference" else f"oracle C port, OpenMP {cores} threads"),
-        "host_cpus": os.cpu_count(), "seconds": round(dt, 2),
-    }
+def cpu_baseline(H, W, GH, GW, GD):
+    """The reference's CPU op timed on this host's cores on bounded samples (oracle/cpu_bench.py):
+    value = one core; legs = nproc whole-image processes, numpy restatement of the JAX twin."""
+    from oracle import cpu_bench
+    return cpu_bench.run(H, W, GH, GW, GD)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` from a bare shell: become N ranks under torch.distributed.run."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def preroll(step_fn, sync_fn, min_seconds=0.06, chunk=64, max_launches=20000):
+    """Untimed launches until >= min_seconds have passed (device out of the idle power state)."""
+    n = 0
+    t0 = time.perf_counter()
+    while n < max_launches:
+        step_fn(chunk, n)
+        sync_fn()
+        n += chunk
+        if time.perf_counter() - t0 >= min_seconds:
+            break
+    return n, time.perf_counter() - t0
 
 
 def main():
@@ -165,16 +200,17 @@ def main():
                     help="also time the cache-resident rate and 1080p (same kernel name at other "
                          "sizes: keep off when collecting rocprofv3 --stats for the roofline line)")
     ap.add_argument("--no-extra", action="store_true", help=argparse.SUPPRESS)  # old spelling, no-op
+    ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)  # tests: gloo + a stub timed body
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run "
-                     "(one process per GPU); see the module docstring")
-        args.gpus = world
+    args.gpus = world  # n_gpus is what the process group says
+    if args.stub_cpu:
+        return stub_main(args, rank, world)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     dev = torch.device("cuda", local_rank)
@@ -194,33 +230,46 @@ def main():
     sets = make_sets(dev, nsets, H, W, GH, GW, GD, seed=1234 + rank)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
+    lib.hdrnet_enable_kernel_names(1)
+    run_steps(lib, sets, dims, stream, 1)
+    kernel = lib.hdrnet_last_kernel().decode()
+    lib.hdrnet_enable_kernel_names(0)  # no bookkeeping on the launch path from here on
+    n_pre, pre_s = preroll(lambda n, k0: run_steps(lib, sets, dims, stream, n, start=k0),
+                           lambda: torch.cuda.synchronize(dev))
     run_steps(lib, sets, dims, stream, args.warmup)
     wall, gpu_s = timed(lib, sets, dims, stream, args.steps, dist_on, dev)
-    kernel = lib.hdrnet_last_kernel().decode()
 
     wall_max, gpu_max = hd.max_over_ranks([wall, gpu_s], device=dev)
 
     mp_per_step = H * W / 1e6
-    value = world * args.steps * mp_per_step / wall_max
+    # Short regions (< 10 ms): the host's synchronise latency is a visible share of the wall
+    # clock, so the HIP-event time of the region is the clock for `value`; disclosed in "clock".
+    clock = "wall" if wall_max >= 0.010 else "events"
+    t_region = wall_max if clock == "wall" else gpu_max
+    value = world * args.steps * mp_per_step / t_region
     avg_kernel_s = gpu_max / args.steps  # events bracket K back-to-back launches of ONE kernel
     achieved = abytes / avg_kernel_s / 1e9
+    traffic, traffic_note = measured_traffic(args.workload, kernel)
 
     result = {
         "metric": "megapixels/sec BilateralSliceApply fwd @4K" if args.workload == "4k"
                   else f"megapixels/sec BilateralSliceApply fwd @{args.workload}",
         "value": round(value, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(wall_max / args.steps * 1e3, 5),
+        "warmup": args.warmup, "ms_per_step": round(t_region / args.steps * 1e3, 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic", "clock": clock,
+        "preroll_launches": n_pre, "preroll_ms": round(pre_s * 1e3, 1),
         "config": {"workload": desc, "images_per_gpu_per_step": 1, "layout": "NHWC fp32",
                    "has_offset": True, "rotating_buffer_sets": nsets,
                    "working_set_MB": round(nsets * abytes / 1e6, 1), "parallelism": f"image-shard x{world}",
                    "kernel": kernel},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                     "traffic": (measured_traffic(args.workload, kernel) or {}).get("bytes_per_launch"),
-                     "traffic_source": (measured_traffic(args.workload, kernel) or {}).get("source"),
+                     "traffic": (traffic or {}).get("bytes_per_launch"),
+                     "traffic_source": (traffic or {}).get("source") or traffic_note,
+                     "source_digest": source_digest(),
                      "algorithmic_bytes_per_launch": abytes, "avg_kernel_us": round(avg_kernel_s * 1e6, 3),
+                     "wall_ms_per_step": round(wall_max / args.steps * 1e3, 5),
                      "timing": "HIP events on the launch stream around the timed region / steps"},
     }
 
@@ -260,6 +309,30 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist_on:
+        import torch.distributed as dist
+        hd.barrier()
+        dist.destroy_process_group()
+
+
+def stub_main(args, rank, world):
+    """CPU stand-in for the distributed skeleton of main() (tests/test_bench_launch.py): same
+    launch path, barrier, max-over-ranks and JSON line, gloo backend, a sleep as the timed body."""
+    from hdrnet_amd import dist as hd
+    if world > 1:
+        hd.init(backend="gloo", device=torch.device("cpu"))
+        hd.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (1 + rank))
+    wall = time.perf_counter() - t0
+    if world > 1:
+        hd.barrier()
+    (wall_max,) = hd.max_over_ranks([wall], device=torch.device("cpu"))
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": round(world * args.steps / wall_max, 1), "unit": "steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(wall_max / max(args.steps, 1) * 1e3, 5),
+                          "higher_is_better": True, "scaling": "weak"}), flush=True)
+    if world > 1:
         import torch.distributed as dist
         hd.barrier()
         dist.destroy_process_group()

@@ -419,11 +419,17 @@ bool apply_fwd_rows_supported(const ApplyArgs& a) {
 
 hipError_t launch_apply_fwd_rows(const ApplyArgs& a, hipStream_t s, const char** name) {
 #ifdef HDRNET_TOOLS_BUILD
-  if (a.variant != 0) {  // benchmark-only kernels (tools build), never selected by flags == 0
+  if (a.variant != 0 && a.variant != 19) {  // benchmark-only kernels (tools build), never selected by flags == 0
     const hipError_t e = launch_apply_fwd_variant(a, s, name);
     if (e != hipErrorNotSupported) return e;
   }
+  const bool round1_kernel = a.variant == 19;  // A/B: the round-1 product kernel below
+#else
+  const bool round1_kernel = false;
 #endif
+  // The product kernel for vec4-able inputs lives in apply_fwd_seg.hip; what remains here is the
+  // scalar kernel (any W / alignment) and the fused guide-network / pyramid instantiations.
+  if (!round1_kernel && apply_fwd_seg_supported(a)) return launch_apply_fwd_seg(a, s, name);
 #define HDRNET_CASE(CI, CO, OFF) \
   if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF) return launch_t<CI, CO, OFF>(a, s, name)
   HDRNET_CASE(3, 3, true);

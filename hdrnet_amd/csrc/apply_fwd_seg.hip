@@ -1,29 +1,48 @@
-// BilateralSliceApply forward for gfx950, second generation ("segment" kernel).
+// BilateralSliceApply forward for gfx950 -- the north-star kernel (second generation).
 //
-// Reference semantics: hdrnet/ops/bilateral_slice_apply.cc:24-82 (CUDA twin:
-// bilateral_slice_apply.cu.cc:36-126).  Same decomposition as apply_fwd_rows.hip -- a workgroup
-// owns a segment of an image row, the two grid rows the image row needs are blended once into an
-// LDS image, a thread owns 4 consecutive pixels -- with the per-pixel instruction stream cut
-// roughly in half and the memory side decoupled from it:
+// Reference semantics: hdrnet/ops/bilateral_slice_apply.cc:24-82 (the CUDA twin,
+// bilateral_slice_apply.cu.cc:36-126, assigns one thread per output CHANNEL and re-derives all
+// weights for each of its 32 scattered grid loads).
 //
+// The op is an HBM stream -- 4 B guide + 4*Cin B input in, 4*Cout B out per pixel -- next to a
+// 96 KiB grid that never leaves L2.  Decomposition:
+//
+//   * a workgroup owns one SEGMENT OF ONE IMAGE ROW (<= 1024 px, 4 px per lane).  For a row,
+//     gy0 / gy1 and both y weights are wave-uniform, so the workgroup first blends the two grid
+//     rows it needs into LDS ("y-pre-lerp"); a pixel then gathers 2(x) x 2(z) coefficient vectors
+//     instead of 8 and computes 2 sqrt instead of the reference's 96.
 //   * PADDED LDS image.  Column j of the image is grid column clamp(cmin + j, 0, GW-1) and carries
 //     GD + 2 z-planes, plane p = grid plane clamp(p - 1, 0, GD-1).  The reference clamps INDICES
 //     but not weights (bilateral_slice_apply.cc:58-68); with the clamped copies materialised once
-//     per workgroup, a pixel's four coefficient vectors sit at a00, a00 + CB, a00 + colb,
-//     a00 + colb + CB -- one address, immediate offsets, no per-pixel min / max.
-//   * the z-corner chain (offsets, squares, 1 - sqrt) runs on 2-wide vectors (v_pk_add / v_pk_fma /
-//     v_pk_mul), both corners at once.
-//   * R > 1: the workgroup keeps its segment for R consecutive rows.  Everything that depends on
-//     x only (gxf, floor, both x weights, the column byte offset) is computed once; row r + 1's
-//     pixel loads and grid-row loads are issued BEFORE row r is sliced (gfx9 vmcnt is in order
-//     and the staging loads are issued ahead of the pixel loads, so waiting for either never
-//     drains the younger prefetch), and the LDS image is double-buffered: one barrier per row.
-//   * pixel loads: per-lane 16-B (LOADS 0), nontemporal lane-contiguous + LDS transpose (1), or
-//     LDS-DMA `global_load_lds_dwordx4` straight into the wave's slab, plain / nontemporal (2 / 3).
-//   * 3-D launch grid (segment, row block, batch): no integer division in the kernel.
+//     per workgroup a pixel's four coefficient vectors sit at a0, a0 + CB, a0 + colb,
+//     a0 + colb + CB: one address, immediate offsets, no per-pixel min / max.  One vector is C
+//     contiguous floats read as ds_read_b128; the 48-B stride (C = 12) keeps the data-dependent
+//     z gather bank-conflict-free.
+//   * the z-corner chain (offsets, squares, 1 - sqrt) runs on 2-wide vectors, both corners at
+//     once; the blend is 24 v_pk_fma_f32 / v_pk_mul_f32 per pixel.
+//   * PIXEL LOADS are LDS-DMA (`global_load_lds_dwordx4 ... nt`): each wave streams its 256-pixel
+//     run (1 KiB of guide, Cin KiB of input) lane-contiguously straight into its LDS slab with the
+//     nontemporal policy, no VGPRs held while in flight; a lane then reads its own 4 pixels back
+//     with ds_read_b128.  Nontemporal loads lower the no-compute floor of this byte mix from
+//     40.8 to 39.4 us per 4K frame, but only as dense per-instruction runs (a per-pixel 48-B
+//     stride re-fetches lines).
+//   * STORES leave through the same slab, transposed to lane-contiguous 16-B runs, as
+//     `buffer_store_dwordx4 ... sc0 sc1` (write-through) on a descriptor that covers exactly the
+//     row segment (lanes past the run are dropped by the bounds check -- no predicate).  Plain
+//     stores leave up to an L2's worth of dirty lines for the end-of-kernel write-back; writing
+//     through is worth 1.5 us per 4K frame and 0.7 us per 1080p frame (profiles/r02/).
+//   * 3-D launch grid (segment, row, batch): no integer division in the kernel.
 //
-// Numerics: identical expressions to apply_fwd_rows.hip (rows_common.hip.h: slice_terms) for the
-// coordinates and weights; only the index clamps moved into the image.
+// Numerics: the coordinate and weight expressions of the reference in the reference's order
+// (products (x+.5)*scale_x, guide*GD explicitly rounded, see numerics.hip.h: mul_rn); the only
+// re-association is wy folded into the LDS image.  max(.,0) of both tents is dropped (floor()
+// keeps both corners within one cell), v_sqrt_f32 (1 ulp) stands in for sqrtf; differences stay
+// at the 1e-7 level (tests/test_gpu_parity.py holds rtol = atol = 1e-5 and reports the
+// reference's own 1e-6 bar).
+//
+// The TOOLS build (HDRNET_TOOLS_BUILD) also instantiates the load / store flavours this design
+// was chosen against (per-lane loads, nontemporal lane-contiguous register loads, plain DMA; plain /
+// nt / sc1 stores) and a per-workgroup timeline trace; tools/ab_bench.py times them interleaved.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -40,16 +59,14 @@ using namespace rows;
 constexpr int kLoadsLane = 0;      // per-lane 16-B loads of the lane's own 4 pixels
 constexpr int kLoadsNtContig = 1;  // nontemporal, lane-contiguous, transposed through the slab
 constexpr int kLoadsDma = 2;       // LDS-DMA (global_load_lds_dwordx4), default cache policy
-constexpr int kLoadsDmaNt = 3;     // LDS-DMA, nontemporal
+constexpr int kLoadsDmaNt = 3;     // LDS-DMA, nontemporal                         <- product
 
 // Output stores (all lane-contiguous 16 B after the per-wave LDS transpose):
-constexpr int kStoresGlobal = 0;  // global_store_dwordx4, predicated on the run length
-constexpr int kStoresBuf = 1;     // buffer_store_dwordx4 on a per-row-segment descriptor (out-of-range lanes dropped by the bounds check)
-constexpr int kStoresBufNt = 2;   // ... nt
-constexpr int kStoresBufSc1 = 3;  // ... sc1 (write-through: the line does not stay dirty in the XCD's L2)
-constexpr int kStoresBufSc01 = 4; // ... sc0 sc1
-
-constexpr int kStageMax = 2;  // staging elements (16 B or 4 B) a thread may hold in registers
+constexpr int kStoresGlobal = 0;   // global_store_dwordx4, predicated on the run length
+constexpr int kStoresBufNt = 2;    // buffer_store_dwordx4 ... nt
+constexpr int kStoresBufSc1 = 3;   // ... sc1 (write-through: the line does not stay dirty in L2)
+constexpr int kStoresBufSc01 = 4;  // ... sc0 sc1                                   <- product
+// (1 = buffer_store_dwordx4 with the default policy)
 
 struct SegParams {
   const float* grid;
@@ -58,8 +75,7 @@ struct SegParams {
   float* out;
   int H, W, GH, GW, GD;
   int seg;         // pixels per segment, multiple of 4
-  int img_floats;  // floats per image buffer (16-B multiple)
-  int slab_off;    // float offset of the per-wave slabs in dynamic LDS
+  int slab_off;    // float offset of the per-wave slabs in dynamic LDS (= size of the image)
   float scale_x, scale_y;
   float inv_col;   // 1 / (GD * C / VEC): column of a staging element by float multiply
   long long* trace;  // TRACE: [nblocks][3] wall-clock ticks (start, end), XCC id; else unused
@@ -106,10 +122,11 @@ __device__ __forceinline__ XTerm x_term(float xf, float scale_x, int cmin, int c
   return t;
 }
 
-// One pixel: z terms, the four-vector blend from the padded image, the affine.
+// One pixel: z terms, the four-vector blend from the padded image, the affine
+// (bilateral_slice_apply.cc:43-80).
 template <int CIN, int COUT, bool OFFSET>
 __device__ __forceinline__ void seg_pixel(const float* __restrict__ img, float gd_f, float zhi, int colb,
-                                          const XTerm& xt, float g, const float (&in)[CIN],
+                                          const XTerm& xt, float g, const float (&in)[CIN > 0 ? CIN : 1],
                                           float (&out)[COUT]) {
   constexpr int CJ = CIN + (OFFSET ? 1 : 0);
   constexpr int C = COUT * CJ;
@@ -132,7 +149,7 @@ __device__ __forceinline__ void seg_pixel(const float* __restrict__ img, float g
     w0 = wx0 * wz;
     w1 = wx1 * wz;
     // plane of z index iz is iz + 1; the clamp to [-1, GD-1] only guards wild guides (the
-    // padded planes already hold the reference's clamped reads).
+    // padded planes already hold the reference's clamped reads; v_med3 of a NaN yields -1).
     const int iz = (int)__builtin_amdgcn_fmed3f(fzl, -1.0f, zhi);
     a0 = __mul24(iz, CB) + xt.xbp;
   }
@@ -150,92 +167,61 @@ __device__ __forceinline__ void seg_pixel(const float* __restrict__ img, float g
   }
 }
 
-// Staging of one image row's blended, padded grid image.  `issue` loads this thread's elements of
-// the two grid rows into registers; `write` blends and stores them (plus the clamped edge planes).
+// Blend the two grid rows image row y needs into the padded LDS image (see the header comment):
+//   img[j][p][c] = wy0 * grid[gy0c][clamp(cmin + j)][clamp(p - 1)][c] + wy1 * grid[gy1c][...]
+// Work item = one VEC-float element of a source (column, plane) vector; two are in flight per
+// thread so that a segment needing more elements than threads still pays one L2 latency.
 template <int C>
-struct Stager {
-  static constexpr int VEC = (C % 4 == 0) ? 4 : 1;
-  static constexpr int CV = C / VEC;
+__device__ __forceinline__ void stage_image(float* __restrict__ img, const float* __restrict__ grid_b,
+                                            int y, int cmin, int ncols, int GH, int GW, int GD,
+                                            float scale_y, float inv_col, int tid, int nthreads) {
+  constexpr int VEC = (C % 4 == 0) ? 4 : 1;
+  constexpr int CV = C / VEC;
   typedef float elem_t __attribute__((ext_vector_type(VEC)));
-  elem_t a[kStageMax], b[kStageMax];
-  float wy0, wy1;
-
-  // Per-thread decode of its staging elements, x-only (hoisted over rows).
-  struct Map {
-    int src[kStageMax];   // element offset inside a grid row (units of VEC floats)
-    int dst[kStageMax];   // element offset inside the image; < 0: no element
-    int edge[kStageMax];  // -1: also plane 0, +1: also plane GD + 1, 0: neither (2: both, GD == 1)
-    int n;                // staging elements of the workgroup; element i of a thread exists iff
-                          // tid + i * nthreads < n, and the whole slot iff i * nthreads < n (uniform)
-    int nthreads;
-  };
-
-  static __device__ __forceinline__ Map make_map(int tid, int nthreads, int ncols, int cmin, int GW,
-                                                 int GD, float inv_col) {
-    Map m;
-    const int per_col = GD * CV;
-    const int n = ncols * per_col;
-    m.n = n;
-    m.nthreads = nthreads;
+  // Wave-uniform y terms (bilateral_slice_apply.cc:42,47,55-56).
+  const float gyf = mul_rn(y + 0.5f, scale_y);
+  const int gy0 = floor_to_int(gyf - 0.5f);
+  const float wy0 = tent_weight(gy0 + 0.5f, gyf);
+  const float wy1 = tent_weight(gy0 + 1 + 0.5f, gyf);
+  const int gy0c = clamp_index(gy0, 0, GH - 1);
+  const int gy1c = clamp_index(gy0 + 1, 0, GH - 1);
+  const elem_t* r0 = reinterpret_cast<const elem_t*>(grid_b + (size_t)gy0c * GW * GD * C);
+  const elem_t* r1 = reinterpret_cast<const elem_t*>(grid_b + (size_t)gy1c * GW * GD * C);
+  elem_t* d = reinterpret_cast<elem_t*>(img);
+  const int per_col = GD * CV;
+  const int n = ncols * per_col;
+  for (int base = 0; base < n; base += 2 * nthreads) {  // `base` is uniform
+    const bool two = base + nthreads < n;                // uniform: a second element exists for some lane
+    elem_t a[2], b[2];
+    int dst[2] = {-1, -1}, rem[2] = {0, 0};
 #pragma unroll
-    for (int i = 0; i < kStageMax; ++i) {
-      m.dst[i] = -1;
-      if (i * nthreads >= n) continue;  // wave-uniform: the slot is empty for the whole workgroup
-      const int e = tid + i * nthreads;
-      const int j = (int)(((float)e + 0.5f) * inv_col);  // e / per_col, exact for e < 2^20
-      const int rem = e - j * per_col;
-      const int sc = min(max(cmin + j, 0), GW - 1);
-      m.src[i] = sc * per_col + rem;
-      m.dst[i] = (e < n) ? e + CV * (2 * j + 1) : -1;
-      const bool lo = rem < CV, hi = rem >= per_col - CV;
-      m.edge[i] = (lo && hi) ? 2 : (lo ? -1 : (hi ? 1 : 0));
-    }
-    return m;
-  }
-
-  __device__ __forceinline__ void issue(const Map& m, const float* __restrict__ grid_b, int y, int GH,
-                                        int GW, int GD, float scale_y) {
-    // Wave-uniform y terms (bilateral_slice_apply.cc:42,47,55-56).
-    const float gyf = mul_rn(y + 0.5f, scale_y);
-    const int gy0 = floor_to_int(gyf - 0.5f);
-    wy0 = tent_weight(gy0 + 0.5f, gyf);
-    wy1 = tent_weight(gy0 + 1 + 0.5f, gyf);
-    const int gy0c = clamp_index(gy0, 0, GH - 1);
-    const int gy1c = clamp_index(gy0 + 1, 0, GH - 1);
-    const elem_t* r0 = reinterpret_cast<const elem_t*>(grid_b + (size_t)gy0c * GW * GD * C);
-    const elem_t* r1 = reinterpret_cast<const elem_t*>(grid_b + (size_t)gy1c * GW * GD * C);
-#pragma unroll
-    for (int i = 0; i < kStageMax; ++i) {
-      if (i * m.nthreads >= m.n) continue;
-      if (m.dst[i] >= 0) {
-        a[i] = r0[m.src[i]];
-        b[i] = r1[m.src[i]];
+    for (int i = 0; i < 2; ++i) {
+      if (i == 1 && !two) continue;
+      const int e = base + i * nthreads + tid;
+      if (e < n) {
+        const int j = (int)(((float)e + 0.5f) * inv_col);  // e / per_col, exact for e < 2^20
+        rem[i] = e - j * per_col;
+        const int sc = min(max(cmin + j, 0), GW - 1);
+        const int src = sc * per_col + rem[i];
+        a[i] = r0[src];
+        b[i] = r1[src];
+        dst[i] = e + CV * (2 * j + 1);  // column j has GD + 2 planes; source plane z is plane z + 1
       }
     }
-  }
-
-  __device__ __forceinline__ void write(const Map& m, float* __restrict__ img) const {
-    elem_t* d = reinterpret_cast<elem_t*>(img);
 #pragma unroll
-    for (int i = 0; i < kStageMax; ++i) {
-      if (i * m.nthreads >= m.n) continue;
-      if (m.dst[i] >= 0) {
+    for (int i = 0; i < 2; ++i) {
+      if (i == 1 && !two) continue;
+      if (dst[i] >= 0) {
         const elem_t v = wy0 * a[i] + wy1 * b[i];
-        d[m.dst[i]] = v;
-        if (m.edge[i] == -1 || m.edge[i] == 2) d[m.dst[i] - CV] = v;
-        if (m.edge[i] == 1 || m.edge[i] == 2) d[m.dst[i] + CV] = v;
+        d[dst[i]] = v;
+        if (rem[i] < CV) d[dst[i] - CV] = v;             // z = 0      -> also plane 0
+        if (rem[i] >= per_col - CV) d[dst[i] + CV] = v;  // z = GD - 1 -> also plane GD + 1
       }
     }
   }
-};
+}
 
-template <int CIN>
-struct PixLoads {
-  float4 g;
-  float4 iv[CIN];
-};
-
-template <int CIN, int COUT, bool OFFSET, int R, int LOADS, int STORES, bool TRACE>
+template <int CIN, int COUT, bool OFFSET, int LOADS, int STORES, bool TRACE>
 __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
   constexpr int CJ = CIN + (OFFSET ? 1 : 0);
   constexpr int C = COUT * CJ;
@@ -243,7 +229,6 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
   constexpr int SLABW = 64 * kPxPerThread * (CIN > COUT ? CIN : COUT);  // floats: in / out run of a wave
   constexpr bool DMA = LOADS >= kLoadsDma;
   constexpr int SLAB = SLABW + (DMA ? 64 * kPxPerThread : 0);           // + the guide run
-  static_assert(!DMA || R == 1, "LDS-DMA loads: single-row workgroups only");
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   long long t_start = 0;
@@ -253,9 +238,8 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (SGPR)
   const int xs = blockIdx.x * p.seg;
   const int xe = min(xs + p.seg, p.W);
-  const int y0 = blockIdx.y * R;
+  const int y = blockIdx.y;
   const int b = blockIdx.z;
-  const int nrows = min(R, p.H - y0);
   const float* grid_b = p.grid + (size_t)b * p.GH * p.GW * p.GD * C;
 
   const int x = xs + kPxPerThread * tid;
@@ -272,56 +256,44 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
   const int colb = (p.GD + 2) * CB;
   const float gd_f = (float)p.GD, zhi = (float)(p.GD - 1);
 
-  // Addressing: a wave-uniform 64-bit segment base (SGPRs) + a 32-bit per-lane element offset,
-  // so that loads / stores take the `saddr + voffset` form without 64-bit VALU arithmetic.
-  const size_t row0 = (size_t)b * p.H + y0;
+  // Addressing: a wave-uniform 64-bit segment base (SGPRs) + a 32-bit per-lane element offset.
+  const size_t row = (size_t)b * p.H + y;
   const unsigned lpx = kPxPerThread * (unsigned)tid;         // this lane's first pixel in the segment
   const unsigned wpx = kPxPerThread * 64u * (unsigned)wave;  // this wave's first pixel in the segment
-  auto issue_pix = [&](size_t row, PixLoads<CIN>& L) {
-    const float* gseg = p.guide + (row * p.W + xs);        // uniform
-    const float* iseg = p.input + (row * p.W + xs) * CIN;  // uniform
-    if constexpr (LOADS == kLoadsLane) {
-      if (active) {
-        L.g = *reinterpret_cast<const float4*>(gseg + lpx);
-#pragma unroll
-        for (int q = 0; q < CIN; ++q) L.iv[q] = *reinterpret_cast<const float4*>(iseg + (lpx * CIN + 4 * q));
-      }
-    } else if constexpr (LOADS == kLoadsNtContig) {
-      if (active) L.g = load_stream4(gseg + lpx);
-#pragma unroll
-      for (int k = 0; k < CIN; ++k) {
-        const int e = lane + 64 * k;
-        if (e < wave_px * CIN / 4) L.iv[k] = load_stream4(iseg + (wpx * CIN + 4u * (unsigned)e));
-      }
-    } else {
-      // LDS-DMA: every lane issues (the LDS side is base + 16 * lane); lanes past the run re-read
-      // its last float4.  An idle wave issues nothing.
-      if (wave_px > 0) {
-        dma16<LOADS == kLoadsDmaNt>(gseg + (wpx + 4u * (unsigned)min(lane, wave_px / 4 - 1)),
-                                    reinterpret_cast<float*>(gslab));
-        const int last = wave_px * CIN / 4 - 1;
-#pragma unroll
-        for (int k = 0; k < CIN; ++k)
-          dma16<LOADS == kLoadsDmaNt>(iseg + (wpx * CIN + 4u * (unsigned)min(lane + 64 * k, last)),
-                                      reinterpret_cast<float*>(slab + 64 * k));
-      }
-    }
-  };
+  const float* gseg = p.guide + (row * p.W + xs);
+  const float* iseg = p.input + (row * p.W + xs) * CIN;
 
-  // Row 0's pixel loads go out first: their HBM latency overlaps the (L2-resident) staging.
-  PixLoads<CIN> cur;
-  cur.g = make_float4(0.f, 0.f, 0.f, 0.f);
-  Stager<C> st;
-  const typename Stager<C>::Map smap =
-      Stager<C>::make_map(tid, (int)blockDim.x, ncols, cmin, p.GW, p.GD, p.inv_col);
-  if constexpr (DMA) {
-    issue_pix(row0, cur);
-    st.issue(smap, grid_b, y0, p.GH, p.GW, p.GD, p.scale_y);
+  // Pixel loads go out first: their HBM latency overlaps the (L2-resident) staging.
+  float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 iv[CIN > 0 ? CIN : 1];
+  if constexpr (LOADS == kLoadsLane) {
+    if (active) {
+      g4 = *reinterpret_cast<const float4*>(gseg + lpx);
+#pragma unroll
+      for (int q = 0; q < CIN; ++q) iv[q] = *reinterpret_cast<const float4*>(iseg + (lpx * CIN + 4 * q));
+    }
+  } else if constexpr (LOADS == kLoadsNtContig) {
+    if (active) g4 = load_stream4(gseg + lpx);
+#pragma unroll
+    for (int k = 0; k < CIN; ++k) {
+      const int e = lane + 64 * k;
+      if (e < wave_px * CIN / 4) iv[k] = load_stream4(iseg + (wpx * CIN + 4u * (unsigned)e));
+    }
   } else {
-    // staging loads first: waiting for them (vmcnt is in order) then leaves the pixel loads in flight
-    st.issue(smap, grid_b, y0, p.GH, p.GW, p.GD, p.scale_y);
-    issue_pix(row0, cur);
+    // LDS-DMA: every lane issues (the LDS side is base + 16 * lane); lanes past the run re-read
+    // its last float4.  An idle wave issues nothing.
+    if (wave_px > 0) {
+      dma16<LOADS == kLoadsDmaNt>(gseg + (wpx + 4u * (unsigned)min(lane, wave_px / 4 - 1)),
+                                  reinterpret_cast<float*>(gslab));
+      const int last = wave_px * CIN / 4 - 1;
+#pragma unroll
+      for (int k = 0; k < CIN; ++k)
+        dma16<LOADS == kLoadsDmaNt>(iseg + (wpx * CIN + 4u * (unsigned)min(lane + 64 * k, last)),
+                                    reinterpret_cast<float*>(slab + 64 * k));
+    }
   }
+
+  stage_image<C>(lds, grid_b, y, cmin, ncols, p.GH, p.GW, p.GD, p.scale_y, p.inv_col, tid, (int)blockDim.x);
 
   // x-only terms of this thread's 4 pixels
   XTerm xt[kPxPerThread];
@@ -329,107 +301,75 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
 #pragma unroll
   for (int k = 0; k < kPxPerThread; ++k) xt[k] = x_term(xf0 + (float)k, p.scale_x, cmin, colb, CB);
 
-  st.write(smap, lds);
-  __syncthreads();
+  __syncthreads();  // image complete; with LDS-DMA in flight the compiler drains vmcnt here too
 
+  // ---- this lane's 4 pixels ---------------------------------------------------------------------
+  if constexpr (LOADS == kLoadsNtContig) {
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    if (r < nrows) {
-      const float* img = lds + (r & 1) * p.img_floats;
-      const size_t row = row0 + r;
-      PixLoads<CIN> nxt;
-      nxt.g = make_float4(0.f, 0.f, 0.f, 0.f);
-      const bool more = (r + 1 < R) && (r + 1 < nrows);
-      if constexpr (R > 1) {
-        if (more) {
-          st.issue(smap, grid_b, y0 + r + 1, p.GH, p.GW, p.GD, p.scale_y);
-          issue_pix(row + 1, nxt);
-        }
-      }
-
-      // ---- this lane's 4 pixels of row r --------------------------------------------------------
-      float4 g4 = cur.g;
-      float4 iv[CIN];
-      if constexpr (LOADS == kLoadsLane) {
-#pragma unroll
-        for (int q = 0; q < CIN; ++q) iv[q] = cur.iv[q];
-      } else if constexpr (LOADS == kLoadsNtContig) {
-#pragma unroll
-        for (int k = 0; k < CIN; ++k) {
-          const int e = lane + 64 * k;
-          if (e < wave_px * CIN / 4) slab[e] = cur.iv[k];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (active) {
-#pragma unroll
-          for (int q = 0; q < CIN; ++q) iv[q] = slab[lane * CIN + q];
-        }
-        __builtin_amdgcn_wave_barrier();  // the slab is reused for the output below
-      } else {
-        if (active) {
-          g4 = gslab[lane];
-#pragma unroll
-          for (int q = 0; q < CIN; ++q) iv[q] = slab[lane * CIN + q];
-        }
-      }
-
-      const float gs[4] = {g4.x, g4.y, g4.z, g4.w};
-      const float* inf = reinterpret_cast<const float*>(iv);
-      float4 ov[COUT];
-      float* of = reinterpret_cast<float*>(ov);
-      if (active) {
-#pragma unroll
-        for (int k = 0; k < kPxPerThread; ++k) {
-          float in[CIN], o[COUT];
-#pragma unroll
-          for (int j = 0; j < CIN; ++j) in[j] = inf[k * CIN + j];
-          seg_pixel<CIN, COUT, OFFSET>(img, gd_f, zhi, colb, xt[k], gs[k], in, o);
-#pragma unroll
-          for (int i = 0; i < COUT; ++i) of[k * COUT + i] = o[i];
-        }
-        // CIN == COUT: a lane reads and writes only ITS slab entries here -- in place, no cross-lane
-        // hazard; otherwise the input reads of all lanes must precede the output writes.
-        if constexpr (LOADS != kLoadsLane && CIN != COUT) __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < COUT; ++q) slab[lane * COUT + q] = ov[q];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      {
-        float* oseg = p.out + (row * p.W + xs) * COUT;  // uniform
-        if constexpr (STORES == kStoresGlobal) {
-          if (wave_px >= 64 * kPxPerThread) {  // full wave (uniform): unpredicated stores
-#pragma unroll
-            for (int k = 0; k < COUT; ++k)
-              *reinterpret_cast<float4*>(oseg + (wpx * COUT + 4u * (unsigned)(lane + 64 * k))) = slab[lane + 64 * k];
-          } else {
-            const int nvalid = wave_px * COUT / 4;  // float4s
-#pragma unroll
-            for (int k = 0; k < COUT; ++k) {
-              const int e = lane + 64 * k;
-              if (e < nvalid) *reinterpret_cast<float4*>(oseg + (wpx * COUT + 4u * (unsigned)e)) = slab[e];
-            }
-          }
-        } else {
-          // descriptor over exactly this row segment: lanes past the run are dropped by the bounds check
-          const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(oseg, (unsigned)(xe - xs) * COUT * 4u);
-#pragma unroll
-          for (int k = 0; k < COUT; ++k)
-            buf_store16<STORES>(slab[lane + 64 * k], orsrc, (wpx * COUT + 4u * (unsigned)(lane + 64 * k)) * 4u);
-        }
-      }
-
-      if constexpr (R > 1) {
-        if (more) {
-          st.write(smap, lds + ((r + 1) & 1) * p.img_floats);
-          __syncthreads();
-          cur = nxt;
-        }
-      }
+    for (int k = 0; k < CIN; ++k) {
+      const int e = lane + 64 * k;
+      if (e < wave_px * CIN / 4) slab[e] = iv[k];
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (active) {
+#pragma unroll
+      for (int q = 0; q < CIN; ++q) iv[q] = slab[lane * CIN + q];
+    }
+  } else if constexpr (DMA) {
+    if (active) {
+      g4 = gslab[lane];
+#pragma unroll
+      for (int q = 0; q < CIN; ++q) iv[q] = slab[lane * CIN + q];
+    }
+  }
+  // CIN == COUT: a lane reads and writes only ITS slab entries -- in place, no cross-lane hazard;
+  // otherwise the input reads of all lanes must precede the output writes below.
+  if constexpr (LOADS != kLoadsLane && CIN != COUT) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+
+  const float gs[4] = {g4.x, g4.y, g4.z, g4.w};
+  const float* inf = reinterpret_cast<const float*>(iv);
+  float4 ov[COUT];
+  float* of = reinterpret_cast<float*>(ov);
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < kPxPerThread; ++k) {
+      float in[CIN > 0 ? CIN : 1], o[COUT];
+#pragma unroll
+      for (int j = 0; j < CIN; ++j) in[j] = inf[k * CIN + j];
+      seg_pixel<CIN, COUT, OFFSET>(lds, gd_f, zhi, colb, xt[k], gs[k], in, o);
+#pragma unroll
+      for (int i = 0; i < COUT; ++i) of[k * COUT + i] = o[i];
+    }
+#pragma unroll
+    for (int q = 0; q < COUT; ++q) slab[lane * COUT + q] = ov[q];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // Store phase: lane l stores float4 number l + 64 k of the wave's output run -- every store
+  // instruction covers one dense 1 KiB (per-lane 16-B stores at a 16*COUT-byte stride cost 6.5 us
+  // per 4K frame, profiles/r01).
+  float* oseg = p.out + (row * p.W + xs) * COUT;  // uniform
+  if constexpr (STORES == kStoresGlobal) {
+    const int nvalid = wave_px * COUT / 4;  // float4s
+#pragma unroll
+    for (int k = 0; k < COUT; ++k) {
+      const int e = lane + 64 * k;
+      if (e < nvalid) *reinterpret_cast<float4*>(oseg + (wpx * COUT + 4u * (unsigned)e)) = slab[e];
+    }
+  } else {
+    // descriptor over exactly this row segment: lanes past the run are dropped by the bounds check
+    const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(oseg, (unsigned)(xe - xs) * COUT * 4u);
+#pragma unroll
+    for (int k = 0; k < COUT; ++k)
+      buf_store16<STORES>(slab[lane + 64 * k], orsrc, (wpx * COUT + 4u * (unsigned)(lane + 64 * k)) * 4u);
   }
 
   if constexpr (TRACE) {
@@ -444,37 +384,34 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
 
 struct SegGeom {
   Plan pl;
-  int max_cols, img_floats, slab_off;
+  int max_cols, slab_off;
   size_t lds;
   bool ok;
 };
 
-template <int CIN, int COUT, bool OFFSET>
-SegGeom seg_geom(const ApplyArgs& a, int R, int loads) {
-  constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
-  constexpr int VEC = (C % 4 == 0) ? 4 : 1;
+constexpr size_t kMaxLdsBytes = 64 * 1024;  // keep >= 2 workgroups per CU
+
+SegGeom seg_geom(const ApplyArgs& a, bool dma) {
+  const int C = a.Cout * a.Cj;
   SegGeom g{};
   const bool aligned =
       (((uintptr_t)a.guide | (uintptr_t)a.input | (uintptr_t)a.out | (uintptr_t)a.grid) & 15u) == 0;
   g.pl = make_row_plan(a.W, a.GW, aligned);
   g.max_cols = (int)(((long long)(g.pl.seg - 1) * a.GW) / a.W + 4);
-  g.img_floats = round_up(g.max_cols * (a.GD + 2) * C, 4);
-  g.slab_off = (R > 1 ? 2 : 1) * g.img_floats;
-  const int slabw = 64 * kPxPerThread * (CIN > COUT ? CIN : COUT) + (loads >= kLoadsDma ? 64 * kPxPerThread : 0);
+  g.slab_off = round_up(g.max_cols * (a.GD + 2) * C, 4);
+  const int slabw = 64 * kPxPerThread * (a.Cin > a.Cout ? a.Cin : a.Cout) + (dma ? 64 * kPxPerThread : 0);
   g.lds = ((size_t)g.slab_off + (size_t)(g.pl.threads / 64) * slabw) * sizeof(float);
-  const long long nstage = (long long)g.max_cols * a.GD * (C / VEC);
-  g.ok = g.pl.vec4 && g.lds <= 64 * 1024 && nstage <= (long long)kStageMax * g.pl.threads &&
-         nstage < (1 << 20) && a.B <= 65535 && (a.H + R - 1) / R <= 65535 &&
-         // a row block may span at most two grid rows ... not required: every row restages.
-         true;
+  const long long nstage = (long long)g.max_cols * a.GD * C;
+  g.ok = g.pl.vec4 && g.lds <= kMaxLdsBytes && nstage < (1 << 20) && a.B <= 65535 && a.H <= 65535 &&
+         (long long)a.W * a.Cout * 4 < (1LL << 31);
   return g;
 }
 
-template <int CIN, int COUT, bool OFFSET, int R, int LOADS, int STORES, bool TRACE>
+template <int CIN, int COUT, bool OFFSET, int LOADS, int STORES, bool TRACE>
 hipError_t launch_seg_t(const ApplyArgs& a, hipStream_t s, long long* trace) {
   constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
   constexpr int VEC = (C % 4 == 0) ? 4 : 1;
-  const SegGeom g = seg_geom<CIN, COUT, OFFSET>(a, R, LOADS);
+  const SegGeom g = seg_geom(a, LOADS >= kLoadsDma);
   if (!g.ok) return hipErrorNotSupported;
   SegParams p;
   p.grid = a.grid;
@@ -487,66 +424,80 @@ hipError_t launch_seg_t(const ApplyArgs& a, hipStream_t s, long long* trace) {
   p.GW = a.GW;
   p.GD = a.GD;
   p.seg = g.pl.seg;
-  p.img_floats = g.img_floats;
   p.slab_off = g.slab_off;
   p.scale_x = (float)a.GW / a.W;
   p.scale_y = (float)a.GH / a.H;
   p.inv_col = 1.0f / (float)(a.GD * (C / VEC));
   p.trace = trace;
-  const dim3 grid3((unsigned)g.pl.nseg, (unsigned)((a.H + R - 1) / R), (unsigned)a.B);
-  apply_fwd_seg<CIN, COUT, OFFSET, R, LOADS, STORES, TRACE><<<grid3, g.pl.threads, g.lds, s>>>(p);
+  const dim3 grid3((unsigned)g.pl.nseg, (unsigned)a.H, (unsigned)a.B);
+  apply_fwd_seg<CIN, COUT, OFFSET, LOADS, STORES, TRACE><<<grid3, g.pl.threads, g.lds, s>>>(p);
   return hipGetLastError();
 }
 
-long long* g_trace = nullptr;  // tools only: device buffer of [nblocks][3]
+bool seg_shape(const ApplyArgs& a) {
+  return (a.Cin == 3 && a.Cout == 3) || (a.Cin == 3 && a.Cout == 4 && a.has_offset) ||
+         (a.Cin == 1 && a.Cout == 1) || (a.Cin == 1 && a.Cout == 3 && a.has_offset) ||
+         (a.Cin == 4 && a.Cout == 4 && a.has_offset);
+}
+
+#ifdef HDRNET_TOOLS_BUILD
+long long* g_trace = nullptr;  // device buffer of [nblocks][3]
+#endif
 
 }  // namespace
 
+// The product configuration: LDS-DMA nontemporal loads, write-through buffer stores.
+bool apply_fwd_seg_supported(const ApplyArgs& a) {
+  if (!seg_shape(a)) return false;
+  // stage_image reads the grid as float4 when C % 4 == 0.
+  if ((a.Cout * a.Cj) % 4 == 0 && ((uintptr_t)a.grid & 15u)) return false;
+  return seg_geom(a, true).ok;
+}
+
+hipError_t launch_apply_fwd_seg(const ApplyArgs& a, hipStream_t s, const char** name) {
+  *name = "apply_fwd_seg/vec4";
+#define HDRNET_CASE(CI, CO, OFF)                                  \
+  if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF)         \
+    return launch_seg_t<CI, CO, OFF, kLoadsDmaNt, kStoresBufSc01, false>(a, s, nullptr)
+  HDRNET_CASE(3, 3, true);
+  HDRNET_CASE(3, 3, false);
+  HDRNET_CASE(3, 4, true);
+  HDRNET_CASE(1, 1, true);
+  HDRNET_CASE(1, 1, false);
+  HDRNET_CASE(1, 3, true);
+  HDRNET_CASE(4, 4, true);
+#undef HDRNET_CASE
+  return hipErrorInvalidValue;
+}
+
+#ifdef HDRNET_TOOLS_BUILD
 void apply_fwd_seg_set_trace(long long* device_buf) { g_trace = device_buf; }
 
-// Tools build: knob = variant - 20.
-//   0..19  R = 1: loads = knob % 4 {lane, nt-contig, dma, dma-nt}, stores = knob / 4 {global, buf, buf-nt, buf-sc1, buf-sc0sc1}
-//   20..39 the same with the timeline trace
-//   40..43 R = 2 {lane, nt-contig}, R = 4 {lane, nt-contig}; 44..47 traced
-hipError_t launch_apply_fwd_seg(const ApplyArgs& a, int knob, hipStream_t s, const char** name) {
+// knob = variant - 20:  0..19 loads = knob % 4 {lane, nt-contig, dma, dma-nt}, stores = knob / 4
+// {global, buffer, buffer nt, buffer sc1, buffer sc0 sc1};  20..39 the same with the timeline trace.
+hipError_t launch_apply_fwd_seg_knob(const ApplyArgs& a, int knob, hipStream_t s, const char** name) {
   if (!(a.Cin == 3 && a.Cout == 3 && a.has_offset)) return hipErrorNotSupported;
   static char namebuf[64];
   static const char* const lname[] = {"lane", "ntcontig", "dma", "dma-nt"};
   static const char* const sname[] = {"", "+bufst", "+bufst-nt", "+bufst-sc1", "+bufst-sc0sc1"};
-  if (knob < 0 || knob >= 48) return hipErrorNotSupported;
-  if (knob < 40) {
-    const bool trace = knob >= 20;
-    const int k = knob % 20, L = k % 4, S = k / 4;
-    if (trace && !g_trace) return hipErrorInvalidValue;
-    snprintf(namebuf, sizeof namebuf, "apply_fwd_seg/R1-%s%s", lname[L], sname[S]);
-    *name = namebuf;
-#define SEG_CASE(LL, SS)                                                              \
-  if (L == LL && S == SS)                                                             \
-    return trace ? launch_seg_t<3, 3, true, 1, LL, SS, true>(a, s, g_trace)           \
-                 : launch_seg_t<3, 3, true, 1, LL, SS, false>(a, s, nullptr)
-    SEG_CASE(0, 0); SEG_CASE(1, 0); SEG_CASE(2, 0); SEG_CASE(3, 0);
-    SEG_CASE(0, 1); SEG_CASE(1, 1); SEG_CASE(2, 1); SEG_CASE(3, 1);
-    SEG_CASE(0, 2); SEG_CASE(1, 2); SEG_CASE(2, 2); SEG_CASE(3, 2);
-    SEG_CASE(0, 3); SEG_CASE(1, 3); SEG_CASE(2, 3); SEG_CASE(3, 3);
-    SEG_CASE(0, 4); SEG_CASE(1, 4); SEG_CASE(2, 4); SEG_CASE(3, 4);
-#undef SEG_CASE
-    return hipErrorNotSupported;
-  }
-  const bool trace = knob >= 44;
-  const int k = (knob - 40) % 4;
+  if (knob < 0 || knob >= 40) return hipErrorNotSupported;
+  const bool trace = knob >= 20;
+  const int k = knob % 20, L = k % 4, S = k / 4;
   if (trace && !g_trace) return hipErrorInvalidValue;
-  snprintf(namebuf, sizeof namebuf, "apply_fwd_seg/R%d-%s", k < 2 ? 2 : 4, lname[k & 1]);
+  snprintf(namebuf, sizeof namebuf, "apply_fwd_seg/%s%s", lname[L], sname[S]);
   *name = namebuf;
-#define SEG_CASE(K, RR, LL)                                                           \
-  if (k == K)                                                                         \
-    return trace ? launch_seg_t<3, 3, true, RR, LL, 0, true>(a, s, g_trace)           \
-                 : launch_seg_t<3, 3, true, RR, LL, 0, false>(a, s, nullptr)
-  SEG_CASE(0, 2, 0);
-  SEG_CASE(1, 2, 1);
-  SEG_CASE(2, 4, 0);
-  SEG_CASE(3, 4, 1);
+#define SEG_CASE(LL, SS)                                                       \
+  if (L == LL && S == SS)                                                      \
+    return trace ? launch_seg_t<3, 3, true, LL, SS, true>(a, s, g_trace)       \
+                 : launch_seg_t<3, 3, true, LL, SS, false>(a, s, nullptr)
+  SEG_CASE(0, 0); SEG_CASE(1, 0); SEG_CASE(2, 0); SEG_CASE(3, 0);
+  SEG_CASE(0, 1); SEG_CASE(1, 1); SEG_CASE(2, 1); SEG_CASE(3, 1);
+  SEG_CASE(0, 2); SEG_CASE(1, 2); SEG_CASE(2, 2); SEG_CASE(3, 2);
+  SEG_CASE(0, 3); SEG_CASE(1, 3); SEG_CASE(2, 3); SEG_CASE(3, 3);
+  SEG_CASE(0, 4); SEG_CASE(1, 4); SEG_CASE(2, 4); SEG_CASE(3, 4);
 #undef SEG_CASE
   return hipErrorNotSupported;
 }
+#endif  // HDRNET_TOOLS_BUILD
 
 }  // namespace hdrnet_amd

@@ -115,10 +115,16 @@ hipError_t launch_apply_fwd_rows(const ApplyArgs& a, hipStream_t s, const char**
 // number; hipErrorNotSupported = no such variant for the shape.
 hipError_t launch_apply_fwd_variant(const ApplyArgs& a, hipStream_t s, const char** name);
 hipError_t launch_apply_fwd_rows_direct_stores(const ApplyArgs& a, hipStream_t s, const char** name, int which);
-// apply_fwd_seg.hip -- second-generation forward (padded LDS image, multi-row workgroups, LDS-DMA).
-// knob: bits 0..1 pixel-load flavour, bits 2..3 log2(rows per workgroup), +16 timeline trace.
-hipError_t launch_apply_fwd_seg(const ApplyArgs& a, int knob, hipStream_t s, const char** name);
+// apply_fwd_seg.hip -- the product forward for 16-B-aligned, W % 4 == 0 inputs: padded LDS image,
+// LDS-DMA nontemporal pixel loads, write-through buffer stores.  launch_apply_fwd_rows routes here
+// when supported (else the scalar kernel of apply_fwd_rows.hip).
+bool apply_fwd_seg_supported(const ApplyArgs& a);
+hipError_t launch_apply_fwd_seg(const ApplyArgs& a, hipStream_t s, const char** name);
+#ifdef HDRNET_TOOLS_BUILD
+// knob: loads + 4 * stores (+ 20: timeline trace); include/hdrnet_amd_tools.h
+hipError_t launch_apply_fwd_seg_knob(const ApplyArgs& a, int knob, hipStream_t s, const char** name);
 void apply_fwd_seg_set_trace(long long* device_buf);
+#endif
 
 // Fused point-wise-NN guide + slice-apply forward (apply_fwd_rows.hip, GUIDE_NN).
 bool apply_fwd_nnguide_supported(const ApplyArgs& a, const float* guide_out);

@@ -10,11 +10,11 @@
  *       2        one wavefront per tile            3..6   persistent software-pipelined stream
  *       7        per-lane strided stores           8      round-1 kernel + nontemporal loads
  *       9..11    2 / 3 / 4 quads per thread        19     the round-1 product kernel (apply_fwd_rows)
- *       20..39   apply_fwd_seg, one row per workgroup: v - 20 = loads + 4 * stores with
+ *       20..39   the product kernel's (apply_fwd_seg) load / store flavours: v - 20 = loads + 4 * stores,
  *                loads  {0 per-lane, 1 nontemporal lane-contiguous, 2 LDS-DMA, 3 LDS-DMA nontemporal}
  *                stores {0 global, 1 buffer, 2 buffer nt, 3 buffer sc1 (write-through), 4 buffer sc0 sc1}
+ *                (39 = the product configuration)
  *       40..59   the same with a per-workgroup timeline trace (hdrnet_tools_set_trace)
- *       60..63   apply_fwd_seg with 2 / 2 / 4 / 4 rows per workgroup (loads 0 / 1 / 0 / 1); 64..67 traced
  *       101, 103..106  memory skeletons
  *   - hdrnet_tools_set_trace: device buffer that the trace variants fill with
  *     [workgroup][3] = {start, end in wall_clock64() ticks (100 MHz), XCC id}.

@@ -1,0 +1,49 @@
+"""`python bench.py --gpus N` must be startable from a bare shell (no WORLD_SIZE in the environment):
+it re-launches itself as N ranks under torch.distributed.run.  Exercised here on CPU with the gloo
+backend and a stub timed body (`--stub-cpu`): same spawn path, barrier, max-over-ranks, one JSON line
+from rank 0 with n_gpus taken from the process group."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def _run(extra, env_drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    env = {k: v for k, v in os.environ.items() if k not in env_drop}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub-cpu", "--steps", "4",
+                          "--warmup", "1"] + extra, capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout + res.stderr  # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks():
+    out = _run(["--gpus", "2"])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 1
+    # max over ranks: rank 1 sleeps 20 ms, rank 0 10 ms
+    assert out["ms_per_step"] * 4 >= 19.0
+
+
+def test_bench_single_rank_needs_no_launcher():
+    out = _run(["--gpus", "1"])
+    assert out["n_gpus"] == 1
+
+
+def test_traffic_record_is_refused_when_sources_differ(tmp_path, monkeypatch):
+    import bench
+    rec = [{"workload": "4k", "kernel": "k", "bytes_per_launch": 1, "source_digest": "deadbeef"}]
+    d = tmp_path / "profiles" / "r99"
+    d.mkdir(parents=True)
+    (d / "traffic.json").write_text(json.dumps(rec))
+    os.makedirs(tmp_path / "hdrnet_amd" / "csrc")
+    (tmp_path / "hdrnet_amd" / "csrc" / "a.hip").write_text("x")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    got, why = bench.measured_traffic("4k", "k")
+    assert got is None and "other kernel sources" in why
+    rec[0]["source_digest"] = bench.source_digest()
+    (d / "traffic.json").write_text(json.dumps(rec))
+    got, why = bench.measured_traffic("4k", "k")
+    assert got["bytes_per_launch"] == 1 and why is None

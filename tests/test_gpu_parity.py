@@ -64,7 +64,7 @@ def test_native_library_loaded(dev, ops):
     assert "libhdrnet_amd.so" in maps
     g = load_golden("apply_forward_default")
     ops.bilateral_slice_apply(T(g["grid"], dev), T(g["guide"], dev), T(g["input"], dev), has_offset=True)
-    assert ops.last_kernel().startswith("apply_fwd_rows")  # AUTO picks the LDS-staged kernel
+    assert ops.last_kernel().startswith(("apply_fwd_seg", "apply_fwd_rows"))  # AUTO picks an LDS-staged kernel
 
 
 # ---- golden fixtures (made from the reference's own CPU code) ---------------------------------
@@ -174,13 +174,11 @@ def test_apply_forward_random(dev, ops, port, shape):
                                             (5, "apply_fwd_stream"), (7, "direct-stores"),
                                             (8, "nt-loads"), (9, "multiquad2"), (11, "multiquad4"),
                                             (19, "apply_fwd_rows/vec4"),
-                                            (20, "seg/R1-lane"), (21, "seg/R1-ntcontig"),
-                                            (22, "seg/R1-dma"), (23, "seg/R1-dma-nt"),
-                                            (25, "seg/R1-ntcontig+bufst"), (29, "seg/R1-ntcontig+bufst-nt"),
-                                            (33, "seg/R1-ntcontig+bufst-sc1"), (35, "seg/R1-dma-nt+bufst-sc1"),
-                                            (37, "seg/R1-ntcontig+bufst-sc0sc1"),
-                                            (60, "seg/R2-lane"), (61, "seg/R2-ntcontig"),
-                                            (62, "seg/R4-lane"), (63, "seg/R4-ntcontig")])
+                                            (20, "seg/lane"), (21, "seg/ntcontig"),
+                                            (22, "seg/dma"), (23, "seg/dma-nt"),
+                                            (25, "seg/ntcontig+bufst"), (29, "seg/ntcontig+bufst-nt"),
+                                            (33, "seg/ntcontig+bufst-sc1"), (35, "seg/dma-nt+bufst-sc1"),
+                                            (39, "seg/dma-nt+bufst-sc0sc1")])
 @pytest.mark.parametrize("shape", [(2, 48, 2048, 16, 16, 8, 3, 3, True, -0.2, 1.2),
                                    (1, 37, 3076, 16, 16, 8, 3, 3, True, 0.0, 1.0),
                                    (1, 21, 1920, 16, 16, 8, 3, 3, True, -0.1, 1.1)])
@@ -202,7 +200,7 @@ def test_apply_forward_benchmark_variants(dev, port, shape, variant, expect):
     torch.cuda.synchronize()
     kern = tools.hdrnet_last_kernel().decode()
     # a variant without a specialisation for the shape falls back to the product kernel
-    assert expect in kern or (variant in (3, 5) and kern == "apply_fwd_rows/vec4"), kern
+    assert expect in kern or (variant in (3, 5) and kern == "apply_fwd_seg/vec4"), kern
     np.testing.assert_allclose(N(out), want, rtol=FWD_RTOL, atol=FWD_ATOL, err_msg=kern)
 
 
@@ -554,7 +552,7 @@ def test_full_frame_identity_grid_returns_input(dev, ops, H, W, GH, GW):
     guide = torch.rand((1, H, W), device=dev, generator=gen)
     inp = torch.rand((1, H, W, 3), device=dev, generator=gen)
     out = ops.bilateral_slice_apply(g.reshape(1, GH, GW, 8, 12), guide, inp, has_offset=True)
-    assert ops.last_kernel() == "apply_fwd_rows/vec4"
+    assert ops.last_kernel() == "apply_fwd_seg/vec4"
     err = (out - inp).abs().max().item()
     assert err < 2.5e-4, err  # bound: |in| * (1 - (wz0 + wz1)) <= 1e-4-ish at cell centres
     frac = ((out - inp).abs() > 1e-5).float().mean().item()
@@ -571,7 +569,7 @@ def test_full_frame_fast_equals_generic(dev, ops, H, W, GH, GW):
     with ops.kernel_override("generic"):
         a = ops.bilateral_slice_apply(grid, guide, inp, has_offset=True)
     b = ops.bilateral_slice_apply(grid, guide, inp, has_offset=True)
-    assert ops.last_kernel() == "apply_fwd_rows/vec4"
+    assert ops.last_kernel() == "apply_fwd_seg/vec4"
     torch.testing.assert_close(b, a, rtol=FWD_RTOL, atol=FWD_ATOL)
     print(f"{H}x{W}: max|fast-generic| = {(a - b).abs().max().item():.3e}")
 

@@ -164,7 +164,7 @@ def test_config3_full_inference_4k():
     m.fuse_guide = False
     with torch.no_grad():
         ref = m(low, full)
-    assert hdrnet_ops.last_kernel() == "apply_fwd_rows/vec4"
+    assert hdrnet_ops.last_kernel() == "apply_fwd_seg/vec4"
     torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-5)
 
 
@@ -376,7 +376,7 @@ def test_pyramid_model_fused_matches_composed():
         assert hdrnet_ops.last_kernel() == "apply_fwd_rows/vec4+nnguide+upadd"
         m.fuse_guide = False
         ref = m(low, full)
-        assert hdrnet_ops.last_kernel() == "apply_fwd_rows/vec4"
+        assert hdrnet_ops.last_kernel() == "apply_fwd_seg/vec4"
     torch.testing.assert_close(out, ref, rtol=5e-5, atol=5e-5)
 
 
@@ -429,7 +429,7 @@ def test_curves_model_fused_matches_composed():
         assert hdrnet_ops.last_kernel() == "apply_fwd_io/f32->f32+curvesguide"
         m.fuse_guide = False
         ref = m(low, full)
-        assert hdrnet_ops.last_kernel() == "apply_fwd_rows/vec4"
+        assert hdrnet_ops.last_kernel() == "apply_fwd_seg/vec4"
     torch.testing.assert_close(out, ref, rtol=3e-5, atol=3e-5)
 
 
