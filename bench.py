@@ -124,14 +124,27 @@ def make_sets(dev, nsets, H, W, GH, GW, GD, seed, smooth_guide=False):
     return sets
 
 
+_BOUND = {}
+
+
 def run_steps(lib, sets, dims, stream, n, start=0):
-    H, W, GH, GW, GD = dims
-    ns = len(sets)
+    """n launches through the C-ABI over the rotating buffer sets.  The argument tuples are bound
+    once per buffer ring (no tensor attribute look-ups on the launch path): at 1080p the kernel
+    (12.6 us) is shorter than a naive Python launch loop."""
+    key = (id(sets), dims, stream)
+    calls = _BOUND.get(key)
+    if calls is None:
+        import ctypes
+        H, W, GH, GW, GD = dims
+        c_int, c_vp = ctypes.c_int, ctypes.c_void_p
+        fixed = tuple(c_int(v) for v in (1, H, W, GH, GW, GD, 3, 3, 1)) + (c_vp(stream),)
+        calls = [tuple(c_vp(t.data_ptr()) for t in st) + fixed for st in sets]
+        _BOUND.clear()
+        _BOUND[key] = calls
+    ns = len(calls)
     fn = lib.hdrnet_bilateral_slice_apply_f32
-    for k in range(n):
-        grid, guide, inp, out = sets[(start + k) % ns]
-        rc = fn(grid.data_ptr(), guide.data_ptr(), inp.data_ptr(), out.data_ptr(),
-                1, H, W, GH, GW, GD, 3, 3, 1, stream)
+    for k in range(start, start + n):
+        rc = fn(*calls[k % ns])
         if rc != 0:
             raise RuntimeError(f"hdrnet_bilateral_slice_apply_f32 rc={rc}: {lib.hdrnet_last_error().decode()}")
 
