@@ -461,7 +461,7 @@ int hdrnet_bilateral_slice_apply_grad_f32_ex(const float* grid, const float* gui
   if (!guide || !dout || (Cin > 0 && !input) || ((dguide || dinput) && !grid))
     return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
   ApplyGradArgs a{grid, guide, input, dout, dgrid, dguide, dinput, B, H, W, GH, GW, GD,
-                  Cin, Cout, Cj, has_offset != 0, workspace, workspace_bytes};
+                  Cin, Cout, Cj, has_offset != 0, workspace, workspace_bytes, variant(flags)};
   // dguide / dinput: one fused LDS-staged pass when a specialisation exists.
   const bool pix_fast = family(flags) != HDRNET_KERNEL_GENERIC && (dguide || dinput) &&
                         apply_vjp_rows_supported(a);
@@ -574,7 +574,7 @@ int hdrnet_bilateral_slice_grad_f32_ex(const float* grid, const float* guide, co
   }
   if (!guide || !dout || (dguide && !grid)) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
   SliceGradArgs a{grid, guide, dout, dgrid, dguide, B, H, W, GH, GW, GD, C, workspace,
-                  workspace_bytes};
+                  workspace_bytes, variant(flags)};
   const bool pix_fast =
       family(flags) != HDRNET_KERNEL_GENERIC && dguide && slice_vjp_rows_supported(a);
   if (family(flags) == HDRNET_KERNEL_FAST && dguide && !pix_fast)

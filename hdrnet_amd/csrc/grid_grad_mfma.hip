@@ -319,6 +319,301 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   }
 }
 
+// ---- stage 1, sorted form ----------------------------------------------------------------------
+// The dense 16 x 16 x 4 tile above spends 81 % of its MACs on zeros: of the 16 rows k = (x corner,
+// gz) a pixel has 4 live ones (2 x corners x 2 z taps).  Here the MFMA is the 16-block
+// v_mfma_f32_4x4x1_16B_f32: every block is ONE pixel's outer product
+//     (4 weights: x corner x z tap)  (x)  (4 channels)
+// accumulated into the block's own 4 x 4 registers -- every MAC is live.  A block's accumulator can
+// only serve pixels of ONE z bin (the lower tap's plane zP), so per 64-pixel chunk:
+//   1. bins: 8 ballots give the per-bin counts (SGPRs) and each lane's rank inside its bin;
+//   2. block slots: an MFMA has 4 pixel slots (x 4 channel groups = 16 blocks); with two accumulator
+//      sets there are 8 slots.  The nb non-empty bins get P = 8 / 4 / 2 / 1 slots each (nb <= 1, 2,
+//      4, 8), pixel of rank r goes to part r & (P-1), round r >> log2 P -- a smooth guide (one or two
+//      bins per chunk) is spread over all slots, a noisy one uses a slot per bin;
+//   3. each lane writes its pixel's 4 weights + C channel values to its slot's record area in LDS
+//      ([slot][component][round], so an MFMA lane reads 4 rounds of its operand as one ds_read_b128);
+//      the weight rows are zero-filled first, which is all the padding there is;
+//   4. max-over-slots rounds of MFMAs per set; 5. the two accumulators are flushed into the wave's
+//      row tile [x corner][z plane 0..8][c] with ds_add_f32 (a wave's LDS atomics execute in program
+//      and lane order: deterministic), plane 8 being the sink of the upper tap of plane 7.
+// At the end of a row the row tile is folded, scaled by the two y weights, into the same register
+// tiles as before; stage 2 is unchanged.  Per chunk: ~24 MFMA x 8 cycles + ~100 VALU instead of
+// 16 MFMA x 32 cycles + ~115 VALU.
+constexpr int kRounds = 16;                       // rounds per pass = record capacity of a slot
+constexpr int kRowTileFloats = 2 * 9 * 16;        // [x corner][z plane 0..8][c 16]
+
+template <int CIN, int COUT, bool OFFSET, bool APPLY>
+__global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1_sorted(GGParams p) {
+  constexpr int CJ = APPLY ? CIN + (OFFSET ? 1 : 0) : 1;
+  constexpr int C = COUT * CJ;
+  static_assert(C <= 16, "16 channel columns");
+  constexpr int CQ = (C + 3) / 4;                 // channel groups of 4 (MFMA block columns)
+  constexpr int NCOMP = 4 + 4 * CQ;               // record components: 4 weights + channels
+  constexpr int kSlotFloats = NCOMP * kRounds;    // [component][round]
+  constexpr int kRecFloats = 8 * kSlotFloats;     // 8 slots
+  constexpr int CIN_Q = (APPLY && CIN > 0) ? CIN : 1;
+  constexpr int kBatch = 2;
+  constexpr int kWaveFloats = kRecFloats + kRowTileFloats + 8;  // + slot -> bin table
+  static_assert(kWaveFloats >= kTileFloats, "the final reduction reuses the wave's LDS");
+  __shared__ __attribute__((aligned(16))) float lds[kWaves * kWaveFloats];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  float* rec = lds + wave * kWaveFloats;          // records
+  float* rowt = rec + kRecFloats;                 // row tile
+  int* slotbin = reinterpret_cast<int*>(rowt + kRowTileFloats);
+  {  // zero everything once (stale record values must at least be finite)
+    f32x4* z4 = reinterpret_cast<f32x4*>(rec);
+    for (int e = lane; e < kWaveFloats / 4; e += 64) z4[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const long long task = blockIdx.x;
+  const int nint = p.GW + 1;
+  const int g = (int)(task % nint) - 1;
+  const int yg = (int)((task / nint) % p.nyg);
+  const long long b = task / ((long long)nint * p.nyg);
+  const int x_lo = interval_start(g, p.W, p.scale_x);
+  const int x_hi = interval_start(g + 1, p.W, p.scale_x);
+  const int y_first = yg * p.rg, y_end = min(y_first + p.rg, p.H);
+  const int gy_base = gy_base_of(y_first, p.scale_y, p.GH);
+  const float gd_f = (float)p.GD;
+  const bool fold_lo = g < 0, fold_hi = g >= p.GW - 1;
+  const float gc0 = g + 0.5f, gc1 = g + 1 + 0.5f;
+  auto x_weights = [&](int x, float& w0, float& w1) {
+    const float live = (x < x_hi) ? 1.0f : 0.0f;
+    const float gxf = mul_rn((float)x + 0.5f, p.scale_x);
+    const float wxa = tent_weight(gc0, gxf) * live;
+    const float wxb = tent_weight(gc1, gxf) * live;
+    w0 = fold_lo ? 0.0f : (fold_hi ? wxa + wxb : wxa);
+    w1 = fold_lo ? wxa + wxb : (fold_hi ? 0.0f : wxb);
+  };
+  const int span = x_hi - x_lo;
+  const int nbr = (span + 64 * kBatch - 1) / (64 * kBatch);
+  float w0c[kBatch], w1c[kBatch];
+#pragma unroll
+  for (int cb = 0; cb < kBatch; ++cb) x_weights(x_lo + 64 * cb + lane, w0c[cb], w1c[cb]);
+
+  // MFMA lane roles (v_mfma_f32_4x4x1_16B_f32): block = lane >> 2 = 4 * (pixel slot r) + (channel
+  // group q); A[i = lane & 3] = weight i of the slot's pixel, B[j = lane & 3] = channel 4 q + j;
+  // D register v of lane (block, j) = row i = v, column j.
+  const int mr = lane >> 4, mq = (lane >> 2) & 3, mi = lane & 3;
+  const int mqc = min(mq, CQ - 1);  // surplus channel groups re-read the last one; never flushed
+  // set s: slot 4 s + mr
+  const f32x4* a_rd[2] = {reinterpret_cast<const f32x4*>(rec + (0 + mr) * kSlotFloats + mi * kRounds),
+                          reinterpret_cast<const f32x4*>(rec + (4 + mr) * kSlotFloats + mi * kRounds)};
+  const f32x4* b_rd[2] = {
+      reinterpret_cast<const f32x4*>(rec + (0 + mr) * kSlotFloats + (4 + 4 * mqc + mi) * kRounds),
+      reinterpret_cast<const f32x4*>(rec + (4 + mr) * kSlotFloats + (4 + 4 * mqc + mi) * kRounds)};
+  const bool flusher = mq < CQ && (4 * mq + mi) < C;
+
+  // final-tile lane roles (as the dense kernel: D[k = 4 * sub + r][c = bc])
+  const int sub = lane >> 4, bc = lane & 15;
+  f32x4 acc[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  struct Batch {
+    float g[kBatch], in[kBatch][CIN_Q], d[kBatch][COUT];
+  };
+  const int nrows = (y_end - (y_first + wave) + kWaves - 1) / kWaves;
+  const int nbt = (span > 0 && nrows > 0) ? nrows * nbr : 0;
+  auto load_batch = [&](int t, Batch& bt) {
+    const int r = t / nbr, bi = t - r * nbr;
+    const int y = y_first + wave + r * kWaves;
+    const size_t prow = ((size_t)b * p.H + y) * p.W;
+    const __amdgpu_buffer_rsrc_t grs = row_rsrc(p.guide + prow);
+    const __amdgpu_buffer_rsrc_t irs = row_rsrc((APPLY && CIN > 0) ? p.input + prow * CIN : p.guide);
+    const __amdgpu_buffer_rsrc_t drs = row_rsrc(p.dout + prow * COUT);
+    const int xb = x_lo + bi * 64 * kBatch;
+#pragma unroll
+    for (int cb = 0; cb < kBatch; ++cb) {
+      const unsigned px = (unsigned)min(xb + 64 * cb + lane, x_hi - 1);
+      buf_load<1>(grs, px * 4u, &bt.g[cb]);
+      if constexpr (APPLY && CIN > 0) buf_load<CIN>(irs, px * (4u * CIN), bt.in[cb]);
+      buf_load<COUT>(drs, px * (4u * COUT), bt.d[cb]);
+    }
+  };
+
+  Batch cur, nxt;
+  if (nbt > 0) load_batch(0, cur);
+  for (int t = 0; t < nbt; ++t) {
+    if (t + 1 < nbt) load_batch(t + 1, nxt);
+    const int r = t / nbr, bi = t - r * nbr;
+    const int y = y_first + wave + r * kWaves;
+    const int xb = x_lo + bi * 64 * kBatch;
+#pragma unroll
+    for (int cb = 0; cb < kBatch; ++cb) {
+      const int x0 = xb + 64 * cb;
+      if (x0 < x_hi) {  // wave-uniform
+        float w0 = w0c[cb], w1 = w1c[cb];
+        if (nbr > 1) x_weights(x0 + lane, w0, w1);
+        const bool live = x0 + lane < x_hi;
+        // z taps (:120-125), as in the dense kernel: P = (zP, wP), Q = (zP + 1, wQ); the outermost
+        // half cells are forced to (1, 0).
+        const float gzf = mul_rn(cur.g[cb], gd_f);
+        const float fz = floorf(gzf - 0.5f);
+        const float dza = (fz + 0.5f) - gzf, dzb = (fz + 1.5f) - gzf;
+        float wP = std_max(1.0f - __builtin_amdgcn_sqrtf(fmaf(dza, dza, kSmoothEps)), 0.0f);
+        float wQ = std_max(1.0f - __builtin_amdgcn_sqrtf(fmaf(dzb, dzb, kSmoothEps)), 0.0f);
+        const bool lo = gzf < 0.5f, hi = gzf > gd_f - 0.5f;
+        int zP = min(max((int)__builtin_amdgcn_fmed3f(fz, -2.0f, 9.0f), 0), p.GD - 1);
+        if (lo) zP = 0;
+        if (hi) zP = p.GD - 1;
+        if (lo || hi) { wP = 1.0f; wQ = 0.0f; }
+        const int bin = live ? zP : 8;  // 8: no record
+
+        // 1. per-bin counts (uniform) and this lane's rank inside its bin
+        int cnt[8];
+        int rank = 0;
+        unsigned nm = 0;  // non-empty bins
+#pragma unroll
+        for (int z = 0; z < 8; ++z) {
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(bin == z);
+          cnt[z] = __builtin_popcountll(m);
+          const int rk = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          rank = (bin == z) ? rk : rank;
+          nm |= (cnt[z] > 0 ? 1u : 0u) << z;
+        }
+        // 2. slots: nb non-empty bins x P parts
+        const int nb = __builtin_popcount(nm);
+        const int lgP = nb <= 1 ? 3 : (nb <= 2 ? 2 : (nb <= 4 ? 1 : 0));
+        const int nzidx = __builtin_popcount(nm & ((1u << (bin & 7)) - 1u));
+        const int slot = (nzidx << lgP) + (rank & ((1 << lgP) - 1));
+        const int idx = rank >> lgP;
+        int rounds0 = 0, rounds1 = 0;  // uniform: rounds needed by the slots of set 0 / set 1
+        {
+          int k = 0;
+#pragma unroll
+          for (int z = 0; z < 8; ++z) {
+            const int len = (cnt[z] + (1 << lgP) - 1) >> lgP;
+            const int s0 = k << lgP;  // first slot of this bin (if non-empty)
+            if (cnt[z] > 0) {
+              if (s0 < 4) rounds0 = max(rounds0, len);
+              if (s0 + (1 << lgP) > 4) rounds1 = max(rounds1, len);
+              ++k;
+            }
+          }
+        }
+        // record components: weights a[i = 2 * xcorner + tap], channels V[c]
+        float comp[NCOMP];
+        comp[0] = w0 * wP;
+        comp[1] = w0 * wQ;
+        comp[2] = w1 * wP;
+        comp[3] = w1 * wQ;
+#pragma unroll
+        for (int c = 0; c < 4 * CQ; ++c) comp[4 + c] = 0.0f;
+        if constexpr (APPLY) {
+#pragma unroll
+          for (int i = 0; i < COUT; ++i) {
+#pragma unroll
+            for (int j = 0; j < CJ; ++j)
+              comp[4 + i * CJ + j] = (j < CIN) ? cur.d[cb][i] * cur.in[cb][j < CIN ? j : 0] : cur.d[cb][i];
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < C; ++c) comp[4 + c] = cur.d[cb][c];
+        }
+        if (live) slotbin[slot] = zP;  // every pixel of a slot writes the same value
+
+        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+        const int maxr = max(rounds0, rounds1);
+        for (int pass = 0; pass * kRounds < maxr; ++pass) {  // uniform; one pass unless a slot holds > 16 px
+          // 3. zero the weight rows of all 8 slots, then scatter this pass's records
+          {
+            const int f = lane;  // 8 slots x 4 weight rows x 16 rounds = 128 float4
+            f32x4* zr0 = reinterpret_cast<f32x4*>(rec + (f >> 4) * kSlotFloats + (f & 15) * 4);
+            f32x4* zr1 = reinterpret_cast<f32x4*>(rec + ((f + 64) >> 4) * kSlotFloats + (f & 15) * 4);
+            *zr0 = f32x4{0.f, 0.f, 0.f, 0.f};
+            *zr1 = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          if (live && (idx >> 4) == pass) {
+            float* rp = rec + slot * kSlotFloats + (idx & (kRounds - 1));
+#pragma unroll
+            for (int c = 0; c < 4 + C; ++c) rp[c * kRounds] = comp[c];
+          }
+          wave_lds_order();
+          // 4. rounds of MFMAs, 4 per ds_read_b128 pair; the two sets alternate
+          const int r0n = min(max(rounds0 - pass * kRounds, 0), kRounds);
+          const int r1n = min(max(rounds1 - pass * kRounds, 0), kRounds);
+#pragma unroll
+          for (int u4 = 0; u4 < kRounds / 4; ++u4) {
+            if (4 * u4 < r0n) {  // uniform
+              const f32x4 av = a_rd[0][u4], bv = b_rd[0][u4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[u], bv[u], d0, 0, 0, 0);
+            }
+            if (4 * u4 < r1n) {
+              const f32x4 av = a_rd[1][u4], bv = b_rd[1][u4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[u], bv[u], d1, 0, 0, 0);
+            }
+          }
+          wave_lds_order();
+        }
+        // 5. flush: lane (slot mr, group mq, column mi) adds D[i][mi], i = (xcorner, tap), into
+        //    row tile [xcorner][bin + tap][4 mq + mi]
+        if (flusher) {
+          float* t0 = rowt + slotbin[mr] * 16 + 4 * mq + mi;
+          float* t1 = rowt + slotbin[4 + mr] * 16 + 4 * mq + mi;
+          if (rounds0 > 0) {
+            __hip_atomic_fetch_add(t0, d0[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(t0 + 16, d0[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(t0 + 9 * 16, d0[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(t0 + 9 * 16 + 16, d0[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          }
+          if (rounds1 > 0) {
+            __hip_atomic_fetch_add(t1, d1[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(t1 + 16, d1[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(t1 + 9 * 16, d1[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_add(t1 + 9 * 16 + 16, d1[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          }
+        }
+        wave_lds_order();
+      }
+    }
+    if (bi == nbr - 1) {
+      // end of the row: fold the row tile, scaled by the row's two y weights, into the register
+      // tiles of the (<= 3) grid rows the group touches, and clear it.
+      const float gyf = mul_rn(y + 0.5f, p.scale_y);
+      const int gy0 = floor_to_int(gyf - 0.5f);
+      const float wy0 = tent_weight(gy0 + 0.5f, gyf);
+      const float wy1 = tent_weight(gy0 + 1 + 0.5f, gyf);
+      const int rel0 = clamp_index(gy0, 0, p.GH - 1) - gy_base;
+      const int rel1 = clamp_index(gy0 + 1, 0, p.GH - 1) - gy_base;
+      // lane (sub, bc): rows k = 4 sub + q -> x corner sub >> 1, plane 4 (sub & 1) + q
+      float* tp = rowt + ((sub >> 1) * 9 + 4 * (sub & 1)) * 16 + bc;
+      f32x4 dacc;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        dacc[q] = tp[q * 16];
+        tp[q * 16] = 0.0f;
+      }
+      if (lane < 32) rowt[((lane >> 4) * 9 + 8) * 16 + (lane & 15)] = 0.0f;  // the sink plane
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) {
+        const float sr = (rel0 == rr ? wy0 : 0.0f) + (rel1 == rr ? wy1 : 0.0f);
+        acc[rr] += sr * dacc;
+      }
+      wave_lds_order();
+    }
+    cur = nxt;
+  }
+  __syncthreads();
+  float* red = lds + wave * kWaveFloats;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[(r * 16 + 4 * sub + q) * 16 + bc] = acc[r][q];
+  }
+  __syncthreads();
+  float* dst = p.partial + (size_t)task * kTileFloats;
+  for (int e = threadIdx.x; e < kTileFloats; e += kWaves * 64) {
+    float sum = lds[e];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) sum += lds[w * kWaveFloats + e];
+    dst[e] = sum;
+  }
+}
+
 // Stage 2.  One 256-thread workgroup per grid cell (b, gy, gx, gz): lane (part, c) adds the
 // partial tiles of row groups yg = yg_lo + part, +16, ... for channel c -- for each group the
 // interval g = gx (its x-corner-0 row) and the interval g = gx - 1 (its x-corner-1 row) --
@@ -379,12 +674,16 @@ bool gg_plan(int B, int H, int W, int GH, int GW, int GD, int C, GGPlan* pl) {
 
 template <int CIN, int COUT, bool OFFSET, bool APPLY>
 hipError_t gg_launch(const float* guide, const float* input, const float* dout, float* dgrid, int B,
-                     int H, int W, int GH, int GW, int GD, void* ws, const GGPlan& pl, hipStream_t s) {
+                     int H, int W, int GH, int GW, int GD, void* ws, const GGPlan& pl, hipStream_t s,
+                     bool dense) {
   constexpr int C = APPLY ? COUT * (CIN + (OFFSET ? 1 : 0)) : COUT;
   GGParams p{guide, input, dout, static_cast<float*>(ws), H, W, GH, GW, GD,
              pl.rg, pl.nyg, pl.ntasks, (float)GW / W, (float)GH / H};
   const long long nblocks = pl.ntasks;
-  grid_grad_stage1<CIN, COUT, OFFSET, APPLY><<<(unsigned)nblocks, kWaves * 64, 0, s>>>(p);
+  if (dense)
+    grid_grad_stage1<CIN, COUT, OFFSET, APPLY><<<(unsigned)nblocks, kWaves * 64, 0, s>>>(p);
+  else
+    grid_grad_stage1_sorted<CIN, COUT, OFFSET, APPLY><<<(unsigned)nblocks, kWaves * 64, 0, s>>>(p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const long long ncell = (long long)B * GH * GW * GD;
@@ -420,11 +719,12 @@ bool apply_grid_grad_mfma_supported(const ApplyGradArgs& a) {
 hipError_t launch_apply_grid_grad_mfma(const ApplyGradArgs& a, hipStream_t s, const char** name) {
   GGPlan pl;
   if (!gg_plan(a.B, a.H, a.W, a.GH, a.GW, a.GD, a.Cout * a.Cj, &pl)) return hipErrorInvalidValue;
-  *name = "grid_grad_mfma";
+  const bool dense = a.variant == 1;
+  *name = dense ? "grid_grad_mfma/dense" : "grid_grad_mfma";
 #define HDRNET_CASE(CI, CO, OFF)                                                                  \
   if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF)                                         \
   return gg_launch<CI, CO, OFF, true>(a.guide, a.input, a.dout, a.dgrid, a.B, a.H, a.W, a.GH, a.GW, \
-                                      a.GD, a.workspace, pl, s)
+                                      a.GD, a.workspace, pl, s, dense)
   HDRNET_CASE(3, 3, true);
   HDRNET_CASE(3, 3, false);
   HDRNET_CASE(3, 4, true);
@@ -451,11 +751,12 @@ bool slice_grid_grad_mfma_supported(const SliceGradArgs& a) {
 hipError_t launch_slice_grid_grad_mfma(const SliceGradArgs& a, hipStream_t s, const char** name) {
   GGPlan pl;
   if (!gg_plan(a.B, a.H, a.W, a.GH, a.GW, a.GD, a.C, &pl)) return hipErrorInvalidValue;
-  *name = "grid_grad_mfma";
+  const bool dense = a.variant == 1;
+  *name = dense ? "grid_grad_mfma/dense" : "grid_grad_mfma";
 #define HDRNET_CASE(CC)                                                                            \
   if (a.C == CC)                                                                                   \
   return gg_launch<0, CC, false, false>(a.guide, nullptr, a.dout, a.dgrid, a.B, a.H, a.W, a.GH, a.GW, \
-                                        a.GD, a.workspace, pl, s)
+                                        a.GD, a.workspace, pl, s, dense)
   HDRNET_CASE(1);
   HDRNET_CASE(2);
   HDRNET_CASE(4);

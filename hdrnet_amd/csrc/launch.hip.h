@@ -49,6 +49,7 @@ struct ApplyGradArgs {
   bool has_offset;
   void* workspace;
   size_t workspace_bytes;
+  int variant = 0;  // tools build: 1 = round-1 kernels (dense-tile dgrid), else the product's
 };
 
 // Training side of the point-wise guide network (guide_grad.hip).
@@ -98,6 +99,7 @@ struct SliceGradArgs {
   int B, H, W, GH, GW, GD, C;
   void* workspace;
   size_t workspace_bytes;
+  int variant = 0;  // as ApplyGradArgs
 };
 
 // generic_kernels.hip -- any shape, bit-exact vs the reference CPU op.

@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Times every entry point of the C-ABI on one MI355X (HIP events, rotating buffer sets).
 
-    python tools/op_bench.py [--workload 4k|1080p] [--steps 50] [--json out.json]
+    python tools/op_bench.py [--workload 4k|1080p|hdrp|refbench] [--steps 50] [--json out.json] [--tools]
+
+`hdrp` = BASELINE config #5 per GPU (4000x3000, grid 32x32x8x12; also the uint16 / 32767 -> f32 wire
+format of hdrnet/data_pipeline.py:267-274); `refbench` = the reference's own micro-benchmark shape
+(hdrnet/hdrnet_ops_jax_tf2_test.py:56-65: batch 4, guide 4 x 1024 x 768 (h x w), grid 16 x 12 x 8 (gh x gw x gd), 2 channels, BilateralSlice,
+10 burn-in + 100 timed iterations there).  --tools loads the tools build and adds the round-1
+kernels (variant 1 of the gradient entry points: dense-tile dgrid) for A/B.
 
 Reports per-launch microseconds and algorithmic GB/s (SURVEY.md section 8d byte counts):
   apply fwd   4*[HW(1+Cin+Cout) + grid]
@@ -46,9 +52,13 @@ def main():
     ap.add_argument("--workload", default="4k")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--tools", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    lib = _lib.load()
+    lib = _lib.load_tools() if args.tools else _lib.load()
+    lib.hdrnet_enable_kernel_names(1)
+    if args.workload == "refbench":
+        return refbench(lib, dev, args)
     H, W, GH, GW, GD, desc = WORKLOADS[args.workload]
     Cin, Cout, C = 3, 3, 12
     npx = H * W
@@ -129,13 +139,24 @@ def main():
         chk(lib.hdrnet_resize_bilinear_f32(S[k % nsets]["inp"].data_ptr(), half[k % nsets].data_ptr(),
                                            1, H, W, H // 2, W // 2, 3, stream))
 
-    def apply_bwd(k, dg=True, dgu=True, di=True):
+    def apply_bwd(k, dg=True, dgu=True, di=True, variant=0):
         s = S[k % nsets]
-        chk(lib.hdrnet_bilateral_slice_apply_grad_f32(
+        chk(lib.hdrnet_bilateral_slice_apply_grad_f32_ex(
             s["grid"].data_ptr(), s["guide"].data_ptr(), s["inp"].data_ptr(), s["dout"].data_ptr(),
             s["dgrid"].data_ptr() if dg else None, s["dguide"].data_ptr() if dgu else None,
             s["dinput"].data_ptr() if di else None, 1, H, W, GH, GW, GD, Cin, Cout, 1,
-            ws.data_ptr(), wsb, stream))
+            ws.data_ptr(), wsb, _lib.KERNEL_AUTO | (variant << 8), stream))
+
+    u16 = None
+    if args.workload == "hdrp":
+        u16 = [torch.randint(0, 32768, (1, H, W, 3), device=dev, dtype=torch.int32).to(torch.uint16)
+               for _ in range(nsets)]
+
+    def apply_io_u16(k):
+        s = S[k % nsets]
+        chk(lib.hdrnet_bilateral_slice_apply_io(
+            s["grid"].data_ptr(), s["guide"].data_ptr(), u16[k % nsets].data_ptr(), s["out"].data_ptr(),
+            1, H, W, GH, GW, GD, 3, 3, 1, 2, 32767.0, 0, None, None, 0, None, stream))
 
     def slice_fwd(k):
         s, t = S[k % nsets], sl[k % 2]
@@ -163,6 +184,8 @@ def main():
 
     print(f"{desc}; {nsets} rotating sets; workspace apply-grad {wsb / 1e6:.1f} MB")
     run("apply fwd", apply_fwd, 4 * npx * (1 + Cin + Cout) + gridb)
+    if u16 is not None:
+        run("u16 / 32767 + guide map -> apply -> f32", apply_io_u16, npx * (4 + 6 + 12) + gridb)
     run("guide-NN(16) + apply fwd fused", apply_fwd_nnguide, 4 * npx * (Cin + Cout) + gridb)
     run("u8 -> guide-NN + apply -> u8", apply_io_u8, npx * 6 + gridb)
     run("u8 + guide map -> apply -> u8", lambda k: apply_io_u8(k, nn=False), npx * 10 + gridb)
@@ -175,10 +198,45 @@ def main():
     run("apply bwd (all three)", apply_bwd, 4 * npx * (1 + Cin + Cout) + 4 * npx * (1 + Cin) + 2 * gridb)
     run("apply bwd dguide+dinput", lambda k: apply_bwd(k, dg=False), 4 * npx * (1 + Cin + Cout) + 4 * npx * (1 + Cin) + gridb)
     run("apply bwd dgrid only", lambda k: apply_bwd(k, dgu=False, di=False), 4 * npx * (1 + Cin + Cout) + gridb)
+    if args.tools:
+        run("apply bwd dgrid only (round-1 dense tile)", lambda k: apply_bwd(k, dgu=False, di=False, variant=1),
+            4 * npx * (1 + Cin + Cout) + gridb)
     run("slice fwd", slice_fwd, 4 * npx * (1 + C) + gridb)
     run("slice bwd (both)", slice_bwd, 4 * npx * (1 + C) + 4 * npx + 2 * gridb)
     if args.json:
         json.dump(dict(workload=desc, rows=rows), open(args.json, "w"), indent=1)
+
+
+def refbench(lib, dev, args):
+    """BilateralSlice at the reference's micro-benchmark shape, its iteration counts."""
+    B, H, W, GH, GW, GD, C = 4, 1024, 768, 16, 12, 8, 2  # guide (4, 1024, 768), grid (4, 16, 12, 8, 2)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    nsets = 16  # 4 * 768 * 1024 * (1 + 2) * 4 B = 37.7 MB per set
+    S = [dict(grid=torch.rand((B, GH, GW, GD, C), device=dev, generator=gen),
+              guide=torch.rand((B, H, W), device=dev, generator=gen),
+              out=torch.empty((B, H, W, C), device=dev)) for _ in range(nsets)]
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def slice_fwd(k):
+        s = S[k % nsets]
+        rc = lib.hdrnet_bilateral_slice_f32(s["grid"].data_ptr(), s["guide"].data_ptr(), s["out"].data_ptr(),
+                                            B, H, W, GH, GW, GD, C, stream)
+        if rc:
+            raise RuntimeError(lib.hdrnet_last_error().decode())
+
+    slice_fwd(0)
+    torch.cuda.synchronize()
+    kern = lib.hdrnet_last_kernel().decode()
+    for k in range(10):  # the reference's burn-in
+        slice_fwd(k)
+    med, mn = timeit(slice_fwd, 100, rounds=5)
+    nbytes = 4 * B * (H * W * (1 + C) + GH * GW * GD * C)
+    print(f"BilateralSlice fwd, reference micro-benchmark shape (batch {B}, {W}x{H}, grid {GW}x{GH}x{GD}x{C}); "
+          f"{nsets} rotating sets\n{'slice fwd':28s} {kern:40s} {med:8.2f} us (min {mn:7.2f})  {nbytes / 1e6:7.1f} MB  "
+          f"{nbytes / med / 1e3:7.1f} GB/s  {nbytes / med / 1e3 / 80:5.1f}% of 8 TB/s   {B * H * W / med:9.0f} MP/s")
+    if args.json:
+        json.dump(dict(workload="refbench", rows=[dict(op="slice fwd", kernel=kern, us=round(med, 2), us_min=round(mn, 2),
+                                                       GBps=round(nbytes / med / 1e3, 1))]), open(args.json, "w"), indent=1)
 
 
 if __name__ == "__main__":
