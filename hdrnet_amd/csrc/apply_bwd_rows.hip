@@ -28,38 +28,6 @@ namespace {
 
 using namespace rows;
 
-// Gather the four vectors once, accumulate with two weight sets.
-template <int C, bool FIRST, bool WA, bool WB>
-__device__ __forceinline__ void accum_vec2(CoefVec<C>& ca, CoefVec<C>& cb,
-                                           const float* __restrict__ colY, int off, float wa,
-                                           float wb) {
-  const f32x2 wa2 = {wa, wa}, wb2 = {wb, wb};
-  const char* base = reinterpret_cast<const char*>(colY) + off;
-  if constexpr (C % 4 == 0) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(base);
-#pragma unroll
-    for (int q = 0; q < C / 4; ++q) {
-      const f32x4 t = p[q];
-      if constexpr (WA) {
-        ca.v[2 * q + 0] = FIRST ? wa2 * t.xy : __builtin_elementwise_fma(wa2, t.xy, ca.v[2 * q + 0]);
-        ca.v[2 * q + 1] = FIRST ? wa2 * t.zw : __builtin_elementwise_fma(wa2, t.zw, ca.v[2 * q + 1]);
-      }
-      if constexpr (WB) {
-        cb.v[2 * q + 0] = FIRST ? wb2 * t.xy : __builtin_elementwise_fma(wb2, t.xy, cb.v[2 * q + 0]);
-        cb.v[2 * q + 1] = FIRST ? wb2 * t.zw : __builtin_elementwise_fma(wb2, t.zw, cb.v[2 * q + 1]);
-      }
-    }
-  } else {
-    const float* p = reinterpret_cast<const float*>(base);
-#pragma unroll
-    for (int q = 0; q < C; ++q) {
-      const float t = p[q];
-      if constexpr (WA) ca.v[q >> 1][q & 1] = FIRST ? wa * t : fmaf(wa, t, ca.v[q >> 1][q & 1]);
-      if constexpr (WB) cb.v[q >> 1][q & 1] = FIRST ? wb * t : fmaf(wb, t, cb.v[q >> 1][q & 1]);
-    }
-  }
-}
-
 // One pixel.  APPLY: dout has COUT channels, grid channel c = i*CJ + j.
 // !APPLY (BilateralSlice): CIN = 0, CJ = 1, COUT = C, dguide = sum_c dout_c dA_c.
 template <int CIN, int COUT, bool OFFSET, bool WANT_GUIDE, bool WANT_INPUT>
@@ -73,31 +41,8 @@ __device__ __forceinline__ void vjp_pixel(const RowCtx& r, float xf, float g,
   // GD * SmoothedLerpWeightGrad(gz + .5, gzf)   (bilateral_slice_apply.cc:186-187)
   const float dw0 = r.gd_f * ((t.sz0 > 1.0f) ? 0.0f : t.dz0 / t.sz0);
   const float dw1 = r.gd_f * ((t.sz1 > 1.0f) ? 0.0f : t.dz1 / t.sz1);
-  CoefVec<C> A, dA;
-  accum_vec2<C, true, WANT_INPUT, WANT_GUIDE>(A, dA, r.colY, t.a00, t.wx0 * t.wz0, t.wx0 * dw0);
-  accum_vec2<C, false, WANT_INPUT, WANT_GUIDE>(A, dA, r.colY, t.a01, t.wx0 * t.wz1, t.wx0 * dw1);
-  accum_vec2<C, false, WANT_INPUT, WANT_GUIDE>(A, dA, r.colY, t.a10, t.wx1 * t.wz0, t.wx1 * dw0);
-  accum_vec2<C, false, WANT_INPUT, WANT_GUIDE>(A, dA, r.colY, t.a11, t.wx1 * t.wz1, t.wx1 * dw1);
-  if constexpr (WANT_GUIDE) {
-    float vjp = 0.0f;
-#pragma unroll
-    for (int i = 0; i < COUT; ++i) {
-      float gv = OFFSET ? dA.get(i * CJ + CIN) : 0.0f;
-#pragma unroll
-      for (int j = 0; j < CIN; ++j) gv = fmaf(dA.get(i * CJ + j), in[j], gv);
-      vjp = fmaf(gv, d[i], vjp);
-    }
-    dguide = vjp;
-  }
-  if constexpr (WANT_INPUT) {
-#pragma unroll
-    for (int j = 0; j < CIN; ++j) {
-      float v = 0.0f;
-#pragma unroll
-      for (int i = 0; i < COUT; ++i) v = fmaf(A.get(i * CJ + j), d[i], v);
-      dinput[j] = v;
-    }
-  }
+  vjp_blend<CIN, COUT, OFFSET, WANT_GUIDE, WANT_INPUT>(r.colY, t.a00, t.a01, t.a10, t.a11, t.wx0, t.wx1,
+                                                       t.wz0, t.wz1, dw0, dw1, in, d, dguide, dinput);
 }
 
 // Same geometry as apply_fwd_rows_vec4: a workgroup owns a segment of one image row, a

@@ -462,6 +462,14 @@ int hdrnet_bilateral_slice_apply_grad_f32_ex(const float* grid, const float* gui
     return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
   ApplyGradArgs a{grid, guide, input, dout, dgrid, dguide, dinput, B, H, W, GH, GW, GD,
                   Cin, Cout, Cj, has_offset != 0, workspace, workspace_bytes, variant(flags)};
+  // All three gradients from ONE pass over the pixels when dgrid and a per-pixel VJP are both
+  // wanted (the training case) and the shape has a fused specialisation.
+  if (family(flags) != HDRNET_KERNEL_GENERIC && a.variant != 3 && apply_bwd_fused_supported(a)) {
+    const char* name = "";
+    const int rc = check_launch(launch_apply_bwd_fused(a, s, &name), "BilateralSliceApplyGrad");
+    if (rc == HDRNET_OK) set_kernel(name);
+    return rc;
+  }
   // dguide / dinput: one fused LDS-staged pass when a specialisation exists.
   const bool pix_fast = family(flags) != HDRNET_KERNEL_GENERIC && (dguide || dinput) &&
                         apply_vjp_rows_supported(a);
@@ -575,6 +583,12 @@ int hdrnet_bilateral_slice_grad_f32_ex(const float* grid, const float* guide, co
   if (!guide || !dout || (dguide && !grid)) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
   SliceGradArgs a{grid, guide, dout, dgrid, dguide, B, H, W, GH, GW, GD, C, workspace,
                   workspace_bytes, variant(flags)};
+  if (family(flags) != HDRNET_KERNEL_GENERIC && a.variant != 3 && slice_bwd_fused_supported(a)) {
+    const char* name = "";
+    const int rc = check_launch(launch_slice_bwd_fused(a, s, &name), "BilateralSliceGrad");
+    if (rc == HDRNET_OK) set_kernel(name);
+    return rc;
+  }
   const bool pix_fast =
       family(flags) != HDRNET_KERNEL_GENERIC && dguide && slice_vjp_rows_supported(a);
   if (family(flags) == HDRNET_KERNEL_FAST && dguide && !pix_fast)

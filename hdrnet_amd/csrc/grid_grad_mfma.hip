@@ -22,6 +22,13 @@
 // mfma_valu_overlap.hip: MFMA-only 483 us + VALU-only 469 us -> 919 us interleaved), and the
 // tile is 19 % dense (4 live weights x 12 channels of 16 x 16).  Stage 1 is therefore bound by
 // FP32 issue: 16 MFMA (512 cycles) + ~115 VALU per 64-pixel chunk.
+// The sparse alternative -- a wave-level counting sort of every 64-pixel chunk by z bin, then
+// v_mfma_f32_4x4x1_16B_f32 blocks of (4 weights) x (4 channels) with every MAC live -- was built
+// and measured in round 2 (git history: "dgrid: sorted 4x4x1-MFMA stage 1"; profiles/r02/
+// exp6, exp7): bit-correct, MFMA busy cycles 70.8 M -> 27.8 M per launch as planned, but the
+// sort / slot bookkeeping costs 260 VALU + 267 SALU per chunk (dense: 168 + 82) and LDS float
+// atomics (ds_add_f32) retire ~1 lane per 2.7 cycles: 389 us vs 80 us.  Even with the flush
+// rewritten without atomics the issue count equals the dense kernel's, so it was dropped.
 //
 // Stage 1 (grid_grad_stage1): one workgroup of 4 waves owns one x-interval (all pixels with
 //   gx0 == g, g = -1 .. GW-1) of RG consecutive rows; its waves take alternate rows.  Per row a
@@ -43,7 +50,22 @@
 namespace hdrnet_amd {
 namespace {
 
+using rows::vjp_blend;
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// SPLIT operands: an f32 value x travels as ONE dword {hi, lo} of two bf16 with
+// hi = bf16(x) (round to nearest even), lo = bf16(x - hi):  x = hi + lo to 2^-17 relative.
+__device__ __forceinline__ float split_pack(float x) {
+  const f32x2 xx = {x, x};
+  const unsigned tb = __builtin_bit_cast(unsigned, __builtin_convertvector(xx, bf16x2));
+  const float hi = __uint_as_float(tb << 16);
+  const f32x2 xr = {x, x - hi};
+  return __uint_as_float(__builtin_bit_cast(unsigned, __builtin_convertvector(xr, bf16x2)));
+}
 
 constexpr int kWaves = 4;      // waves per workgroup; they share ONE task and split its rows
 constexpr int kTileFloats = 3 * 16 * 16;  // partial tile: [rel 3][k 16][c 16]
@@ -52,6 +74,9 @@ struct GGParams {
   const float* guide;
   const float* input;  // null for slice
   const float* dout;
+  const float* grid;   // fused backward only (WG || WI)
+  float* dguide;       // fused backward: [B][H][W] or null
+  float* dinput;       // fused backward: [B][H][W][CIN] or null
   float* partial;  // [B][nyg][GW + 1][3][16][16]
   int H, W, GH, GW, GD;
   int rg, nyg;
@@ -126,20 +151,42 @@ __device__ __forceinline__ void buf_load(__amdgpu_buffer_rsrc_t rs, unsigned byt
 
 constexpr int kTStride = 68;  // floats per operand row: 64 pixels + 4 (16-B aligned, 4-bank skew)
 
-template <int CIN, int COUT, bool OFFSET, bool APPLY>
+// SPLIT = true: the contraction runs on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16, 16x the
+// f32-input rate) with every f32 operand split into two bf16 terms.  A K-slot pair is one pixel's
+// {hi, lo}; with A2 = [a_hi, a_lo] and the V dword [v_hi, v_lo] re-arranged as B1 = [v_hi, v_hi],
+// B2 = [v_lo, 0], two MFMAs give a_hi v_hi + a_lo v_hi + a_hi v_lo -- every product term except
+// a_lo v_lo (<= 2^-16 relative), accumulated in f32.  Per 64-pixel chunk: 8 MFMA x ~17 cycles
+// instead of 16 x 32, for 4 extra VALU per operand value (16 values per pixel).  The LDS traffic
+// is unchanged: a record is still one dword per (row, pixel).
+//
+// WG / WI (FUSED BACKWARD): the same pass also produces the per-pixel VJPs -- dguide (WG) and dinput
+// (WI), bilateral_slice_apply.cc:140-259 -- from the pixel data it has loaded anyway (guide, input,
+// dout are read ONCE for all three gradients: 28 B/px in, 16 B/px out, instead of two kernels reading
+// 28 B/px each).  In this geometry every pixel of the workgroup has gx0 == g, so the forward's
+// y-pre-lerped coefficient image shrinks to the two grid columns (g, g + 1) (clamped), padded in z
+// like apply_fwd_seg.hip: 2 x (GD + 2) x C floats per wave, re-blended by the wave at the start of
+// each row from grid rows it prefetched with the row's first pixel batch.  The z tent and its
+// derivative share one v_sqrt_f32 per tap with the dgrid weights.
+template <int CIN, int COUT, bool OFFSET, bool APPLY, bool SPLIT, bool WG = false, bool WI = false>
 __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   constexpr int CJ = APPLY ? CIN + (OFFSET ? 1 : 0) : 1;
   constexpr int C = COUT * CJ;
   static_assert(C <= 16, "one 16-column MFMA tile");
+  constexpr bool FUSED = WG || WI;
+  static_assert(!FUSED || C % 4 == 0, "fused backward: float4 coefficient vectors");
+  static_assert(!WI || (APPLY && CIN > 0), "dinput needs an input");
+  constexpr int CB = C * (int)sizeof(float);
   constexpr int CIN_Q = (APPLY && CIN > 0) ? CIN : 1;
   constexpr int kBatch = 2;  // chunks of 64 pixels loaded ahead (4: 132 VGPRs, 3 waves / SIMD, 6 % slower)
-  constexpr int kSlab = (16 + C) * kTStride;  // floats per wave: A^T [16][68] then V^T [C][68]
+  constexpr int kImg = FUSED ? 2 * 10 * C : 0;  // [x corner][plane 0 .. GD + 1 (GD <= 8)][c]
+  constexpr int kSlab = (16 + C) * kTStride + kImg;  // floats per wave: A^T [16][68], V^T [C][68], image
   static_assert(kSlab >= kTileFloats, "the final reduction reuses the slabs");
   __shared__ __attribute__((aligned(16))) float lds[kWaves * kSlab];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   float* at = lds + wave * kSlab;    // A^T[k][px]
   float* vt = at + 16 * kTStride;    // V^T[c][px]
+  float* img = vt + C * kTStride;    // fused: coefficient image of the current row
   {  // zero the A slab once; afterwards every chunk restores the entries it wrote
     f32x4* az = reinterpret_cast<f32x4*>(at);
 #pragma unroll
@@ -162,19 +209,33 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   // Two x weights of pixel x; columns that clamp onto each other (g = -1: corner 0 -> column 0
   // == corner 1; g = GW-1: corner 1 -> column GW-1 == corner 0) are folded into ONE A row, so
   // stage 2 never sees a column twice.  Pixels past the interval get zero weights.
-  auto x_weights = [&](int x, float& w0, float& w1) {
+  auto x_weights = [&](int x, float& w0, float& w1, float& wa, float& wb) {
     const float live = (x < x_hi) ? 1.0f : 0.0f;
     const float gxf = mul_rn((float)x + 0.5f, p.scale_x);
     const float wxa = tent_weight(gc0, gxf) * live;
     const float wxb = tent_weight(gc1, gxf) * live;
+    wa = wxa;  // the forward's two x weights (fused VJPs gather from the clamped columns g, g + 1)
+    wb = wxb;
     w0 = fold_lo ? 0.0f : (fold_hi ? wxa + wxb : wxa);
     w1 = fold_lo ? wxa + wxb : (fold_hi ? 0.0f : wxb);
   };
   const int span = x_hi - x_lo;
   const int nbr = (span + 64 * kBatch - 1) / (64 * kBatch);  // batches per row
   float w0c[kBatch], w1c[kBatch];  // the common case nbr == 1: one batch per row, same x every row
+  float wac[kBatch], wbc[kBatch];
 #pragma unroll
-  for (int cb = 0; cb < kBatch; ++cb) x_weights(x_lo + 64 * cb + lane, w0c[cb], w1c[cb]);
+  for (int cb = 0; cb < kBatch; ++cb) x_weights(x_lo + 64 * cb + lane, w0c[cb], w1c[cb], wac[cb], wbc[cb]);
+
+  // fused: this lane's element of the row's coefficient image (2 columns x GD planes x C / 4 float4)
+  constexpr int C4 = C / 4 > 0 ? C / 4 : 1;
+  const int nst = 2 * p.GD * C4;
+  const int st_col = lane / (p.GD * C4), st_rem = lane - st_col * (p.GD * C4);  // lane < nst
+  const int st_src = (min(max(g + st_col, 0), p.GW - 1) * p.GD * C4 + st_rem);  // float4 index in a grid row
+  const int st_z = st_rem / C4;
+  const int st_dst = (st_col * (p.GD + 2) + st_z + 1) * C4 + (st_rem - st_z * C4);
+  const float* grid_b = FUSED ? p.grid + (size_t)b * p.GH * p.GW * p.GD * C : nullptr;
+  const int colb = (p.GD + 2) * CB;
+  const float zhi = (float)(p.GD - 1);
 
   // MFMA lane roles (v_mfma_f32_16x16x4_f32): A[k = lane & 15][kk = lane >> 4],
   // B[kk = lane >> 4][c = lane & 15], D[k = 4 * (lane >> 4) + r][c = lane & 15] in register r.
@@ -188,6 +249,7 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
 
   struct Batch {
     float g[kBatch], in[kBatch][CIN_Q], d[kBatch][COUT];
+    f32x4 sa, sb;  // fused, first batch of a row: this lane's element of the two grid rows to blend
   };
   const int nrows = (y_end - (y_first + wave) + kWaves - 1) / kWaves;
   const int nbt = (span > 0 && nrows > 0) ? nrows * nbr : 0;
@@ -208,6 +270,15 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
       if constexpr (APPLY && CIN > 0) buf_load<CIN>(irs, px * (4u * CIN), bt.in[cb]);
       buf_load<COUT>(drs, px * (4u * COUT), bt.d[cb]);
     }
+    if constexpr (FUSED) {
+      if (bi == 0 && lane < nst) {  // the two grid rows image row y blends (L2-resident)
+        const float gyf = mul_rn(y + 0.5f, p.scale_y);
+        const int gy0 = floor_to_int(gyf - 0.5f);
+        const int gy0c = clamp_index(gy0, 0, p.GH - 1), gy1c = clamp_index(gy0 + 1, 0, p.GH - 1);
+        bt.sa = reinterpret_cast<const f32x4*>(grid_b + (size_t)gy0c * p.GW * p.GD * C)[st_src];
+        bt.sb = reinterpret_cast<const f32x4*>(grid_b + (size_t)gy1c * p.GW * p.GD * C)[st_src];
+      }
+    }
   };
 
   Batch cur, nxt;
@@ -218,12 +289,28 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
     const int r = t / nbr, bi = t - r * nbr;
     const int y = y_first + wave + r * kWaves;
     const int xb = x_lo + bi * 64 * kBatch;
+    if constexpr (FUSED) {
+      if (bi == 0) {  // new row: blend its coefficient image (wy folded in, planes padded in z)
+        const float gyf = mul_rn(y + 0.5f, p.scale_y);
+        const int gy0 = floor_to_int(gyf - 0.5f);
+        const float wy0 = tent_weight(gy0 + 0.5f, gyf), wy1 = tent_weight(gy0 + 1 + 0.5f, gyf);
+        if (lane < nst) {
+          const f32x4 v = wy0 * cur.sa + wy1 * cur.sb;
+          f32x4* d4 = reinterpret_cast<f32x4*>(img);
+          d4[st_dst] = v;
+          if (st_z == 0) d4[st_dst - C4] = v;
+          if (st_z == p.GD - 1) d4[st_dst + C4] = v;
+        }
+        wave_lds_order();
+      }
+    }
+    const size_t prow_out = ((size_t)b * p.H + y) * p.W;  // wave-uniform
 #pragma unroll
     for (int cb = 0; cb < kBatch; ++cb) {
       const int x0 = xb + 64 * cb;
       if (x0 < x_hi) {  // wave-uniform
-        float w0 = w0c[cb], w1 = w1c[cb];
-        if (nbr > 1) x_weights(x0 + lane, w0, w1);  // wave-uniform; only intervals wider than 256 px
+        float w0 = w0c[cb], w1 = w1c[cb], wa = wac[cb], wb = wbc[cb];
+        if (nbr > 1) x_weights(x0 + lane, w0, w1, wa, wb);  // wave-uniform; only intervals wider than 256 px
         // z: only the two corners around gzf carry weight (:121); the outermost half cells are
         // forced to 1 (:122-125).  Two v_sqrt_f32 per pixel (1 ulp; argument >= 1e-8, no
         // denormals; a weight moves by <= 6e-8, far below the summation noise of a 30 000-term
@@ -232,8 +319,33 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
         const float gzf = mul_rn(cur.g[cb], gd_f);  // gzf = guide * GD  (:120)
         const float fz = floorf(gzf - 0.5f);
         const float dza = (fz + 0.5f) - gzf, dzb = (fz + 1.5f) - gzf;
-        float wP = std_max(1.0f - __builtin_amdgcn_sqrtf(fmaf(dza, dza, kSmoothEps)), 0.0f);
-        float wQ = std_max(1.0f - __builtin_amdgcn_sqrtf(fmaf(dzb, dzb, kSmoothEps)), 0.0f);
+        // v_sqrt_f32 (1 ulp; argument >= 1e-8, no denormals).  Both taps lie within one cell of the
+        // sample by construction (dza in (-1, 0], dzb in (0, 1]), so dz^2 + eps rounds to <= 1.0f and
+        // the reference's `abs_dx > 1 ? 0 : dx / abs_dx` (numerics.h:116-126) never takes its zero
+        // branch here: the derivative is dz / s, formed with v_rcp_f32.
+        const float sza = __builtin_amdgcn_sqrtf(fmaf(dza, dza, kSmoothEps));
+        const float szb = __builtin_amdgcn_sqrtf(fmaf(dzb, dzb, kSmoothEps));
+        if constexpr (FUSED) {
+          // per-pixel VJPs from the row's coefficient image: vectors at (x corner, plane iz + 1 + tap)
+          const int iz = (int)__builtin_amdgcn_fmed3f(fz, -1.0f, zhi);
+          const int a0 = (iz + 1) * CB;
+          const float dw0 = gd_f * (dza * __builtin_amdgcn_rcpf(sza));  // GD * SmoothedLerpWeightGrad (:186-187)
+          const float dw1 = gd_f * (dzb * __builtin_amdgcn_rcpf(szb));
+          float dgv = 0.0f, div[CIN_Q];
+          vjp_blend<APPLY ? CIN : 0, COUT, APPLY ? OFFSET : true, WG, WI>(
+              img, a0, a0 + CB, a0 + colb, a0 + colb + CB, wa, wb, 1.0f - sza, 1.0f - szb, dw0, dw1,
+              cur.in[cb], cur.d[cb], dgv, div);
+          if (x0 + lane < x_hi) {
+            const unsigned px = (unsigned)(x0 + lane);
+            if constexpr (WG) p.dguide[prow_out + px] = dgv;
+            if constexpr (WI) {
+#pragma unroll
+              for (int j = 0; j < CIN; ++j) p.dinput[(prow_out + px) * CIN + j] = div[j];
+            }
+          }
+        }
+        float wP = std_max(1.0f - sza, 0.0f);
+        float wQ = std_max(1.0f - szb, 0.0f);
         const bool lo = gzf < 0.5f, hi = gzf > gd_f - 0.5f;
         int zP = min(max((int)__builtin_amdgcn_fmed3f(fz, -2.0f, 9.0f), 0), 7), zQ = min(zP + 1, 7);
         if (lo) { zP = 0; zQ = 1; }
@@ -241,21 +353,23 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
         if (lo || hi) { wP = 1.0f; wQ = 0.0f; }
         float* aP = at + zP * kTStride + lane;
         float* aQ = at + zQ * kTStride + lane;
-        aQ[0] = w0 * wQ;
-        aQ[8 * kTStride] = w1 * wQ;
-        aP[0] = w0 * wP;
-        aP[8 * kTStride] = w1 * wP;
+        auto enc = [](float v) { return SPLIT ? split_pack(v) : v; };
+        aQ[0] = enc(w0 * wQ);
+        aQ[8 * kTStride] = enc(w1 * wQ);
+        aP[0] = enc(w0 * wP);
+        aP[8 * kTStride] = enc(w1 * wP);
         // V^T[c][px]: dout x [in; 1] (slice: dout)
         if constexpr (APPLY) {
 #pragma unroll
           for (int i = 0; i < COUT; ++i) {
 #pragma unroll
             for (int j = 0; j < CJ; ++j)
-              vt[(i * CJ + j) * kTStride + lane] = (j < CIN) ? cur.d[cb][i] * cur.in[cb][j < CIN ? j : 0] : cur.d[cb][i];
+              vt[(i * CJ + j) * kTStride + lane] =
+                  enc((j < CIN) ? cur.d[cb][i] * cur.in[cb][j < CIN ? j : 0] : cur.d[cb][i]);
           }
         } else {
 #pragma unroll
-          for (int c = 0; c < C; ++c) vt[c * kTStride + lane] = cur.d[cb][c];
+          for (int c = 0; c < C; ++c) vt[c * kTStride + lane] = enc(cur.d[cb][c]);
         }
         wave_lds_order();
         // D[k, c] += sum_px A[k, px] * V[px, c]; two accumulators break the dependent-issue chain.
@@ -265,12 +379,29 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
           av[q] = a_rd[q];
           bv[q] = v_rd[q];
         }
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][0], bv[q][0], dacc, 0, 0, 0);
-          dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][1], bv[q][1], dacc2, 0, 0, 0);
-          dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][2], bv[q][2], dacc, 0, 0, 0);
-          dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][3], bv[q][3], dacc2, 0, 0, 0);
+          for (int q = 0; q < 4; ++q) {
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            const u32x4_t vb = __builtin_bit_cast(u32x4_t, bv[q]);
+            u32x4_t b1, b2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              b1[e] = __builtin_amdgcn_perm(vb[e], vb[e], 0x01000100u);  // [v_hi, v_hi]
+              b2[e] = vb[e] >> 16;                                        // [v_lo, 0]
+            }
+            const bf16x8 a8 = __builtin_bit_cast(bf16x8, av[q]);
+            dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, b1), dacc, 0, 0, 0);
+            dacc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, b2), dacc2, 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][0], bv[q][0], dacc, 0, 0, 0);
+            dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][1], bv[q][1], dacc2, 0, 0, 0);
+            dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][2], bv[q][2], dacc, 0, 0, 0);
+            dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][3], bv[q][3], dacc2, 0, 0, 0);
+          }
         }
         wave_lds_order();
         aQ[0] = 0.0f;
@@ -315,301 +446,6 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
     float sum = lds[e];
 #pragma unroll
     for (int w = 1; w < kWaves; ++w) sum += lds[w * kSlab + e];
-    dst[e] = sum;
-  }
-}
-
-// ---- stage 1, sorted form ----------------------------------------------------------------------
-// The dense 16 x 16 x 4 tile above spends 81 % of its MACs on zeros: of the 16 rows k = (x corner,
-// gz) a pixel has 4 live ones (2 x corners x 2 z taps).  Here the MFMA is the 16-block
-// v_mfma_f32_4x4x1_16B_f32: every block is ONE pixel's outer product
-//     (4 weights: x corner x z tap)  (x)  (4 channels)
-// accumulated into the block's own 4 x 4 registers -- every MAC is live.  A block's accumulator can
-// only serve pixels of ONE z bin (the lower tap's plane zP), so per 64-pixel chunk:
-//   1. bins: 8 ballots give the per-bin counts (SGPRs) and each lane's rank inside its bin;
-//   2. block slots: an MFMA has 4 pixel slots (x 4 channel groups = 16 blocks); with two accumulator
-//      sets there are 8 slots.  The nb non-empty bins get P = 8 / 4 / 2 / 1 slots each (nb <= 1, 2,
-//      4, 8), pixel of rank r goes to part r & (P-1), round r >> log2 P -- a smooth guide (one or two
-//      bins per chunk) is spread over all slots, a noisy one uses a slot per bin;
-//   3. each lane writes its pixel's 4 weights + C channel values to its slot's record area in LDS
-//      ([slot][component][round], so an MFMA lane reads 4 rounds of its operand as one ds_read_b128);
-//      the weight rows are zero-filled first, which is all the padding there is;
-//   4. max-over-slots rounds of MFMAs per set; 5. the two accumulators are flushed into the wave's
-//      row tile [x corner][z plane 0..8][c] with ds_add_f32 (a wave's LDS atomics execute in program
-//      and lane order: deterministic), plane 8 being the sink of the upper tap of plane 7.
-// At the end of a row the row tile is folded, scaled by the two y weights, into the same register
-// tiles as before; stage 2 is unchanged.  Per chunk: ~24 MFMA x 8 cycles + ~100 VALU instead of
-// 16 MFMA x 32 cycles + ~115 VALU.
-constexpr int kRounds = 16;                       // rounds per pass = record capacity of a slot
-constexpr int kRowTileFloats = 2 * 9 * 16;        // [x corner][z plane 0..8][c 16]
-
-template <int CIN, int COUT, bool OFFSET, bool APPLY>
-__global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1_sorted(GGParams p) {
-  constexpr int CJ = APPLY ? CIN + (OFFSET ? 1 : 0) : 1;
-  constexpr int C = COUT * CJ;
-  static_assert(C <= 16, "16 channel columns");
-  constexpr int CQ = (C + 3) / 4;                 // channel groups of 4 (MFMA block columns)
-  constexpr int NCOMP = 4 + 4 * CQ;               // record components: 4 weights + channels
-  constexpr int kSlotFloats = NCOMP * kRounds;    // [component][round]
-  constexpr int kRecFloats = 8 * kSlotFloats;     // 8 slots
-  constexpr int CIN_Q = (APPLY && CIN > 0) ? CIN : 1;
-  constexpr int kBatch = 2;
-  constexpr int kWaveFloats = kRecFloats + kRowTileFloats + 8;  // + slot -> bin table
-  static_assert(kWaveFloats >= kTileFloats, "the final reduction reuses the wave's LDS");
-  __shared__ __attribute__((aligned(16))) float lds[kWaves * kWaveFloats];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  float* rec = lds + wave * kWaveFloats;          // records
-  float* rowt = rec + kRecFloats;                 // row tile
-  int* slotbin = reinterpret_cast<int*>(rowt + kRowTileFloats);
-  {  // zero everything once (stale record values must at least be finite)
-    f32x4* z4 = reinterpret_cast<f32x4*>(rec);
-    for (int e = lane; e < kWaveFloats / 4; e += 64) z4[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  const long long task = blockIdx.x;
-  const int nint = p.GW + 1;
-  const int g = (int)(task % nint) - 1;
-  const int yg = (int)((task / nint) % p.nyg);
-  const long long b = task / ((long long)nint * p.nyg);
-  const int x_lo = interval_start(g, p.W, p.scale_x);
-  const int x_hi = interval_start(g + 1, p.W, p.scale_x);
-  const int y_first = yg * p.rg, y_end = min(y_first + p.rg, p.H);
-  const int gy_base = gy_base_of(y_first, p.scale_y, p.GH);
-  const float gd_f = (float)p.GD;
-  const bool fold_lo = g < 0, fold_hi = g >= p.GW - 1;
-  const float gc0 = g + 0.5f, gc1 = g + 1 + 0.5f;
-  auto x_weights = [&](int x, float& w0, float& w1) {
-    const float live = (x < x_hi) ? 1.0f : 0.0f;
-    const float gxf = mul_rn((float)x + 0.5f, p.scale_x);
-    const float wxa = tent_weight(gc0, gxf) * live;
-    const float wxb = tent_weight(gc1, gxf) * live;
-    w0 = fold_lo ? 0.0f : (fold_hi ? wxa + wxb : wxa);
-    w1 = fold_lo ? wxa + wxb : (fold_hi ? 0.0f : wxb);
-  };
-  const int span = x_hi - x_lo;
-  const int nbr = (span + 64 * kBatch - 1) / (64 * kBatch);
-  float w0c[kBatch], w1c[kBatch];
-#pragma unroll
-  for (int cb = 0; cb < kBatch; ++cb) x_weights(x_lo + 64 * cb + lane, w0c[cb], w1c[cb]);
-
-  // MFMA lane roles (v_mfma_f32_4x4x1_16B_f32): block = lane >> 2 = 4 * (pixel slot r) + (channel
-  // group q); A[i = lane & 3] = weight i of the slot's pixel, B[j = lane & 3] = channel 4 q + j;
-  // D register v of lane (block, j) = row i = v, column j.
-  const int mr = lane >> 4, mq = (lane >> 2) & 3, mi = lane & 3;
-  const int mqc = min(mq, CQ - 1);  // surplus channel groups re-read the last one; never flushed
-  // set s: slot 4 s + mr
-  const f32x4* a_rd[2] = {reinterpret_cast<const f32x4*>(rec + (0 + mr) * kSlotFloats + mi * kRounds),
-                          reinterpret_cast<const f32x4*>(rec + (4 + mr) * kSlotFloats + mi * kRounds)};
-  const f32x4* b_rd[2] = {
-      reinterpret_cast<const f32x4*>(rec + (0 + mr) * kSlotFloats + (4 + 4 * mqc + mi) * kRounds),
-      reinterpret_cast<const f32x4*>(rec + (4 + mr) * kSlotFloats + (4 + 4 * mqc + mi) * kRounds)};
-  const bool flusher = mq < CQ && (4 * mq + mi) < C;
-
-  // final-tile lane roles (as the dense kernel: D[k = 4 * sub + r][c = bc])
-  const int sub = lane >> 4, bc = lane & 15;
-  f32x4 acc[3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  struct Batch {
-    float g[kBatch], in[kBatch][CIN_Q], d[kBatch][COUT];
-  };
-  const int nrows = (y_end - (y_first + wave) + kWaves - 1) / kWaves;
-  const int nbt = (span > 0 && nrows > 0) ? nrows * nbr : 0;
-  auto load_batch = [&](int t, Batch& bt) {
-    const int r = t / nbr, bi = t - r * nbr;
-    const int y = y_first + wave + r * kWaves;
-    const size_t prow = ((size_t)b * p.H + y) * p.W;
-    const __amdgpu_buffer_rsrc_t grs = row_rsrc(p.guide + prow);
-    const __amdgpu_buffer_rsrc_t irs = row_rsrc((APPLY && CIN > 0) ? p.input + prow * CIN : p.guide);
-    const __amdgpu_buffer_rsrc_t drs = row_rsrc(p.dout + prow * COUT);
-    const int xb = x_lo + bi * 64 * kBatch;
-#pragma unroll
-    for (int cb = 0; cb < kBatch; ++cb) {
-      const unsigned px = (unsigned)min(xb + 64 * cb + lane, x_hi - 1);
-      buf_load<1>(grs, px * 4u, &bt.g[cb]);
-      if constexpr (APPLY && CIN > 0) buf_load<CIN>(irs, px * (4u * CIN), bt.in[cb]);
-      buf_load<COUT>(drs, px * (4u * COUT), bt.d[cb]);
-    }
-  };
-
-  Batch cur, nxt;
-  if (nbt > 0) load_batch(0, cur);
-  for (int t = 0; t < nbt; ++t) {
-    if (t + 1 < nbt) load_batch(t + 1, nxt);
-    const int r = t / nbr, bi = t - r * nbr;
-    const int y = y_first + wave + r * kWaves;
-    const int xb = x_lo + bi * 64 * kBatch;
-#pragma unroll
-    for (int cb = 0; cb < kBatch; ++cb) {
-      const int x0 = xb + 64 * cb;
-      if (x0 < x_hi) {  // wave-uniform
-        float w0 = w0c[cb], w1 = w1c[cb];
-        if (nbr > 1) x_weights(x0 + lane, w0, w1);
-        const bool live = x0 + lane < x_hi;
-        // z taps (:120-125), as in the dense kernel: P = (zP, wP), Q = (zP + 1, wQ); the outermost
-        // half cells are forced to (1, 0).
-        const float gzf = mul_rn(cur.g[cb], gd_f);
-        const float fz = floorf(gzf - 0.5f);
-        const float dza = (fz + 0.5f) - gzf, dzb = (fz + 1.5f) - gzf;
-        float wP = std_max(1.0f - __builtin_amdgcn_sqrtf(fmaf(dza, dza, kSmoothEps)), 0.0f);
-        float wQ = std_max(1.0f - __builtin_amdgcn_sqrtf(fmaf(dzb, dzb, kSmoothEps)), 0.0f);
-        const bool lo = gzf < 0.5f, hi = gzf > gd_f - 0.5f;
-        int zP = min(max((int)__builtin_amdgcn_fmed3f(fz, -2.0f, 9.0f), 0), p.GD - 1);
-        if (lo) zP = 0;
-        if (hi) zP = p.GD - 1;
-        if (lo || hi) { wP = 1.0f; wQ = 0.0f; }
-        const int bin = live ? zP : 8;  // 8: no record
-
-        // 1. per-bin counts (uniform) and this lane's rank inside its bin
-        int cnt[8];
-        int rank = 0;
-        unsigned nm = 0;  // non-empty bins
-#pragma unroll
-        for (int z = 0; z < 8; ++z) {
-          const unsigned long long m = __builtin_amdgcn_ballot_w64(bin == z);
-          cnt[z] = __builtin_popcountll(m);
-          const int rk = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-          rank = (bin == z) ? rk : rank;
-          nm |= (cnt[z] > 0 ? 1u : 0u) << z;
-        }
-        // 2. slots: nb non-empty bins x P parts
-        const int nb = __builtin_popcount(nm);
-        const int lgP = nb <= 1 ? 3 : (nb <= 2 ? 2 : (nb <= 4 ? 1 : 0));
-        const int nzidx = __builtin_popcount(nm & ((1u << (bin & 7)) - 1u));
-        const int slot = (nzidx << lgP) + (rank & ((1 << lgP) - 1));
-        const int idx = rank >> lgP;
-        int rounds0 = 0, rounds1 = 0;  // uniform: rounds needed by the slots of set 0 / set 1
-        {
-          int k = 0;
-#pragma unroll
-          for (int z = 0; z < 8; ++z) {
-            const int len = (cnt[z] + (1 << lgP) - 1) >> lgP;
-            const int s0 = k << lgP;  // first slot of this bin (if non-empty)
-            if (cnt[z] > 0) {
-              if (s0 < 4) rounds0 = max(rounds0, len);
-              if (s0 + (1 << lgP) > 4) rounds1 = max(rounds1, len);
-              ++k;
-            }
-          }
-        }
-        // record components: weights a[i = 2 * xcorner + tap], channels V[c]
-        float comp[NCOMP];
-        comp[0] = w0 * wP;
-        comp[1] = w0 * wQ;
-        comp[2] = w1 * wP;
-        comp[3] = w1 * wQ;
-#pragma unroll
-        for (int c = 0; c < 4 * CQ; ++c) comp[4 + c] = 0.0f;
-        if constexpr (APPLY) {
-#pragma unroll
-          for (int i = 0; i < COUT; ++i) {
-#pragma unroll
-            for (int j = 0; j < CJ; ++j)
-              comp[4 + i * CJ + j] = (j < CIN) ? cur.d[cb][i] * cur.in[cb][j < CIN ? j : 0] : cur.d[cb][i];
-          }
-        } else {
-#pragma unroll
-          for (int c = 0; c < C; ++c) comp[4 + c] = cur.d[cb][c];
-        }
-        if (live) slotbin[slot] = zP;  // every pixel of a slot writes the same value
-
-        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-        const int maxr = max(rounds0, rounds1);
-        for (int pass = 0; pass * kRounds < maxr; ++pass) {  // uniform; one pass unless a slot holds > 16 px
-          // 3. zero the weight rows of all 8 slots, then scatter this pass's records
-          {
-            const int f = lane;  // 8 slots x 4 weight rows x 16 rounds = 128 float4
-            f32x4* zr0 = reinterpret_cast<f32x4*>(rec + (f >> 4) * kSlotFloats + (f & 15) * 4);
-            f32x4* zr1 = reinterpret_cast<f32x4*>(rec + ((f + 64) >> 4) * kSlotFloats + (f & 15) * 4);
-            *zr0 = f32x4{0.f, 0.f, 0.f, 0.f};
-            *zr1 = f32x4{0.f, 0.f, 0.f, 0.f};
-          }
-          if (live && (idx >> 4) == pass) {
-            float* rp = rec + slot * kSlotFloats + (idx & (kRounds - 1));
-#pragma unroll
-            for (int c = 0; c < 4 + C; ++c) rp[c * kRounds] = comp[c];
-          }
-          wave_lds_order();
-          // 4. rounds of MFMAs, 4 per ds_read_b128 pair; the two sets alternate
-          const int r0n = min(max(rounds0 - pass * kRounds, 0), kRounds);
-          const int r1n = min(max(rounds1 - pass * kRounds, 0), kRounds);
-#pragma unroll
-          for (int u4 = 0; u4 < kRounds / 4; ++u4) {
-            if (4 * u4 < r0n) {  // uniform
-              const f32x4 av = a_rd[0][u4], bv = b_rd[0][u4];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[u], bv[u], d0, 0, 0, 0);
-            }
-            if (4 * u4 < r1n) {
-              const f32x4 av = a_rd[1][u4], bv = b_rd[1][u4];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[u], bv[u], d1, 0, 0, 0);
-            }
-          }
-          wave_lds_order();
-        }
-        // 5. flush: lane (slot mr, group mq, column mi) adds D[i][mi], i = (xcorner, tap), into
-        //    row tile [xcorner][bin + tap][4 mq + mi]
-        if (flusher) {
-          float* t0 = rowt + slotbin[mr] * 16 + 4 * mq + mi;
-          float* t1 = rowt + slotbin[4 + mr] * 16 + 4 * mq + mi;
-          if (rounds0 > 0) {
-            __hip_atomic_fetch_add(t0, d0[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            __hip_atomic_fetch_add(t0 + 16, d0[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            __hip_atomic_fetch_add(t0 + 9 * 16, d0[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            __hip_atomic_fetch_add(t0 + 9 * 16 + 16, d0[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          }
-          if (rounds1 > 0) {
-            __hip_atomic_fetch_add(t1, d1[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            __hip_atomic_fetch_add(t1 + 16, d1[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            __hip_atomic_fetch_add(t1 + 9 * 16, d1[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            __hip_atomic_fetch_add(t1 + 9 * 16 + 16, d1[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          }
-        }
-        wave_lds_order();
-      }
-    }
-    if (bi == nbr - 1) {
-      // end of the row: fold the row tile, scaled by the row's two y weights, into the register
-      // tiles of the (<= 3) grid rows the group touches, and clear it.
-      const float gyf = mul_rn(y + 0.5f, p.scale_y);
-      const int gy0 = floor_to_int(gyf - 0.5f);
-      const float wy0 = tent_weight(gy0 + 0.5f, gyf);
-      const float wy1 = tent_weight(gy0 + 1 + 0.5f, gyf);
-      const int rel0 = clamp_index(gy0, 0, p.GH - 1) - gy_base;
-      const int rel1 = clamp_index(gy0 + 1, 0, p.GH - 1) - gy_base;
-      // lane (sub, bc): rows k = 4 sub + q -> x corner sub >> 1, plane 4 (sub & 1) + q
-      float* tp = rowt + ((sub >> 1) * 9 + 4 * (sub & 1)) * 16 + bc;
-      f32x4 dacc;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        dacc[q] = tp[q * 16];
-        tp[q * 16] = 0.0f;
-      }
-      if (lane < 32) rowt[((lane >> 4) * 9 + 8) * 16 + (lane & 15)] = 0.0f;  // the sink plane
-#pragma unroll
-      for (int rr = 0; rr < 3; ++rr) {
-        const float sr = (rel0 == rr ? wy0 : 0.0f) + (rel1 == rr ? wy1 : 0.0f);
-        acc[rr] += sr * dacc;
-      }
-      wave_lds_order();
-    }
-    cur = nxt;
-  }
-  __syncthreads();
-  float* red = lds + wave * kWaveFloats;
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) red[(r * 16 + 4 * sub + q) * 16 + bc] = acc[r][q];
-  }
-  __syncthreads();
-  float* dst = p.partial + (size_t)task * kTileFloats;
-  for (int e = threadIdx.x; e < kTileFloats; e += kWaves * 64) {
-    float sum = lds[e];
-#pragma unroll
-    for (int w = 1; w < kWaves; ++w) sum += lds[w * kWaveFloats + e];
     dst[e] = sum;
   }
 }
@@ -672,22 +508,46 @@ bool gg_plan(int B, int H, int W, int GH, int GW, int GD, int C, GGPlan* pl) {
   return true;
 }
 
+struct GGPtrs {
+  const float *guide, *input, *dout, *grid;
+  float *dgrid, *dguide, *dinput;
+};
+
 template <int CIN, int COUT, bool OFFSET, bool APPLY>
-hipError_t gg_launch(const float* guide, const float* input, const float* dout, float* dgrid, int B,
-                     int H, int W, int GH, int GW, int GD, void* ws, const GGPlan& pl, hipStream_t s,
-                     bool dense) {
+hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int GD, void* ws, const GGPlan& pl,
+                     hipStream_t s, bool split) {
   constexpr int C = APPLY ? COUT * (CIN + (OFFSET ? 1 : 0)) : COUT;
-  GGParams p{guide, input, dout, static_cast<float*>(ws), H, W, GH, GW, GD,
+  GGParams p{q.guide, q.input, q.dout, q.grid, q.dguide, q.dinput, static_cast<float*>(ws), H, W, GH, GW, GD,
              pl.rg, pl.nyg, pl.ntasks, (float)GW / W, (float)GH / H};
-  const long long nblocks = pl.ntasks;
-  if (dense)
-    grid_grad_stage1<CIN, COUT, OFFSET, APPLY><<<(unsigned)nblocks, kWaves * 64, 0, s>>>(p);
-  else
-    grid_grad_stage1_sorted<CIN, COUT, OFFSET, APPLY><<<(unsigned)nblocks, kWaves * 64, 0, s>>>(p);
+  const unsigned nblocks = (unsigned)pl.ntasks;
+  const bool wg = q.dguide != nullptr, wi = q.dinput != nullptr;
+  if constexpr (C % 4 == 0) {
+    if (wg || wi) {  // fused backward: dgrid + the per-pixel VJPs in one pass
+      constexpr bool CAN_WI = APPLY && CIN > 0;
+      if (wg && wi && CAN_WI)
+        grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, true, CAN_WI><<<nblocks, kWaves * 64, 0, s>>>(p);
+      else if (wg)
+        grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, true, false><<<nblocks, kWaves * 64, 0, s>>>(p);
+      else if (CAN_WI)
+        grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, false, CAN_WI><<<nblocks, kWaves * 64, 0, s>>>(p);
+      else
+        return hipErrorInvalidValue;
+    } else if (split) {
+      grid_grad_stage1<CIN, COUT, OFFSET, APPLY, true><<<nblocks, kWaves * 64, 0, s>>>(p);
+    } else {
+      grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false><<<nblocks, kWaves * 64, 0, s>>>(p);
+    }
+  } else {
+    if (wg || wi) return hipErrorInvalidValue;
+    if (split)
+      grid_grad_stage1<CIN, COUT, OFFSET, APPLY, true><<<nblocks, kWaves * 64, 0, s>>>(p);
+    else
+      grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false><<<nblocks, kWaves * 64, 0, s>>>(p);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const long long ncell = (long long)B * GH * GW * GD;
-  grid_grad_stage2<<<(unsigned)ncell, 256, 0, s>>>(static_cast<const float*>(ws), dgrid, GH, GW, GD,
+  grid_grad_stage2<<<(unsigned)ncell, 256, 0, s>>>(static_cast<const float*>(ws), q.dgrid, GH, GW, GD,
                                                    C, pl.rg, pl.nyg, (float)GH / H);
   return hipGetLastError();
 }
@@ -716,15 +576,16 @@ bool apply_grid_grad_mfma_supported(const ApplyGradArgs& a) {
          a.workspace_bytes >= pl.ws_bytes;
 }
 
-hipError_t launch_apply_grid_grad_mfma(const ApplyGradArgs& a, hipStream_t s, const char** name) {
+// variant (tools A/B): 2 = bf16-split contraction.  fused: also write a.dguide / a.dinput.
+static hipError_t apply_gg(const ApplyGradArgs& a, bool fused, hipStream_t s) {
   GGPlan pl;
   if (!gg_plan(a.B, a.H, a.W, a.GH, a.GW, a.GD, a.Cout * a.Cj, &pl)) return hipErrorInvalidValue;
-  const bool dense = a.variant == 1;
-  *name = dense ? "grid_grad_mfma/dense" : "grid_grad_mfma";
+  const GGPtrs q{a.guide, a.input, a.dout, a.grid, a.dgrid, fused ? a.dguide : nullptr,
+                 fused ? a.dinput : nullptr};
+  const bool split = a.variant == 2;
 #define HDRNET_CASE(CI, CO, OFF)                                                                  \
   if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF)                                         \
-  return gg_launch<CI, CO, OFF, true>(a.guide, a.input, a.dout, a.dgrid, a.B, a.H, a.W, a.GH, a.GW, \
-                                      a.GD, a.workspace, pl, s, dense)
+  return gg_launch<CI, CO, OFF, true>(q, a.B, a.H, a.W, a.GH, a.GW, a.GD, a.workspace, pl, s, split)
   HDRNET_CASE(3, 3, true);
   HDRNET_CASE(3, 3, false);
   HDRNET_CASE(3, 4, true);
@@ -734,6 +595,24 @@ hipError_t launch_apply_grid_grad_mfma(const ApplyGradArgs& a, hipStream_t s, co
   HDRNET_CASE(4, 4, false);
 #undef HDRNET_CASE
   return hipErrorInvalidValue;
+}
+
+hipError_t launch_apply_grid_grad_mfma(const ApplyGradArgs& a, hipStream_t s, const char** name) {
+  *name = a.variant == 2 ? "grid_grad_mfma/bf16x2" : "grid_grad_mfma";
+  return apply_gg(a, false, s);
+}
+
+// Fused backward: dgrid AND dguide / dinput in one pass over the pixels (C % 4 == 0 shapes).
+bool apply_bwd_fused_supported(const ApplyGradArgs& a) {
+  if (!a.dgrid || !(a.dguide || a.dinput) || !a.grid) return false;
+  if ((a.Cout * a.Cj) % 4 != 0 || ((uintptr_t)a.grid & 15u)) return false;
+  if (a.dinput && a.Cin == 0) return false;
+  return apply_grid_grad_mfma_supported(a);
+}
+
+hipError_t launch_apply_bwd_fused(const ApplyGradArgs& a, hipStream_t s, const char** name) {
+  *name = "apply_bwd_fused/mfma";
+  return apply_gg(a, true, s);
 }
 
 size_t slice_grid_grad_mfma_workspace(int B, int H, int W, int GH, int GW, int GD, int C) {
@@ -748,15 +627,14 @@ bool slice_grid_grad_mfma_supported(const SliceGradArgs& a) {
          a.workspace != nullptr && a.workspace_bytes >= pl.ws_bytes;
 }
 
-hipError_t launch_slice_grid_grad_mfma(const SliceGradArgs& a, hipStream_t s, const char** name) {
+static hipError_t slice_gg(const SliceGradArgs& a, bool fused, hipStream_t s) {
   GGPlan pl;
   if (!gg_plan(a.B, a.H, a.W, a.GH, a.GW, a.GD, a.C, &pl)) return hipErrorInvalidValue;
-  const bool dense = a.variant == 1;
-  *name = dense ? "grid_grad_mfma/dense" : "grid_grad_mfma";
+  const GGPtrs q{a.guide, nullptr, a.dout, a.grid, a.dgrid, fused ? a.dguide : nullptr, nullptr};
+  const bool split = a.variant == 2;
 #define HDRNET_CASE(CC)                                                                            \
   if (a.C == CC)                                                                                   \
-  return gg_launch<0, CC, false, false>(a.guide, nullptr, a.dout, a.dgrid, a.B, a.H, a.W, a.GH, a.GW, \
-                                        a.GD, a.workspace, pl, s, dense)
+  return gg_launch<0, CC, false, false>(q, a.B, a.H, a.W, a.GH, a.GW, a.GD, a.workspace, pl, s, split)
   HDRNET_CASE(1);
   HDRNET_CASE(2);
   HDRNET_CASE(4);
@@ -765,6 +643,22 @@ hipError_t launch_slice_grid_grad_mfma(const SliceGradArgs& a, hipStream_t s, co
   HDRNET_CASE(16);
 #undef HDRNET_CASE
   return hipErrorInvalidValue;
+}
+
+hipError_t launch_slice_grid_grad_mfma(const SliceGradArgs& a, hipStream_t s, const char** name) {
+  *name = a.variant == 2 ? "grid_grad_mfma/bf16x2" : "grid_grad_mfma";
+  return slice_gg(a, false, s);
+}
+
+bool slice_bwd_fused_supported(const SliceGradArgs& a) {
+  if (!a.dgrid || !a.dguide || !a.grid) return false;
+  if (a.C % 4 != 0 || ((uintptr_t)a.grid & 15u)) return false;
+  return slice_grid_grad_mfma_supported(a);
+}
+
+hipError_t launch_slice_bwd_fused(const SliceGradArgs& a, hipStream_t s, const char** name) {
+  *name = "slice_bwd_fused/mfma";
+  return slice_gg(a, true, s);
 }
 
 }  // namespace hdrnet_amd

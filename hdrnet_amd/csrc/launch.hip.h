@@ -49,7 +49,7 @@ struct ApplyGradArgs {
   bool has_offset;
   void* workspace;
   size_t workspace_bytes;
-  int variant = 0;  // tools build: 1 = round-1 kernels (dense-tile dgrid), else the product's
+  int variant = 0;  // tools build A/B: 2 = bf16-split dgrid contraction, 3 = separate (un-fused) kernels
 };
 
 // Training side of the point-wise guide network (guide_grad.hip).
@@ -165,9 +165,14 @@ size_t apply_grid_grad_mfma_workspace(int B, int H, int W, int GH, int GW, int G
                                       bool has_offset);
 bool apply_grid_grad_mfma_supported(const ApplyGradArgs& a);  // shape AND workspace large enough
 hipError_t launch_apply_grid_grad_mfma(const ApplyGradArgs& a, hipStream_t s, const char** name);
+// The same pass also producing dguide / dinput (fused backward: pixels read once for all gradients).
+bool apply_bwd_fused_supported(const ApplyGradArgs& a);
+hipError_t launch_apply_bwd_fused(const ApplyGradArgs& a, hipStream_t s, const char** name);
 size_t slice_grid_grad_mfma_workspace(int B, int H, int W, int GH, int GW, int GD, int C);
 bool slice_grid_grad_mfma_supported(const SliceGradArgs& a);
 hipError_t launch_slice_grid_grad_mfma(const SliceGradArgs& a, hipStream_t s, const char** name);
+bool slice_bwd_fused_supported(const SliceGradArgs& a);
+hipError_t launch_slice_bwd_fused(const SliceGradArgs& a, hipStream_t s, const char** name);
 
 // guide_grad.hip -- VJP of the folded point-wise guide network; input moments for batch norm.
 size_t guide_grad_workspace_bytes(long long npx, int Cin, int n);

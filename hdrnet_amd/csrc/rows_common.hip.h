@@ -207,6 +207,78 @@ __device__ __forceinline__ void slice_apply_pixel(const RowCtx& r, float xf, flo
   }
 }
 
+// ---- per-pixel VJP core shared by apply_bwd_rows.hip and the fused backward (grid_grad_mfma.hip) ----
+// Gather the four vectors once, accumulate with two weight sets.
+template <int C, bool FIRST, bool WA, bool WB>
+__device__ __forceinline__ void accum_vec2(CoefVec<C>& ca, CoefVec<C>& cb,
+                                           const float* __restrict__ colY, int off, float wa,
+                                           float wb) {
+  const f32x2 wa2 = {wa, wa}, wb2 = {wb, wb};
+  const char* base = reinterpret_cast<const char*>(colY) + off;
+  if constexpr (C % 4 == 0) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(base);
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q) {
+      const f32x4 t = p[q];
+      if constexpr (WA) {
+        ca.v[2 * q + 0] = FIRST ? wa2 * t.xy : __builtin_elementwise_fma(wa2, t.xy, ca.v[2 * q + 0]);
+        ca.v[2 * q + 1] = FIRST ? wa2 * t.zw : __builtin_elementwise_fma(wa2, t.zw, ca.v[2 * q + 1]);
+      }
+      if constexpr (WB) {
+        cb.v[2 * q + 0] = FIRST ? wb2 * t.xy : __builtin_elementwise_fma(wb2, t.xy, cb.v[2 * q + 0]);
+        cb.v[2 * q + 1] = FIRST ? wb2 * t.zw : __builtin_elementwise_fma(wb2, t.zw, cb.v[2 * q + 1]);
+      }
+    }
+  } else {
+    const float* p = reinterpret_cast<const float*>(base);
+#pragma unroll
+    for (int q = 0; q < C; ++q) {
+      const float t = p[q];
+      if constexpr (WA) ca.v[q >> 1][q & 1] = FIRST ? wa * t : fmaf(wa, t, ca.v[q >> 1][q & 1]);
+      if constexpr (WB) cb.v[q >> 1][q & 1] = FIRST ? wb * t : fmaf(wb, t, cb.v[q >> 1][q & 1]);
+    }
+  }
+}
+
+// The four (x corner, z tap) coefficient vectors at byte offsets a<x><z> of an LDS image, blended
+// once with the tent weights (-> sliced coefficients A_ij, dinput_j = sum_i dout_i A_ij) and once
+// with the z tent's derivative dw = GD * d wz / d gz (-> dA_ij, dguide = sum_i dout_i (sum_j dA_ij
+// in_j + dA_i,offset)).  bilateral_slice_apply.cc:140-259; BilateralSlice: CIN = 0, CJ = 1.
+template <int CIN, int COUT, bool OFFSET, bool WANT_GUIDE, bool WANT_INPUT>
+__device__ __forceinline__ void vjp_blend(const float* __restrict__ img, int a00, int a01, int a10, int a11,
+                                          float wx0, float wx1, float wz0, float wz1, float dw0, float dw1,
+                                          const float* __restrict__ in,  // [CIN]
+                                          const float* __restrict__ d,   // [COUT]
+                                          float& dguide, float* __restrict__ dinput) {
+  constexpr int CJ = CIN + (OFFSET ? 1 : 0);
+  constexpr int C = COUT * CJ;
+  CoefVec<C> A, dA;
+  accum_vec2<C, true, WANT_INPUT, WANT_GUIDE>(A, dA, img, a00, wx0 * wz0, wx0 * dw0);
+  accum_vec2<C, false, WANT_INPUT, WANT_GUIDE>(A, dA, img, a01, wx0 * wz1, wx0 * dw1);
+  accum_vec2<C, false, WANT_INPUT, WANT_GUIDE>(A, dA, img, a10, wx1 * wz0, wx1 * dw0);
+  accum_vec2<C, false, WANT_INPUT, WANT_GUIDE>(A, dA, img, a11, wx1 * wz1, wx1 * dw1);
+  if constexpr (WANT_GUIDE) {
+    float vjp = 0.0f;
+#pragma unroll
+    for (int i = 0; i < COUT; ++i) {
+      float gv = OFFSET ? dA.get(i * CJ + CIN) : 0.0f;
+#pragma unroll
+      for (int j = 0; j < CIN; ++j) gv = fmaf(dA.get(i * CJ + j), in[j], gv);
+      vjp = fmaf(gv, d[i], vjp);
+    }
+    dguide = vjp;
+  }
+  if constexpr (WANT_INPUT) {
+#pragma unroll
+    for (int j = 0; j < CIN; ++j) {
+      float v = 0.0f;
+#pragma unroll
+      for (int i = 0; i < COUT; ++i) v = fmaf(A.get(i * CJ + j), d[i], v);
+      dinput[j] = v;
+    }
+  }
+}
+
 // Streaming 16-B load of pixel data that is read exactly once (guide / input / dout): the `nt`
 // policy.  Measured with the forward's byte volume and launch geometry and no compute
 // (tools/debug/ubench/stream_cache_policy.hip): plain loads + plain stores 41.2 us, nontemporal

@@ -240,8 +240,8 @@ def test_apply_backward_random(dev, ops, port, shape):
 
 
 def test_backward_uses_fast_kernels_and_is_deterministic(dev, ops):
-    """HDRNet's shape (Cin 3 -> Cout 3 + offset): dguide/dinput from the fused LDS-staged pass,
-    dgrid from the two-stage MFMA reduction; no atomics => bitwise repeatable."""
+    """HDRNet's shape (Cin 3 -> Cout 3 + offset): all three gradients from the fused backward pass
+    (per-pixel VJPs + the two-stage MFMA dgrid reduction); no atomics => bitwise repeatable."""
     gen = torch.Generator(device=dev).manual_seed(77)
     grid = torch.rand((2, 16, 16, 8, 12), device=dev, generator=gen)
     guide = torch.rand((2, 270, 480), device=dev, generator=gen)
@@ -251,7 +251,7 @@ def test_backward_uses_fast_kernels_and_is_deterministic(dev, ops):
     for _ in range(2):
         tg, tgu, ti = (t.clone().requires_grad_(True) for t in (grid, guide, inp))
         ops.bilateral_slice_apply(tg, tgu, ti, has_offset=True).backward(dout)
-        assert ops.last_kernel() == "apply_vjp_rows/vec4+grid_grad_mfma", ops.last_kernel()
+        assert ops.last_kernel() == "apply_bwd_fused/mfma", ops.last_kernel()
         res.append((tg.grad.clone(), tgu.grad.clone(), ti.grad.clone()))
     for a, b in zip(*res):
         assert torch.equal(a, b)

@@ -198,8 +198,11 @@ def main():
     run("apply bwd (all three)", apply_bwd, 4 * npx * (1 + Cin + Cout) + 4 * npx * (1 + Cin) + 2 * gridb)
     run("apply bwd dguide+dinput", lambda k: apply_bwd(k, dg=False), 4 * npx * (1 + Cin + Cout) + 4 * npx * (1 + Cin) + gridb)
     run("apply bwd dgrid only", lambda k: apply_bwd(k, dgu=False, di=False), 4 * npx * (1 + Cin + Cout) + gridb)
+    run("apply bwd dgrid+dguide", lambda k: apply_bwd(k, di=False), 4 * npx * (1 + Cin + Cout) + 4 * npx + 2 * gridb)
     if args.tools:
-        run("apply bwd dgrid only (round-1 dense tile)", lambda k: apply_bwd(k, dgu=False, di=False, variant=1),
+        run("apply bwd (all three), un-fused kernels", lambda k: apply_bwd(k, variant=3),
+            4 * npx * (1 + Cin + Cout) + 4 * npx * (1 + Cin) + 2 * gridb)
+        run("apply bwd dgrid only (bf16-split MFMA)", lambda k: apply_bwd(k, dgu=False, di=False, variant=2),
             4 * npx * (1 + Cin + Cout) + gridb)
     run("slice fwd", slice_fwd, 4 * npx * (1 + C) + gridb)
     run("slice bwd (both)", slice_bwd, 4 * npx * (1 + C) + 4 * npx + 2 * gridb)
