@@ -115,7 +115,9 @@ __global__ __launch_bounds__(256) void apply_vjp_rows_vec4(
         for (int j = 0; j < CIN; ++j) dif[k * CIN + j] = di[j];
       }
     }
-    if constexpr (WANT_GUIDE) *reinterpret_cast<float4*>(dguide + p) = dgv;
+    if constexpr (WANT_GUIDE)  // descriptor over the row segment (wave-uniform base), lane offset 16 B * tid
+      buf_store16<kAuxStream>(dgv, make_rsrc(dguide + ((size_t)row * W + xs), (unsigned)(xe - xs) * 4u),
+                              16u * threadIdx.x);
   }
   if constexpr (WANT_INPUT) {
     // lane-contiguous stores through the per-wave LDS slab (see apply_fwd_rows.hip)
@@ -130,12 +132,11 @@ __global__ __launch_bounds__(256) void apply_vjp_rows_vec4(
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int wave_x0 = xs + kPxPerThread * (int)(threadIdx.x & ~63u);
     const int nvalid = (min(xe, wave_x0 + 64 * kPxPerThread) - wave_x0) * CIN / 4;
-    float4* gp = reinterpret_cast<float4*>(dinput + ((size_t)row * W + wave_x0) * CIN);
+    // write-through buffer stores on a descriptor over exactly this wave's run (rows_common.hip.h)
+    const __amdgpu_buffer_rsrc_t orsrc =
+        make_rsrc(dinput + ((size_t)row * W + wave_x0) * CIN, nvalid > 0 ? (unsigned)nvalid * 16u : 0u);
 #pragma unroll
-    for (int k = 0; k < CIN; ++k) {
-      const int e = lane + 64 * k;
-      if (e < nvalid) gp[e] = slab[e];
-    }
+    for (int k = 0; k < CIN; ++k) buf_store16<kAuxStream>(slab[lane + 64 * k], orsrc, (unsigned)(lane + 64 * k) * 16u);
   }
 }
 

@@ -231,13 +231,12 @@ __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // write-through buffer stores on a descriptor over exactly this wave's run (rows_common.hip.h)
   const int nvalid = wave_px * COUT / 4;  // float4s
-  float4* gp = reinterpret_cast<float4*>(out + ((size_t)row * W + wave_x0) * COUT);
+  const __amdgpu_buffer_rsrc_t orsrc =
+      make_rsrc(out + ((size_t)row * W + wave_x0) * COUT, nvalid > 0 ? (unsigned)nvalid * 16u : 0u);
 #pragma unroll
-  for (int k = 0; k < COUT; ++k) {
-    const int e = lane + 64 * k;
-    if (e < nvalid) gp[e] = slab[e];
-  }
+  for (int k = 0; k < COUT; ++k) buf_store16<kAuxStream>(slab[lane + 64 * k], orsrc, (unsigned)(lane + 64 * k) * 16u);
 }
 
 // ---- scalar variant: any W / alignment; thread t takes pixels xs + t + k*blockDim ------

@@ -81,18 +81,9 @@ struct SegParams {
   long long* trace;  // TRACE: [nblocks][3] wall-clock ticks (start, end), XCC id; else unused
 };
 
-typedef int v4i32 __attribute__((ext_vector_type(4)));
-
-// Raw buffer descriptor over `bytes` bytes at `base` (gfx9 family: dword 3 = 0x00020000).
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
-
 template <int STORES>
-__device__ __forceinline__ void buf_store16(float4 v, __amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  constexpr int aux = STORES == kStoresBufNt ? 2 : STORES == kStoresBufSc1 ? 16 : STORES == kStoresBufSc01 ? 17 : 0;
-  const v4i32 d = {__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)};
-  __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)byte_off, 0, aux);
+constexpr int store_aux() {
+  return STORES == kStoresBufNt ? kAuxNt : STORES == kStoresBufSc1 ? kAuxSc1 : STORES == kStoresBufSc01 ? kAuxSc0Sc1 : kAuxPlain;
 }
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -369,7 +360,7 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
     const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(oseg, (unsigned)(xe - xs) * COUT * 4u);
 #pragma unroll
     for (int k = 0; k < COUT; ++k)
-      buf_store16<STORES>(slab[lane + 64 * k], orsrc, (wpx * COUT + 4u * (unsigned)(lane + 64 * k)) * 4u);
+      buf_store16<store_aux<STORES>()>(slab[lane + 64 * k], orsrc, (wpx * COUT + 4u * (unsigned)(lane + 64 * k)) * 4u);
   }
 
   if constexpr (TRACE) {

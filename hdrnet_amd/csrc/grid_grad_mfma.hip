@@ -131,21 +131,22 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
 }
 
-template <int N>
+// AUX: cache policy (rows_common.hip.h: kAuxNt for data that is read exactly once).
+template <int N, int AUX = 0>
 __device__ __forceinline__ void buf_load(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, float* dst) {
   if constexpr (N >= 4) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, AUX);
     dst[0] = __uint_as_float(v.x); dst[1] = __uint_as_float(v.y);
     dst[2] = __uint_as_float(v.z); dst[3] = __uint_as_float(v.w);
-    if constexpr (N > 4) buf_load<N - 4>(rs, byte_off + 16, dst + 4);
+    if constexpr (N > 4) buf_load<N - 4, AUX>(rs, byte_off + 16, dst + 4);
   } else if constexpr (N == 3) {
-    const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs, byte_off, 0, 0);
+    const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rs, byte_off, 0, AUX);
     dst[0] = __uint_as_float(v.x); dst[1] = __uint_as_float(v.y); dst[2] = __uint_as_float(v.z);
   } else if constexpr (N == 2) {
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 0);
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, AUX);
     dst[0] = __uint_as_float(v.x); dst[1] = __uint_as_float(v.y);
   } else if constexpr (N == 1) {
-    dst[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 0));
+    dst[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, AUX));
   }
 }
 
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   constexpr int CB = C * (int)sizeof(float);
   constexpr int CIN_Q = (APPLY && CIN > 0) ? CIN : 1;
   constexpr int kBatch = 2;  // chunks of 64 pixels loaded ahead (4: 132 VGPRs, 3 waves / SIMD, 6 % slower)
+  constexpr int kLoadAux = FUSED ? rows::kAuxNt : 0;  // fused pass is an HBM stream: nontemporal pixel loads
   constexpr int kImg = FUSED ? 2 * 10 * C : 0;  // [x corner][plane 0 .. GD + 1 (GD <= 8)][c]
   constexpr int kSlab = (16 + C) * kTStride + kImg;  // floats per wave: A^T [16][68], V^T [C][68], image
   static_assert(kSlab >= kTileFloats, "the final reduction reuses the slabs");
@@ -266,9 +268,11 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
       // unconditional (clamped) loads: no exec-masked branch around VMEM keeps the compiler's
       // vmcnt counts exact; pixels past the interval carry zero x weights.
       const unsigned px = (unsigned)min(xb + 64 * cb + lane, x_hi - 1);
-      buf_load<1>(grs, px * 4u, &bt.g[cb]);
-      if constexpr (APPLY && CIN > 0) buf_load<CIN>(irs, px * (4u * CIN), bt.in[cb]);
-      buf_load<COUT>(drs, px * (4u * COUT), bt.d[cb]);
+      // nontemporal only where ONE instruction covers the wave's whole run of a tensor (<= 16 B per
+      // pixel): an nt line is not kept for a second instruction touching it (profiles/r01, r02/exp6)
+      buf_load<1, kLoadAux>(grs, px * 4u, &bt.g[cb]);
+      if constexpr (APPLY && CIN > 0) buf_load<CIN, (CIN <= 4 ? kLoadAux : 0)>(irs, px * (4u * CIN), bt.in[cb]);
+      buf_load<COUT, (COUT <= 4 ? kLoadAux : 0)>(drs, px * (4u * COUT), bt.d[cb]);
     }
     if constexpr (FUSED) {
       if (bi == 0 && lane < nst) {  // the two grid rows image row y blends (L2-resident)
@@ -335,12 +339,25 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
           vjp_blend<APPLY ? CIN : 0, COUT, APPLY ? OFFSET : true, WG, WI>(
               img, a0, a0 + CB, a0 + colb, a0 + colb + CB, wa, wb, 1.0f - sza, 1.0f - szb, dw0, dw1,
               cur.in[cb], cur.d[cb], dgv, div);
-          if (x0 + lane < x_hi) {
+          {  // write-through buffer stores; descriptors end at the interval, so dead lanes are dropped
             const unsigned px = (unsigned)(x0 + lane);
-            if constexpr (WG) p.dguide[prow_out + px] = dgv;
+            if constexpr (WG) {
+              const __amdgpu_buffer_rsrc_t rs = rows::make_rsrc(p.dguide + prow_out, (unsigned)x_hi * 4u);
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dgv), rs, px * 4u, 0, rows::kAuxStream);
+            }
             if constexpr (WI) {
+              const __amdgpu_buffer_rsrc_t rs = rows::make_rsrc(p.dinput + prow_out * CIN, (unsigned)x_hi * (4u * CIN));
+              if constexpr (CIN == 3) {
+                const u32x3 v = {__float_as_uint(div[0]), __float_as_uint(div[1]), __float_as_uint(div[2])};
+                __builtin_amdgcn_raw_buffer_store_b96(v, rs, px * 12u, 0, rows::kAuxStream);
+              } else if constexpr (CIN == 4) {
+                const u32x4 v = {__float_as_uint(div[0]), __float_as_uint(div[1]), __float_as_uint(div[2]), __float_as_uint(div[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, px * 16u, 0, rows::kAuxStream);
+              } else {
 #pragma unroll
-              for (int j = 0; j < CIN; ++j) p.dinput[(prow_out + px) * CIN + j] = div[j];
+                for (int j = 0; j < CIN; ++j)
+                  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(div[j]), rs, (px * CIN + j) * 4u, 0, rows::kAuxStream);
+              }
             }
           }
         }

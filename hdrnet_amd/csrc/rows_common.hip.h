@@ -279,6 +279,27 @@ __device__ __forceinline__ void vjp_blend(const float* __restrict__ img, int a00
   }
 }
 
+// ---- buffer stores with a cache policy -------------------------------------------------------------
+// Output streams are written exactly once and never re-read by the kernel.  Plain stores leave up
+// to an L2's worth of dirty lines for the end-of-kernel write-back; `sc0 sc1` (write-through) and
+// `nt` stores drain during the kernel: worth 1.5 us per 4K frame and 0.7 us per 1080p frame on the
+// forward (profiles/r02/exp2_store_policy_*.txt).  A raw buffer descriptor over exactly the run
+// being written also drops out-of-range lanes in hardware (no predicate).
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+constexpr int kAuxPlain = 0, kAuxNt = 2, kAuxSc1 = 16, kAuxSc0Sc1 = 17;
+constexpr int kAuxStream = kAuxSc0Sc1;  // the policy the product kernels store with
+
+// Raw buffer descriptor over `bytes` bytes at `base` (gfx9 family: dword 3 = 0x00020000).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+template <int AUX>
+__device__ __forceinline__ void buf_store16(float4 v, __amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const v4i32 d = {__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)byte_off, 0, AUX);
+}
+
 // Streaming 16-B load of pixel data that is read exactly once (guide / input / dout): the `nt`
 // policy.  Measured with the forward's byte volume and launch geometry and no compute
 // (tools/debug/ubench/stream_cache_policy.hip): plain loads + plain stores 41.2 us, nontemporal

@@ -69,13 +69,11 @@ __global__ __launch_bounds__(256) void slice_fwd_rows(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // write-through buffer stores on a descriptor over exactly this run (rows_common.hip.h)
     const int nvalid = (min(xe, xk0 + 64) - xk0) * (C / 4);  // float4s of this run
-    float4* gp = reinterpret_cast<float4*>(out + (prow + xk0) * C);
+    const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(out + (prow + xk0) * C, (unsigned)nvalid * 16u);
 #pragma unroll
-    for (int q = 0; q < C / 4; ++q) {
-      const int e = lane + 64 * q;
-      if (e < nvalid) gp[e] = slab[e];
-    }
+    for (int q = 0; q < C / 4; ++q) buf_store16<kAuxStream>(slab[lane + 64 * q], orsrc, (unsigned)(lane + 64 * q) * 16u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }

@@ -183,6 +183,9 @@ def main():
               f"{nbytes / med / 1e3:7.1f} GB/s  {nbytes / med / 1e3 / 80:5.1f}% of 8 TB/s")
 
     print(f"{desc}; {nsets} rotating sets; workspace apply-grad {wsb / 1e6:.1f} MB")
+    for k in range(1500):  # pre-roll: ~60 ms of launches take the device out of the idle power state
+        apply_fwd(k)
+    torch.cuda.synchronize()
     run("apply fwd", apply_fwd, 4 * npx * (1 + Cin + Cout) + gridb)
     if u16 is not None:
         run("u16 / 32767 + guide map -> apply -> f32", apply_io_u16, npx * (4 + 6 + 12) + gridb)
