@@ -35,7 +35,7 @@
 //
 // Numerics: the coordinate and weight expressions of the reference in the reference's order
 // (products (x+.5)*scale_x, guide*GD explicitly rounded, see numerics.hip.h: mul_rn); the only
-// re-association is wy folded into the LDS image.  max(.,0) of both tents is dropped (floor()
+// re-association is wy folded into the LDS image.  max(.,0) of the x tent is dropped (floor()
 // keeps both corners within one cell), v_sqrt_f32 (1 ulp) stands in for sqrtf; differences stay
 // at the 1e-7 level (tests/test_gpu_parity.py holds rtol = atol = 1e-5 and reports the
 // reference's own 1e-6 bar).
@@ -128,14 +128,20 @@ __device__ __forceinline__ void seg_pixel(const float* __restrict__ img, float g
 #pragma clang fp contract(off)
     const float gzf = mul_rn(g, gd_f);
     const float fzl = floorf(gzf - 0.5f);
-    const f32x2 cz = {fzl + 0.5f, fzl + 1.5f};
+    // corner centres as the reference forms them, (float)gz + 0.5f with gz1 = gz0 + 1: identical to
+    // fzl + 1.5f while gzf is exact, and the same rounding as the reference once it is not
+    const f32x2 cz = {fzl + 0.5f, (fzl + 1.0f) + 0.5f};
     const f32x2 gz2 = {gzf, gzf};
     const f32x2 dz = cz - gz2;  // (gz0 + .5) - gzf, (gz0 + 1.5) - gzf
     const f32x2 eps2 = {kSmoothEps, kSmoothEps};
     const f32x2 q = __builtin_elementwise_fma(dz, dz, eps2);
     const f32x2 s = {__builtin_amdgcn_sqrtf(q.x), __builtin_amdgcn_sqrtf(q.y)};
     const f32x2 one2 = {1.0f, 1.0f};
-    const f32x2 wz = one2 - s;
+    // max(., 0) as the reference (numerics.h:108-113): never binds for a guide whose gzf is exact
+    // in f32, but once |guide * GD| reaches 2^23 the rounding of (gz0 + 1.5) - gzf can make a corner
+    // offset 2 and its un-clamped weight -1
+    const f32x2 zero2 = {0.0f, 0.0f};
+    const f32x2 wz = __builtin_elementwise_max(one2 - s, zero2);
     const f32x2 wx0 = {xt.wx0, xt.wx0}, wx1 = {xt.wx1, xt.wx1};
     w0 = wx0 * wz;
     w1 = wx1 * wz;

@@ -322,22 +322,24 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
         // P's slot (za == 7) P's value wins; there wb == 0 anyway.
         const float gzf = mul_rn(cur.g[cb], gd_f);  // gzf = guide * GD  (:120)
         const float fz = floorf(gzf - 0.5f);
-        const float dza = (fz + 0.5f) - gzf, dzb = (fz + 1.5f) - gzf;
+        const float dza = (fz + 0.5f) - gzf, dzb = ((fz + 1.0f) + 0.5f) - gzf;  // (float)gz + 0.5f, gz1 = gz0 + 1
         // v_sqrt_f32 (1 ulp; argument >= 1e-8, no denormals).  Both taps lie within one cell of the
         // sample by construction (dza in (-1, 0], dzb in (0, 1]), so dz^2 + eps rounds to <= 1.0f and
-        // the reference's `abs_dx > 1 ? 0 : dx / abs_dx` (numerics.h:116-126) never takes its zero
-        // branch here: the derivative is dz / s, formed with v_rcp_f32.
+        // the reference's `abs_dx > 1 ? 0 : dx / abs_dx` (numerics.h:116-126) takes its zero branch
+        // only for wild guides whose f32 offsets round to 2; for every guide with an exact gzf a
+        // 1-ulp sqrt cannot flip it (sqrt(1.0f) is exact).  The derivative is dz / s with v_rcp_f32.
         const float sza = __builtin_amdgcn_sqrtf(fmaf(dza, dza, kSmoothEps));
         const float szb = __builtin_amdgcn_sqrtf(fmaf(dzb, dzb, kSmoothEps));
         if constexpr (FUSED) {
           // per-pixel VJPs from the row's coefficient image: vectors at (x corner, plane iz + 1 + tap)
           const int iz = (int)__builtin_amdgcn_fmed3f(fz, -1.0f, zhi);
           const int a0 = (iz + 1) * CB;
-          const float dw0 = gd_f * (dza * __builtin_amdgcn_rcpf(sza));  // GD * SmoothedLerpWeightGrad (:186-187)
-          const float dw1 = gd_f * (dzb * __builtin_amdgcn_rcpf(szb));
+          // GD * SmoothedLerpWeightGrad (:186-187); the s > 1 branch binds only for wild guides (see above)
+          const float dw0 = (sza > 1.0f) ? 0.0f : gd_f * (dza * __builtin_amdgcn_rcpf(sza));
+          const float dw1 = (szb > 1.0f) ? 0.0f : gd_f * (dzb * __builtin_amdgcn_rcpf(szb));
           float dgv = 0.0f, div[CIN_Q];
           vjp_blend<APPLY ? CIN : 0, COUT, APPLY ? OFFSET : true, WG, WI>(
-              img, a0, a0 + CB, a0 + colb, a0 + colb + CB, wa, wb, 1.0f - sza, 1.0f - szb, dw0, dw1,
+              img, a0, a0 + CB, a0 + colb, a0 + colb + CB, wa, wb, std_max(1.0f - sza, 0.0f), std_max(1.0f - szb, 0.0f), dw0, dw1,
               cur.in[cb], cur.d[cb], dgv, div);
           {  // write-through buffer stores; descriptors end at the interval, so dead lanes are dropped
             const unsigned px = (unsigned)(x0 + lane);

@@ -159,13 +159,15 @@ __device__ __forceinline__ SliceTerms slice_terms(const RowCtx& r, float xf, flo
   const float gzf = mul_rn(g, r.gd_f);
   const float fzl = floorf(gzf - 0.5f);
   t.dz0 = (fzl + 0.5f) - gzf;
-  t.dz1 = (fzl + 1.5f) - gzf;  // NOT dz0 + 1: near a bin centre that loses the low bits of dz1,
+  t.dz1 = ((fzl + 1.0f) + 0.5f) - gzf;  // the reference's (float)(gz0 + 1) + 0.5f - gzf.  NOT dz0 + 1: near a bin centre that loses the low bits of dz1,
                                // and the guide VJP's d wz/d gz has slope 1e4 there
   const float q0 = fmaf(t.dz0, t.dz0, kSmoothEps), q1 = fmaf(t.dz1, t.dz1, kSmoothEps);
   t.sz0 = EXACT_SQRT ? sqrtf(q0) : __builtin_amdgcn_sqrtf(q0);
   t.sz1 = EXACT_SQRT ? sqrtf(q1) : __builtin_amdgcn_sqrtf(q1);
-  t.wz0 = 1.0f - t.sz0;
-  t.wz1 = 1.0f - t.sz1;
+  // max(., 0) as the reference (numerics.h:108-113): binds only for wild guides (|guide * GD| >= 2^23,
+  // where the rounding of (gz0 + 1.5) - gzf can make a corner offset 2 and its weight -1)
+  t.wz0 = fmaxf(1.0f - t.sz0, 0.0f);
+  t.wz1 = fmaxf(1.0f - t.sz1, 0.0f);
   // floor of a wild guide is clamped in float before the int conversion so that the
   // byte-space arithmetic below cannot overflow (v_med3_f32).
   const int iz = (int)__builtin_amdgcn_fmed3f(fzl, -2.0f, r.gd_f + 1.0f);

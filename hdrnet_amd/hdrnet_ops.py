@@ -169,10 +169,10 @@ def _apply_backward(grid, guide, inp, dout, has_offset: bool, need, flags: Optio
     dguide = torch.empty_like(guide) if need[1] else None
     dinput = torch.empty_like(inp) if need[2] else None
     lib = _lib.load()
-    wbytes = lib.hdrnet_bilateral_slice_apply_grad_workspace_bytes(
-        B, H, W, GH, GW, GD, Cin, Cout, int(has_offset)) if need[0] else 0
-    ws = torch.empty((wbytes,), dtype=torch.uint8, device=dev) if wbytes else None
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev):  # workspace sizes may depend on the CURRENT device (CU count)
+        wbytes = lib.hdrnet_bilateral_slice_apply_grad_workspace_bytes(
+            B, H, W, GH, GW, GD, Cin, Cout, int(has_offset)) if need[0] else 0
+        ws = torch.empty((wbytes,), dtype=torch.uint8, device=dev) if wbytes else None
         rc = lib.hdrnet_bilateral_slice_apply_grad_f32_ex(
             grid.data_ptr(), guide.data_ptr(), inp.data_ptr(), dout.data_ptr(),
             _ptr(dgrid), _ptr(dguide), _ptr(dinput),
@@ -208,9 +208,9 @@ def _slice_backward(grid, guide, dout, need, flags: Optional[int] = None):
     dgrid = torch.empty_like(grid) if need[0] else None
     dguide = torch.empty_like(guide) if need[1] else None
     lib = _lib.load()
-    wbytes = lib.hdrnet_bilateral_slice_grad_workspace_bytes(B, H, W, GH, GW, GD, C) if need[0] else 0
-    ws = torch.empty((wbytes,), dtype=torch.uint8, device=dev) if wbytes else None
     with torch.cuda.device(dev):
+        wbytes = lib.hdrnet_bilateral_slice_grad_workspace_bytes(B, H, W, GH, GW, GD, C) if need[0] else 0
+        ws = torch.empty((wbytes,), dtype=torch.uint8, device=dev) if wbytes else None
         rc = lib.hdrnet_bilateral_slice_grad_f32_ex(
             grid.data_ptr(), guide.data_ptr(), dout.data_ptr(), _ptr(dgrid), _ptr(dguide),
             B, H, W, GH, GW, GD, C, _ptr(ws), wbytes, _flags() if flags is None else flags, _stream(dev))
@@ -315,9 +315,9 @@ def _guide_backward(inp, guide, dguide, c1, c2, dinput, accumulate: bool):
     npx, Cin, n = guide.numel(), inp.shape[-1], c1.shape[0]
     dc1, dc2 = torch.empty_like(c1), torch.empty_like(c2)
     lib = _lib.load()
-    wbytes = lib.hdrnet_pointwise_guide_grad_workspace_bytes(npx, Cin, n)
-    ws = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
+        wbytes = lib.hdrnet_pointwise_guide_grad_workspace_bytes(npx, Cin, n)
+        ws = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=dev)
         rc = lib.hdrnet_pointwise_guide_grad_f32(
             inp.data_ptr(), guide.data_ptr(), dguide.data_ptr(), c1.data_ptr(), c2.data_ptr(),
             _ptr(dinput), int(bool(accumulate)), dc1.data_ptr(), dc2.data_ptr(), npx, Cin, n,
@@ -374,7 +374,15 @@ def bilateral_slice_apply_nnguide(grid: torch.Tensor, input: torch.Tensor,  # no
         return _nnguide_forward(grid.detach(), input.detach(), guide_conv1.detach(), guide_conv2.detach(),
                                 has_offset, want_guide=True)
     if torch.is_grad_enabled() and any(t.requires_grad for t in (grid, input, guide_conv1, guide_conv2)):
-        _check_nnguide(grid, input, guide_conv1, guide_conv2, has_offset)
+        dims = _check_nnguide(grid, input, guide_conv1, guide_conv2, has_offset)
+        # the guide-network VJP has specialisations for a few widths only: say so NOW, not from
+        # inside backward() on the autograd thread
+        with torch.cuda.device(input.device):
+            if _lib.load().hdrnet_pointwise_guide_grad_workspace_bytes(1024, dims[6], dims[8]) == 0:
+                raise ValueError(
+                    f"bilateral_slice_apply_nnguide: no guide-network VJP for Cin = {dims[6]}, n_feats = {dims[8]} "
+                    "(Cin in {1, 3}, n_feats in {4, 8, 16}); compose the guide network from torch ops and "
+                    "call bilateral_slice_apply, or run without autograd")
         return _BilateralSliceApplyNNGuide.apply(grid, input, guide_conv1, guide_conv2, has_offset)
     return _nnguide_forward(grid.detach(), input.detach(), guide_conv1.detach(), guide_conv2.detach(),
                             has_offset, want_guide=False)[0]
@@ -411,9 +419,9 @@ class _BilateralSliceApplyCurves(torch.autograd.Function):
             outs = [torch.empty_like(t) for t in params]
             npx, npts = dguide.numel(), shifts.shape[0]
             lib = _lib.load()
-            wbytes = lib.hdrnet_curves_guide_grad_workspace_bytes(npx, 3, npts)
-            ws = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=inp.device)
             with torch.cuda.device(inp.device):
+                wbytes = lib.hdrnet_curves_guide_grad_workspace_bytes(npx, 3, npts)
+                ws = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=inp.device)
                 rc = lib.hdrnet_curves_guide_grad_f32(
                     inp_c.data_ptr(), dguide.data_ptr(), *[t.data_ptr() for t in params], _ptr(dinput), 1,
                     *[t.data_ptr() for t in outs], npx, 3, npts, ws.data_ptr(), wbytes, _stream(inp.device))
@@ -450,9 +458,9 @@ def input_moments(input: torch.Tensor):  # noqa: A002
     sums = torch.empty((Cin,), dtype=torch.float32, device=dev)
     mom = torch.empty((Cin, Cin), dtype=torch.float32, device=dev)
     lib = _lib.load()
-    wbytes = lib.hdrnet_input_moments_workspace_bytes(npx, Cin)
-    ws = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
+        wbytes = lib.hdrnet_input_moments_workspace_bytes(npx, Cin)
+        ws = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=dev)
         rc = lib.hdrnet_input_moments_f32(inp.data_ptr(), npx, Cin, sums.data_ptr(), mom.data_ptr(),
                                           ws.data_ptr(), wbytes, _stream(dev))
     _lib.check(rc, "InputMoments")
@@ -519,11 +527,35 @@ def bilateral_slice_apply_upadd(grid: torch.Tensor, input: torch.Tensor, coarse:
 _DTYPE_CODE = {torch.float32: 0, torch.uint8: 1, torch.uint16: 2}
 
 
+def _check_io(grid, input, has_offset):  # noqa: A002
+    """Rank / batch / channel / dtype rules shared by the wire-format entry points (the OP_REQUIRES of
+    bilateral_slice_apply_op.cc:147-193 on an input that may be uint8 / uint16).  Returns
+    (B, H, W, GH, GW, GD, Cin, Cout)."""
+    if not isinstance(input, torch.Tensor) or input.dim() != 4:
+        raise ValueError("Input image should be 4D (batch_size, height, width, input_channels)")
+    if input.dtype not in _DTYPE_CODE:
+        raise TypeError(f"input must be float32, uint8 or uint16, got {input.dtype}")
+    _require_f32("grid", grid)
+    if grid.dim() != 5:
+        raise ValueError(f"Input grid should be 5D, got {tuple(grid.shape)}")
+    B, H, W, Cin = input.shape
+    if grid.shape[0] != B:
+        raise ValueError("Batch sizes should match.")
+    GH, GW, GD, C = grid.shape[1:]
+    Cj = Cin + (1 if has_offset else 0)
+    if Cj <= 0 or C % Cj:
+        raise ValueError(
+            "Slicing with affine offset, grid should have output_channels * (input_channels + 1) channels."
+            if has_offset else
+            "Slicing without affine offset, grid should have output_channels * input_channels channels.")
+    return B, H, W, GH, GW, GD, Cin, C // Cj
+
+
 def _apply_io_curves(grid, input, curves, input_white_level, out_dtype, has_offset, return_guide):  # noqa: A002
     if len(curves) != 4:
         raise ValueError("guide_curves should be (ccm, shifts, slopes, mix)")
     ccm, shifts, slopes, mix = curves
-    B, H, W, Cin = input.shape
+    B, H, W, GH, GW, GD, Cin, Cout = _check_io(grid, input, has_offset)
     npts = shifts.shape[0] if shifts.dim() == 2 else -1
     for nm, t, shape in (("ccm", ccm, (Cin, Cin + 1)), ("shifts", shifts, (npts, Cin)),
                          ("slopes", slopes, (npts, Cin)), ("mix", mix, (Cin + 1,))):
@@ -532,16 +564,6 @@ def _apply_io_curves(grid, input, curves, input_white_level, out_dtype, has_offs
             raise ValueError(f"guide_curves.{nm} should be {list(shape)}, got {list(t.shape)}")
     if input_white_level is None:
         input_white_level = {torch.float32: 1.0, torch.uint8: 255.0, torch.uint16: 65535.0}[input.dtype]
-    _require_f32("grid", grid)
-    if grid.dim() != 5:
-        raise ValueError(f"Input grid should be 5D, got {tuple(grid.shape)}")
-    if grid.shape[0] != B:
-        raise ValueError("Batch sizes should match.")
-    GH, GW, GD, C = grid.shape[1:]
-    Cj = Cin + (1 if has_offset else 0)
-    if C % Cj:
-        raise ValueError("Slicing with affine offset, grid should have output_channels * (input_channels + 1) channels.")
-    Cout = C // Cj
     for nm, t in (("grid", grid), ("input", input), ("guide_curves.ccm", ccm), ("guide_curves.shifts", shifts),
                   ("guide_curves.slopes", slopes), ("guide_curves.mix", mix)):
         _require_gpu(nm, t)
@@ -594,17 +616,7 @@ def bilateral_slice_apply_io(grid: torch.Tensor, input: torch.Tensor,  # noqa: A
         raise ValueError("give either a guide map or both guide_conv1 and guide_conv2")
     if input_white_level is None:
         input_white_level = {torch.float32: 1.0, torch.uint8: 255.0, torch.uint16: 65535.0}[input.dtype]
-    _require_f32("grid", grid)
-    if grid.dim() != 5:
-        raise ValueError(f"Input grid should be 5D, got {tuple(grid.shape)}")
-    B, H, W, Cin = input.shape
-    if grid.shape[0] != B:
-        raise ValueError("Batch sizes should match.")
-    GH, GW, GD, C = grid.shape[1:]
-    Cj = Cin + (1 if has_offset else 0)
-    if C % Cj:
-        raise ValueError("Slicing with affine offset, grid should have output_channels * (input_channels + 1) channels.")
-    Cout = C // Cj
+    B, H, W, GH, GW, GD, Cin, Cout = _check_io(grid, input, has_offset)
     n = 0
     if guide is not None:
         _require_f32("guide", guide)

@@ -295,6 +295,11 @@ class HDRNetPointwiseNNGuide(HDRNetCurves):
             fullres_input.requires_grad or any(p.requires_grad for p in self.parameters()))
         if differentiable and n_feats not in (4, 8, 16):
             fusable = False  # no guide-network VJP kernel for this width: compose the ops
+        if self.training and torch.is_grad_enabled() and fullres_input.requires_grad:
+            # The fused training path takes the batch-norm statistics from the input's moments as
+            # constants: the statistics' own contribution to d/d(fullres_input) would be dropped.
+            # The composed graph (and the reference's TF graph) carries it, so compose here.
+            fusable = False
         if not fusable:
             return super().forward(lowres_input, fullres_input)
         from . import hdrnet_ops
@@ -333,7 +338,11 @@ class HDRNetGaussianPyrNN(HDRNetPointwiseNNGuide):
                    and fullres_input.shape[2] % 16 == 0)
         if fusable and not self.training and not torch.is_grad_enabled():
             return self._forward_fused(lowres_input, fullres_input)
-        if fusable and self.params["guide_complexity"] in (4, 8, 16):
+        # The fused autograd path builds the pyramid levels with the resize kernel outside autograd and
+        # (in training) treats the batch-norm statistics as constants: complete for the parameters, NOT
+        # for d/d(fullres_input) -- when the input itself requires a gradient, compose the torch ops.
+        input_grad = torch.is_grad_enabled() and fullres_input.requires_grad
+        if fusable and not input_grad and self.params["guide_complexity"] in (4, 8, 16):
             return self._forward_fused_differentiable(lowres_input, fullres_input)
         coeffs = self.coefficients(lowres_input)
         lvls: List[torch.Tensor] = [fullres_input]

@@ -1,0 +1,195 @@
+"""Direct oracle parity of the HIP path at every BASELINE.json config size, forward AND backward, plus
+the reference tests that round 1 only ran shortened or at reduced size:
+
+* config #2 (1920x1080, grid 16x16x8x12) and config #5 (4000x3000, grid 32x32x8x12; also through the
+  uint16 / 32767 wire format of hdrnet/data_pipeline.py:267-274) forward vs the C oracle (OpenMP);
+* 1080p and 4K backward, all three VJPs, vs the C oracle's gather-form gradients
+  (hdrnet/ops/bilateral_slice_apply.cc:84-259);
+* hdrnet/test/ops_test.py:189-322 -- test_grid_optimize / test_guide_optimize / test_optimize_both
+  with the reference's data, optimiser (plain gradient descent on the summed squared error),
+  learning rates, step counts and thresholds, on the HIP ops;
+* hdrnet/hdrnet_ops_jax_tf2_test.py:26-48 -- JAX twin == op at the reference's real size
+  (batch 4, 640x480, grid 16x12x8x2), assertAllClose defaults (rtol = atol = 1e-6).
+
+The oracle is only the checker here (tests/ may import oracle/).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+FWD_RTOL = FWD_ATOL = 1e-5   # required; the 1e-6 bar is reported
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "run with -m gpu on the MI355X box"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from hdrnet_amd import hdrnet_ops
+    return hdrnet_ops
+
+
+@pytest.fixture(scope="module")
+def mt_port(port):
+    port.set_threads(os.cpu_count() or 1)
+    yield port
+    port.set_threads(1)
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def frame(rng, H, W, GH, GW, GD, lo=-0.02, hi=1.02):
+    grid = rng.random((1, GH, GW, GD, 12), dtype=np.float32)
+    guide = (rng.random((1, H, W), dtype=np.float32) * (hi - lo) + lo).astype(np.float32)
+    inp = rng.random((1, H, W, 3), dtype=np.float32)
+    return grid, guide, inp
+
+
+CONFIGS = {
+    "1080p (config #2)": (1080, 1920, 16, 16, 8),
+    "4K (config #3 hot path)": (2160, 3840, 16, 16, 8),
+    "hdrp 4000x3000 (config #5)": (3000, 4000, 32, 32, 8),
+}
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_forward_vs_oracle_at_config_size(dev, ops, mt_port, name):
+    H, W, GH, GW, GD = CONFIGS[name]
+    rng = np.random.default_rng(H * 7 + W)
+    grid, guide, inp = frame(rng, H, W, GH, GW, GD)
+    want = mt_port.bilateral_slice_apply(grid, guide, inp, True)
+    got = N(ops.bilateral_slice_apply(T(grid, dev), T(guide, dev), T(inp, dev), has_offset=True))
+    assert ops.last_kernel() == "apply_fwd_seg/vec4"
+    err = np.abs(got - want)
+    worst = float((err / (1e-6 + 1e-6 * np.abs(want))).max())
+    print(f"{name}: max|err| = {err.max():.3e}, worst / (1e-6 bar) = {worst:.2f}")
+    np.testing.assert_allclose(got, want, rtol=FWD_RTOL, atol=FWD_ATOL)
+    assert worst < 4.0, worst
+
+
+def test_hdrp_uint16_wire_format_vs_oracle(dev, ops, mt_port):
+    """Config #5 as stated: uint16 linear in [0, 32767] -> float / 32767 (data_pipeline.py:267-274),
+    4000x3000, grid 32x32x8x12, through the fused wire-format entry point."""
+    H, W, GH, GW, GD = CONFIGS["hdrp 4000x3000 (config #5)"]
+    rng = np.random.default_rng(55)
+    grid, guide, _ = frame(rng, H, W, GH, GW, GD)
+    raw = rng.integers(0, 32768, size=(1, H, W, 3), dtype=np.uint16)
+    inp = (raw.astype(np.float32) / np.float32(32767.0)).astype(np.float32)
+    want = mt_port.bilateral_slice_apply(grid, guide, inp, True)
+    traw = torch.from_numpy(raw.astype(np.int32)).to(dev).to(torch.uint16)
+    got = N(ops.bilateral_slice_apply_io(T(grid, dev), traw, guide=T(guide, dev), input_white_level=32767.0,
+                                         has_offset=True))
+    assert ops.last_kernel().startswith("apply_fwd_io/u16->f32"), ops.last_kernel()
+    np.testing.assert_allclose(got, want, rtol=FWD_RTOL, atol=FWD_ATOL)
+
+
+@pytest.mark.parametrize("name", ["1080p (config #2)", "4K (config #3 hot path)"])
+def test_backward_vs_oracle_at_config_size(dev, ops, mt_port, name):
+    """All three VJPs of a full frame against the oracle's gather-form gradients.  Tolerance: rtol
+    1e-4; atol = 1e-5 x max|want| per tensor (dgrid cells are sums of ~30 000 terms of random sign:
+    the summation-order noise of ANY f32 evaluation is ~1e-6 of the largest cell)."""
+    H, W, GH, GW, GD = CONFIGS[name]
+    rng = np.random.default_rng(H + 3 * W)
+    grid, guide, inp = frame(rng, H, W, GH, GW, GD)
+    dout = rng.standard_normal((1, H, W, 3)).astype(np.float32)
+    wg, wgu, wi = mt_port.bilateral_slice_apply_grad(grid, guide, inp, dout, True)
+    tg, tgu, ti = (T(a, dev).requires_grad_(True) for a in (grid, guide, inp))
+    ops.bilateral_slice_apply(tg, tgu, ti, has_offset=True).backward(T(dout, dev))
+    assert ops.last_kernel() == "apply_bwd_fused/mfma", ops.last_kernel()
+    for got, want, nm in ((tg.grad, wg, "dgrid"), (tgu.grad, wgu, "dguide"), (ti.grad, wi, "dinput")):
+        got = N(got)
+        scale = max(1.0, float(np.abs(want).max()))
+        print(f"{name} {nm}: max|err| = {np.abs(got - want).max():.3e} (scale {scale:.3g})")
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5 * scale, err_msg=nm)
+
+
+# ---- hdrnet/test/ops_test.py:178-322, the reference's data / optimiser / step counts / thresholds ----
+def _fit(ops, grid, guide_logits, target, lr, steps, opt_grid, opt_guide):
+    params = [p for p, on in ((grid, opt_grid), (guide_logits, opt_guide)) if on]
+    opt = torch.optim.SGD(params, lr=lr)  # tf.train.GradientDescentOptimizer(lr) on sum of squares
+    for _ in range(steps):
+        opt.zero_grad(set_to_none=True)
+        guide = torch.sigmoid(guide_logits) if opt_guide else guide_logits
+        out = ops.bilateral_slice(grid, guide)
+        loss = ((target - out) ** 2).sum()
+        loss.backward()
+        opt.step()
+    with torch.no_grad():
+        guide = torch.sigmoid(guide_logits) if opt_guide else guide_logits
+        out = ops.bilateral_slice(grid, guide)
+    return float(((out - target) ** 2).sum())
+
+
+def _sine_target(dev, w):
+    t = np.sin(np.linspace(0, 2 * np.pi, w)).astype(np.float32)
+    return T(t[np.newaxis, np.newaxis, :, np.newaxis], dev)
+
+
+def test_grid_optimize_reference(dev, ops):
+    """ops_test.py:189-230: 10 000 steps of gradient descent (lr 1e-2) on the grid, SSE < 0.0085."""
+    np.random.seed(1234)
+    w, gw, gd = 32, 16, 8
+    guide = T(np.linspace(0, 1, w).astype(np.float32)[np.newaxis, np.newaxis, :], dev)
+    grid = T(np.random.rand(1, 1, gw, gd, 1).astype(np.float32), dev).requires_grad_(True)
+    sse = _fit(ops, grid, guide, _sine_target(dev, w), 1e-2, 10000, True, False)
+    assert sse < 0.0085, sse
+
+
+def test_guide_optimize_reference(dev, ops):
+    """ops_test.py:232-278: 6 000 steps (lr 1e-3) on the guide logits through a sigmoid, SSE < 1e-4."""
+    w, gw, gd = 32, 8, 2
+    guide0 = np.linspace(0.5 / gd, 1 - 0.5 / gd, w).astype(np.float32)[np.newaxis, np.newaxis, :]
+    grid = np.linspace(-1, 1, gd).astype(np.float32)[np.newaxis, np.newaxis, np.newaxis, :, np.newaxis]
+    grid = np.tile(grid, [1, 1, gw, 1, 1])
+    logits = T(guide0, dev).requires_grad_(True)
+    sse = _fit(ops, T(grid, dev), logits, _sine_target(dev, w), 1e-3, 6000, False, True)
+    assert sse < 1e-4, sse
+
+
+# The reference draws its data with an UNSEEDED np.random, and whether its threshold holds depends on
+# the draw: the CPU oracle (reference semantics) itself ends at these SSEs
+# (tests/golden/optimize_both_oracle.py), two of six above 1e-4.
+OPTIMIZE_BOTH_ORACLE_SSE = {1234: 4.2299519e-04, 2: 1.6063153e-05, 3: 3.7598593e-06}
+
+
+@pytest.mark.parametrize("seed", sorted(OPTIMIZE_BOTH_ORACLE_SSE))
+def test_optimize_both_reference(dev, ops, seed):
+    """ops_test.py:280-322: 10 000 steps (lr 1e-1) on grid AND guide logits.  The HIP ops must land
+    where the reference's own CPU op lands from the same draw (10 000 chained f32 steps: 2 %), and meet
+    the reference's `SSE < 1e-4` for the draws for which the reference itself meets it."""
+    np.random.seed(seed)
+    w, gw, gd = 32, 8, 2
+    logits = T((np.random.rand(1, 1, w).astype(np.float32) * 2.0 - 1.0), dev).requires_grad_(True)
+    grid = T(np.random.rand(1, 1, gw, gd, 1).astype(np.float32), dev).requires_grad_(True)
+    sse = _fit(ops, grid, logits, _sine_target(dev, w), 1e-1, 10000, True, True)
+    want = OPTIMIZE_BOTH_ORACLE_SSE[seed]
+    assert abs(sse - want) <= 0.02 * want + 1e-7, (sse, want)
+    if want < 1e-4:
+        assert sse < 1e-4, sse
+
+
+def test_jax_twin_equals_op_at_reference_size(dev, ops):
+    """hdrnet_ops_jax_tf2_test.py:26-48 at its real size: batch 4, guide 640x480, grid 16x12x8, 2
+    channels; assertAllClose defaults rtol = atol = 1e-6."""
+    from oracle import jax_np
+    rng = np.random.default_rng(1234)
+    grid = rng.random((4, 16, 12, 8, 2), dtype=np.float32)
+    guide = rng.random((4, 640, 480), dtype=np.float32)
+    want = jax_np.batched(jax_np.bilateral_slice, grid, guide)
+    got = N(ops.bilateral_slice(T(grid, dev), T(guide, dev)))
+    assert got.shape == (4, 640, 480, 2)
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)

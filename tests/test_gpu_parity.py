@@ -665,6 +665,29 @@ def test_misaligned_buffers_take_the_scalar_kernels(dev, ops, port):
     grads_close(N(ti.grad), wi, "dinput")
 
 
+def test_wild_guide_values_fast_equals_generic(dev, ops):
+    """Guides far outside [0, 1] (|guide * GD| beyond 2^23, where f32 rounding makes a corner offset 2):
+    the fast kernels keep the reference's max(., 0) on the z tent, so they agree with the generic
+    (bit-exact-to-reference) kernels instead of applying a weight of -1."""
+    gen = torch.Generator(device=dev).manual_seed(3)
+    B, H, W = 1, 16, 256
+    grid = torch.rand((B, 16, 16, 8, 12), device=dev, generator=gen)
+    inp = torch.rand((B, H, W, 3), device=dev, generator=gen)
+    vals = torch.tensor([1e8, -1e8, 3.1e7, -3.1e7, 2.0 ** 21, 2.0 ** 21 + 0.25, 2.0 ** 20 + 0.125, 1.0e6 + 0.3,
+                         -5.0, 7.5, 1.0, 0.0, 2097151.9, 1048576.06, 12345678.0, -2.0 ** 22], device=dev)
+    guide = vals.repeat(B * H * W // vals.numel()).reshape(B, H, W).contiguous()
+    outs = {}
+    for which in ("generic", "fast"):
+        with ops.kernel_override(which):
+            outs[which] = ops.bilateral_slice_apply(grid, guide, inp, has_offset=True)
+    assert torch.isfinite(outs["fast"]).all()
+    torch.testing.assert_close(outs["fast"], outs["generic"], rtol=1e-5, atol=1e-5)
+    with ops.kernel_override("generic"):
+        want = ops.bilateral_slice(grid, guide)
+    got = ops.bilateral_slice(grid, guide)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
 def test_fast_flag_rejects_unsupported_shape(dev, ops):
     from hdrnet_amd import _lib
     with ops.kernel_override("fast"):

@@ -511,3 +511,41 @@ def test_training_fused_curves_matches_unfused_module():
         scale = q.grad.abs().max().item()
         err = (p.grad - q.grad).abs().max().item()
         assert err <= 2e-3 * scale + 1e-7, (name, err, scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls,train", [("HDRNetPointwiseNNGuide", True), ("HDRNetPointwiseNNGuide", False),
+                                       ("HDRNetGaussianPyrNN", True), ("HDRNetGaussianPyrNN", False),
+                                       ("HDRNetCurves", True)])
+def test_input_gradient_fused_equals_composed(cls, train):
+    """d loss / d fullres_input must be COMPLETE whichever path the module takes: the fused
+    training paths treat the batch-norm statistics as constants and build the pyramid outside autograd,
+    so when the full-resolution input itself requires a gradient the modules must route to a path that
+    carries every term.  fuse_guide = True vs False: same loss, same input gradient, same parameter
+    gradients."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(21)
+    m = getattr(models, cls)(dict(batch_norm=True)).to(dev)
+    ref = getattr(models, cls)(dict(batch_norm=True)).to(dev)
+    ref.load_state_dict(m.state_dict())
+    ref.fuse_guide = False
+    m.train(train)
+    ref.train(train)
+    low = torch.rand(2, 256, 256, 3, device=dev)
+    full0 = torch.rand(2, 48, 64, 3, device=dev)
+    target = torch.rand(2, 48, 64, 3, device=dev)
+    grads = []
+    for mod in (m, ref):
+        full = full0.clone().requires_grad_(True)
+        loss = (mod(low, full) - target).square().mean()
+        loss.backward()
+        assert full.grad is not None
+        grads.append((loss.detach(), full.grad.clone()))
+    torch.testing.assert_close(grads[0][0], grads[1][0], rtol=2e-5, atol=1e-7)
+    scale = grads[1][1].abs().max().item()
+    err = (grads[0][1] - grads[1][1]).abs().max().item()
+    assert err <= 2e-3 * scale + 1e-9, (cls, train, err, scale)
+    for (name, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        if p.requires_grad and q.grad is not None:
+            s = q.grad.abs().max().item()
+            assert (p.grad - q.grad).abs().max().item() <= 2e-3 * s + 1e-7, name
