@@ -231,7 +231,10 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   // fused: this lane's element of the row's coefficient image (2 columns x GD planes x C / 4 float4)
   constexpr int C4 = C / 4 > 0 ? C / 4 : 1;
   const int nst = 2 * p.GD * C4;
-  const int st_col = lane / (p.GD * C4), st_rem = lane - st_col * (p.GD * C4);  // lane < nst
+  // (decoded for min(lane, nst - 1): every lane issues the two staging loads -- a VMEM op under an exec
+  //  mask makes the compiler's vmcnt bookkeeping fall back to vmcnt(0), which drains the prefetch)
+  const int st_lane = min(lane, nst - 1);
+  const int st_col = st_lane / (p.GD * C4), st_rem = st_lane - st_col * (p.GD * C4);
   const int st_src = (min(max(g + st_col, 0), p.GW - 1) * p.GD * C4 + st_rem);  // float4 index in a grid row
   const int st_z = st_rem / C4;
   const int st_dst = (st_col * (p.GD + 2) + st_z + 1) * C4 + (st_rem - st_z * C4);
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
       buf_load<COUT, (COUT <= 4 ? kLoadAux : 0)>(drs, px * (4u * COUT), bt.d[cb]);
     }
     if constexpr (FUSED) {
-      if (bi == 0 && lane < nst) {  // the two grid rows image row y blends (L2-resident)
+      if (bi == 0) {  // wave-uniform: the two grid rows image row y blends (L2-resident)
         const float gyf = mul_rn(y + 0.5f, p.scale_y);
         const int gy0 = floor_to_int(gyf - 0.5f);
         const int gy0c = clamp_index(gy0, 0, p.GH - 1), gy1c = clamp_index(gy0 + 1, 0, p.GH - 1);
@@ -543,14 +546,22 @@ hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int G
   if constexpr (C % 4 == 0) {
     if (wg || wi) {  // fused backward: dgrid + the per-pixel VJPs in one pass
       constexpr bool CAN_WI = APPLY && CIN > 0;
-      if (wg && wi && CAN_WI)
-        grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, true, CAN_WI><<<nblocks, kWaves * 64, 0, s>>>(p);
-      else if (wg)
-        grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, true, false><<<nblocks, kWaves * 64, 0, s>>>(p);
-      else if (CAN_WI)
-        grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, false, CAN_WI><<<nblocks, kWaves * 64, 0, s>>>(p);
+#define GG_FUSED(SPL)                                                                                   \
+  do {                                                                                                  \
+    if (wg && wi && CAN_WI)                                                                             \
+      grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, true, CAN_WI><<<nblocks, kWaves * 64, 0, s>>>(p); \
+    else if (wg)                                                                                        \
+      grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, true, false><<<nblocks, kWaves * 64, 0, s>>>(p);  \
+    else if (CAN_WI)                                                                                    \
+      grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, false, CAN_WI><<<nblocks, kWaves * 64, 0, s>>>(p);\
+    else                                                                                                \
+      return hipErrorInvalidValue;                                                                      \
+  } while (0)
+      if (split)
+        GG_FUSED(true);
       else
-        return hipErrorInvalidValue;
+        GG_FUSED(false);
+#undef GG_FUSED
     } else if (split) {
       grid_grad_stage1<CIN, COUT, OFFSET, APPLY, true><<<nblocks, kWaves * 64, 0, s>>>(p);
     } else {
@@ -630,7 +641,7 @@ bool apply_bwd_fused_supported(const ApplyGradArgs& a) {
 }
 
 hipError_t launch_apply_bwd_fused(const ApplyGradArgs& a, hipStream_t s, const char** name) {
-  *name = "apply_bwd_fused/mfma";
+  *name = a.variant == 2 ? "apply_bwd_fused/mfma-bf16x2" : "apply_bwd_fused/mfma";
   return apply_gg(a, true, s);
 }
 

@@ -286,3 +286,74 @@ def test_curves_guide_restatement_closed_forms():
     mix3 = np.array([4.0, 0.0, 0.0, -1.0], np.float32)
     g = oracle.curves_guide(x, ccm, shifts, slopes, mix3)
     np.testing.assert_allclose(g, np.clip(4 * x[..., 0] - 1, 0, 1), rtol=0, atol=1e-6)
+
+
+# ---- the guide restatements vs the reference's OWN second implementation: its GL shaders ------------
+def _export_curves(rng):
+    """Random curves-guide variables pushed through hdrnet/bin/freeze_graph.py:107-127's export code
+    (restated line by line) -> the four flat files the renderer loads."""
+    ccm_ = (np.identity(3) + 0.2 * rng.standard_normal((3, 3))).astype(np.float32)     # 'inference/guide/ccm'
+    ccm_bias_ = (0.1 * rng.standard_normal(3)).astype(np.float32)
+    shifts_ = np.tile(np.linspace(0, 1, 16, endpoint=False, dtype=np.float32)[None, None, None, :], (1, 1, 3, 1))
+    shifts_ = (shifts_ + 0.02 * rng.standard_normal(shifts_.shape)).astype(np.float32)  # [1, 1, nchans, npts]
+    slopes_ = (0.3 * rng.standard_normal((1, 1, 1, 3, 16))).astype(np.float32)
+    mixing_weights_ = rng.standard_normal((1, 1, 3, 1)).astype(np.float32)
+    mixing_bias_ = rng.standard_normal(1).astype(np.float32)
+    shifts_ = np.squeeze(shifts_).astype(np.float32)                                    # [3, 16]
+    slopes_ = np.squeeze(slopes_).astype(np.float32)
+    mix_matrix_dump = np.append(np.squeeze(mixing_weights_), mixing_bias_[0]).astype(np.float32)
+    ccm34_ = np.vstack((ccm_, ccm_bias_[np.newaxis, :]))                                # [4, 3]
+    files = dict(ccm=np.ascontiguousarray(ccm34_.T).ravel(), shifts=np.ascontiguousarray(shifts_.T).ravel(),
+                 slopes=np.ascontiguousarray(slopes_.T).ravel(), mix=mix_matrix_dump.ravel())
+    return {k: v.astype(np.float32) for k, v in files.items()}
+
+
+def test_curves_guide_restatement_equals_std_frag():
+    """oracle.curves_guide (numpy restatement of hdrnet/models.py:145-190 on the exported layout) ==
+    the transliterated benchmark/assets/std.frag:36-45 on the same FILES (renderer.cc:203-223)."""
+    import oracle
+    from oracle import gl_shaders
+    rng = np.random.default_rng(17)
+    f = _export_curves(rng)
+    px = rng.random((64, 3)).astype(np.float32) * 1.2 - 0.1
+    want = np.array([gl_shaders.std_frag_guide(p, f["ccm"], f["shifts"], f["slopes"], f["mix"]) for p in px])
+    got = oracle.curves_guide(px[None, None], f["ccm"].reshape(3, 4), f["shifts"].reshape(16, 3),
+                              f["slopes"].reshape(16, 3), f["mix"])[0, 0]
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+
+
+def test_pointwise_nn_guide_restatement_equals_gpyrnn_frag():
+    """oracle.pointwise_nn_guide (hdrnet/models.py:203-210 folded as freeze_graph.py:129-184) == the
+    transliterated benchmark/assets/gpyrnn.frag:49-63 on the same FILES (renderer.cc:274-295), every
+    pyramid level; the shader's literal bias index (uGuideConv2[16] at every level) is pinned too."""
+    import oracle
+    from oracle import gl_shaders
+    rng = np.random.default_rng(23)
+    conv1_file, conv2_file, per_level = [], [], []
+    for lvl in range(3):
+        # freeze_graph.py:139-157: fold batch norm (no scale: hdrnet/layers.py:40-58), stack, transpose
+        conv1w_ = rng.standard_normal((1, 1, 3, 16)).astype(np.float32)
+        conv1b_ = rng.standard_normal(16).astype(np.float32)            # BatchNorm/beta
+        mu, sigma, eps = rng.standard_normal(16).astype(np.float32), rng.random(16).astype(np.float32) + 0.5, 1e-3
+        conv1b_ = conv1b_ - mu / np.sqrt(sigma + eps)
+        conv1w_ = conv1w_ / np.sqrt(sigma + eps)
+        conv1w_ = np.squeeze(conv1w_.astype(np.float32))                # [3, 16]
+        conv1b_ = np.squeeze(conv1b_.astype(np.float32))[np.newaxis, :]
+        conv2w_ = np.squeeze(rng.standard_normal((1, 1, 16, 1)).astype(np.float32))
+        conv2b_ = np.squeeze(rng.standard_normal(1).astype(np.float32))
+        conv2 = np.append(conv2w_, conv2b_).astype(np.float32)
+        conv1 = np.vstack([conv1w_, conv1b_]).astype(np.float32)        # [4, 16]
+        conv1_file.append(np.ascontiguousarray(conv1.T).ravel())        # save(conv1.T, ...)
+        conv2_file.append(conv2.ravel())
+        per_level.append((np.ascontiguousarray(conv1.T), conv2))        # [16, 4], [17]: the C-ABI's layout
+    conv1_file, conv2_file = np.concatenate(conv1_file), np.concatenate(conv2_file)
+    px = rng.random((48, 3)).astype(np.float32)
+    for lvl, (c1, c2) in enumerate(per_level):
+        want = np.array([gl_shaders.gpyrnn_frag_guide(p, lvl, conv1_file, conv2_file) for p in px])
+        got = oracle.pointwise_nn_guide(px[None, None], c1, c2)[0, 0]
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+    # the shader as written: level 0's bias everywhere
+    lit = gl_shaders.gpyrnn_frag_guide(px[0], 2, conv1_file, conv2_file, literal_bias_index=True)
+    c2_lit = per_level[2][1].copy()
+    c2_lit[16] = per_level[0][1][16]
+    np.testing.assert_allclose(oracle.pointwise_nn_guide(px[:1][None], per_level[2][0], c2_lit)[0, 0], lit, atol=2e-6)

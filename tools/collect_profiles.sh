@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the round's evidence on an MI355X box into gpurun_out/profiles/ (copy what you want judged
-# into profiles/rNN/).  Run from the repo root:  gpurun --timeout 900 -- 'bash tools/collect_profiles.sh'
+# into profiles/rNN/).  Run from the repo root:  gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh'
 set -u
 R=$(pwd)
 O=$R/gpurun_out/profiles
@@ -8,24 +8,32 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # 1. the default bench command, un-profiled and under rocprofv3 --kernel-trace --stats
 python $R/bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats -d $O/stats -o fwd --output-format csv -- python $R/bench.py > $O/bench_under_rocprof.log 2>&1
+python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_steps20.json 2>> $O/bench.err
+python $R/bench.py --workload 1080p --no-cpu-baseline > $O/bench_1080p.json 2>> $O/bench.err
+python $R/bench.py --workload hdrp --no-cpu-baseline > $O/bench_hdrp.json 2>> $O/bench.err
+for i in 1 2 3 4 5; do python $R/bench.py --no-cpu-baseline; done > $O/bench_repeat.txt 2>> $O/bench.err
+rocprofv3 --kernel-trace --stats -d $O/stats -o fwd --output-format csv -- python $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
 grep '^{"metric' $O/bench_under_rocprof.log > $O/bench_under_rocprof.json
-cp $O/stats/*kernel_stats.csv $O/fwd_kernel_stats.csv 2>/dev/null || find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/fwd_kernel_stats.csv \;
-# 2. HBM traffic of the forward kernel: separate --pmc passes (never combined with trace domains)
-rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES -d $O/pmc_sq -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 > /dev/null 2>&1
+find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/fwd_kernel_stats.csv \;
+# 2. HBM traffic of the forward kernel: separate --pmc passes (never combined with trace domains), each
+#    with a calibration twin on the memory skeleton (known byte count, same access widths)
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $O/cal_fetch -o p --output-format csv -- python $R/tools/ab_bench.py --variants 106 --rounds 1 --steps 20 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/cal_write -o p --output-format csv -- python $R/tools/ab_bench.py --variants 106 --rounds 1 --steps 20 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -d $O/pmc_sq -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 python $R/tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_sq --match apply_fwd > $O/fwd_pmc.txt 2>&1
-# 3. every entry point, both sizes; A/B of the forward variants; end-to-end configs
+python $R/tools/pmc_summary.py $O/cal_fetch $O/cal_write --match skeleton > $O/fwd_pmc_calibration.txt 2>&1
+python $R/tools/make_traffic.py --fetch $O/pmc_fetch --write $O/pmc_write --calib-fetch $O/cal_fetch --calib-write $O/cal_write --workload 4k --out $O/traffic.json > $O/traffic.log 2>&1
+# 3. every entry point, all sizes; A/B of the forward variants; end-to-end configs
 cd $R
-python tools/op_bench.py --workload 4k --json $O/ops_4k.json > $O/ops_4k.txt 2>&1
-python tools/op_bench.py --workload 1080p --json $O/ops_1080p.json > $O/ops_1080p.txt 2>&1
-python tools/ab_bench.py --variants 0,2,3,7,8,9,11,101,103,104,105,106 --rounds 5 --steps 100 > $O/ab_variants_4k.txt 2>&1
+python tools/op_bench.py --tools --workload 4k --json $O/ops_4k.json > $O/ops_4k.txt 2>&1
+python tools/op_bench.py --tools --workload 1080p --json $O/ops_1080p.json > $O/ops_1080p.txt 2>&1
+python tools/op_bench.py --workload hdrp --json $O/ops_hdrp.json > $O/ops_hdrp.txt 2>&1
+python tools/op_bench.py --workload refbench --json $O/ops_refbench.json > $O/ops_refbench.txt 2>&1
+python tools/ab_bench.py --variants 0,19,8,20,21,23,31,35,39,105,106 --rounds 5 --steps 100 --trace 39 > $O/ab_variants_4k.txt 2>&1
+python tools/ab_bench.py --workload 1080p --variants 0,19,23,31,35,39,105,106 --rounds 5 --steps 400 --trace 39 > $O/ab_variants_1080p.txt 2>&1
 python tools/e2e_bench.py > $O/e2e.txt 2>&1
-# 4. device micro-benchmarks
-for b in stream_patterns valu_rates mfma_valu_overlap; do
-  ./tools/debug/ubench/bin/$b > $O/ubench_$b.txt 2>&1
-done
-rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_sq
+rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/cal_fetch $O/cal_write
 ls -la $O
-tail -3 $O/fwd_pmc.txt; cat $O/bench.json
+tail -3 $O/fwd_pmc.txt; cat $O/traffic.log | tail -25; cat $O/bench.json

@@ -205,6 +205,10 @@ def main():
     if args.tools:
         run("apply bwd (all three), un-fused kernels", lambda k: apply_bwd(k, variant=3),
             4 * npx * (1 + Cin + Cout) + 4 * npx * (1 + Cin) + 2 * gridb)
+        run("apply bwd (all three), bf16-split MFMA", lambda k: apply_bwd(k, variant=2),
+            4 * npx * (1 + Cin + Cout) + 4 * npx * (1 + Cin) + 2 * gridb)
+        run("apply bwd dgrid+dguide, bf16-split MFMA", lambda k: apply_bwd(k, di=False, variant=2),
+            4 * npx * (1 + Cin + Cout) + 4 * npx + 2 * gridb)
         run("apply bwd dgrid only (bf16-split MFMA)", lambda k: apply_bwd(k, dgu=False, di=False, variant=2),
             4 * npx * (1 + Cin + Cout) + gridb)
     run("slice fwd", slice_fwd, 4 * npx * (1 + C) + gridb)
