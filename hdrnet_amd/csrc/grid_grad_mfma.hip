@@ -340,10 +340,56 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
           // GD * SmoothedLerpWeightGrad (:186-187); the s > 1 branch binds only for wild guides (see above)
           const float dw0 = (sza > 1.0f) ? 0.0f : gd_f * (dza * __builtin_amdgcn_rcpf(sza));
           const float dw1 = (szb > 1.0f) ? 0.0f : gd_f * (dzb * __builtin_amdgcn_rcpf(szb));
+          // Direct form (no 2 x C blended-coefficient accumulators: 4 scalars instead of 24 registers
+          // live, which is what keeps this kernel at 4 waves per SIMD).  With U[c] = dout_i * [in; 1]_j
+          // -- the SAME per-pixel products the dgrid contraction uses -- and G_v the coefficient
+          // vector of corner v = (x corner, z tap):
+          //   dguide   = sum_v (wx dw)_v <G_v, U>                 (bilateral_slice_apply.cc:140-206)
+          //   dinput_j = sum_v (wx wz)_v sum_i dout_i G_v[i, j]   (:208-259)
           float dgv = 0.0f, div[CIN_Q];
-          vjp_blend<APPLY ? CIN : 0, COUT, APPLY ? OFFSET : true, WG, WI>(
-              img, a0, a0 + CB, a0 + colb, a0 + colb + CB, wa, wb, std_max(1.0f - sza, 0.0f), std_max(1.0f - szb, 0.0f), dw0, dw1,
-              cur.in[cb], cur.d[cb], dgv, div);
+#pragma unroll
+          for (int j = 0; j < CIN_Q; ++j) div[j] = 0.0f;
+          {
+            const float wz0 = std_max(1.0f - sza, 0.0f), wz1 = std_max(1.0f - szb, 0.0f);
+            const float wgt[4] = {wa * wz0, wa * wz1, wb * wz0, wb * wz1};
+            const float dwg[4] = {wa * dw0, wa * dw1, wb * dw0, wb * dw1};
+            const int off[4] = {a0, a0 + CB, a0 + colb, a0 + colb + CB};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              float G[C];
+              const f32x4* gp4 = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(img) + off[v]);
+#pragma unroll
+              for (int q = 0; q < C / 4; ++q) {
+                const f32x4 t = gp4[q];
+                G[4 * q] = t.x; G[4 * q + 1] = t.y; G[4 * q + 2] = t.z; G[4 * q + 3] = t.w;
+              }
+              if constexpr (WG) {
+                float sdot = 0.0f;
+                if constexpr (APPLY) {
+#pragma unroll
+                  for (int i = 0; i < COUT; ++i) {
+                    float e = OFFSET ? G[i * CJ + CIN] : 0.0f;
+#pragma unroll
+                    for (int j = 0; j < CIN; ++j) e = fmaf(G[i * CJ + j], cur.in[cb][j < CIN ? j : 0], e);
+                    sdot = fmaf(e, cur.d[cb][i], sdot);
+                  }
+                } else {
+#pragma unroll
+                  for (int c = 0; c < C; ++c) sdot = fmaf(G[c], cur.d[cb][c], sdot);
+                }
+                dgv = fmaf(dwg[v], sdot, dgv);
+              }
+              if constexpr (WI) {
+#pragma unroll
+                for (int j = 0; j < CIN; ++j) {
+                  float t = 0.0f;
+#pragma unroll
+                  for (int i = 0; i < COUT; ++i) t = fmaf(G[i * CJ + j], cur.d[cb][i], t);
+                  div[j] = fmaf(wgt[v], t, div[j]);
+                }
+              }
+            }
+          }
           {  // write-through buffer stores; descriptors end at the interval, so dead lanes are dropped
             const unsigned px = (unsigned)(x0 + lane);
             if constexpr (WG) {
