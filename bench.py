@@ -226,12 +226,16 @@ def main():
         return stub_main(args, rank, world)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
-    dev = torch.device("cuda", local_rank)
+    # One process per GPU.  (On a box with fewer GPUs than ranks -- the 1-GPU development box -- the
+    # ranks share devices; RCCL refuses two ranks on one device, so that smoke test of the N > 1 path
+    # sets HDRNET_BENCH_BACKEND=gloo.  The driver's 8-GPU runs use the default: nccl = RCCL.)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     dist_on = world > 1
     from hdrnet_amd import dist as hd
+    backend = os.environ.get("HDRNET_BENCH_BACKEND", "nccl")
     if dist_on:
-        hd.init(backend="nccl", device=dev)  # RCCL over xGMI; control plane only (barrier, max-time)
+        hd.init(backend=backend, device=dev)  # RCCL over xGMI; control plane only (barrier, max-time)
 
     from hdrnet_amd import _lib
     lib = _lib.load()  # raises loudly if the HIP library is missing
@@ -252,7 +256,7 @@ def main():
     run_steps(lib, sets, dims, stream, args.warmup)
     wall, gpu_s = timed(lib, sets, dims, stream, args.steps, dist_on, dev)
 
-    wall_max, gpu_max = hd.max_over_ranks([wall, gpu_s], device=dev)
+    wall_max, gpu_max = hd.max_over_ranks([wall, gpu_s], device=dev if backend == "nccl" else torch.device("cpu"))
 
     mp_per_step = H * W / 1e6
     # Short regions (< 10 ms): the host's synchronise latency is a visible share of the wall
