@@ -166,8 +166,8 @@ __device__ __forceinline__ void seg_pixel(const float* __restrict__ img, float g
 
 // Blend the two grid rows image row y needs into the padded LDS image (see the header comment):
 //   img[j][p][c] = wy0 * grid[gy0c][clamp(cmin + j)][clamp(p - 1)][c] + wy1 * grid[gy1c][...]
-// Work item = one VEC-float element of a source (column, plane) vector; two are in flight per
-// thread so that a segment needing more elements than threads still pays one L2 latency.
+// Work item = one VEC-float element of a source (column, plane) vector (one per thread at 4K; a
+// rolled loop keeps the kernel at <= 64 VGPRs, i.e. 8 waves per SIMD, for every load flavour).
 template <int C>
 __device__ __forceinline__ void stage_image(float* __restrict__ img, const float* __restrict__ grid_b,
                                             int y, int cmin, int ncols, int GH, int GW, int GD,
@@ -187,34 +187,16 @@ __device__ __forceinline__ void stage_image(float* __restrict__ img, const float
   elem_t* d = reinterpret_cast<elem_t*>(img);
   const int per_col = GD * CV;
   const int n = ncols * per_col;
-  for (int base = 0; base < n; base += 2 * nthreads) {  // `base` is uniform
-    const bool two = base + nthreads < n;                // uniform: a second element exists for some lane
-    elem_t a[2], b[2];
-    int dst[2] = {-1, -1}, rem[2] = {0, 0};
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (i == 1 && !two) continue;
-      const int e = base + i * nthreads + tid;
-      if (e < n) {
-        const int j = (int)(((float)e + 0.5f) * inv_col);  // e / per_col, exact for e < 2^20
-        rem[i] = e - j * per_col;
-        const int sc = min(max(cmin + j, 0), GW - 1);
-        const int src = sc * per_col + rem[i];
-        a[i] = r0[src];
-        b[i] = r1[src];
-        dst[i] = e + CV * (2 * j + 1);  // column j has GD + 2 planes; source plane z is plane z + 1
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (i == 1 && !two) continue;
-      if (dst[i] >= 0) {
-        const elem_t v = wy0 * a[i] + wy1 * b[i];
-        d[dst[i]] = v;
-        if (rem[i] < CV) d[dst[i] - CV] = v;             // z = 0      -> also plane 0
-        if (rem[i] >= per_col - CV) d[dst[i] + CV] = v;  // z = GD - 1 -> also plane GD + 1
-      }
-    }
+  for (int e = tid; e < n; e += nthreads) {
+    const int j = (int)(((float)e + 0.5f) * inv_col);  // e / per_col, exact for e < 2^20
+    const int rem = e - j * per_col;
+    const int sc = min(max(cmin + j, 0), GW - 1);
+    const int src = sc * per_col + rem;
+    const elem_t v = wy0 * r0[src] + wy1 * r1[src];
+    const int dst = e + CV * (2 * j + 1);  // column j has GD + 2 planes; source plane z is plane z + 1
+    d[dst] = v;
+    if (rem < CV) d[dst - CV] = v;             // z = 0      -> also plane 0
+    if (rem >= per_col - CV) d[dst + CV] = v;  // z = GD - 1 -> also plane GD + 1
   }
 }
 
