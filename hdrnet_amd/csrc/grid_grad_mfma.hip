@@ -562,11 +562,16 @@ struct GGPlan {
   size_t ws_bytes;
 };
 
+#ifndef HDRNET_GG_MAX_RG
+#define HDRNET_GG_MAX_RG 8
+#endif
+constexpr int kMaxRg = HDRNET_GG_MAX_RG;  // rows per workgroup task (4 waves take alternate rows)
+
 bool gg_plan(int B, int H, int W, int GH, int GW, int GD, int C, GGPlan* pl) {
   if (GD > 8 || C > 16 || C < 1) return false;
   // rows of a group may span at most 3 (clamped) grid rows: rg <= cell height
   int rg = H / GH;
-  if (rg > 8) rg = 8;
+  if (rg > kMaxRg) rg = kMaxRg;
   if (rg < 1) rg = 1;
   pl->rg = rg;
   pl->nyg = (H + rg - 1) / rg;
