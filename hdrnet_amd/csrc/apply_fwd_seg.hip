@@ -27,10 +27,11 @@
 //     40.8 to 39.4 us per 4K frame, but only as dense per-instruction runs (a per-pixel 48-B
 //     stride re-fetches lines).
 //   * STORES leave through the same slab, transposed to lane-contiguous 16-B runs, as
-//     `buffer_store_dwordx4 ... sc0 sc1` (write-through) on a descriptor that covers exactly the
-//     row segment (lanes past the run are dropped by the bounds check -- no predicate).  Plain
-//     stores leave up to an L2's worth of dirty lines for the end-of-kernel write-back; writing
-//     through is worth 1.5 us per 4K frame and 0.7 us per 1080p frame (profiles/r02/).
+//     `buffer_store_dwordx4 ... nt` on a descriptor that covers exactly the row segment (lanes past
+//     the run are dropped by the bounds check -- no predicate).  Plain stores leave up to an L2's
+//     worth of dirty lines for the end-of-kernel write-back; streaming them out is worth 1.5 us per
+//     4K frame and 0.7 us per 1080p frame; write-through (sc0 sc1) is as good on line-aligned
+//     segments and 10 % worse on unaligned ones (rows_common.hip.h; profiles/r02/).
 //   * 3-D launch grid (segment, row, batch): no integer division in the kernel.
 //
 // Numerics: the coordinate and weight expressions of the reference in the reference's order
@@ -63,9 +64,9 @@ constexpr int kLoadsDmaNt = 3;     // LDS-DMA, nontemporal                      
 
 // Output stores (all lane-contiguous 16 B after the per-wave LDS transpose):
 constexpr int kStoresGlobal = 0;   // global_store_dwordx4, predicated on the run length
-constexpr int kStoresBufNt = 2;    // buffer_store_dwordx4 ... nt
+constexpr int kStoresBufNt = 2;    // buffer_store_dwordx4 ... nt                  <- product
 constexpr int kStoresBufSc1 = 3;   // ... sc1 (write-through: the line does not stay dirty in L2)
-constexpr int kStoresBufSc01 = 4;  // ... sc0 sc1                                   <- product
+constexpr int kStoresBufSc01 = 4;  // ... sc0 sc1
 // (1 = buffer_store_dwordx4 with the default policy)
 
 struct SegParams {
@@ -425,7 +426,7 @@ long long* g_trace = nullptr;  // device buffer of [nblocks][3]
 
 }  // namespace
 
-// The product configuration: LDS-DMA nontemporal loads, write-through buffer stores.
+// The product configuration: LDS-DMA nontemporal loads, nontemporal buffer stores.
 bool apply_fwd_seg_supported(const ApplyArgs& a) {
   if (!seg_shape(a)) return false;
   // stage_image reads the grid as float4 when C % 4 == 0.
@@ -437,7 +438,7 @@ hipError_t launch_apply_fwd_seg(const ApplyArgs& a, hipStream_t s, const char** 
   *name = "apply_fwd_seg/vec4";
 #define HDRNET_CASE(CI, CO, OFF)                                  \
   if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF)         \
-    return launch_seg_t<CI, CO, OFF, kLoadsDmaNt, kStoresBufSc01, false>(a, s, nullptr)
+    return launch_seg_t<CI, CO, OFF, kLoadsDmaNt, kStoresBufNt, false>(a, s, nullptr)
   HDRNET_CASE(3, 3, true);
   HDRNET_CASE(3, 3, false);
   HDRNET_CASE(3, 4, true);

@@ -283,13 +283,18 @@ __device__ __forceinline__ void vjp_blend(const float* __restrict__ img, int a00
 
 // ---- buffer stores with a cache policy -------------------------------------------------------------
 // Output streams are written exactly once and never re-read by the kernel.  Plain stores leave up
-// to an L2's worth of dirty lines for the end-of-kernel write-back; `sc0 sc1` (write-through) and
-// `nt` stores drain during the kernel: worth 1.5 us per 4K frame and 0.7 us per 1080p frame on the
-// forward (profiles/r02/exp2_store_policy_*.txt).  A raw buffer descriptor over exactly the run
-// being written also drops out-of-range lanes in hardware (no predicate).
+// to an L2's worth of dirty lines for the end-of-kernel write-back; `nt` (streaming) and `sc0 sc1`
+// (write-through) stores drain during the kernel: worth 1.5 us per 4K frame and 0.7 us per 1080p
+// frame on the forward (profiles/r02/exp2_store_policy_*.txt).  The two are equal where a
+// workgroup's run is a whole number of 128-B lines (4K: 768 px x 12 B, 1080p: 960 px x 12 B), but
+// write-through pays for every PARTIAL line at a run boundary -- 4000-px rows cut into 1000-px
+// segments (12 000 B): 64.8 us write-through vs 58.7 us nt vs 63.7 us plain (profiles/r02/
+// exp10_hdrp_flavours.txt) -- so `nt` is the policy the product kernels store with.  A raw buffer
+// descriptor over exactly the run being written also drops out-of-range lanes in hardware (no
+// predicate).
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 constexpr int kAuxPlain = 0, kAuxNt = 2, kAuxSc1 = 16, kAuxSc0Sc1 = 17;
-constexpr int kAuxStream = kAuxSc0Sc1;  // the policy the product kernels store with
+constexpr int kAuxStream = kAuxNt;  // the policy the product kernels store with
 
 // Raw buffer descriptor over `bytes` bytes at `base` (gfx9 family: dword 3 = 0x00020000).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {

@@ -13,7 +13,7 @@
  *       20..39   the product kernel's (apply_fwd_seg) load / store flavours: v - 20 = loads + 4 * stores,
  *                loads  {0 per-lane, 1 nontemporal lane-contiguous, 2 LDS-DMA, 3 LDS-DMA nontemporal}
  *                stores {0 global, 1 buffer, 2 buffer nt, 3 buffer sc1 (write-through), 4 buffer sc0 sc1}
- *                (39 = the product configuration)
+ *                (31 = the product configuration)
  *       40..59   the same with a per-workgroup timeline trace (hdrnet_tools_set_trace)
  *       101, 103..106  memory skeletons
  *   - hdrnet_tools_set_trace: device buffer that the trace variants fill with
