@@ -25,7 +25,10 @@ __global__ __launch_bounds__(256) void slice_fwd_rows(
     const float* __restrict__ grid, const float* __restrict__ guide, float* __restrict__ out,
     int H, int W, int GH, int GW, int GD, int nseg, int seg, int slab_offset_floats,
     float scale_x, float scale_y) {
-  static_assert(C % 4 == 0, "float4 slab rows");
+  // C % 4 == 0: a pixel's C floats are float4s.  C in {1, 2} (the reference's own micro-benchmark
+  // slices 2 channels, hdrnet_ops_jax_tf2_test.py:56-65): scalar slab writes; the run of 64 pixels
+  // is still whole float4s because 64 C % 4 == 0.
+  static_assert(C % 4 == 0 || C == 1 || C == 2, "float4 slab rows");
   extern __shared__ __attribute__((aligned(16))) float colY[];
   const int bid = blockIdx.x;
   const int segi = bid % nseg;
@@ -47,7 +50,7 @@ __global__ __launch_bounds__(256) void slice_fwd_rows(
   }
 
   const RowCtx r = stage_row<C, false>(colY, grid_b, y, xs, xe, GH, GW, GD, scale_x, scale_y);
-  float4* slab = reinterpret_cast<float4*>(colY + slab_offset_floats) + (threadIdx.x >> 6) * (64 * C / 4);
+  float4* slab = reinterpret_cast<float4*>(colY + slab_offset_floats) + (threadIdx.x >> 6) * (64 * C / 4);  // 64 C % 4 == 0
 
 #pragma unroll
   for (int k = 0; k < kPxPerThread; ++k) {
@@ -61,19 +64,31 @@ __global__ __launch_bounds__(256) void slice_fwd_rows(
       accum_vec<C, false>(coef, r.colY, t.a01, t.wx0 * t.wz1);
       accum_vec<C, false>(coef, r.colY, t.a10, t.wx1 * t.wz0);
       accum_vec<C, false>(coef, r.colY, t.a11, t.wx1 * t.wz1);
+      if constexpr (C % 4 == 0) {
 #pragma unroll
-      for (int q = 0; q < C / 4; ++q)
-        slab[lane * (C / 4) + q] = make_float4(coef.v[2 * q][0], coef.v[2 * q][1], coef.v[2 * q + 1][0],
-                                               coef.v[2 * q + 1][1]);
+        for (int q = 0; q < C / 4; ++q)
+          slab[lane * (C / 4) + q] = make_float4(coef.v[2 * q][0], coef.v[2 * q][1], coef.v[2 * q + 1][0],
+                                                 coef.v[2 * q + 1][1]);
+      } else {
+        float* sf = reinterpret_cast<float*>(slab);
+#pragma unroll
+        for (int c = 0; c < C; ++c) sf[lane * C + c] = coef.get(c);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // write-through buffer stores on a descriptor over exactly this run (rows_common.hip.h)
-    const int nvalid = (min(xe, xk0 + 64) - xk0) * (C / 4);  // float4s of this run
-    const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(out + (prow + xk0) * C, (unsigned)nvalid * 16u);
+    // (the descriptor ends at the run's last float: the bounds check is per dword, so a final
+    //  partial float4 -- possible for C < 4 -- is written up to the run's end and no further)
+    const unsigned run_bytes = (unsigned)(min(xe, xk0 + 64) - xk0) * (unsigned)C * 4u;
+    const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(out + (prow + xk0) * C, run_bytes);
+    constexpr int NQ = (64 * C / 4 + 63) / 64;  // store instructions per run: C / 4, or 1 for C < 4
 #pragma unroll
-    for (int q = 0; q < C / 4; ++q) buf_store16<kAuxStream>(slab[lane + 64 * q], orsrc, (unsigned)(lane + 64 * q) * 16u);
+    for (int q = 0; q < NQ; ++q) {
+      if (C % 4 == 0 || lane + 64 * q < 64 * C / 4)
+        buf_store16<kAuxStream>(slab[lane + 64 * q], orsrc, (unsigned)(lane + 64 * q) * 16u);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -104,7 +119,7 @@ hipError_t launch_c(const SliceArgs& a, const Plan& pl, size_t lds, int slab_off
 }  // namespace
 
 bool slice_fwd_rows_supported(const SliceArgs& a) {
-  if (!(a.C == 4 || a.C == 8 || a.C == 12 || a.C == 16)) return false;
+  if (!(a.C == 1 || a.C == 2 || a.C == 4 || a.C == 8 || a.C == 12 || a.C == 16)) return false;
   Plan pl;
   size_t lds;
   int so;
@@ -118,6 +133,8 @@ hipError_t launch_slice_fwd_rows(const SliceArgs& a, hipStream_t s, const char**
   if (!plan_for(a, &pl, &lds, &so)) return hipErrorInvalidValue;
   *name = "slice_fwd_rows";
   switch (a.C) {
+    case 1: return launch_c<1>(a, pl, lds, so, s);
+    case 2: return launch_c<2>(a, pl, lds, so, s);
     case 4: return launch_c<4>(a, pl, lds, so, s);
     case 8: return launch_c<8>(a, pl, lds, so, s);
     case 12: return launch_c<12>(a, pl, lds, so, s);
