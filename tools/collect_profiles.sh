@@ -31,8 +31,9 @@ python tools/op_bench.py --tools --workload 4k --json $O/ops_4k.json > $O/ops_4k
 python tools/op_bench.py --tools --workload 1080p --json $O/ops_1080p.json > $O/ops_1080p.txt 2>&1
 python tools/op_bench.py --workload hdrp --json $O/ops_hdrp.json > $O/ops_hdrp.txt 2>&1
 python tools/op_bench.py --workload refbench --json $O/ops_refbench.json > $O/ops_refbench.txt 2>&1
-python tools/ab_bench.py --variants 0,19,8,20,21,23,31,35,39,105,106 --rounds 5 --steps 100 --trace 39 > $O/ab_variants_4k.txt 2>&1
-python tools/ab_bench.py --workload 1080p --variants 0,19,23,31,35,39,105,106 --rounds 5 --steps 400 --trace 39 > $O/ab_variants_1080p.txt 2>&1
+python tools/ab_bench.py --variants 0,19,8,20,23,27,28,30,31,35,39,105,106 --rounds 5 --steps 100 --trace 23,31 > $O/ab_variants_4k.txt 2>&1
+python tools/ab_bench.py --workload 1080p --variants 0,19,23,28,31,39,105,106 --rounds 5 --steps 400 --trace 31 > $O/ab_variants_1080p.txt 2>&1
+python tools/ab_bench.py --workload hdrp --variants 0,19,23,31,39 --rounds 5 --steps 100 > $O/ab_variants_hdrp.txt 2>&1
 python tools/e2e_bench.py > $O/e2e.txt 2>&1
 rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/cal_fetch $O/cal_write
 ls -la $O
