@@ -43,6 +43,8 @@
 //   tiles of the row groups and the two intervals that cover it.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "launch.hip.h"
 #include "numerics.hip.h"
 #include "rows_common.hip.h"
@@ -168,7 +170,7 @@ constexpr int kTStride = 68;  // floats per operand row: 64 pixels + 4 (16-B ali
 // like apply_fwd_seg.hip: 2 x (GD + 2) x C floats per wave, re-blended by the wave at the start of
 // each row from grid rows it prefetched with the row's first pixel batch.  The z tent and its
 // derivative share one v_sqrt_f32 per tap with the dgrid weights.
-template <int CIN, int COUT, bool OFFSET, bool APPLY, bool SPLIT, bool WG = false, bool WI = false>
+template <int CIN, int COUT, bool OFFSET, bool APPLY, bool SPLIT, bool WG = false, bool WI = false, int ABL = 0>
 __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   constexpr int CJ = APPLY ? CIN + (OFFSET ? 1 : 0) : 1;
   constexpr int C = COUT * CJ;
@@ -189,45 +191,30 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   float* at = lds + wave * kSlab;    // A^T[k][px]
   float* vt = at + 16 * kTStride;    // V^T[c][px]
   float* img = vt + C * kTStride;    // fused: coefficient image of the current row
-  {  // zero the A slab once; afterwards every chunk restores the entries it wrote
-    f32x4* az = reinterpret_cast<f32x4*>(at);
-#pragma unroll
-    for (int q = 0; q < (16 * kTStride / 4 + 63) / 64; ++q)
-      if (lane + 64 * q < 16 * kTStride / 4) az[lane + 64 * q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  const long long task = blockIdx.x;  // one (image, row group, x-interval) per workgroup
+  // one (image, row group, x-interval) per workgroup: grid = (GW + 1, nyg, B)
   const int nint = p.GW + 1;
-  const int g = (int)(task % nint) - 1;  // gx0 of this workgroup's pixels
-  const int yg = (int)((task / nint) % p.nyg);
-  const long long b = task / ((long long)nint * p.nyg);
+  const int g = (int)blockIdx.x - 1;  // gx0 of this workgroup's pixels
+  const int yg = blockIdx.y;
+  const long long b = blockIdx.z;
+  const long long task = ((long long)b * p.nyg + yg) * nint + blockIdx.x;
   const int x_lo = interval_start(g, p.W, p.scale_x);
   const int x_hi = interval_start(g + 1, p.W, p.scale_x);
   const int y_first = yg * p.rg, y_end = min(y_first + p.rg, p.H);
   const int gy_base = gy_base_of(y_first, p.scale_y, p.GH);
   const float gd_f = (float)p.GD;
-  const bool fold_lo = g < 0, fold_hi = g >= p.GW - 1;
   const float gc0 = g + 0.5f, gc1 = g + 1 + 0.5f;
 
-  // Two x weights of pixel x; columns that clamp onto each other (g = -1: corner 0 -> column 0
-  // == corner 1; g = GW-1: corner 1 -> column GW-1 == corner 0) are folded into ONE A row, so
-  // stage 2 never sees a column twice.  Pixels past the interval get zero weights.
-  auto x_weights = [&](int x, float& w0, float& w1, float& wa, float& wb) {
+  // The forward's two x weights of pixel x (corner columns g, g + 1; un-clamped weights, :58-68).  A rows
+  // 0-7 always carry corner 0 and rows 8-15 corner 1; where a corner's column clamps onto the other's
+  // (g = -1, g = GW - 1) stage 2 adds that tile half to the edge column.  Pixels past the interval get zero.
+  auto x_weights = [&](int x, float& w0, float& w1) {
     const float live = (x < x_hi) ? 1.0f : 0.0f;
     const float gxf = mul_rn((float)x + 0.5f, p.scale_x);
-    const float wxa = tent_weight(gc0, gxf) * live;
-    const float wxb = tent_weight(gc1, gxf) * live;
-    wa = wxa;  // the forward's two x weights (fused VJPs gather from the clamped columns g, g + 1)
-    wb = wxb;
-    w0 = fold_lo ? 0.0f : (fold_hi ? wxa + wxb : wxa);
-    w1 = fold_lo ? wxa + wxb : (fold_hi ? 0.0f : wxb);
+    w0 = tent_weight(gc0, gxf) * live;
+    w1 = tent_weight(gc1, gxf) * live;
   };
   const int span = x_hi - x_lo;
   const int nbr = (span + 64 * kBatch - 1) / (64 * kBatch);  // batches per row
-  float w0c[kBatch], w1c[kBatch];  // the common case nbr == 1: one batch per row, same x every row
-  float wac[kBatch], wbc[kBatch];
-#pragma unroll
-  for (int cb = 0; cb < kBatch; ++cb) x_weights(x_lo + 64 * cb + lane, w0c[cb], w1c[cb], wac[cb], wbc[cb]);
-
   // fused: this lane's element of the row's coefficient image (2 columns x GD planes x C / 4 float4)
   constexpr int C4 = C / 4 > 0 ? C / 4 : 1;
   const int nst = 2 * p.GD * C4;
@@ -244,9 +231,19 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
 
   // MFMA lane roles (v_mfma_f32_16x16x4_f32): A[k = lane & 15][kk = lane >> 4],
   // B[kk = lane >> 4][c = lane & 15], D[k = 4 * (lane >> 4) + r][c = lane & 15] in register r.
+  // Operand reads are ds_read_b64: its lane groups are {0-31}, {32-63} (ds_read_b128's are 4 x 16 in an
+  // interleaved lane order under which the 68-float row stride is 2-way conflicted, measured as 45 % of
+  // all LDS cycles: profiles/r02/exp7).  Lane (sub, bc) reads the pixel pairs 32 (sub >> 1) + 2 (sub & 1)
+  // + 4 e, e = 0 .. 7: bank pair = 2 bc + (sub & 1) + const within a group -- conflict-free -- and MFMA
+  // u = 2 e + i contracts pixel P(sub, e) + i (any bijection of the 64 pixels onto (u, kk) is the same sum).
   const int sub = lane >> 4, bc = lane & 15;
-  const f32x4* a_rd = reinterpret_cast<const f32x4*>(at + bc * kTStride + 16 * sub);
-  const f32x4* v_rd = reinterpret_cast<const f32x4*>(vt + min(bc, C - 1) * kTStride + 16 * sub);
+  const int rd_off = 32 * (sub >> 1) + 2 * (sub & 1);
+  // (volatile: keeps the compiler from pairing them into ds_read2_b64, which runs at half the rate with
+  //  ds_read_b128-like lane groups)
+  typedef const volatile __attribute__((address_space(3))) f32x2 lds_vf32x2;
+  typedef __attribute__((address_space(3))) float lds_float;
+  lds_vf32x2* a_rd = (lds_vf32x2*)((lds_float*)at + bc * kTStride + rd_off);
+  lds_vf32x2* v_rd = (lds_vf32x2*)((lds_float*)vt + min(bc, C - 1) * kTStride + rd_off);
 
   f32x4 acc[3];
 #pragma unroll
@@ -254,10 +251,9 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
 
   struct Batch {
     float g[kBatch], in[kBatch][CIN_Q], d[kBatch][COUT];
-    f32x4 sa, sb;  // fused, first batch of a row: this lane's element of the two grid rows to blend
   };
   const int nrows = (y_end - (y_first + wave) + kWaves - 1) / kWaves;
-  const int nbt = (span > 0 && nrows > 0) ? nrows * nbr : 0;
+  const int nbt = (ABL != 3 && span > 0 && nrows > 0) ? nrows * nbr : 0;  // ABL 3: prologue + epilogue only
   auto load_batch = [&](int t, Batch& bt) {
     const int r = t / nbr, bi = t - r * nbr;
     const int y = y_first + wave + r * kWaves;
@@ -277,22 +273,42 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
       if constexpr (APPLY && CIN > 0) buf_load<CIN, (CIN <= 4 ? kLoadAux : 0)>(irs, px * (4u * CIN), bt.in[cb]);
       buf_load<COUT, (COUT <= 4 ? kLoadAux : 0)>(drs, px * (4u * COUT), bt.d[cb]);
     }
-    if constexpr (FUSED) {
-      if (bi == 0) {  // wave-uniform: the two grid rows image row y blends (L2-resident)
-        const float gyf = mul_rn(y + 0.5f, p.scale_y);
-        const int gy0 = floor_to_int(gyf - 0.5f);
-        const int gy0c = clamp_index(gy0, 0, p.GH - 1), gy1c = clamp_index(gy0 + 1, 0, p.GH - 1);
-        bt.sa = reinterpret_cast<const f32x4*>(grid_b + (size_t)gy0c * p.GW * p.GD * C)[st_src];
-        bt.sb = reinterpret_cast<const f32x4*>(grid_b + (size_t)gy1c * p.GW * p.GD * C)[st_src];
-      }
-    }
   };
 
   Batch cur, nxt;
-  if (nbt > 0) load_batch(0, cur);
+  if (nbt > 0) load_batch(0, cur);  // issued first: the rest of the prologue runs under its latency
+  // fused: this lane's element of the two grid rows the coefficient image blends.  They change only when
+  // gy0 does (once per cell height), so they stay in registers across the wave's rows.
+  f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = sa;
+  int gy0_held = -0x7fffffff;
+  auto load_grid_rows = [&](int gy0) {
+    gy0_held = gy0;
+    const int gy0c = clamp_index(gy0, 0, p.GH - 1), gy1c = clamp_index(gy0 + 1, 0, p.GH - 1);
+    sa = reinterpret_cast<const f32x4*>(grid_b + (size_t)gy0c * p.GW * p.GD * C)[st_src];
+    sb = reinterpret_cast<const f32x4*>(grid_b + (size_t)gy1c * p.GW * p.GD * C)[st_src];
+  };
+  if constexpr (FUSED) {
+    if (nbt > 0) load_grid_rows(floor_to_int(mul_rn(y_first + wave + 0.5f, p.scale_y) - 0.5f));
+  }
+  {  // zero the A slab once; afterwards every chunk restores the entries it wrote
+    f32x4* az = reinterpret_cast<f32x4*>(at);
+#pragma unroll
+    for (int q = 0; q < (16 * kTStride / 4 + 63) / 64; ++q)
+      if (lane + 64 * q < 16 * kTStride / 4) az[lane + 64 * q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // x weights depend on (chunk-in-row, lane) only: cached for the first kXW chunks of a row (every
+  // interval up to 256 px: 4K's 240, 1080p's 120), recomputed per chunk only beyond that
+  constexpr int kXW = 4;
+  float w0c[kXW], w1c[kXW];
+#pragma unroll
+  for (int cb = 0; cb < kXW; ++cb) x_weights(x_lo + 64 * cb + lane, w0c[cb], w1c[cb]);
   f32x4 dacc = {0.f, 0.f, 0.f, 0.f}, dacc2 = {0.f, 0.f, 0.f, 0.f};
   for (int t = 0; t < nbt; ++t) {
-    if (t + 1 < nbt) load_batch(t + 1, nxt);
+    if constexpr (ABL == 1 || ABL == 4) {  // tools ablation: the first batch is all a wave ever loads
+      nxt = cur;
+    } else {
+      if (t + 1 < nbt) load_batch(t + 1, nxt);
+    }
     const int r = t / nbr, bi = t - r * nbr;
     const int y = y_first + wave + r * kWaves;
     const int xb = x_lo + bi * 64 * kBatch;
@@ -301,8 +317,9 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
         const float gyf = mul_rn(y + 0.5f, p.scale_y);
         const int gy0 = floor_to_int(gyf - 0.5f);
         const float wy0 = tent_weight(gy0 + 0.5f, gyf), wy1 = tent_weight(gy0 + 1 + 0.5f, gyf);
+        if (gy0 != gy0_held) load_grid_rows(gy0);  // wave-uniform; at most once more per wave (rg <= cell height)
         if (lane < nst) {
-          const f32x4 v = wy0 * cur.sa + wy1 * cur.sb;
+          const f32x4 v = wy0 * sa + wy1 * sb;
           f32x4* d4 = reinterpret_cast<f32x4*>(img);
           d4[st_dst] = v;
           if (st_z == 0) d4[st_dst - C4] = v;
@@ -316,8 +333,15 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
     for (int cb = 0; cb < kBatch; ++cb) {
       const int x0 = xb + 64 * cb;
       if (x0 < x_hi) {  // wave-uniform
-        float w0 = w0c[cb], w1 = w1c[cb], wa = wac[cb], wb = wbc[cb];
-        if (nbr > 1) x_weights(x0 + lane, w0, w1, wa, wb);  // wave-uniform; only intervals wider than 256 px
+        float w0, w1;
+        if (bi == 0) {  // wave-uniform
+          w0 = w0c[cb]; w1 = w1c[cb];
+        } else if (bi == 1) {
+          w0 = w0c[kBatch + cb]; w1 = w1c[kBatch + cb];
+        } else {
+          x_weights(x0 + lane, w0, w1);  // only intervals wider than 256 px
+        }
+        const float wa = w0, wb = w1;
         // z: only the two corners around gzf carry weight (:121); the outermost half cells are
         // forced to 1 (:122-125).  Two v_sqrt_f32 per pixel (1 ulp; argument >= 1e-8, no
         // denormals; a weight moves by <= 6e-8, far below the summation noise of a 30 000-term
@@ -441,34 +465,39 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
         }
         wave_lds_order();
         // D[k, c] += sum_px A[k, px] * V[px, c]; two accumulators break the dependent-issue chain.
-        f32x4 av[4], bv[4];
+        f32x2 av[8], bv[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          av[q] = a_rd[q];
-          bv[q] = v_rd[q];
+        for (int e = 0; e < 8; ++e) {
+          av[e] = a_rd[2 * e];
+          bv[e] = v_rd[2 * e];
         }
         if constexpr (SPLIT) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-            const u32x4_t vb = __builtin_bit_cast(u32x4_t, bv[q]);
+            const f32x4 a4 = {av[2 * q][0], av[2 * q][1], av[2 * q + 1][0], av[2 * q + 1][1]};
+            const f32x4 b4 = {bv[2 * q][0], bv[2 * q][1], bv[2 * q + 1][0], bv[2 * q + 1][1]};
+            const u32x4_t vb = __builtin_bit_cast(u32x4_t, b4);
             u32x4_t b1, b2;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               b1[e] = __builtin_amdgcn_perm(vb[e], vb[e], 0x01000100u);  // [v_hi, v_hi]
               b2[e] = vb[e] >> 16;                                        // [v_lo, 0]
             }
-            const bf16x8 a8 = __builtin_bit_cast(bf16x8, av[q]);
+            const bf16x8 a8 = __builtin_bit_cast(bf16x8, a4);
             dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, b1), dacc, 0, 0, 0);
             dacc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, b2), dacc2, 0, 0, 0);
           }
         } else {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][0], bv[q][0], dacc, 0, 0, 0);
-            dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][1], bv[q][1], dacc2, 0, 0, 0);
-            dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][2], bv[q][2], dacc, 0, 0, 0);
-            dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][3], bv[q][3], dacc2, 0, 0, 0);
+          for (int e = 0; e < 8; ++e) {
+            if constexpr (ABL == 2 || ABL == 4) {  // tools ablation: no MFMAs
+              dacc[0] += av[e][0] * bv[e][0];
+              dacc2[0] += av[e][1] * bv[e][1];
+              continue;
+            }
+            dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e][0], bv[e][0], dacc, 0, 0, 0);
+            dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e][1], bv[e][1], dacc2, 0, 0, 0);
           }
         }
         wave_lds_order();
@@ -545,6 +574,9 @@ __global__ __launch_bounds__(256) void grid_grad_stage2(const float* __restrict_
     const size_t t0 = ((size_t)b * nyg + yg) * nint;
     s += partial[(t0 + gx + 1) * kTileFloats + (rel * 16 + z) * 16 + c];
     s += partial[(t0 + gx) * kTileFloats + (rel * 16 + 8 + z) * 16 + c];
+    // clamp-to-edge: interval g = -1's corner 0 and interval g = GW - 1's corner 1 land on the edge columns
+    if (gx == 0) s += partial[t0 * kTileFloats + (rel * 16 + z) * 16 + c];
+    if (gx == GW - 1) s += partial[(t0 + GW) * kTileFloats + (rel * 16 + 8 + z) * 16 + c];
   }
   red[part][c] = s;
   __syncthreads();
@@ -562,21 +594,25 @@ struct GGPlan {
   size_t ws_bytes;
 };
 
-#ifndef HDRNET_GG_MAX_RG
-#define HDRNET_GG_MAX_RG 8
-#endif
-constexpr int kMaxRg = HDRNET_GG_MAX_RG;  // rows per workgroup task (4 waves take alternate rows)
+// Rows per workgroup task (4 waves take alternate rows).  More rows amortise a wave's start-up (prologue
+// + the one pixel load nothing hides) over more chunks: 16 rows when that still leaves >= 2048 tasks (~1.6
+// rounds of the 1280 resident workgroups: 4K 76 -> 72 us, 4000x3000 121 -> 110 us), else 8 (1080p).
+constexpr int kMaxRg = 16, kMinTasks = 2048;
 
 bool gg_plan(int B, int H, int W, int GH, int GW, int GD, int C, GGPlan* pl) {
   if (GD > 8 || C > 16 || C < 1) return false;
   // rows of a group may span at most 3 (clamped) grid rows: rg <= cell height
-  int rg = H / GH;
-  if (rg > kMaxRg) rg = kMaxRg;
+  const int cell = H / GH > 1 ? H / GH : 1;
+  int rg = cell < kMaxRg ? cell : kMaxRg;
+  if ((long long)B * ((H + rg - 1) / rg) * (GW + 1) < kMinTasks && rg > kMaxRg / 2) rg = kMaxRg / 2;
+#ifdef HDRNET_TOOLS_BUILD
+  if (const char* e = getenv("HDRNET_GG_RG")) rg = atoi(e) < cell ? atoi(e) : cell;  // experiments only
+#endif
   if (rg < 1) rg = 1;
   pl->rg = rg;
   pl->nyg = (H + rg - 1) / rg;
   pl->ntasks = (long long)B * pl->nyg * (GW + 1);
-  if (pl->ntasks > 0x7fffffffLL || (long long)B * GH * GW * GD > 0x7fffffffLL) return false;
+  if (pl->ntasks > 0x7fffffffLL || (long long)B * GH * GW * GD > 0x7fffffffLL || pl->nyg > 65535 || B > 65535) return false;
   pl->ws_bytes = (size_t)pl->ntasks * kTileFloats * sizeof(float);
   return true;
 }
@@ -588,13 +624,30 @@ struct GGPtrs {
 
 template <int CIN, int COUT, bool OFFSET, bool APPLY>
 hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int GD, void* ws, const GGPlan& pl,
-                     hipStream_t s, bool split) {
+                     hipStream_t s, bool split, int ablate = 0) {
   constexpr int C = APPLY ? COUT * (CIN + (OFFSET ? 1 : 0)) : COUT;
   GGParams p{q.guide, q.input, q.dout, q.grid, q.dguide, q.dinput, static_cast<float*>(ws), H, W, GH, GW, GD,
              pl.rg, pl.nyg, pl.ntasks, (float)GW / W, (float)GH / H};
-  const unsigned nblocks = (unsigned)pl.ntasks;
+  const dim3 nblocks((unsigned)(GW + 1), (unsigned)pl.nyg, (unsigned)B);
   const bool wg = q.dguide != nullptr, wi = q.dinput != nullptr;
-  if constexpr (C % 4 == 0) {
+  bool ablated = false;
+#ifdef HDRNET_TOOLS_BUILD
+  if constexpr (APPLY && CIN == 3 && COUT == 3 && OFFSET) {  // ablations (tools variants 4, 5): timing only
+    if (ablate >= 1 && ablate <= 4) {
+#define GG_ABL(A)                                                                                          \
+  do {                                                                                                     \
+    if (wg && wi) grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, true, true, A><<<nblocks, kWaves * 64, 0, s>>>(p);        \
+    else if (wg) grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, true, false, A><<<nblocks, kWaves * 64, 0, s>>>(p);        \
+    else grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, false, false, A><<<nblocks, kWaves * 64, 0, s>>>(p);               \
+  } while (0)
+      if (ablate == 1) GG_ABL(1); else if (ablate == 2) GG_ABL(2); else if (ablate == 3) GG_ABL(3); else GG_ABL(4);
+#undef GG_ABL
+      ablated = true;
+    }
+  }
+#endif
+  if (ablated) {
+  } else if constexpr (C % 4 == 0) {
     if (wg || wi) {  // fused backward: dgrid + the per-pixel VJPs in one pass
       constexpr bool CAN_WI = APPLY && CIN > 0;
 #define GG_FUSED(SPL)                                                                                   \
@@ -666,7 +719,8 @@ static hipError_t apply_gg(const ApplyGradArgs& a, bool fused, hipStream_t s) {
   const bool split = a.variant == 2;
 #define HDRNET_CASE(CI, CO, OFF)                                                                  \
   if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF)                                         \
-  return gg_launch<CI, CO, OFF, true>(q, a.B, a.H, a.W, a.GH, a.GW, a.GD, a.workspace, pl, s, split)
+  return gg_launch<CI, CO, OFF, true>(q, a.B, a.H, a.W, a.GH, a.GW, a.GD, a.workspace, pl, s, split, \
+                                      (a.variant >= 4 && a.variant <= 7) ? a.variant - 3 : 0)
   HDRNET_CASE(3, 3, true);
   HDRNET_CASE(3, 3, false);
   HDRNET_CASE(3, 4, true);

@@ -1,0 +1,115 @@
+#!/usr/bin/env python
+"""Interleaved A/B of the gradient entry point's kernel variants (tools build), same process.
+
+    python tools/bwd_ab.py [--workload 4k] [--rounds 5] [--steps 50] [--cases all,gg,g] [--variants 0,3,2,4,5]
+
+cases: all = dgrid + dguide + dinput, gg = dgrid + dguide, g = dgrid only, v = dguide + dinput only,
+       sl = BilateralSlice grads (C = 12).
+variants (include/hdrnet_amd_tools.h): 0 product, 2 bf16-split contraction, 3 un-fused kernels,
+4 ABLATION: pixels loaded once per wave (no memory waits), 5 ABLATION: no MFMAs.
+"""
+import argparse
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from bench import CACHE_BYTES, WORKLOADS  # noqa: E402
+from hdrnet_amd import _lib  # noqa: E402
+
+
+def time_launches(fn, steps):
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for k in range(steps):
+        fn(k)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / steps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="4k")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--cases", default="all,gg,g")
+    ap.add_argument("--variants", default="0,3,4,5")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    lib = _lib.load_tools()
+    lib.hdrnet_enable_kernel_names(1)
+    H, W, GH, GW, GD, desc = WORKLOADS[args.workload]
+    Cin, Cout, C = 3, 3, 12
+    npx = H * W
+    nsets = max(3, -(-int(CACHE_BYTES * 1.5) // (4 * npx * 11)))
+    gen = torch.Generator(device=dev).manual_seed(1)
+    S = [dict(grid=torch.rand((1, GH, GW, GD, C), device=dev, generator=gen),
+              guide=torch.rand((1, H, W), device=dev, generator=gen),
+              inp=torch.rand((1, H, W, Cin), device=dev, generator=gen),
+              dout=torch.randn((1, H, W, Cout), device=dev, generator=gen),
+              dgrid=torch.empty((1, GH, GW, GD, C), device=dev),
+              dguide=torch.empty((1, H, W), device=dev),
+              dinput=torch.empty((1, H, W, Cin), device=dev)) for _ in range(nsets)]
+    sl = [torch.randn((1, H, W, C), device=dev, generator=gen) for _ in range(2)]
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    wsb = lib.hdrnet_bilateral_slice_apply_grad_workspace_bytes(1, H, W, GH, GW, GD, Cin, Cout, 1)
+    ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
+    wsb2 = lib.hdrnet_bilateral_slice_grad_workspace_bytes(1, H, W, GH, GW, GD, C)
+    ws2 = torch.empty((max(wsb2, 16),), dtype=torch.uint8, device=dev)
+
+    def chk(rc):
+        if rc:
+            raise RuntimeError(lib.hdrnet_last_error().decode())
+
+    def make(case, variant):
+        dg, dgu, di = {"all": (1, 1, 1), "gg": (1, 1, 0), "g": (1, 0, 0), "v": (0, 1, 1), "sl": (1, 1, 0)}[case]
+
+        def fn(k):
+            s = S[k % nsets]
+            if case == "sl":
+                chk(lib.hdrnet_bilateral_slice_grad_f32_ex(
+                    s["grid"].data_ptr(), s["guide"].data_ptr(), sl[k % 2].data_ptr(), s["dgrid"].data_ptr(),
+                    s["dguide"].data_ptr(), 1, H, W, GH, GW, GD, C, ws2.data_ptr(), wsb2,
+                    _lib.KERNEL_AUTO | (variant << 8), stream))
+            else:
+                chk(lib.hdrnet_bilateral_slice_apply_grad_f32_ex(
+                    s["grid"].data_ptr(), s["guide"].data_ptr(), s["inp"].data_ptr(), s["dout"].data_ptr(),
+                    s["dgrid"].data_ptr() if dg else None, s["dguide"].data_ptr() if dgu else None,
+                    s["dinput"].data_ptr() if di else None, 1, H, W, GH, GW, GD, Cin, Cout, 1,
+                    ws.data_ptr(), wsb, _lib.KERNEL_AUTO | (variant << 8), stream))
+        return fn
+
+    cases = args.cases.split(",")
+    variants = [int(v) for v in args.variants.split(",")]
+    fns, names = {}, {}
+    for c in cases:
+        for v in variants:
+            try:
+                f = make(c, v)
+                f(0)
+                torch.cuda.synchronize()
+                fns[(c, v)] = f
+                names[(c, v)] = lib.hdrnet_last_kernel().decode()
+            except Exception as e:  # noqa: BLE001
+                print(f"case {c} variant {v}: unavailable ({e})")
+    time_launches(next(iter(fns.values())), 400)  # power-state pre-roll
+    res = {k: [] for k in fns}
+    for _ in range(args.rounds):
+        for k, f in fns.items():
+            f(0)
+            res[k].append(time_launches(f, args.steps))
+    print(desc)
+    for (c, v), t in res.items():
+        print(f"case {c:4s} variant {v:3d} {names[(c, v)]:34s} median {statistics.median(t):8.2f} us  min {min(t):8.2f}"
+              f"   all: {[round(x, 1) for x in t]}")
+
+
+if __name__ == "__main__":
+    main()

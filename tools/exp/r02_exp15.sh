@@ -1,0 +1,8 @@
+#!/bin/bash
+set -u
+R=$(pwd); O=$R/gpurun_out; mkdir -p $O
+python -m pytest tests -q -x -m gpu 2>&1 | tail -3
+{
+python tools/bwd_ab.py --rounds 4 --steps 50 --cases all,gg,g,sl,v --variants 0,2 2>&1 | grep "^case"
+python tools/bwd_ab.py --workload 1080p --rounds 4 --steps 100 --cases all,gg,g,sl,v --variants 0 2>&1 | grep "^case"
+} | tee $O/exp15_bwd.txt
