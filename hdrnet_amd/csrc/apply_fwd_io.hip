@@ -22,6 +22,7 @@
 #include "launch.hip.h"
 #include "numerics.hip.h"
 #include "rows_common.hip.h"
+#include "seg_common.hip.h"
 
 namespace hdrnet_amd {
 namespace {
@@ -46,44 +47,51 @@ struct GuideNet {
   int n;               // NN: features                curves: knots per channel
 };
 
-template <int CIN>
-__device__ __forceinline__ float guide_net_pixel(const GuideNet& gn, const float (&in)[CIN]) {
-  float acc = gn.conv2[gn.n];
-#pragma unroll 4
-  for (int k = 0; k < gn.n; ++k) {
-    const float* w = gn.conv1 + k * (CIN + 1);
-    float h = w[CIN];
-#pragma unroll
-    for (int j = 0; j < CIN; ++j) h = fmaf(w[j], in[j], h);
-    acc = fmaf(gn.conv2[k], fmaxf(h, 0.0f), acc);
-  }
-  return 1.0f / (1.0f + expf(-acc));
-}
+typedef __attribute__((address_space(4))) const float cfloat;  // wave-uniform parameters: s_load
 
 // guide = clip(mix[CIN] + sum_c mix[c] * sum_k slopes[k][c] * relu(t_c - shifts[k][c]), 0, 1),
-// t_c = ccm[c][CIN] + sum_j ccm[c][j] * in_j     (models.py:157-188)
+// t_c = ccm[c][CIN] + sum_j ccm[c][j] * in_j     (models.py:157-188), for a lane's 4 pixels at once: one
+// pass over the knots, every parameter read once through the constant address space.
 template <int CIN>
-__device__ __forceinline__ float guide_curves_pixel(const GuideNet& gn, const float (&in)[CIN]) {
-  float t[CIN], cv[CIN];
+__device__ __forceinline__ void guide_curves_quad(const GuideNet& gn, const float* inf, float (&g)[kPxPerThread]) {
+  cfloat* ccm = (cfloat*)gn.conv1;
+  cfloat* mix = (cfloat*)gn.conv2;
+  cfloat* shifts = (cfloat*)gn.shifts;
+  cfloat* slopes = (cfloat*)gn.slopes;
+  float t[kPxPerThread][CIN], cv[kPxPerThread][CIN];
 #pragma unroll
   for (int c = 0; c < CIN; ++c) {
-    const float* w = gn.conv1 + c * (CIN + 1);  // wave-uniform -> scalar loads
-    float h = w[CIN];
+    float w[CIN + 1];
 #pragma unroll
-    for (int j = 0; j < CIN; ++j) h = fmaf(w[j], in[j], h);
-    t[c] = h;
-    cv[c] = 0.0f;
+    for (int j = 0; j <= CIN; ++j) w[j] = ccm[c * (CIN + 1) + j];
+#pragma unroll
+    for (int q = 0; q < kPxPerThread; ++q) {
+      float h = w[CIN];
+#pragma unroll
+      for (int j = 0; j < CIN; ++j) h = fmaf(w[j], inf[q * CIN + j], h);
+      t[q][c] = h;
+      cv[q][c] = 0.0f;
+    }
   }
 #pragma unroll 4
   for (int k = 0; k < gn.n; ++k) {
 #pragma unroll
-    for (int c = 0; c < CIN; ++c)
-      cv[c] = fmaf(gn.slopes[k * CIN + c], fmaxf(t[c] - gn.shifts[k * CIN + c], 0.0f), cv[c]);
-  }
-  float g = gn.conv2[CIN];
+    for (int c = 0; c < CIN; ++c) {
+      const float sl = slopes[k * CIN + c], sh = shifts[k * CIN + c];
 #pragma unroll
-  for (int c = 0; c < CIN; ++c) g = fmaf(gn.conv2[c], cv[c], g);
-  return fminf(fmaxf(g, 0.0f), 1.0f);  // tf.clip_by_value(guidemap, 0, 1)
+      for (int q = 0; q < kPxPerThread; ++q) cv[q][c] = fmaf(sl, fmaxf(t[q][c] - sh, 0.0f), cv[q][c]);
+    }
+  }
+  float m[CIN + 1];
+#pragma unroll
+  for (int c = 0; c <= CIN; ++c) m[c] = mix[c];
+#pragma unroll
+  for (int q = 0; q < kPxPerThread; ++q) {
+    float v = m[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) v = fmaf(m[c], cv[q][c], v);
+    g[q] = fminf(fmaxf(v, 0.0f), 1.0f);  // tf.clip_by_value(guidemap, 0, 1)
+  }
 }
 
 // Load 4 pixels x CIN channels of TI starting at element index e0, as floats / white level.
@@ -110,25 +118,37 @@ __device__ __forceinline__ void load_pixels(const TI* __restrict__ src, size_t e
   }
 }
 
+struct IoParams {
+  const float* grid;
+  const float* guide;
+  const void* input;
+  void* out;
+  int H, W, GH, GW, GD;
+  int seg, slab_off;
+  float scale_x, scale_y, inv_col, white_level;
+  GuideNet gn;
+};
+
+// Geometry, LDS image and pixel core are apply_fwd_seg.hip's (seg_common.hip.h): a workgroup owns a row
+// segment, 3-D launch grid (segment, row, image), padded y-pre-lerped coefficient image.
 template <int CIN, int COUT, bool OFFSET, int GUIDE, typename TI, typename TO>
-__global__ __launch_bounds__(256) void apply_fwd_io_rows(
-    const float* __restrict__ grid, const float* __restrict__ guide, const TI* __restrict__ input,
-    TO* __restrict__ out, int H, int W, int GH, int GW, int GD, int nseg, int seg,
-    int slab_offset_floats, float scale_x, float scale_y, float white_level, GuideNet gn) {
+__global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
   constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
+  constexpr int CB = C * (int)sizeof(float);
   constexpr int NI = CIN * kPxPerThread, NO = COUT * kPxPerThread;
-  extern __shared__ __attribute__((aligned(16))) float colY[];
-  const int bid = blockIdx.x;
-  const int segi = bid % nseg;
-  const int row = bid / nseg;  // = b * H + y
-  const int y = row % H;
-  const int b = row / H;
-  const int xs = segi * seg;
-  const int xe = min(xs + seg, W);
-  const float* grid_b = grid + (size_t)b * GH * GW * GD * C;
-  const int x = xs + kPxPerThread * threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xs = blockIdx.x * p.seg;
+  const int xe = min(xs + p.seg, p.W);
+  const int y = blockIdx.y;
+  const int b = blockIdx.z;
+  const float* grid_b = p.grid + (size_t)b * p.GH * p.GW * p.GD * C;
+  const int x = xs + kPxPerThread * tid;
   const bool active = x < xe;
-  const size_t p = (size_t)row * W + x;
+  const size_t row = (size_t)b * p.H + y;
+  const size_t px = row * p.W + x;
+  const TI* input = static_cast<const TI*>(p.input);
 
   float gs[kPxPerThread] = {0.f, 0.f, 0.f, 0.f};
   float inf[NI];
@@ -136,43 +156,39 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(
   for (int q = 0; q < NI; ++q) inf[q] = 0.0f;
   if (active) {
     if constexpr (GUIDE == kGuideMap) {
-      const float4 g4 = *reinterpret_cast<const float4*>(guide + p);
+      const float4 g4 = *reinterpret_cast<const float4*>(p.guide + px);
       gs[0] = g4.x; gs[1] = g4.y; gs[2] = g4.z; gs[3] = g4.w;
     }
-    load_pixels<TI, NI>(input, p * CIN, white_level, inf);
+    load_pixels<TI, NI>(input, px * CIN, p.white_level, inf);
   }
 
-  const RowCtx r = stage_row<C, false>(colY, grid_b, y, xs, xe, GH, GW, GD, scale_x, scale_y);
+  const SegCols sc = seg_cols(xs, xe, p.scale_x);
+  const int colb = (p.GD + 2) * CB;
+  const float gd_f = (float)p.GD, zhi = (float)(p.GD - 1);
+  stage_image<C>(lds, grid_b, y, sc.cmin, sc.ncols, p.GH, p.GW, p.GD, p.scale_y, p.inv_col, tid, (int)blockDim.x);
+  XTerm xt[kPxPerThread];
+  const float xf0 = (float)x + 0.5f;
+#pragma unroll
+  for (int k = 0; k < kPxPerThread; ++k) xt[k] = x_term(xf0 + (float)k, p.scale_x, sc.cmin, colb, CB);
+  __syncthreads();
 
   float of[NO];
   if (active) {
     if constexpr (GUIDE != kGuideMap) {
-#pragma unroll
-      for (int k = 0; k < kPxPerThread; ++k) {
-        float in[CIN];
-#pragma unroll
-        for (int j = 0; j < CIN; ++j) in[j] = inf[k * CIN + j];
-        gs[k] = GUIDE == kGuideNN ? guide_net_pixel<CIN>(gn, in) : guide_curves_pixel<CIN>(gn, in);
-      }
-      if (gn.guide_out) *reinterpret_cast<float4*>(gn.guide_out + p) = make_float4(gs[0], gs[1], gs[2], gs[3]);
+      if constexpr (GUIDE == kGuideNN)
+        guide_nn_quad<CIN>(GuideNN{p.gn.conv1, p.gn.conv2, nullptr, p.gn.n}, inf, gs);
+      else
+        guide_curves_quad<CIN>(p.gn, inf, gs);
+      if (p.gn.guide_out) *reinterpret_cast<float4*>(p.gn.guide_out + px) = make_float4(gs[0], gs[1], gs[2], gs[3]);
     }
-    const float xf0 = (float)x + 0.5f;
 #pragma unroll
     for (int k = 0; k < kPxPerThread; ++k) {
-      const SliceTerms t = slice_terms<C, false>(r, xf0 + (float)k, gs[k]);
-      CoefVec<C> coef;
-      accum_vec<C, true>(coef, r.colY, t.a00, t.wx0 * t.wz0);
-      accum_vec<C, false>(coef, r.colY, t.a01, t.wx0 * t.wz1);
-      accum_vec<C, false>(coef, r.colY, t.a10, t.wx1 * t.wz0);
-      accum_vec<C, false>(coef, r.colY, t.a11, t.wx1 * t.wz1);
-      constexpr int CJ = CIN + (OFFSET ? 1 : 0);
+      float in[CIN], o[COUT];
 #pragma unroll
-      for (int i = 0; i < COUT; ++i) {
-        float v = OFFSET ? coef.get(i * CJ + CIN) : 0.0f;
+      for (int j = 0; j < CIN; ++j) in[j] = inf[k * CIN + j];
+      seg_pixel<CIN, COUT, OFFSET>(lds, gd_f, zhi, colb, xt[k], gs[k], in, o);
 #pragma unroll
-        for (int j = 0; j < CIN; ++j) v = fmaf(coef.get(i * CJ + j), inf[k * CIN + j], v);
-        of[k * COUT + i] = v;
-      }
+      for (int i = 0; i < COUT; ++i) of[k * COUT + i] = o[i];
     }
   }
 
@@ -189,14 +205,14 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(
         const float c = fminf(fmaxf(of[q], 0.0f), 1.0f);
         w[q >> 2] |= ((uint32_t)(255.0f * c)) << (8 * (q & 3));
       }
-      uint32_t* op = reinterpret_cast<uint32_t*>(out + p * COUT);
+      uint32_t* op = reinterpret_cast<uint32_t*>(static_cast<TO*>(p.out) + px * COUT);
 #pragma unroll
       for (int q = 0; q < NO / 4; ++q) op[q] = w[q];
     }
   } else {
-    // float output: lane-contiguous stores through the per-wave LDS slab (apply_fwd_rows.hip)
-    float4* slab = reinterpret_cast<float4*>(colY + slab_offset_floats) + (threadIdx.x >> 6) * (64 * COUT);
-    const int lane = threadIdx.x & 63;
+    // float output: lane-contiguous nontemporal buffer stores through the per-wave LDS slab
+    // (apply_fwd_seg.hip); the descriptor covers exactly the row segment
+    float4* slab = reinterpret_cast<float4*>(lds + p.slab_off) + wave * (64 * COUT);
     if (active) {
 #pragma unroll
       for (int q = 0; q < COUT; ++q)
@@ -205,27 +221,49 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int wave_x0 = xs + kPxPerThread * (int)(threadIdx.x & ~63u);
-    const int nvalid = (min(xe, wave_x0 + 64 * kPxPerThread) - wave_x0) * COUT / 4;
-    float4* gp = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + ((size_t)row * W + wave_x0) * COUT);
+    const unsigned wpx = kPxPerThread * 64u * (unsigned)wave;
+    float* oseg = static_cast<float*>(p.out) + (row * p.W + xs) * COUT;
+    const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(oseg, (unsigned)(xe - xs) * COUT * 4u);
 #pragma unroll
-    for (int k = 0; k < COUT; ++k) {
-      const int e = lane + 64 * k;
-      if (e < nvalid) gp[e] = slab[e];
-    }
+    for (int k = 0; k < COUT; ++k)
+      buf_store16<kAuxStream>(slab[lane + 64 * k], orsrc, (wpx * COUT + 4u * (unsigned)(lane + 64 * k)) * 4u);
   }
 }
 
+struct IoGeom {
+  Plan pl;
+  int slab_off;
+  size_t lds;
+};
+
+IoGeom io_geom(int W, int GW, int GD, int C, int Cout) {
+  IoGeom g;
+  g.pl = make_row_plan(W, GW, true);
+  const int max_cols = (int)(((long long)(g.pl.seg - 1) * GW) / W + 4);
+  g.slab_off = round_up(max_cols * (GD + 2) * C, 4);
+  g.lds = ((size_t)g.slab_off + (size_t)(g.pl.threads / 64) * 64 * kPxPerThread * Cout) * sizeof(float);
+  return g;
+}
+
 template <int CIN, int COUT, bool OFFSET, int GUIDE, typename TI, typename TO>
-hipError_t launch_io(const ApplyIoArgs& a, const Plan& pl, hipStream_t s) {
+hipError_t launch_io(const ApplyIoArgs& a, const Plan&, hipStream_t s) {
   constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
-  const int slab_off = round_up(pl.max_cols * a.GD * C, 4);
-  const size_t lds = ((size_t)slab_off + (size_t)(pl.threads / 64) * 64 * kPxPerThread * COUT) * sizeof(float);
-  const long long nblocks = (long long)a.B * a.H * pl.nseg;
-  const GuideNet gn{a.guide_conv1, a.guide_conv2, a.guide_shifts, a.guide_slopes, a.guide_out, a.n_feats};
-  apply_fwd_io_rows<CIN, COUT, OFFSET, GUIDE, TI, TO><<<(unsigned)nblocks, pl.threads, lds, s>>>(
-      a.grid, a.guide, static_cast<const TI*>(a.input), static_cast<TO*>(a.out), a.H, a.W, a.GH, a.GW,
-      a.GD, pl.nseg, pl.seg, slab_off, (float)a.GW / a.W, (float)a.GH / a.H, a.white_level, gn);
+  const IoGeom g = io_geom(a.W, a.GW, a.GD, C, COUT);
+  IoParams p;
+  p.grid = a.grid;
+  p.guide = a.guide;
+  p.input = a.input;
+  p.out = a.out;
+  p.H = a.H; p.W = a.W; p.GH = a.GH; p.GW = a.GW; p.GD = a.GD;
+  p.seg = g.pl.seg;
+  p.slab_off = g.slab_off;
+  p.scale_x = (float)a.GW / a.W;
+  p.scale_y = (float)a.GH / a.H;
+  p.inv_col = 1.0f / (float)(a.GD * (C / 4));
+  p.white_level = a.white_level;
+  p.gn = GuideNet{a.guide_conv1, a.guide_conv2, a.guide_shifts, a.guide_slopes, a.guide_out, a.n_feats};
+  const dim3 grid3((unsigned)g.pl.nseg, (unsigned)a.H, (unsigned)a.B);
+  apply_fwd_io_rows<CIN, COUT, OFFSET, GUIDE, TI, TO><<<grid3, g.pl.threads, g.lds, s>>>(p);
   return hipGetLastError();
 }
 
@@ -255,10 +293,11 @@ bool plan_io(const ApplyIoArgs& a, Plan* pl) {
                          (a.input_dtype == 0 ? (uintptr_t)a.input : 0);
   if (bits & 15u) return false;
   if (((uintptr_t)a.input | (uintptr_t)a.out) & 3u) return false;
-  *pl = make_row_plan(a.W, a.GW, true);
-  if ((long long)a.B * a.H * pl->nseg > 0x7fffffffLL) return false;
-  const size_t lds = ((size_t)pl->max_cols * a.GD * 12 + 4 + (size_t)(pl->threads / 64) * 64 * kPxPerThread * 3) * sizeof(float);
-  return lds <= 64 * 1024;
+  const IoGeom g = io_geom(a.W, a.GW, a.GD, 12, 3);
+  *pl = g.pl;
+  if (a.B > 65535 || a.H > 65535 || (long long)a.W * a.Cout * 4 >= (1LL << 31)) return false;
+  if ((long long)(g.slab_off) >= (1 << 20)) return false;
+  return g.lds <= 64 * 1024;
 }
 
 }  // namespace

@@ -45,49 +45,8 @@ using namespace rows;
 // ---- 4 consecutive pixels per thread, 16-byte global accesses -----------------------
 // Requires W % 4 == 0, seg % 4 == 0 and 16-B aligned guide / input / out.
 //
-// GUIDE_NN: the guide is not read from memory but computed per pixel from the input by the
-// reference's point-wise guide network with batch-norm folded (HDRNetPointwiseNNGuide._guide,
-// hdrnet/models.py:203-210; parameters in the layout hdrnet/bin/freeze_graph.py:170-184 exports):
-//   guide = sigmoid(conv2[n] + sum_k conv2[k] * relu(conv1[k][CIN] + sum_j conv1[k][j] * in_j))
-// -- the fusion the reference's own GL renderer performs (benchmark/assets/gpyrnn.frag:42-63).
-// The guide never touches HBM (24 instead of 28 B/px) and the 16-channel full-resolution
-// intermediate of the un-fused graph disappears.
-//
 // LDS_STORES = false keeps the naive per-lane stores (16 B at a 16*COUT-byte lane stride); it
 // exists only to document the 6.5 us per 4K frame they cost (tools/ab_bench.py, variant 7).
-struct GuideNN {
-  const float* conv1;  // [n][CIN + 1]: weights then bias of feature k
-  const float* conv2;  // [n + 1]: mixing weights then bias
-  float* guide_out;    // optional [B][H][W] copy of the guide (null: not written)
-  int n;
-};
-
-template <int CIN>
-__device__ __forceinline__ float guide_nn_pixel(const GuideNN& gn, const float (&in)[CIN]) {
-  float acc = gn.conv2[gn.n];
-#pragma unroll 4
-  for (int k = 0; k < gn.n; ++k) {
-    const float* w = gn.conv1 + k * (CIN + 1);  // wave-uniform -> scalar loads
-    float h = w[CIN];
-#pragma unroll
-    for (int j = 0; j < CIN; ++j) h = fmaf(w[j], in[j], h);
-    acc = fmaf(gn.conv2[k], fmaxf(h, 0.0f), acc);
-  }
-  return 1.0f / (1.0f + expf(-acc));  // tf.nn.sigmoid
-}
-// UPADD: out += the coarser pyramid level's output, bilinearly up-sampled with align_corners = True
-// -- the `tf.image.resize_images(current, sz, BILINEAR, align_corners=True)` + `tf.add` of
-// HDRNetGaussianPyrNN._output (hdrnet/models.py:283-287).  TensorFlow (requirements.txt:
-// tensorflow_gpu==2.12.0; not vendored) computes, per axis, scale = (in - 1) / float(out - 1),
-// src = i * scale, lower = floor(src), upper = min(ceil(src), in - 1), lerp = src - lower, and
-// top + (bottom - top) * y_lerp with top = tl + (tr - tl) * x_lerp
-// (tensorflow/core/kernels/image/resize_bilinear_op.cc, legacy non-half-pixel path).
-struct UpAdd {
-  const float* coarse;  // [B][Hc][Wc][COUT]
-  int Hc, Wc;
-  float sh, sw;  // (Hc - 1) / float(H - 1), (Wc - 1) / float(W - 1)   (in / out when out == 1)
-};
-
 template <int CIN, int COUT, bool OFFSET, bool GUIDE_NN = false, bool LDS_STORES = true, bool UPADD = false,
           bool NT_LOADS = false>
 __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
@@ -334,10 +293,6 @@ hipError_t launch_nnguide_t(const ApplyArgs& a, const GuideNN& gn, hipStream_t s
   return hipGetLastError();
 }
 
-float resize_scale(int in, int out) {  // TF CalculateResizeScale, align_corners = true
-  return out > 1 ? (float)(in - 1) / (float)(out - 1) : (float)in / (float)out;
-}
-
 template <bool GUIDE_NN>
 hipError_t launch_upadd_t(const ApplyArgs& a, const GuideNN& gn, const float* coarse, int Hc, int Wc,
                           hipStream_t s) {
@@ -365,6 +320,8 @@ bool apply_fwd_nnguide_supported(const ApplyArgs& a, const float* guide_out) {
 hipError_t launch_apply_fwd_nnguide(const ApplyArgs& a, const float* conv1, const float* conv2,
                                     int n_feats, float* guide_out, hipStream_t s,
                                     const char** name) {
+  if (apply_fwd_seg_nnguide_supported(a, guide_out))
+    return launch_apply_fwd_seg_nnguide(a, conv1, conv2, n_feats, guide_out, s, name);
   const GuideNN gn{conv1, conv2, guide_out, n_feats};
   ApplyArgs t = a;
   t.guide = a.input;
@@ -390,6 +347,8 @@ bool apply_fwd_upadd_supported(const ApplyArgs& a, const float* coarse, bool gui
 hipError_t launch_apply_fwd_upadd(const ApplyArgs& a, const float* coarse, int Hc, int Wc,
                                   const float* conv1, const float* conv2, int n_feats,
                                   hipStream_t s, const char** name) {
+  if (apply_fwd_seg_upadd_supported(a, coarse, conv1 != nullptr))
+    return launch_apply_fwd_seg_upadd(a, coarse, Hc, Wc, conv1, conv2, n_feats, s, name);
   if (conv1) {
     const GuideNN gn{conv1, conv2, nullptr, n_feats};
     ApplyArgs t = a;

@@ -51,6 +51,7 @@
 #include "launch.hip.h"
 #include "numerics.hip.h"
 #include "rows_common.hip.h"
+#include "seg_common.hip.h"
 
 namespace hdrnet_amd {
 namespace {
@@ -80,6 +81,8 @@ struct SegParams {
   float scale_x, scale_y;
   float inv_col;   // 1 / (GD * C / VEC): column of a staging element by float multiply
   long long* trace;  // TRACE: [nblocks][3] wall-clock ticks (start, end), XCC id; else unused
+  GuideNN gn;        // GUIDE_NN: the folded point-wise guide network (rows_common.hip.h)
+  UpAdd up;          // UPADD: the coarser pyramid level to up-sample and add
 };
 
 template <int STORES>
@@ -96,119 +99,18 @@ __device__ __forceinline__ void dma16(const float* src, float* dst_wave_base) {
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst_wave_base, 16, 0, NT ? 2 : 0);
 }
 
-// x-only terms of a pixel (bilateral_slice_apply.cc:41,46,53-54,61-62).
-struct XTerm {
-  float wx0, wx1;
-  int xbp;  // byte offset of (column gx0, plane 0 + 1) in the image
-};
-
-__device__ __forceinline__ XTerm x_term(float xf, float scale_x, int cmin, int colb, int cb) {
-#pragma clang fp contract(off)
-  XTerm t;
-  const float gxf = mul_rn(xf, scale_x);
-  const float fxl = floorf(gxf - 0.5f);
-  const float dx0 = (fxl + 0.5f) - gxf;  // in (-1, 0]
-  t.wx0 = 1.0f + dx0;
-  t.wx1 = -dx0;
-  t.xbp = __mul24((int)fxl - cmin, colb) + cb;
-  return t;
-}
-
-// One pixel: z terms, the four-vector blend from the padded image, the affine
-// (bilateral_slice_apply.cc:43-80).
-template <int CIN, int COUT, bool OFFSET>
-__device__ __forceinline__ void seg_pixel(const float* __restrict__ img, float gd_f, float zhi, int colb,
-                                          const XTerm& xt, float g, const float (&in)[CIN > 0 ? CIN : 1],
-                                          float (&out)[COUT]) {
-  constexpr int CJ = CIN + (OFFSET ? 1 : 0);
-  constexpr int C = COUT * CJ;
-  constexpr int CB = C * (int)sizeof(float);
-  f32x2 w0, w1;
-  int a0;
-  {
-#pragma clang fp contract(off)
-    const float gzf = mul_rn(g, gd_f);
-    const float fzl = floorf(gzf - 0.5f);
-    // corner centres as the reference forms them, (float)gz + 0.5f with gz1 = gz0 + 1: identical to
-    // fzl + 1.5f while gzf is exact, and the same rounding as the reference once it is not
-    const f32x2 cz = {fzl + 0.5f, (fzl + 1.0f) + 0.5f};
-    const f32x2 gz2 = {gzf, gzf};
-    const f32x2 dz = cz - gz2;  // (gz0 + .5) - gzf, (gz0 + 1.5) - gzf
-    const f32x2 eps2 = {kSmoothEps, kSmoothEps};
-    const f32x2 q = __builtin_elementwise_fma(dz, dz, eps2);
-    const f32x2 s = {__builtin_amdgcn_sqrtf(q.x), __builtin_amdgcn_sqrtf(q.y)};
-    const f32x2 one2 = {1.0f, 1.0f};
-    // max(., 0) as the reference (numerics.h:108-113): never binds for a guide whose gzf is exact
-    // in f32, but once |guide * GD| reaches 2^23 the rounding of (gz0 + 1.5) - gzf can make a corner
-    // offset 2 and its un-clamped weight -1
-    const f32x2 zero2 = {0.0f, 0.0f};
-    const f32x2 wz = __builtin_elementwise_max(one2 - s, zero2);
-    const f32x2 wx0 = {xt.wx0, xt.wx0}, wx1 = {xt.wx1, xt.wx1};
-    w0 = wx0 * wz;
-    w1 = wx1 * wz;
-    // plane of z index iz is iz + 1; the clamp to [-1, GD-1] only guards wild guides (the
-    // padded planes already hold the reference's clamped reads; v_med3 of a NaN yields -1).
-    const int iz = (int)__builtin_amdgcn_fmed3f(fzl, -1.0f, zhi);
-    a0 = __mul24(iz, CB) + xt.xbp;
-  }
-  CoefVec<C> coef;
-  accum_vec<C, true>(coef, img, a0, w0.x);
-  accum_vec<C, false>(coef, img, a0 + CB, w0.y);
-  accum_vec<C, false>(coef, img, a0 + colb, w1.x);
-  accum_vec<C, false>(coef, img, a0 + colb + CB, w1.y);
-#pragma unroll
-  for (int i = 0; i < COUT; ++i) {
-    float v = OFFSET ? coef.get(i * CJ + CIN) : 0.0f;
-#pragma unroll
-    for (int j = 0; j < CIN; ++j) v = fmaf(coef.get(i * CJ + j), in[j], v);
-    out[i] = v;
-  }
-}
-
-// Blend the two grid rows image row y needs into the padded LDS image (see the header comment):
-//   img[j][p][c] = wy0 * grid[gy0c][clamp(cmin + j)][clamp(p - 1)][c] + wy1 * grid[gy1c][...]
-// Work item = one VEC-float element of a source (column, plane) vector (one per thread at 4K; a
-// rolled loop keeps the kernel at <= 64 VGPRs, i.e. 8 waves per SIMD, for every load flavour).
-template <int C>
-__device__ __forceinline__ void stage_image(float* __restrict__ img, const float* __restrict__ grid_b,
-                                            int y, int cmin, int ncols, int GH, int GW, int GD,
-                                            float scale_y, float inv_col, int tid, int nthreads) {
-  constexpr int VEC = (C % 4 == 0) ? 4 : 1;
-  constexpr int CV = C / VEC;
-  typedef float elem_t __attribute__((ext_vector_type(VEC)));
-  // Wave-uniform y terms (bilateral_slice_apply.cc:42,47,55-56).
-  const float gyf = mul_rn(y + 0.5f, scale_y);
-  const int gy0 = floor_to_int(gyf - 0.5f);
-  const float wy0 = tent_weight(gy0 + 0.5f, gyf);
-  const float wy1 = tent_weight(gy0 + 1 + 0.5f, gyf);
-  const int gy0c = clamp_index(gy0, 0, GH - 1);
-  const int gy1c = clamp_index(gy0 + 1, 0, GH - 1);
-  const elem_t* r0 = reinterpret_cast<const elem_t*>(grid_b + (size_t)gy0c * GW * GD * C);
-  const elem_t* r1 = reinterpret_cast<const elem_t*>(grid_b + (size_t)gy1c * GW * GD * C);
-  elem_t* d = reinterpret_cast<elem_t*>(img);
-  const int per_col = GD * CV;
-  const int n = ncols * per_col;
-  for (int e = tid; e < n; e += nthreads) {
-    const int j = (int)(((float)e + 0.5f) * inv_col);  // e / per_col, exact for e < 2^20
-    const int rem = e - j * per_col;
-    const int sc = min(max(cmin + j, 0), GW - 1);
-    const int src = sc * per_col + rem;
-    const elem_t v = wy0 * r0[src] + wy1 * r1[src];
-    const int dst = e + CV * (2 * j + 1);  // column j has GD + 2 planes; source plane z is plane z + 1
-    d[dst] = v;
-    if (rem < CV) d[dst - CV] = v;             // z = 0      -> also plane 0
-    if (rem >= per_col - CV) d[dst + CV] = v;  // z = GD - 1 -> also plane GD + 1
-  }
-}
-
-template <int CIN, int COUT, bool OFFSET, int LOADS, int STORES, bool TRACE>
+// GUIDE_NN / UPADD: the guide is computed in registers from the input run
+// the wave has just streamed in (no guide DMA: 24 instead of 28 B/px), and / or the coarser pyramid
+// level is up-sampled and added before the store -- HDRNetPointwiseNNGuide / HDRNetGaussianPyrNN.
+template <int CIN, int COUT, bool OFFSET, int LOADS, int STORES, bool TRACE, bool GUIDE_NN = false,
+          bool UPADD = false>
 __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
   constexpr int CJ = CIN + (OFFSET ? 1 : 0);
   constexpr int C = COUT * CJ;
   constexpr int CB = C * (int)sizeof(float);
   constexpr int SLABW = 64 * kPxPerThread * (CIN > COUT ? CIN : COUT);  // floats: in / out run of a wave
   constexpr bool DMA = LOADS >= kLoadsDma;
-  constexpr int SLAB = SLABW + (DMA ? 64 * kPxPerThread : 0);           // + the guide run
+  constexpr int SLAB = SLABW + ((DMA && !GUIDE_NN) ? 64 * kPxPerThread : 0);  // + the guide run
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   long long t_start = 0;
@@ -227,7 +129,7 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
   const int wave_x0 = xs + kPxPerThread * 64 * wave;
   const int wave_px = min(xe, wave_x0 + 64 * kPxPerThread) - wave_x0;  // <= 0: idle wave
   float4* slab = reinterpret_cast<float4*>(lds + p.slab_off + wave * SLAB);
-  float4* gslab = slab + SLABW / 4;  // DMA only
+  [[maybe_unused]] float4* gslab = slab + SLABW / 4;  // DMA only
 
   // Grid columns of this segment, unclamped: gx0 of the first pixel .. gx0 + 1 of the last.
   const int cmin = floor_to_int(mul_rn(xs + 0.5f, p.scale_x) - 0.5f);
@@ -240,7 +142,7 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
   const size_t row = (size_t)b * p.H + y;
   const unsigned lpx = kPxPerThread * (unsigned)tid;         // this lane's first pixel in the segment
   const unsigned wpx = kPxPerThread * 64u * (unsigned)wave;  // this wave's first pixel in the segment
-  const float* gseg = p.guide + (row * p.W + xs);
+  [[maybe_unused]] const float* gseg = GUIDE_NN ? nullptr : p.guide + (row * p.W + xs);
   const float* iseg = p.input + (row * p.W + xs) * CIN;
 
   // Pixel loads go out first: their HBM latency overlaps the (L2-resident) staging.
@@ -248,12 +150,14 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
   float4 iv[CIN > 0 ? CIN : 1];
   if constexpr (LOADS == kLoadsLane) {
     if (active) {
-      g4 = *reinterpret_cast<const float4*>(gseg + lpx);
+      if constexpr (!GUIDE_NN) g4 = *reinterpret_cast<const float4*>(gseg + lpx);
 #pragma unroll
       for (int q = 0; q < CIN; ++q) iv[q] = *reinterpret_cast<const float4*>(iseg + (lpx * CIN + 4 * q));
     }
   } else if constexpr (LOADS == kLoadsNtContig) {
-    if (active) g4 = load_stream4(gseg + lpx);
+    if constexpr (!GUIDE_NN) {
+      if (active) g4 = load_stream4(gseg + lpx);
+    }
 #pragma unroll
     for (int k = 0; k < CIN; ++k) {
       const int e = lane + 64 * k;
@@ -263,8 +167,9 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
     // LDS-DMA: every lane issues (the LDS side is base + 16 * lane); lanes past the run re-read
     // its last float4.  An idle wave issues nothing.
     if (wave_px > 0) {
-      dma16<LOADS == kLoadsDmaNt>(gseg + (wpx + 4u * (unsigned)min(lane, wave_px / 4 - 1)),
-                                  reinterpret_cast<float*>(gslab));
+      if constexpr (!GUIDE_NN)
+        dma16<LOADS == kLoadsDmaNt>(gseg + (wpx + 4u * (unsigned)min(lane, wave_px / 4 - 1)),
+                                    reinterpret_cast<float*>(gslab));
       const int last = wave_px * CIN / 4 - 1;
 #pragma unroll
       for (int k = 0; k < CIN; ++k)
@@ -299,7 +204,7 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
     }
   } else if constexpr (DMA) {
     if (active) {
-      g4 = gslab[lane];
+      if constexpr (!GUIDE_NN) g4 = gslab[lane];
 #pragma unroll
       for (int q = 0; q < CIN; ++q) iv[q] = slab[lane * CIN + q];
     }
@@ -312,11 +217,16 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 
-  const float gs[4] = {g4.x, g4.y, g4.z, g4.w};
+  float gs[4] = {g4.x, g4.y, g4.z, g4.w};
   const float* inf = reinterpret_cast<const float*>(iv);
   float4 ov[COUT];
   float* of = reinterpret_cast<float*>(ov);
   if (active) {
+    if constexpr (GUIDE_NN) {
+      guide_nn_quad<CIN>(p.gn, inf, gs);
+      if (p.gn.guide_out)  // wave-uniform
+        *reinterpret_cast<float4*>(p.gn.guide_out + (row * p.W + xs) + lpx) = make_float4(gs[0], gs[1], gs[2], gs[3]);
+    }
 #pragma unroll
     for (int k = 0; k < kPxPerThread; ++k) {
       float in[CIN > 0 ? CIN : 1], o[COUT];
@@ -326,6 +236,7 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
 #pragma unroll
       for (int i = 0; i < COUT; ++i) of[k * COUT + i] = o[i];
     }
+    if constexpr (UPADD) upadd_quad<COUT>(p.up, b, y, x, of);
 #pragma unroll
     for (int q = 0; q < COUT; ++q) slab[lane * COUT + q] = ov[q];
   }
@@ -371,15 +282,15 @@ struct SegGeom {
 
 constexpr size_t kMaxLdsBytes = 64 * 1024;  // keep >= 2 workgroups per CU
 
-SegGeom seg_geom(const ApplyArgs& a, bool dma) {
+SegGeom seg_geom(const ApplyArgs& a, bool dma, bool guide_map = true) {
   const int C = a.Cout * a.Cj;
   SegGeom g{};
-  const bool aligned =
-      (((uintptr_t)a.guide | (uintptr_t)a.input | (uintptr_t)a.out | (uintptr_t)a.grid) & 15u) == 0;
+  const bool aligned = (((guide_map ? (uintptr_t)a.guide : 0) | (uintptr_t)a.input | (uintptr_t)a.out |
+                         (uintptr_t)a.grid) & 15u) == 0;
   g.pl = make_row_plan(a.W, a.GW, aligned);
   g.max_cols = (int)(((long long)(g.pl.seg - 1) * a.GW) / a.W + 4);
   g.slab_off = round_up(g.max_cols * (a.GD + 2) * C, 4);
-  const int slabw = 64 * kPxPerThread * (a.Cin > a.Cout ? a.Cin : a.Cout) + (dma ? 64 * kPxPerThread : 0);
+  const int slabw = 64 * kPxPerThread * (a.Cin > a.Cout ? a.Cin : a.Cout) + ((dma && guide_map) ? 64 * kPxPerThread : 0);
   g.lds = ((size_t)g.slab_off + (size_t)(g.pl.threads / 64) * slabw) * sizeof(float);
   const long long nstage = (long long)g.max_cols * a.GD * C;
   g.ok = g.pl.vec4 && g.lds <= kMaxLdsBytes && nstage < (1 << 20) && a.B <= 65535 && a.H <= 65535 &&
@@ -387,13 +298,18 @@ SegGeom seg_geom(const ApplyArgs& a, bool dma) {
   return g;
 }
 
-template <int CIN, int COUT, bool OFFSET, int LOADS, int STORES, bool TRACE>
-hipError_t launch_seg_t(const ApplyArgs& a, hipStream_t s, long long* trace) {
+template <int CIN, int COUT, bool OFFSET, int LOADS, int STORES, bool TRACE, bool GUIDE_NN = false,
+          bool UPADD = false>
+hipError_t launch_seg_t(const ApplyArgs& a, hipStream_t s, long long* trace,
+                        const GuideNN& gn = GuideNN{nullptr, nullptr, nullptr, 0},
+                        const UpAdd& up = UpAdd{nullptr, 0, 0, 0.f, 0.f}) {
   constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
   constexpr int VEC = (C % 4 == 0) ? 4 : 1;
-  const SegGeom g = seg_geom(a, LOADS >= kLoadsDma);
+  const SegGeom g = seg_geom(a, LOADS >= kLoadsDma, !GUIDE_NN);
   if (!g.ok) return hipErrorNotSupported;
   SegParams p;
+  p.gn = gn;
+  p.up = up;
   p.grid = a.grid;
   p.guide = a.guide;
   p.input = a.input;
@@ -410,7 +326,7 @@ hipError_t launch_seg_t(const ApplyArgs& a, hipStream_t s, long long* trace) {
   p.inv_col = 1.0f / (float)(a.GD * (C / VEC));
   p.trace = trace;
   const dim3 grid3((unsigned)g.pl.nseg, (unsigned)a.H, (unsigned)a.B);
-  apply_fwd_seg<CIN, COUT, OFFSET, LOADS, STORES, TRACE><<<grid3, g.pl.threads, g.lds, s>>>(p);
+  apply_fwd_seg<CIN, COUT, OFFSET, LOADS, STORES, TRACE, GUIDE_NN, UPADD><<<grid3, g.pl.threads, g.lds, s>>>(p);
   return hipGetLastError();
 }
 
@@ -448,6 +364,49 @@ hipError_t launch_apply_fwd_seg(const ApplyArgs& a, hipStream_t s, const char** 
   HDRNET_CASE(4, 4, true);
 #undef HDRNET_CASE
   return hipErrorInvalidValue;
+}
+
+// Fused guide network (+ optional guide copy): Cin = Cout in {3, 1} as the round-1 kernel offered.
+bool apply_fwd_seg_nnguide_supported(const ApplyArgs& a, const float* guide_out) {
+  if (!((a.Cin == 3 && a.Cout == 3) || (a.Cin == 1 && a.Cout == 1))) return false;
+  if (((uintptr_t)guide_out & 15u) || ((a.Cout * a.Cj) % 4 == 0 && ((uintptr_t)a.grid & 15u))) return false;
+  return seg_geom(a, true, false).ok;
+}
+
+hipError_t launch_apply_fwd_seg_nnguide(const ApplyArgs& a, const float* conv1, const float* conv2, int n_feats,
+                                        float* guide_out, hipStream_t s, const char** name) {
+  const GuideNN gn{conv1, conv2, guide_out, n_feats};
+  *name = "apply_fwd_seg/vec4+nnguide";
+#define HDRNET_CASE(CI, CO, OFF)                          \
+  if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF) \
+    return launch_seg_t<CI, CO, OFF, kLoadsDmaNt, kStoresBufNt, false, true, false>(a, s, nullptr, gn)
+  HDRNET_CASE(3, 3, true);
+  HDRNET_CASE(3, 3, false);
+  HDRNET_CASE(1, 1, true);
+  HDRNET_CASE(1, 1, false);
+#undef HDRNET_CASE
+  return hipErrorInvalidValue;
+}
+
+// Slice-apply (+ optional fused guide network) + bilinear up-add of the coarser pyramid level:
+// Cin = Cout = 3 with offset (the reference's pyramid model).
+bool apply_fwd_seg_upadd_supported(const ApplyArgs& a, const float* coarse, bool guide_nn) {
+  if (!(a.Cin == 3 && a.Cout == 3 && a.has_offset) || ((uintptr_t)coarse & 3u) || ((uintptr_t)a.grid & 15u))
+    return false;
+  return seg_geom(a, true, !guide_nn).ok;
+}
+
+hipError_t launch_apply_fwd_seg_upadd(const ApplyArgs& a, const float* coarse, int Hc, int Wc, const float* conv1,
+                                      const float* conv2, int n_feats, hipStream_t s, const char** name) {
+  const UpAdd up{coarse, Hc, Wc, resize_scale(Hc, a.H), resize_scale(Wc, a.W)};
+  if (conv1) {
+    *name = "apply_fwd_seg/vec4+nnguide+upadd";
+    return launch_seg_t<3, 3, true, kLoadsDmaNt, kStoresBufNt, false, true, true>(
+        a, s, nullptr, GuideNN{conv1, conv2, nullptr, n_feats}, up);
+  }
+  *name = "apply_fwd_seg/vec4+upadd";
+  return launch_seg_t<3, 3, true, kLoadsDmaNt, kStoresBufNt, false, false, true>(
+      a, s, nullptr, GuideNN{nullptr, nullptr, nullptr, 0}, up);
 }
 
 #ifdef HDRNET_TOOLS_BUILD

@@ -180,7 +180,9 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   static_assert(!WI || (APPLY && CIN > 0), "dinput needs an input");
   constexpr int CB = C * (int)sizeof(float);
   constexpr int CIN_Q = (APPLY && CIN > 0) ? CIN : 1;
-  constexpr int kBatch = 2;  // chunks of 64 pixels loaded ahead (4: 132 VGPRs, 3 waves / SIMD, 6 % slower)
+  // chunks of 64 pixels loaded ahead (4: 132 VGPRs, 3 waves / SIMD, 6 % slower; 1 with dinput fused, which
+  // then fits 4 waves / SIMD instead of 3: 113 -> 120 us, the shorter prefetch costs more than the wave buys)
+  constexpr int kBatch = 2;
   constexpr int kLoadAux = FUSED ? rows::kAuxNt : 0;  // fused pass is an HBM stream: nontemporal pixel loads
   constexpr int kImg = FUSED ? 2 * 10 * C : 0;  // [x corner][plane 0 .. GD + 1 (GD <= 8)][c]
   constexpr int kSlab = (16 + C) * kTStride + kImg;  // floats per wave: A^T [16][68], V^T [C][68], image
@@ -202,16 +204,17 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   const int y_first = yg * p.rg, y_end = min(y_first + p.rg, p.H);
   const int gy_base = gy_base_of(y_first, p.scale_y, p.GH);
   const float gd_f = (float)p.GD;
-  const float gc0 = g + 0.5f, gc1 = g + 1 + 0.5f;
+  const float gc0 = g + 0.5f;
 
-  // The forward's two x weights of pixel x (corner columns g, g + 1; un-clamped weights, :58-68).  A rows
-  // 0-7 always carry corner 0 and rows 8-15 corner 1; where a corner's column clamps onto the other's
-  // (g = -1, g = GW - 1) stage 2 adds that tile half to the edge column.  Pixels past the interval get zero.
-  auto x_weights = [&](int x, float& w0, float& w1) {
-    const float live = (x < x_hi) ? 1.0f : 0.0f;
+  // The forward's two x weights of pixel x (corner columns g, g + 1; un-clamped weights, :58-68) from ONE
+  // cached float per (chunk-in-row, lane): dx = (g + 0.5) - gxf.  w0 = max(1 - |dx|, 0), and corner 1's
+  // offset (g + 1.5) - gxf equals dx + 1 exactly for gxf >= 1 (both differences are exact) and to 3e-8
+  // below.  Pixels past the interval carry dx = 2: both weights 0.  A rows 0-7 always carry corner 0 and
+  // rows 8-15 corner 1; where a corner's column clamps onto the other's (g = -1, g = GW - 1) stage 2 adds
+  // that tile half to the edge column.
+  auto x_offset = [&](int x) {
     const float gxf = mul_rn((float)x + 0.5f, p.scale_x);
-    w0 = tent_weight(gc0, gxf) * live;
-    w1 = tent_weight(gc1, gxf) * live;
+    return (x < x_hi) ? gc0 - gxf : 2.0f;
   };
   const int span = x_hi - x_lo;
   const int nbr = (span + 64 * kBatch - 1) / (64 * kBatch);  // batches per row
@@ -238,12 +241,11 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   // u = 2 e + i contracts pixel P(sub, e) + i (any bijection of the 64 pixels onto (u, kk) is the same sum).
   const int sub = lane >> 4, bc = lane & 15;
   const int rd_off = 32 * (sub >> 1) + 2 * (sub & 1);
-  // (volatile: keeps the compiler from pairing them into ds_read2_b64, which runs at half the rate with
-  //  ds_read_b128-like lane groups)
-  typedef const volatile __attribute__((address_space(3))) f32x2 lds_vf32x2;
+  // They are issued from inline asm: the compiler pairs neighbouring ds_read_b64 into ds_read2_b64 (half
+  // the rate, ds_read_b128-like lane groups), and `volatile` reads serialise read -> wait -> MFMA.
   typedef __attribute__((address_space(3))) float lds_float;
-  lds_vf32x2* a_rd = (lds_vf32x2*)((lds_float*)at + bc * kTStride + rd_off);
-  lds_vf32x2* v_rd = (lds_vf32x2*)((lds_float*)vt + min(bc, C - 1) * kTStride + rd_off);
+  const unsigned a_addr = (unsigned)(uintptr_t)((lds_float*)at + bc * kTStride + rd_off);
+  const unsigned v_addr = (unsigned)(uintptr_t)((lds_float*)vt + min(bc, C - 1) * kTStride + rd_off);
 
   f32x4 acc[3];
 #pragma unroll
@@ -296,12 +298,12 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
     for (int q = 0; q < (16 * kTStride / 4 + 63) / 64; ++q)
       if (lane + 64 * q < 16 * kTStride / 4) az[lane + 64 * q] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  // x weights depend on (chunk-in-row, lane) only: cached for the first kXW chunks of a row (every
+  // x offsets depend on (chunk-in-row, lane) only: cached for the first kXW chunks of a row (every
   // interval up to 256 px: 4K's 240, 1080p's 120), recomputed per chunk only beyond that
   constexpr int kXW = 4;
-  float w0c[kXW], w1c[kXW];
+  float dxc[kXW];
 #pragma unroll
-  for (int cb = 0; cb < kXW; ++cb) x_weights(x_lo + 64 * cb + lane, w0c[cb], w1c[cb]);
+  for (int cb = 0; cb < kXW; ++cb) dxc[cb] = x_offset(x_lo + 64 * cb + lane);
   f32x4 dacc = {0.f, 0.f, 0.f, 0.f}, dacc2 = {0.f, 0.f, 0.f, 0.f};
   for (int t = 0; t < nbt; ++t) {
     if constexpr (ABL == 1 || ABL == 4) {  // tools ablation: the first batch is all a wave ever loads
@@ -333,14 +335,14 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
     for (int cb = 0; cb < kBatch; ++cb) {
       const int x0 = xb + 64 * cb;
       if (x0 < x_hi) {  // wave-uniform
-        float w0, w1;
-        if (bi == 0) {  // wave-uniform
-          w0 = w0c[cb]; w1 = w1c[cb];
-        } else if (bi == 1) {
-          w0 = w0c[kBatch + cb]; w1 = w1c[kBatch + cb];
-        } else {
-          x_weights(x0 + lane, w0, w1);  // only intervals wider than 256 px
-        }
+        const int ci = bi * kBatch + cb;  // chunk in row, wave-uniform
+        float dx;
+        if (ci == 0) dx = dxc[0];
+        else if (ci == 1) dx = dxc[1];
+        else if (ci == 2) dx = dxc[2];
+        else if (ci == 3) dx = dxc[3];
+        else dx = x_offset(x0 + lane);  // only intervals wider than 256 px
+        const float w0 = std_max(1.0f - fabsf(dx), 0.0f), w1 = std_max(1.0f - fabsf(dx + 1.0f), 0.0f);
         const float wa = w0, wb = w1;
         // z: only the two corners around gzf carry weight (:121); the outermost half cells are
         // forced to 1 (:122-125).  Two v_sqrt_f32 per pixel (1 ulp; argument >= 1e-8, no
@@ -411,6 +413,8 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
                   for (int i = 0; i < COUT; ++i) t = fmaf(G[i * CJ + j], cur.d[cb][i], t);
                   div[j] = fmaf(wgt[v], t, div[j]);
                 }
+                // one corner's coefficient vector in registers at a time (all four hoisted: 144 VGPRs, 3 waves)
+                __builtin_amdgcn_sched_barrier(0);
               }
             }
           }
@@ -465,46 +469,66 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
         }
         wave_lds_order();
         // D[k, c] += sum_px A[k, px] * V[px, c]; two accumulators break the dependent-issue chain.
-        f32x2 av[8], bv[8];
+        // Two half-chunks: 8 operand reads (A, V pairs in MFMA order) -> 8 MFMAs, twice, through the SAME 16
+        // registers (the second half's reads are tied to the first half's variables, so they issue after the
+        // first half's MFMAs have read them).
+        f32x2 av[4], bv[4];
+#define HDRNET_GG_READS(OFF, TIE)                                                                          \
+  asm volatile("ds_read_b64 %0, %8 offset:" #OFF "+0\n\tds_read_b64 %4, %9 offset:" #OFF "+0\n\t"           \
+               "ds_read_b64 %1, %8 offset:" #OFF "+16\n\tds_read_b64 %5, %9 offset:" #OFF "+16\n\t"         \
+               "ds_read_b64 %2, %8 offset:" #OFF "+32\n\tds_read_b64 %6, %9 offset:" #OFF "+32\n\t"         \
+               "ds_read_b64 %3, %8 offset:" #OFF "+48\n\tds_read_b64 %7, %9 offset:" #OFF "+48\n\t"         \
+               "s_waitcnt lgkmcnt(0)"                                                                      \
+               : TIE(av[0]), TIE(av[1]), TIE(av[2]), TIE(av[3]), TIE(bv[0]), TIE(bv[1]), TIE(bv[2]),       \
+                 TIE(bv[3])                                                                                \
+               : "v"(a_addr), "v"(v_addr)                                                                  \
+               : "memory")
+#define HDRNET_GG_OUT(x) "=&v"(x)
+#define HDRNET_GG_INOUT(x) "+v"(x)
+        auto contract = [&]() {
+          if constexpr (SPLIT) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          av[e] = a_rd[2 * e];
-          bv[e] = v_rd[2 * e];
-        }
-        if constexpr (SPLIT) {
+            for (int q = 0; q < 2; ++q) {
+              typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+              const f32x4 a4 = {av[2 * q][0], av[2 * q][1], av[2 * q + 1][0], av[2 * q + 1][1]};
+              const f32x4 b4 = {bv[2 * q][0], bv[2 * q][1], bv[2 * q + 1][0], bv[2 * q + 1][1]};
+              const u32x4_t vb = __builtin_bit_cast(u32x4_t, b4);
+              u32x4_t b1, b2;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-            const f32x4 a4 = {av[2 * q][0], av[2 * q][1], av[2 * q + 1][0], av[2 * q + 1][1]};
-            const f32x4 b4 = {bv[2 * q][0], bv[2 * q][1], bv[2 * q + 1][0], bv[2 * q + 1][1]};
-            const u32x4_t vb = __builtin_bit_cast(u32x4_t, b4);
-            u32x4_t b1, b2;
+              for (int e = 0; e < 4; ++e) {
+                b1[e] = __builtin_amdgcn_perm(vb[e], vb[e], 0x01000100u);  // [v_hi, v_hi]
+                b2[e] = vb[e] >> 16;                                        // [v_lo, 0]
+              }
+              const bf16x8 a8 = __builtin_bit_cast(bf16x8, a4);
+              dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, b1), dacc, 0, 0, 0);
+              dacc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, b2), dacc2, 0, 0, 0);
+            }
+          } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              b1[e] = __builtin_amdgcn_perm(vb[e], vb[e], 0x01000100u);  // [v_hi, v_hi]
-              b2[e] = vb[e] >> 16;                                        // [v_lo, 0]
+              if constexpr (ABL == 2 || ABL == 4) {  // tools ablation: no MFMAs
+                dacc[0] += av[e][0] * bv[e][0];
+                dacc2[0] += av[e][1] * bv[e][1];
+                continue;
+              }
+              dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e][0], bv[e][0], dacc, 0, 0, 0);
+              dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e][1], bv[e][1], dacc2, 0, 0, 0);
             }
-            const bf16x8 a8 = __builtin_bit_cast(bf16x8, a4);
-            dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, b1), dacc, 0, 0, 0);
-            dacc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, b2), dacc2, 0, 0, 0);
           }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            if constexpr (ABL == 2 || ABL == 4) {  // tools ablation: no MFMAs
-              dacc[0] += av[e][0] * bv[e][0];
-              dacc2[0] += av[e][1] * bv[e][1];
-              continue;
-            }
-            dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e][0], bv[e][0], dacc, 0, 0, 0);
-            dacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e][1], bv[e][1], dacc2, 0, 0, 0);
-          }
-        }
+        };
+        HDRNET_GG_READS(0, HDRNET_GG_OUT);
+        contract();
+        HDRNET_GG_READS(64, HDRNET_GG_INOUT);
+        contract();
+#undef HDRNET_GG_READS
+#undef HDRNET_GG_OUT
+#undef HDRNET_GG_INOUT
         wave_lds_order();
         aQ[0] = 0.0f;
         aQ[8 * kTStride] = 0.0f;
         aP[0] = 0.0f;
         aP[8 * kTStride] = 0.0f;
+        if constexpr (WI) __builtin_amdgcn_sched_barrier(0);  // chunk by chunk: keeps the live set of one
       }
     }
     if (bi == nbr - 1) {

@@ -122,6 +122,13 @@ hipError_t launch_apply_fwd_rows_direct_stores(const ApplyArgs& a, hipStream_t s
 // when supported (else the scalar kernel of apply_fwd_rows.hip).
 bool apply_fwd_seg_supported(const ApplyArgs& a);
 hipError_t launch_apply_fwd_seg(const ApplyArgs& a, hipStream_t s, const char** name);
+// the same kernel with the guide network evaluated in registers / the coarser pyramid level added
+bool apply_fwd_seg_nnguide_supported(const ApplyArgs& a, const float* guide_out);
+hipError_t launch_apply_fwd_seg_nnguide(const ApplyArgs& a, const float* conv1, const float* conv2, int n_feats,
+                                        float* guide_out, hipStream_t s, const char** name);
+bool apply_fwd_seg_upadd_supported(const ApplyArgs& a, const float* coarse, bool guide_nn);
+hipError_t launch_apply_fwd_seg_upadd(const ApplyArgs& a, const float* coarse, int Hc, int Wc, const float* conv1,
+                                      const float* conv2, int n_feats, hipStream_t s, const char** name);
 #ifdef HDRNET_TOOLS_BUILD
 // knob: loads + 4 * stores (+ 20: timeline trace); include/hdrnet_amd_tools.h
 hipError_t launch_apply_fwd_seg_knob(const ApplyArgs& a, int knob, hipStream_t s, const char** name);

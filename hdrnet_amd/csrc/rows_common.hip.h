@@ -328,6 +328,109 @@ inline int max_cols_for(int npx, int GW, int W) {
   return (int)(cols < GW ? cols : GW);
 }
 
+// ---- fused guide network / pyramid up-add (shared by apply_fwd_seg.hip and apply_fwd_rows.hip) ----
+// GUIDE_NN: the guide is not read from memory but computed per pixel from the input by the
+// reference's point-wise guide network with batch-norm folded (HDRNetPointwiseNNGuide._guide,
+// hdrnet/models.py:203-210; parameters in the layout hdrnet/bin/freeze_graph.py:170-184 exports):
+//   guide = sigmoid(conv2[n] + sum_k conv2[k] * relu(conv1[k][CIN] + sum_j conv1[k][j] * in_j))
+// -- the fusion the reference's own GL renderer performs (benchmark/assets/gpyrnn.frag:42-63).
+// The guide never touches HBM (24 instead of 28 B/px) and the 16-channel full-resolution
+// intermediate of the un-fused graph disappears.
+//
+struct GuideNN {
+  const float* conv1;  // [n][CIN + 1]: weights then bias of feature k
+  const float* conv2;  // [n + 1]: mixing weights then bias
+  float* guide_out;    // optional [B][H][W] copy of the guide (null: not written)
+  int n;
+};
+
+template <int CIN>
+__device__ __forceinline__ float guide_nn_pixel(const GuideNN& gn, const float (&in)[CIN]) {
+  float acc = gn.conv2[gn.n];
+#pragma unroll 4
+  for (int k = 0; k < gn.n; ++k) {
+    const float* w = gn.conv1 + k * (CIN + 1);  // wave-uniform -> scalar loads
+    float h = w[CIN];
+#pragma unroll
+    for (int j = 0; j < CIN; ++j) h = fmaf(w[j], in[j], h);
+    acc = fmaf(gn.conv2[k], fmaxf(h, 0.0f), acc);
+  }
+  return 1.0f / (1.0f + expf(-acc));  // tf.nn.sigmoid
+}
+// The same for a lane's 4 consecutive pixels (inf = [pixel][CIN] floats): one pass over the features, the
+// weights read ONCE per feature through the constant address space (wave-uniform s_load; a plain global
+// pointer next to the kernel's stores is not provably invariant and compiles to per-lane vector loads).
+template <int CIN>
+__device__ __forceinline__ void guide_nn_quad(const GuideNN& gn, const float* inf, float (&g)[kPxPerThread]) {
+  typedef __attribute__((address_space(4))) const float cfloat;
+  cfloat* c1 = (cfloat*)gn.conv1;
+  cfloat* c2 = (cfloat*)gn.conv2;
+  const float bias = c2[gn.n];
+  float acc[kPxPerThread];
+#pragma unroll
+  for (int q = 0; q < kPxPerThread; ++q) acc[q] = bias;
+#pragma unroll 4
+  for (int k = 0; k < gn.n; ++k) {
+    float w[CIN + 1];
+#pragma unroll
+    for (int j = 0; j <= CIN; ++j) w[j] = c1[k * (CIN + 1) + j];
+    const float m = c2[k];
+#pragma unroll
+    for (int q = 0; q < kPxPerThread; ++q) {
+      float h = w[CIN];
+#pragma unroll
+      for (int j = 0; j < CIN; ++j) h = fmaf(w[j], inf[q * CIN + j], h);
+      acc[q] = fmaf(m, fmaxf(h, 0.0f), acc[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kPxPerThread; ++q) g[q] = 1.0f / (1.0f + expf(-acc[q]));  // tf.nn.sigmoid
+}
+
+// UPADD: out += the coarser pyramid level's output, bilinearly up-sampled with align_corners = True
+// -- the `tf.image.resize_images(current, sz, BILINEAR, align_corners=True)` + `tf.add` of
+// HDRNetGaussianPyrNN._output (hdrnet/models.py:283-287).  TensorFlow (requirements.txt:
+// tensorflow_gpu==2.12.0; not vendored) computes, per axis, scale = (in - 1) / float(out - 1),
+// src = i * scale, lower = floor(src), upper = min(ceil(src), in - 1), lerp = src - lower, and
+// top + (bottom - top) * y_lerp with top = tl + (tr - tl) * x_lerp
+// (tensorflow/core/kernels/image/resize_bilinear_op.cc, legacy non-half-pixel path).
+struct UpAdd {
+  const float* coarse;  // [B][Hc][Wc][COUT]
+  int Hc, Wc;
+  float sh, sw;  // (Hc - 1) / float(H - 1), (Wc - 1) / float(W - 1)   (in / out when out == 1)
+};
+
+inline float resize_scale(int in, int out) {  // TF CalculateResizeScale, align_corners = true
+  return out > 1 ? (float)(in - 1) / (float)(out - 1) : (float)in / (float)out;
+}
+
+// of[k * COUT + i] += up-sampled coarse level at pixel (x + k, y), k = 0 .. 3.  Row terms are
+// workgroup-uniform; the 2 x 2 x COUT gathers hit the (small, cache-resident) coarse level.
+template <int COUT>
+__device__ __forceinline__ void upadd_quad(const UpAdd& up, int b, int y, int x, float* of) {
+  const float sy = mul_rn((float)y, up.sh);
+  const float fy = floorf(sy);
+  const float ly = sy - fy;
+  const int y0 = (int)fy, y1 = min((int)ceilf(sy), up.Hc - 1);
+  const float* r0 = up.coarse + ((size_t)b * up.Hc + y0) * up.Wc * COUT;
+  const float* r1 = up.coarse + ((size_t)b * up.Hc + y1) * up.Wc * COUT;
+#pragma unroll
+  for (int k = 0; k < kPxPerThread; ++k) {
+    const float sxf = mul_rn((float)(x + k), up.sw);
+    const float fx = floorf(sxf);
+    const float lx = sxf - fx;
+    const int x0 = (int)fx * COUT, x1 = min((int)ceilf(sxf), up.Wc - 1) * COUT;
+#pragma unroll
+    for (int i = 0; i < COUT; ++i) {
+      const float tl = r0[x0 + i], tr = r0[x1 + i], bl = r1[x0 + i], br = r1[x1 + i];
+      const float top = tl + (tr - tl) * lx;
+      const float bot = bl + (br - bl) * lx;
+      of[k * COUT + i] += top + (bot - top) * ly;
+    }
+  }
+}
+
+
 // How a row is cut into workgroup segments: `threads` lanes x 4 pixels per segment, the
 // segment width balanced over the row (e.g. W = 3840 -> 5 segments of 768 px / 192 threads;
 // W = 1920 -> 2 x 960 px / 256 threads with 16 idle lanes).

@@ -1,0 +1,132 @@
+// The pixel core of the row-segment forward kernels (apply_fwd_seg.hip, apply_fwd_io.hip): the padded,
+// y-pre-lerped LDS coefficient image of a row segment and the per-pixel gather / blend / affine from it.
+// See apply_fwd_seg.hip's header comment for the layout and its rationale.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "numerics.hip.h"
+#include "rows_common.hip.h"
+
+namespace hdrnet_amd {
+namespace rows {
+
+// x-only terms of a pixel (bilateral_slice_apply.cc:41,46,53-54,61-62).
+struct XTerm {
+  float wx0, wx1;
+  int xbp;  // byte offset of (column gx0, plane 0 + 1) in the image
+};
+
+__device__ __forceinline__ XTerm x_term(float xf, float scale_x, int cmin, int colb, int cb) {
+#pragma clang fp contract(off)
+  XTerm t;
+  const float gxf = mul_rn(xf, scale_x);
+  const float fxl = floorf(gxf - 0.5f);
+  const float dx0 = (fxl + 0.5f) - gxf;  // in (-1, 0]
+  t.wx0 = 1.0f + dx0;
+  t.wx1 = -dx0;
+  t.xbp = __mul24((int)fxl - cmin, colb) + cb;
+  return t;
+}
+
+// One pixel: z terms, the four-vector blend from the padded image, the affine
+// (bilateral_slice_apply.cc:43-80).
+template <int CIN, int COUT, bool OFFSET>
+__device__ __forceinline__ void seg_pixel(const float* __restrict__ img, float gd_f, float zhi, int colb,
+                                          const XTerm& xt, float g, const float (&in)[CIN > 0 ? CIN : 1],
+                                          float (&out)[COUT]) {
+  constexpr int CJ = CIN + (OFFSET ? 1 : 0);
+  constexpr int C = COUT * CJ;
+  constexpr int CB = C * (int)sizeof(float);
+  f32x2 w0, w1;
+  int a0;
+  {
+#pragma clang fp contract(off)
+    const float gzf = mul_rn(g, gd_f);
+    const float fzl = floorf(gzf - 0.5f);
+    // corner centres as the reference forms them, (float)gz + 0.5f with gz1 = gz0 + 1: identical to
+    // fzl + 1.5f while gzf is exact, and the same rounding as the reference once it is not
+    const f32x2 cz = {fzl + 0.5f, (fzl + 1.0f) + 0.5f};
+    const f32x2 gz2 = {gzf, gzf};
+    const f32x2 dz = cz - gz2;  // (gz0 + .5) - gzf, (gz0 + 1.5) - gzf
+    const f32x2 eps2 = {kSmoothEps, kSmoothEps};
+    const f32x2 q = __builtin_elementwise_fma(dz, dz, eps2);
+    const f32x2 s = {__builtin_amdgcn_sqrtf(q.x), __builtin_amdgcn_sqrtf(q.y)};
+    const f32x2 one2 = {1.0f, 1.0f};
+    // max(., 0) as the reference (numerics.h:108-113): never binds for a guide whose gzf is exact
+    // in f32, but once |guide * GD| reaches 2^23 the rounding of (gz0 + 1.5) - gzf can make a corner
+    // offset 2 and its un-clamped weight -1
+    const f32x2 zero2 = {0.0f, 0.0f};
+    const f32x2 wz = __builtin_elementwise_max(one2 - s, zero2);
+    const f32x2 wx0 = {xt.wx0, xt.wx0}, wx1 = {xt.wx1, xt.wx1};
+    w0 = wx0 * wz;
+    w1 = wx1 * wz;
+    // plane of z index iz is iz + 1; the clamp to [-1, GD-1] only guards wild guides (the
+    // padded planes already hold the reference's clamped reads; v_med3 of a NaN yields -1).
+    const int iz = (int)__builtin_amdgcn_fmed3f(fzl, -1.0f, zhi);
+    a0 = __mul24(iz, CB) + xt.xbp;
+  }
+  CoefVec<C> coef;
+  accum_vec<C, true>(coef, img, a0, w0.x);
+  accum_vec<C, false>(coef, img, a0 + CB, w0.y);
+  accum_vec<C, false>(coef, img, a0 + colb, w1.x);
+  accum_vec<C, false>(coef, img, a0 + colb + CB, w1.y);
+#pragma unroll
+  for (int i = 0; i < COUT; ++i) {
+    float v = OFFSET ? coef.get(i * CJ + CIN) : 0.0f;
+#pragma unroll
+    for (int j = 0; j < CIN; ++j) v = fmaf(coef.get(i * CJ + j), in[j], v);
+    out[i] = v;
+  }
+}
+
+// Blend the two grid rows image row y needs into the padded LDS image (see the header comment):
+//   img[j][p][c] = wy0 * grid[gy0c][clamp(cmin + j)][clamp(p - 1)][c] + wy1 * grid[gy1c][...]
+// Work item = one VEC-float element of a source (column, plane) vector (one per thread at 4K; a
+// rolled loop keeps the kernel at <= 64 VGPRs, i.e. 8 waves per SIMD, for every load flavour).
+template <int C>
+__device__ __forceinline__ void stage_image(float* __restrict__ img, const float* __restrict__ grid_b,
+                                            int y, int cmin, int ncols, int GH, int GW, int GD,
+                                            float scale_y, float inv_col, int tid, int nthreads) {
+  constexpr int VEC = (C % 4 == 0) ? 4 : 1;
+  constexpr int CV = C / VEC;
+  typedef float elem_t __attribute__((ext_vector_type(VEC)));
+  // Wave-uniform y terms (bilateral_slice_apply.cc:42,47,55-56).
+  const float gyf = mul_rn(y + 0.5f, scale_y);
+  const int gy0 = floor_to_int(gyf - 0.5f);
+  const float wy0 = tent_weight(gy0 + 0.5f, gyf);
+  const float wy1 = tent_weight(gy0 + 1 + 0.5f, gyf);
+  const int gy0c = clamp_index(gy0, 0, GH - 1);
+  const int gy1c = clamp_index(gy0 + 1, 0, GH - 1);
+  const elem_t* r0 = reinterpret_cast<const elem_t*>(grid_b + (size_t)gy0c * GW * GD * C);
+  const elem_t* r1 = reinterpret_cast<const elem_t*>(grid_b + (size_t)gy1c * GW * GD * C);
+  elem_t* d = reinterpret_cast<elem_t*>(img);
+  const int per_col = GD * CV;
+  const int n = ncols * per_col;
+  for (int e = tid; e < n; e += nthreads) {
+    const int j = (int)(((float)e + 0.5f) * inv_col);  // e / per_col, exact for e < 2^20
+    const int rem = e - j * per_col;
+    const int sc = min(max(cmin + j, 0), GW - 1);
+    const int src = sc * per_col + rem;
+    const elem_t v = wy0 * r0[src] + wy1 * r1[src];
+    const int dst = e + CV * (2 * j + 1);  // column j has GD + 2 planes; source plane z is plane z + 1
+    d[dst] = v;
+    if (rem < CV) d[dst - CV] = v;             // z = 0      -> also plane 0
+    if (rem >= per_col - CV) d[dst + CV] = v;  // z = GD - 1 -> also plane GD + 1
+  }
+}
+
+
+// Grid columns a segment [xs, xe) touches, unclamped: gx0 of the first pixel .. gx0 + 1 of the last.
+struct SegCols {
+  int cmin, ncols;
+};
+
+__device__ __forceinline__ SegCols seg_cols(int xs, int xe, float scale_x) {
+  const int cmin = floor_to_int(mul_rn(xs + 0.5f, scale_x) - 0.5f);
+  const int cmax = floor_to_int(mul_rn(xe - 1 + 0.5f, scale_x) - 0.5f) + 1;
+  return SegCols{cmin, cmax - cmin + 1};
+}
+
+}  // namespace rows
+}  // namespace hdrnet_amd

@@ -349,7 +349,7 @@ def test_nnguide_fused_matches_composed_oracle(dev, ops, port, shape):
     want = port.bilateral_slice_apply(grid, guide, inp, True)
     out, gout = ops.bilateral_slice_apply_nnguide(T(grid, dev), T(inp, dev), T(conv1, dev), T(conv2, dev),
                                                   has_offset=True, return_guide=True)
-    assert ops.last_kernel() == "apply_fwd_rows/vec4+nnguide"
+    assert ops.last_kernel() == "apply_fwd_seg/vec4+nnguide"
     np.testing.assert_allclose(N(gout), guide, rtol=0, atol=1e-6)
     np.testing.assert_allclose(N(out), want, rtol=2e-5, atol=2e-5)
     # and against the un-fused HIP path fed with the fused kernel's own guide: same slicing code
@@ -433,11 +433,11 @@ def test_upadd_matches_composed_oracle(dev, ops, port, case, fused_guide):
     if fused_guide:
         got = ops.bilateral_slice_apply_upadd(T(grid, dev), T(inp, dev), T(coarse, dev), guide_conv1=T(conv1, dev),
                                               guide_conv2=T(conv2, dev))
-        assert ops.last_kernel() == "apply_fwd_rows/vec4+nnguide+upadd"
+        assert ops.last_kernel() == "apply_fwd_seg/vec4+nnguide+upadd"
         tol = 2e-5
     else:
         got = ops.bilateral_slice_apply_upadd(T(grid, dev), T(inp, dev), T(coarse, dev), guide=T(guide, dev))
-        assert ops.last_kernel() == "apply_fwd_rows/vec4+upadd"
+        assert ops.last_kernel() == "apply_fwd_seg/vec4+upadd"
         tol = 1e-5
     np.testing.assert_allclose(N(got), want, rtol=tol, atol=tol)
 

@@ -159,7 +159,7 @@ def test_config3_full_inference_4k():
     with torch.no_grad():
         out = m(low, full)
     from hdrnet_amd import hdrnet_ops
-    assert hdrnet_ops.last_kernel() == "apply_fwd_rows/vec4+nnguide"  # guide net fused in eval mode
+    assert hdrnet_ops.last_kernel() == "apply_fwd_seg/vec4+nnguide"  # guide net fused in eval mode
     assert out.shape == (1, 2160, 3840, 3) and torch.isfinite(out).all()
     m.fuse_guide = False
     with torch.no_grad():
@@ -297,7 +297,7 @@ def test_training_fused_guide_matches_unfused_module():
     full = torch.rand(2, 136, 240, 3, device=dev)
     target = torch.rand(2, 136, 240, 3, device=dev)
     loss = (m(low, full) - target).square().mean()
-    assert hdrnet_ops.last_kernel() == "apply_fwd_rows/vec4+nnguide"
+    assert hdrnet_ops.last_kernel() == "apply_fwd_seg/vec4+nnguide"
     loss.backward()
     loss_ref = (ref(low, full) - target).square().mean()
     loss_ref.backward()
@@ -373,7 +373,7 @@ def test_pyramid_model_fused_matches_composed():
     full = torch.rand(1, 272, 480, 3, device=dev)
     with torch.no_grad():
         out = m(low, full)
-        assert hdrnet_ops.last_kernel() == "apply_fwd_rows/vec4+nnguide+upadd"
+        assert hdrnet_ops.last_kernel() == "apply_fwd_seg/vec4+nnguide+upadd"
         m.fuse_guide = False
         ref = m(low, full)
         assert hdrnet_ops.last_kernel() == "apply_fwd_seg/vec4"
