@@ -188,6 +188,7 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   constexpr int kSlab = (16 + C) * kTStride + kImg;  // floats per wave: A^T [16][68], V^T [C][68], image
   static_assert(kSlab >= kTileFloats, "the final reduction reuses the slabs");
   __shared__ __attribute__((aligned(16))) float lds[kWaves * kSlab];
+  if constexpr (ABL == 5) return;  // tools ablation: the launch alone
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   float* at = lds + wave * kSlab;    // A^T[k][px]
@@ -657,14 +658,14 @@ hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int G
   bool ablated = false;
 #ifdef HDRNET_TOOLS_BUILD
   if constexpr (APPLY && CIN == 3 && COUT == 3 && OFFSET) {  // ablations (tools variants 4, 5): timing only
-    if (ablate >= 1 && ablate <= 4) {
+    if (ablate >= 1 && ablate <= 5) {
 #define GG_ABL(A)                                                                                          \
   do {                                                                                                     \
     if (wg && wi) grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, true, true, A><<<nblocks, kWaves * 64, 0, s>>>(p);        \
     else if (wg) grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, true, false, A><<<nblocks, kWaves * 64, 0, s>>>(p);        \
     else grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, false, false, A><<<nblocks, kWaves * 64, 0, s>>>(p);               \
   } while (0)
-      if (ablate == 1) GG_ABL(1); else if (ablate == 2) GG_ABL(2); else if (ablate == 3) GG_ABL(3); else GG_ABL(4);
+      if (ablate == 1) GG_ABL(1); else if (ablate == 2) GG_ABL(2); else if (ablate == 3) GG_ABL(3); else if (ablate == 4) GG_ABL(4); else GG_ABL(5);
 #undef GG_ABL
       ablated = true;
     }
@@ -744,7 +745,7 @@ static hipError_t apply_gg(const ApplyGradArgs& a, bool fused, hipStream_t s) {
 #define HDRNET_CASE(CI, CO, OFF)                                                                  \
   if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF)                                         \
   return gg_launch<CI, CO, OFF, true>(q, a.B, a.H, a.W, a.GH, a.GW, a.GD, a.workspace, pl, s, split, \
-                                      (a.variant >= 4 && a.variant <= 7) ? a.variant - 3 : 0)
+                                      (a.variant >= 4 && a.variant <= 8) ? a.variant - 3 : 0)
   HDRNET_CASE(3, 3, true);
   HDRNET_CASE(3, 3, false);
   HDRNET_CASE(3, 4, true);

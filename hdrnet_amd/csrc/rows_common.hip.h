@@ -384,7 +384,8 @@ __device__ __forceinline__ void guide_nn_quad(const GuideNN& gn, const float* in
     }
   }
 #pragma unroll
-  for (int q = 0; q < kPxPerThread; ++q) g[q] = 1.0f / (1.0f + expf(-acc[q]));  // tf.nn.sigmoid
+  for (int q = 0; q < kPxPerThread; ++q) g[q] = 1.0f / (1.0f + expf(-acc[q]));  // tf.nn.sigmoid (IEEE divide:
+  // the guide's VJP is steep near bin centres, and a 1-ulp guide moves dinput by 3e-4 of its scale there)
 }
 
 // UPADD: out += the coarser pyramid level's output, bilinearly up-sampled with align_corners = True
