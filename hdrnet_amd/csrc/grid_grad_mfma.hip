@@ -278,8 +278,16 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
     }
   };
 
-  Batch cur, nxt;
-  if (nbt > 0) load_batch(0, cur);  // issued first: the rest of the prologue runs under its latency
+  // kAhead batches are in flight beyond the one being contracted (a ring of kAhead + 1 register sets, the
+  // loop unrolled over it).  Two ahead in the fused pass measured the same as one (118.5 vs 120 us all
+  // three, 101 vs 101 us dgrid + dguide at 4K; profiles/r02/exp21): what tools variant 4 removes is the
+  // exposed first load of every wave, not a too-short steady-state distance.
+  constexpr int kAhead = 1;
+  Batch ring[kAhead + 1];
+  if (nbt > 0) load_batch(0, ring[0]);  // issued first: the rest of the prologue runs under its latency
+  if constexpr (kAhead > 1 && ABL != 1 && ABL != 4) {
+    if (nbt > 1) load_batch(1, ring[1]);
+  }
   // fused: this lane's element of the two grid rows the coefficient image blends.  They change only when
   // gy0 does (once per cell height), so they stay in registers across the wave's rows.
   f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = sa;
@@ -306,11 +314,9 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
 #pragma unroll
   for (int cb = 0; cb < kXW; ++cb) dxc[cb] = x_offset(x_lo + 64 * cb + lane);
   f32x4 dacc = {0.f, 0.f, 0.f, 0.f}, dacc2 = {0.f, 0.f, 0.f, 0.f};
-  for (int t = 0; t < nbt; ++t) {
-    if constexpr (ABL == 1 || ABL == 4) {  // tools ablation: the first batch is all a wave ever loads
-      nxt = cur;
-    } else {
-      if (t + 1 < nbt) load_batch(t + 1, nxt);
+  auto process = [&](int t, const Batch& cur, Batch& refill) {
+    if constexpr (ABL != 1 && ABL != 4) {  // (tools ablation 1 / 4: the first batch is all a wave ever loads)
+      if (t + kAhead < nbt) load_batch(t + kAhead, refill);
     }
     const int r = t / nbr, bi = t - r * nbr;
     const int y = y_first + wave + r * kWaves;
@@ -551,7 +557,20 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
       dacc = f32x4{0.f, 0.f, 0.f, 0.f};
       dacc2 = dacc;
     }
-    cur = nxt;
+  };
+  if constexpr (ABL == 1 || ABL == 4) {
+    for (int t = 0; t < nbt; ++t) process(t, ring[0], ring[0]);
+  } else if constexpr (kAhead == 1) {
+    for (int t = 0; t < nbt; t += 2) {
+      process(t, ring[0], ring[1]);
+      if (t + 1 < nbt) process(t + 1, ring[1], ring[0]);
+    }
+  } else {
+    for (int t = 0; t < nbt; t += 3) {
+      process(t, ring[0], ring[2]);
+      if (t + 1 < nbt) process(t + 1, ring[1], ring[0]);
+      if (t + 2 < nbt) process(t + 2, ring[2], ring[1]);
+    }
   }
   // Sum the four waves' register tiles in fixed order (wave 0 + 1 + 2 + 3) through LDS -- the
   // operand slabs are free now -- and write one partial tile per workgroup.
