@@ -342,26 +342,42 @@ long long* g_trace = nullptr;  // device buffer of [nblocks][3]
 
 }  // namespace
 
-// The product configuration: LDS-DMA nontemporal loads, nontemporal buffer stores.
+// The product configurations (measured per frame size across boxes, profiles/r02/d_ab_variants_*.txt):
+//   * grids deeper than ~1.25 rounds of resident workgroups (4K, batched 1080p): LDS-DMA nontemporal loads;
+//     stores write-through (sc0 sc1) where every row segment is whole 128-B lines (4K: 38.9-39.4 us, the
+//     tightest spread of all flavours), else nontemporal (a write-through of a partial line costs a
+//     read-modify-write: 4000-px rows 67 vs 58.6 us);
+//   * a grid of about one round (one 1080p frame): per-lane loads + nontemporal stores -- with no second
+//     round to overlap, the DMA's longer path to first use costs more than its registers save
+//     (11.3-12.2 vs 12.5-13.7 us).
 bool apply_fwd_seg_supported(const ApplyArgs& a) {
   if (!seg_shape(a)) return false;
   // stage_image reads the grid as float4 when C % 4 == 0.
   if ((a.Cout * a.Cj) % 4 == 0 && ((uintptr_t)a.grid & 15u)) return false;
-  return seg_geom(a, true).ok;
+  return seg_geom(a, true).ok && seg_geom(a, false).ok;
 }
 
 hipError_t launch_apply_fwd_seg(const ApplyArgs& a, hipStream_t s, const char** name) {
   *name = "apply_fwd_seg/vec4";
-#define HDRNET_CASE(CI, CO, OFF)                                  \
-  if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF)         \
-    return launch_seg_t<CI, CO, OFF, kLoadsDmaNt, kStoresBufNt, false>(a, s, nullptr)
-  HDRNET_CASE(3, 3, true);
-  HDRNET_CASE(3, 3, false);
-  HDRNET_CASE(3, 4, true);
-  HDRNET_CASE(1, 1, true);
-  HDRNET_CASE(1, 1, false);
-  HDRNET_CASE(1, 3, true);
-  HDRNET_CASE(4, 4, true);
+  const SegGeom g = seg_geom(a, true);
+  const long long nblocks = (long long)g.pl.nseg * a.H * a.B;
+  const long long one_round = 256LL * (32 / (g.pl.threads / 64));  // workgroups resident on 256 CUs
+  const bool small = 4 * nblocks <= 5 * one_round;
+  const bool whole_lines = ((uintptr_t)a.out % 128 == 0) && ((long long)g.pl.seg * a.Cout * 4) % 128 == 0 &&
+                           ((long long)a.W * a.Cout * 4) % 128 == 0;
+#define HDRNET_CASE(CI, CO, OFF)                                                                     \
+  if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF) {                                          \
+    if (small) return launch_seg_t<CI, CO, OFF, kLoadsLane, kStoresBufNt, false>(a, s, nullptr);     \
+    if (whole_lines) return launch_seg_t<CI, CO, OFF, kLoadsDmaNt, kStoresBufSc01, false>(a, s, nullptr); \
+    return launch_seg_t<CI, CO, OFF, kLoadsDmaNt, kStoresBufNt, false>(a, s, nullptr);               \
+  }
+  HDRNET_CASE(3, 3, true)
+  HDRNET_CASE(3, 3, false)
+  HDRNET_CASE(3, 4, true)
+  HDRNET_CASE(1, 1, true)
+  HDRNET_CASE(1, 1, false)
+  HDRNET_CASE(1, 3, true)
+  HDRNET_CASE(4, 4, true)
 #undef HDRNET_CASE
   return hipErrorInvalidValue;
 }
