@@ -2,7 +2,7 @@
 """In-process interleaved A/B timing of BilateralSliceApply forward kernel variants.
 
     python tools/ab_bench.py [--workload 4k] [--variants 0,19,20] [--rounds 5] [--steps 100]
-                             [--trace 36,39] [--out gpurun_out/ab.json]
+                             [--trace 36,39] [--settle 80] [--out gpurun_out/ab.json]
 
 Uses the TOOLS build of the library (libhdrnet_amd_tools.so, include/hdrnet_amd_tools.h): variant 0
 is the product kernel, the others are documented in that header.  Every round times each variant
@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--yardstick", action="store_true")
     ap.add_argument("--trace", default="")
+    ap.add_argument("--settle", type=int, default=80, help="untimed launches of a variant before its timed window")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -140,7 +141,9 @@ def main():
     for r in range(args.rounds):
         for v in variants:
             fn = launcher(_lib.KERNEL_FAST | (v << 8))
-            time_launches(fn, 10)
+            # settle: cache-policy stores run ~15 % slower for the first ~50 launches after a kernel that left
+            # plain-store dirty lines behind (profiles/r02/exp25); a timed window must not start inside that
+            time_launches(fn, args.settle)
             results[v].append(time_launches(fn, args.steps))
         if args.yardstick:
             def cp(k):

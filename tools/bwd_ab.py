@@ -103,7 +103,7 @@ def main():
     res = {k: [] for k in fns}
     for _ in range(args.rounds):
         for k, f in fns.items():
-            f(0)
+            time_launches(f, 20)  # settle (see tools/ab_bench.py)
             res[k].append(time_launches(f, args.steps))
     print(desc)
     for (c, v), t in res.items():

@@ -1,11 +1,20 @@
 #!/bin/bash
 # Collects the round's evidence on an MI355X box into gpurun_out/profiles/ (copy what you want judged
-# into profiles/rNN/).  Run from the repo root:  gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh'
+# into profiles/rNN/).  Two calls, each on a fresh box, from the repo root:
+#   gpurun --timeout 600 -- 'bash tools/collect_profiles.sh pmc'      counters -> traffic.json; copy it to
+#                                                                     profiles/rNN/ BEFORE the second call
+#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh timing'  every timing, on a box no counter
+#                                                                     session has touched (timings taken
+#                                                                     after rocprofv3 --pmc passes on the
+#                                                                     same box were intermittently 5 us
+#                                                                     slower: profiles/r02/README.md)
 set -u
 R=$(pwd)
 O=$R/gpurun_out/profiles
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+MODE=${1:-timing}
+if [ "$MODE" = pmc ]; then
 # 1. HBM traffic of the forward kernel: separate --pmc passes (never combined with trace domains), each
 #    with a calibration twin on the memory skeleton (known byte count, same access widths)
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
@@ -16,18 +25,20 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CO
 python $R/tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_sq --match apply_fwd > $O/fwd_pmc.txt 2>&1
 python $R/tools/pmc_summary.py $O/cal_fetch $O/cal_write --match skeleton > $O/fwd_pmc_calibration.txt 2>&1
 python $R/tools/make_traffic.py --fetch $O/pmc_fetch --write $O/pmc_write --calib-fetch $O/cal_fetch --calib-write $O/cal_write --workload 4k --out $O/traffic.json > $O/traffic.log 2>&1
-# the record the bench lines below quote as roofline.traffic (accepted only for this source digest)
-cp $O/traffic.json $R/profiles/r02/traffic.json
-cd /tmp
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/cal_fetch $O/cal_write
+tail -3 $O/fwd_pmc.txt; tail -25 $O/traffic.log
+exit 0
+fi
 # 2. the default bench command, un-profiled and under rocprofv3 --kernel-trace --stats
 python $R/bench.py > $O/bench.json 2> $O/bench.err
+# the same command under rocprofv3 --kernel-trace --stats (its per-kernel average must agree with the line above)
+rocprofv3 --kernel-trace --stats -d $O/stats -o fwd --output-format csv -- python $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
+grep '^{"metric' $O/bench_under_rocprof.log > $O/bench_under_rocprof.json
+find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/fwd_kernel_stats.csv \;
 python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_steps20.json 2>> $O/bench.err
 python $R/bench.py --workload 1080p --no-cpu-baseline > $O/bench_1080p.json 2>> $O/bench.err
 python $R/bench.py --workload hdrp --no-cpu-baseline > $O/bench_hdrp.json 2>> $O/bench.err
 for i in 1 2 3 4 5; do python $R/bench.py --no-cpu-baseline; done > $O/bench_repeat.txt 2>> $O/bench.err
-rocprofv3 --kernel-trace --stats -d $O/stats -o fwd --output-format csv -- python $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
-grep '^{"metric' $O/bench_under_rocprof.log > $O/bench_under_rocprof.json
-find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/fwd_kernel_stats.csv \;
 # 3. every entry point, all sizes; A/B of the forward variants; end-to-end configs
 cd $R
 python tools/op_bench.py --tools --workload 4k --json $O/ops_4k.json > $O/ops_4k.txt 2>&1
@@ -40,6 +51,6 @@ python tools/ab_bench.py --workload hdrp --variants 0,19,23,31,39 --rounds 5 --s
 python tools/bwd_ab.py --rounds 5 --steps 50 --cases all,gg,g,sl,v --variants 0,2,3,4,5,6,7,8 > $O/bwd_ab_4k.txt 2>&1
 python tools/bwd_ab.py --workload 1080p --rounds 5 --steps 100 --cases all,gg,g,sl,v --variants 0,3 > $O/bwd_ab_1080p.txt 2>&1
 python tools/e2e_bench.py > $O/e2e.txt 2>&1
-rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/cal_fetch $O/cal_write
+rm -rf $O/stats
 ls -la $O
-tail -3 $O/fwd_pmc.txt; cat $O/traffic.log | tail -25; cat $O/bench.json
+cat $O/bench.json
