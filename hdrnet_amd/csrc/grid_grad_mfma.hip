@@ -43,6 +43,7 @@
 //   tiles of the row groups and the two intervals that cover it.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 
 #include "launch.hip.h"
@@ -638,27 +639,75 @@ struct GGPlan {
   size_t ws_bytes;
 };
 
-// Rows per workgroup task (4 waves take alternate rows).  More rows amortise a wave's start-up (prologue
-// + the one pixel load nothing hides) over more chunks: 16 rows when that still leaves >= 2048 tasks (~1.6
-// rounds of the 1280 resident workgroups: 4K 76 -> 72 us, 4000x3000 121 -> 110 us), else 8 (1080p).
-constexpr int kMaxRg = 16, kMinTasks = 2048;
+// Rows per workgroup task (4 waves take alternate rows).  The grid's fit to the machine is a first-order
+// effect: a wave's start-up (prologue + the one pixel load nothing hides) is paid per task, and a last,
+// partly filled round of workgroups runs the chip below its occupancy.  At 4K, dgrid + dguide: 16 rows
+// per task = 2295 tasks over 1024 resident workgroups (2.24 rounds) 99.5 us; 36 rows = 1020 tasks, one
+// exact round, 90.9 us; 34 rows = 1088 tasks, one round and a sliver, 109 us (profiles/r02/exp27).  So
+// rg is chosen per launch from the kernel's resident-workgroup count (`slots`): the number of rounds
+// R <= 6 whose exact-fit rg fills them best, rg within [4, cell height] (a task's rows may span at most 3
+// clamped grid rows).  slots <= 0: the smallest rg any launch may pick -- the workspace bound.
+constexpr int kMinRg = 4, kMaxRounds = 6;
 
-bool gg_plan(int B, int H, int W, int GH, int GW, int GD, int C, GGPlan* pl) {
+bool gg_plan(int B, int H, int W, int GH, int GW, int GD, int C, long long slots, GGPlan* pl) {
   if (GD > 8 || C > 16 || C < 1) return false;
-  // rows of a group may span at most 3 (clamped) grid rows: rg <= cell height
   const int cell = H / GH > 1 ? H / GH : 1;
-  int rg = cell < kMaxRg ? cell : kMaxRg;
-  if ((long long)B * ((H + rg - 1) / rg) * (GW + 1) < kMinTasks && rg > kMaxRg / 2) rg = kMaxRg / 2;
+  const int rg_lo = cell < kMinRg ? cell : kMinRg;
+  const long long cols = (long long)B * (GW + 1);
+  int rg = rg_lo;
+  if (slots > 0) {
+    double best = -1.0;
+    for (int R = 1; R <= kMaxRounds; ++R) {
+      const long long per_col = (slots * R) / cols;  // row groups a column of tasks may have
+      if (per_col < 1) continue;
+      int cand = (int)((H + per_col - 1) / per_col);
+      if (cand > cell) continue;  // would need more rows per task than a cell is high
+      if (cand < rg_lo) cand = rg_lo;
+      const long long ntasks = cols * ((H + cand - 1) / cand);
+      const long long rounds = (ntasks + slots - 1) / slots;
+      const double eff = (double)ntasks / (double)(rounds * slots);
+      if (eff > best + 1e-9) {
+        best = eff;
+        rg = cand;
+      }
+    }
+    if (best < 0.0) rg = cell;  // fewer tasks than slots even at the largest rg a cell allows
+  }
 #ifdef HDRNET_TOOLS_BUILD
   if (const char* e = getenv("HDRNET_GG_RG")) rg = atoi(e) < cell ? atoi(e) : cell;  // experiments only
 #endif
   if (rg < 1) rg = 1;
   pl->rg = rg;
   pl->nyg = (H + rg - 1) / rg;
-  pl->ntasks = (long long)B * pl->nyg * (GW + 1);
+  pl->ntasks = cols * pl->nyg;
   if (pl->ntasks > 0x7fffffffLL || (long long)B * GH * GW * GD > 0x7fffffffLL || pl->nyg > 65535 || B > 65535) return false;
   pl->ws_bytes = (size_t)pl->ntasks * kTileFloats * sizeof(float);
   return true;
+}
+
+// Workgroups of `kfn` resident on the device at once (occupancy x CUs).  Queried once per kernel.
+typedef void (*Stage1Fn)(GGParams);
+
+long long resident_slots(Stage1Fn kfn, std::atomic<int>* cache) {
+  int occ = cache ? cache->load(std::memory_order_relaxed) : 0;
+  if (occ <= 0) {
+    occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kfn), kWaves * 64, 0) !=
+            hipSuccess || occ <= 0)
+      occ = 1;
+    if (cache) cache->store(occ, std::memory_order_relaxed);
+  }
+  static std::atomic<int> ncu{0};
+  int n = ncu.load(std::memory_order_relaxed);
+  if (n <= 0) {
+    int dev = 0;
+    n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    ncu.store(n, std::memory_order_relaxed);
+  }
+  return (long long)occ * n;
 }
 
 struct GGPtrs {
@@ -667,61 +716,50 @@ struct GGPtrs {
 };
 
 template <int CIN, int COUT, bool OFFSET, bool APPLY>
-hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int GD, void* ws, const GGPlan& pl,
+hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int GD, void* ws, size_t ws_bytes,
                      hipStream_t s, bool split, int ablate = 0) {
   constexpr int C = APPLY ? COUT * (CIN + (OFFSET ? 1 : 0)) : COUT;
-  GGParams p{q.guide, q.input, q.dout, q.grid, q.dguide, q.dinput, static_cast<float*>(ws), H, W, GH, GW, GD,
-             pl.rg, pl.nyg, pl.ntasks, (float)GW / W, (float)GH / H};
-  const dim3 nblocks((unsigned)(GW + 1), (unsigned)pl.nyg, (unsigned)B);
   const bool wg = q.dguide != nullptr, wi = q.dinput != nullptr;
-  bool ablated = false;
+  Stage1Fn kfn = nullptr;
+  std::atomic<int>* occ = nullptr;
+  static std::atomic<int> occ_cache[8];  // per (split, dguide, dinput) of this shape
 #ifdef HDRNET_TOOLS_BUILD
-  if constexpr (APPLY && CIN == 3 && COUT == 3 && OFFSET) {  // ablations (tools variants 4, 5): timing only
+  if constexpr (APPLY && CIN == 3 && COUT == 3 && OFFSET) {  // ablations (tools variants 4 .. 8): timing only
     if (ablate >= 1 && ablate <= 5) {
-#define GG_ABL(A)                                                                                          \
-  do {                                                                                                     \
-    if (wg && wi) grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, true, true, A><<<nblocks, kWaves * 64, 0, s>>>(p);        \
-    else if (wg) grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, true, false, A><<<nblocks, kWaves * 64, 0, s>>>(p);        \
-    else grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, false, false, A><<<nblocks, kWaves * 64, 0, s>>>(p);               \
-  } while (0)
-      if (ablate == 1) GG_ABL(1); else if (ablate == 2) GG_ABL(2); else if (ablate == 3) GG_ABL(3); else if (ablate == 4) GG_ABL(4); else GG_ABL(5);
+#define GG_ABL(A)                                                                              \
+  (wg && wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, true, true, A>       \
+            : wg ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, true, false, A> \
+                 : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, false, false, A>)
+      kfn = ablate == 1 ? GG_ABL(1) : ablate == 2 ? GG_ABL(2) : ablate == 3 ? GG_ABL(3) : ablate == 4 ? GG_ABL(4) : GG_ABL(5);
 #undef GG_ABL
-      ablated = true;
     }
   }
 #endif
-  if (ablated) {
-  } else if constexpr (C % 4 == 0) {
-    if (wg || wi) {  // fused backward: dgrid + the per-pixel VJPs in one pass
+  if (!kfn) {
+    occ = &occ_cache[(split ? 4 : 0) + (wg ? 2 : 0) + (wi ? 1 : 0)];
+    if constexpr (C % 4 == 0) {
       constexpr bool CAN_WI = APPLY && CIN > 0;
-#define GG_FUSED(SPL)                                                                                   \
-  do {                                                                                                  \
-    if (wg && wi && CAN_WI)                                                                             \
-      grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, true, CAN_WI><<<nblocks, kWaves * 64, 0, s>>>(p); \
-    else if (wg)                                                                                        \
-      grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, true, false><<<nblocks, kWaves * 64, 0, s>>>(p);  \
-    else if (CAN_WI)                                                                                    \
-      grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, false, CAN_WI><<<nblocks, kWaves * 64, 0, s>>>(p);\
-    else                                                                                                \
-      return hipErrorInvalidValue;                                                                      \
-  } while (0)
-      if (split)
-        GG_FUSED(true);
-      else
-        GG_FUSED(false);
-#undef GG_FUSED
-    } else if (split) {
-      grid_grad_stage1<CIN, COUT, OFFSET, APPLY, true><<<nblocks, kWaves * 64, 0, s>>>(p);
+      if (wi && !CAN_WI) return hipErrorInvalidValue;
+#define GG_PICK(SPL)                                                                                  \
+  (wg && wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, true, CAN_WI>                 \
+            : wg ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, true, false>             \
+                 : wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, false, CAN_WI>      \
+                      : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, false, false>)
+      kfn = split ? GG_PICK(true) : GG_PICK(false);
+#undef GG_PICK
     } else {
-      grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false><<<nblocks, kWaves * 64, 0, s>>>(p);
+      if (wg || wi) return hipErrorInvalidValue;  // fused VJPs read the coefficient image as float4
+      kfn = split ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, true>
+                  : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false>;
     }
-  } else {
-    if (wg || wi) return hipErrorInvalidValue;
-    if (split)
-      grid_grad_stage1<CIN, COUT, OFFSET, APPLY, true><<<nblocks, kWaves * 64, 0, s>>>(p);
-    else
-      grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false><<<nblocks, kWaves * 64, 0, s>>>(p);
   }
+  GGPlan pl;
+  if (!gg_plan(B, H, W, GH, GW, GD, C, resident_slots(kfn, occ), &pl) || pl.ws_bytes > ws_bytes)
+    return hipErrorInvalidValue;
+  GGParams p{q.guide, q.input, q.dout, q.grid, q.dguide, q.dinput, static_cast<float*>(ws), H, W, GH, GW, GD,
+             pl.rg, pl.nyg, pl.ntasks, (float)GW / W, (float)GH / H};
+  const dim3 nblocks((unsigned)(GW + 1), (unsigned)pl.nyg, (unsigned)B);
+  kfn<<<nblocks, kWaves * 64, 0, s>>>(p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const long long ncell = (long long)B * GH * GW * GD;
@@ -743,27 +781,25 @@ size_t apply_grid_grad_mfma_workspace(int B, int H, int W, int GH, int GW, int G
                                       bool has_offset) {
   GGPlan pl;
   if (!apply_shape_ok(Cin, Cout, has_offset)) return 0;
-  if (!gg_plan(B, H, W, GH, GW, GD, Cout * (Cin + (has_offset ? 1 : 0)), &pl)) return 0;
+  if (!gg_plan(B, H, W, GH, GW, GD, Cout * (Cin + (has_offset ? 1 : 0)), 0, &pl)) return 0;
   return pl.ws_bytes;
 }
 
 bool apply_grid_grad_mfma_supported(const ApplyGradArgs& a) {
   GGPlan pl;
   return apply_shape_ok(a.Cin, a.Cout, a.has_offset) &&
-         gg_plan(a.B, a.H, a.W, a.GH, a.GW, a.GD, a.Cout * a.Cj, &pl) && a.workspace != nullptr &&
+         gg_plan(a.B, a.H, a.W, a.GH, a.GW, a.GD, a.Cout * a.Cj, 0, &pl) && a.workspace != nullptr &&
          a.workspace_bytes >= pl.ws_bytes;
 }
 
 // variant (tools A/B): 2 = bf16-split contraction.  fused: also write a.dguide / a.dinput.
 static hipError_t apply_gg(const ApplyGradArgs& a, bool fused, hipStream_t s) {
-  GGPlan pl;
-  if (!gg_plan(a.B, a.H, a.W, a.GH, a.GW, a.GD, a.Cout * a.Cj, &pl)) return hipErrorInvalidValue;
   const GGPtrs q{a.guide, a.input, a.dout, a.grid, a.dgrid, fused ? a.dguide : nullptr,
                  fused ? a.dinput : nullptr};
   const bool split = a.variant == 2;
 #define HDRNET_CASE(CI, CO, OFF)                                                                  \
   if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF)                                         \
-  return gg_launch<CI, CO, OFF, true>(q, a.B, a.H, a.W, a.GH, a.GW, a.GD, a.workspace, pl, s, split, \
+  return gg_launch<CI, CO, OFF, true>(q, a.B, a.H, a.W, a.GH, a.GW, a.GD, a.workspace, a.workspace_bytes, s, split, \
                                       (a.variant >= 4 && a.variant <= 8) ? a.variant - 3 : 0)
   HDRNET_CASE(3, 3, true);
   HDRNET_CASE(3, 3, false);
@@ -796,24 +832,22 @@ hipError_t launch_apply_bwd_fused(const ApplyGradArgs& a, hipStream_t s, const c
 
 size_t slice_grid_grad_mfma_workspace(int B, int H, int W, int GH, int GW, int GD, int C) {
   GGPlan pl;
-  if (!slice_c_ok(C) || !gg_plan(B, H, W, GH, GW, GD, C, &pl)) return 0;
+  if (!slice_c_ok(C) || !gg_plan(B, H, W, GH, GW, GD, C, 0, &pl)) return 0;
   return pl.ws_bytes;
 }
 
 bool slice_grid_grad_mfma_supported(const SliceGradArgs& a) {
   GGPlan pl;
-  return slice_c_ok(a.C) && gg_plan(a.B, a.H, a.W, a.GH, a.GW, a.GD, a.C, &pl) &&
+  return slice_c_ok(a.C) && gg_plan(a.B, a.H, a.W, a.GH, a.GW, a.GD, a.C, 0, &pl) &&
          a.workspace != nullptr && a.workspace_bytes >= pl.ws_bytes;
 }
 
 static hipError_t slice_gg(const SliceGradArgs& a, bool fused, hipStream_t s) {
-  GGPlan pl;
-  if (!gg_plan(a.B, a.H, a.W, a.GH, a.GW, a.GD, a.C, &pl)) return hipErrorInvalidValue;
   const GGPtrs q{a.guide, nullptr, a.dout, a.grid, a.dgrid, fused ? a.dguide : nullptr, nullptr};
   const bool split = a.variant == 2;
 #define HDRNET_CASE(CC)                                                                            \
   if (a.C == CC)                                                                                   \
-  return gg_launch<0, CC, false, false>(q, a.B, a.H, a.W, a.GH, a.GW, a.GD, a.workspace, pl, s, split)
+  return gg_launch<0, CC, false, false>(q, a.B, a.H, a.W, a.GH, a.GW, a.GD, a.workspace, a.workspace_bytes, s, split)
   HDRNET_CASE(1);
   HDRNET_CASE(2);
   HDRNET_CASE(4);
