@@ -117,6 +117,35 @@ def test_backward_vs_oracle_at_config_size(dev, ops, mt_port, name):
         np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5 * scale, err_msg=nm)
 
 
+@pytest.mark.parametrize("B,H,W,GH,GW", [(3, 540, 960, 8, 8), (4, 270, 480, 16, 16), (2, 600, 450, 5, 9)])
+def test_batched_backward_vs_oracle_every_gradient_subset(dev, ops, mt_port, B, H, W, GH, GW):
+    """The rows-per-task plan of the fused backward depends on the batch, the frame, the grid AND on which
+    gradients are requested (each kernel variant has its own resident-workgroup count): every subset that
+    includes dgrid, batched, against the oracle; the subsets must also agree with each other to rounding."""
+    GD = 8
+    rng = np.random.default_rng(B * 1000 + H)
+    grid = rng.random((B, GH, GW, GD, 12), dtype=np.float32)
+    guide = rng.random((B, H, W), dtype=np.float32)
+    inp = rng.random((B, H, W, 3), dtype=np.float32)
+    dout = rng.standard_normal((B, H, W, 3)).astype(np.float32)
+    wg, wgu, wi = mt_port.bilateral_slice_apply_grad(grid, guide, inp, dout, True)
+    want = {"dgrid": wg, "dguide": wgu, "dinput": wi}
+    for need_guide, need_input in ((True, True), (True, False), (False, True), (False, False)):
+        tg = T(grid, dev).requires_grad_(True)
+        tgu = T(guide, dev).requires_grad_(need_guide)
+        ti = T(inp, dev).requires_grad_(need_input)
+        ops.bilateral_slice_apply(tg, tgu, ti, has_offset=True).backward(T(dout, dev))
+        kern = ops.last_kernel()
+        assert kern == ("apply_bwd_fused/mfma" if (need_guide or need_input) else "grid_grad_mfma"), kern
+        got = {"dgrid": tg.grad, "dguide": tgu.grad, "dinput": ti.grad}
+        for nm, g in got.items():
+            if g is None:
+                continue
+            scale = max(1.0, float(np.abs(want[nm]).max()))
+            np.testing.assert_allclose(N(g), want[nm], rtol=1e-4, atol=1e-5 * scale,
+                                       err_msg=f"{nm} (dguide={need_guide}, dinput={need_input})")
+
+
 # ---- hdrnet/test/ops_test.py:178-322, the reference's data / optimiser / step counts / thresholds ----
 def _fit(ops, grid, guide_logits, target, lr, steps, opt_grid, opt_guide):
     params = [p for p, on in ((grid, opt_grid), (guide_logits, opt_guide)) if on]
