@@ -127,13 +127,7 @@ __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
   float* of = reinterpret_cast<float*>(ov);
   if (active) {
     if constexpr (GUIDE_NN) {
-#pragma unroll
-      for (int k = 0; k < kPxPerThread; ++k) {
-        float in[CIN];
-#pragma unroll
-        for (int j = 0; j < CIN; ++j) in[j] = inf[k * CIN + j];
-        gs[k] = guide_nn_pixel<CIN>(gn, in);
-      }
+      guide_nn_quad<CIN>(gn, inf, gs);
       if (gn.guide_out) *reinterpret_cast<float4*>(gn.guide_out + p) = make_float4(gs[0], gs[1], gs[2], gs[3]);
     }
 #pragma unroll

@@ -108,6 +108,7 @@ void hdrnet_enable_kernel_names(int on) { g_kernel_names.store(on ? 1 : 0, std::
 // tools build only (include/hdrnet_amd_tools.h)
 void hdrnet_tools_set_trace(void* device_buf) {
   hdrnet_amd::apply_fwd_seg_set_trace(static_cast<long long*>(device_buf));
+  hdrnet_amd::grid_grad_set_trace(static_cast<long long*>(device_buf));
 }
 #endif
 

@@ -72,6 +72,7 @@ __device__ __forceinline__ float split_pack(float x) {
 
 constexpr int kWaves = 4;      // waves per workgroup; they share ONE task and split its rows
 constexpr int kTileFloats = 3 * 16 * 16;  // partial tile: [rel 3][k 16][c 16]
+constexpr int kTraceChunks = 16;          // tools phase trace: chunks recorded per workgroup
 
 struct GGParams {
   const float* guide;
@@ -85,6 +86,7 @@ struct GGParams {
   int rg, nyg;
   long long ntasks;
   float scale_x, scale_y;  // GW / W, GH / H  (forward's expressions)
+  long long* trace;        // tools variant 9 (ABL 6): per-chunk phase stamps of wave 0, [task][kTraceChunks][5]
 };
 
 // LDS traffic of ONE wave needs no fence: the LDS executes a wave's instructions in order, so
@@ -343,6 +345,8 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
     for (int cb = 0; cb < kBatch; ++cb) {
       const int x0 = xb + 64 * cb;
       if (x0 < x_hi) {  // wave-uniform
+        [[maybe_unused]] long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+        if constexpr (ABL == 6) ts0 = clock64();
         const int ci = bi * kBatch + cb;  // chunk in row, wave-uniform
         float dx;
         if (ci == 0) dx = dxc[0];
@@ -524,9 +528,12 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
             }
           }
         };
+        if constexpr (ABL == 6) ts1 = clock64();  // VALU phase + staging writes issued
         HDRNET_GG_READS(0, HDRNET_GG_OUT);
+        if constexpr (ABL == 6) ts2 = clock64();  // first half's operands have arrived
         contract();
         HDRNET_GG_READS(64, HDRNET_GG_INOUT);
+        if constexpr (ABL == 6) ts3 = clock64();  // first half's MFMAs issued, second half's operands arrived
         contract();
 #undef HDRNET_GG_READS
 #undef HDRNET_GG_OUT
@@ -536,6 +543,13 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
         aQ[8 * kTStride] = 0.0f;
         aP[0] = 0.0f;
         aP[8 * kTStride] = 0.0f;
+        if constexpr (ABL == 6) {
+          const int nch = t * kBatch + cb;  // chunk ordinal of this wave
+          if (wave == 0 && lane == 0 && nch < kTraceChunks) {
+            long long* tr = p.trace + ((size_t)task * kTraceChunks + nch) * 5;
+            tr[0] = ts0; tr[1] = ts1; tr[2] = ts2; tr[3] = ts3; tr[4] = clock64();
+          }
+        }
         if constexpr (WI) __builtin_amdgcn_sched_barrier(0);  // chunk by chunk: keeps the live set of one
       }
     }
@@ -685,6 +699,8 @@ bool gg_plan(int B, int H, int W, int GH, int GW, int GD, int C, long long slots
   return true;
 }
 
+long long* g_gg_trace = nullptr;  // tools: phase-trace buffer (grid_grad_set_trace)
+
 // Workgroups of `kfn` resident on the device at once (occupancy x CUs).  Queried once per kernel.
 typedef void (*Stage1Fn)(GGParams);
 
@@ -725,12 +741,13 @@ hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int G
   static std::atomic<int> occ_cache[8];  // per (split, dguide, dinput) of this shape
 #ifdef HDRNET_TOOLS_BUILD
   if constexpr (APPLY && CIN == 3 && COUT == 3 && OFFSET) {  // ablations (tools variants 4 .. 8): timing only
-    if (ablate >= 1 && ablate <= 5) {
+    if (ablate >= 1 && ablate <= 6) {
+      if (ablate == 6 && !g_gg_trace) return hipErrorInvalidValue;
 #define GG_ABL(A)                                                                              \
   (wg && wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, true, true, A>       \
             : wg ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, true, false, A> \
                  : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, false, false, A>)
-      kfn = ablate == 1 ? GG_ABL(1) : ablate == 2 ? GG_ABL(2) : ablate == 3 ? GG_ABL(3) : ablate == 4 ? GG_ABL(4) : GG_ABL(5);
+      kfn = ablate == 1 ? GG_ABL(1) : ablate == 2 ? GG_ABL(2) : ablate == 3 ? GG_ABL(3) : ablate == 4 ? GG_ABL(4) : ablate == 5 ? GG_ABL(5) : GG_ABL(6);
 #undef GG_ABL
     }
   }
@@ -757,7 +774,7 @@ hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int G
   if (!gg_plan(B, H, W, GH, GW, GD, C, resident_slots(kfn, occ), &pl) || pl.ws_bytes > ws_bytes)
     return hipErrorInvalidValue;
   GGParams p{q.guide, q.input, q.dout, q.grid, q.dguide, q.dinput, static_cast<float*>(ws), H, W, GH, GW, GD,
-             pl.rg, pl.nyg, pl.ntasks, (float)GW / W, (float)GH / H};
+             pl.rg, pl.nyg, pl.ntasks, (float)GW / W, (float)GH / H, g_gg_trace};
   const dim3 nblocks((unsigned)(GW + 1), (unsigned)pl.nyg, (unsigned)B);
   kfn<<<nblocks, kWaves * 64, 0, s>>>(p);
   hipError_t e = hipGetLastError();
@@ -776,6 +793,10 @@ bool apply_shape_ok(int Cin, int Cout, bool off) {
 bool slice_c_ok(int C) { return C == 1 || C == 2 || C == 4 || C == 8 || C == 12 || C == 16; }
 
 }  // namespace
+
+#ifdef HDRNET_TOOLS_BUILD
+void grid_grad_set_trace(long long* device_buf) { g_gg_trace = device_buf; }
+#endif
 
 size_t apply_grid_grad_mfma_workspace(int B, int H, int W, int GH, int GW, int GD, int Cin, int Cout,
                                       bool has_offset) {
@@ -800,7 +821,7 @@ static hipError_t apply_gg(const ApplyGradArgs& a, bool fused, hipStream_t s) {
 #define HDRNET_CASE(CI, CO, OFF)                                                                  \
   if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF)                                         \
   return gg_launch<CI, CO, OFF, true>(q, a.B, a.H, a.W, a.GH, a.GW, a.GD, a.workspace, a.workspace_bytes, s, split, \
-                                      (a.variant >= 4 && a.variant <= 8) ? a.variant - 3 : 0)
+                                      (a.variant >= 4 && a.variant <= 9) ? a.variant - 3 : 0)
   HDRNET_CASE(3, 3, true);
   HDRNET_CASE(3, 3, false);
   HDRNET_CASE(3, 4, true);

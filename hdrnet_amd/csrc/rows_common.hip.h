@@ -344,21 +344,8 @@ struct GuideNN {
   int n;
 };
 
-template <int CIN>
-__device__ __forceinline__ float guide_nn_pixel(const GuideNN& gn, const float (&in)[CIN]) {
-  float acc = gn.conv2[gn.n];
-#pragma unroll 4
-  for (int k = 0; k < gn.n; ++k) {
-    const float* w = gn.conv1 + k * (CIN + 1);  // wave-uniform -> scalar loads
-    float h = w[CIN];
-#pragma unroll
-    for (int j = 0; j < CIN; ++j) h = fmaf(w[j], in[j], h);
-    acc = fmaf(gn.conv2[k], fmaxf(h, 0.0f), acc);
-  }
-  return 1.0f / (1.0f + expf(-acc));  // tf.nn.sigmoid
-}
-// The same for a lane's 4 consecutive pixels (inf = [pixel][CIN] floats): one pass over the features, the
-// weights read ONCE per feature through the constant address space (wave-uniform s_load; a plain global
+// Evaluated for a lane's 4 consecutive pixels at once (inf = [pixel][CIN] floats): one pass over the
+// features, the weights read ONCE per feature through the constant address space (wave-uniform s_load; a plain global
 // pointer next to the kernel's stores is not provably invariant and compiles to per-lane vector loads).
 template <int CIN>
 __device__ __forceinline__ void guide_nn_quad(const GuideNN& gn, const float* inf, float (&g)[kPxPerThread]) {

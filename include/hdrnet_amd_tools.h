@@ -20,7 +20,9 @@
  *     hdrnet_bilateral_slice{,_apply}_grad_f32_ex; tools/bwd_ab.py times them interleaved):
  *       2  bf16-split contraction (two v_mfma_f32_16x16x32_bf16 per 16 pixels)   3  un-fused kernels
  *       4..8  ABLATIONS of the fused pass (timing only, results are garbage): 4 pixels loaded once per
- *             wave, 5 no MFMAs, 6 prologue + epilogue only, 7 = 4 + 5, 8 the launch alone
+ *             wave, 5 no MFMAs, 6 prologue + epilogue only, 7 = 4 + 5, 8 the launch alone; 9 = the product
+ *             pass with per-chunk phase stamps of wave 0 ([task][16][5] clock64 values in the buffer
+ *             given to hdrnet_tools_set_trace; tools/exp/r02_exp29.py)
  *       HDRNET_GG_RG (environment): rows per workgroup task
  *   - hdrnet_tools_set_trace: device buffer that the trace variants fill with
  *     [workgroup][3] = {start, end in wall_clock64() ticks (100 MHz), XCC id}.
