@@ -58,19 +58,22 @@ __device__ __forceinline__ void guide_curves_quad(const GuideNet& gn, const floa
   cfloat* mix = (cfloat*)gn.conv2;
   cfloat* shifts = (cfloat*)gn.shifts;
   cfloat* slopes = (cfloat*)gn.slopes;
-  float t[kPxPerThread][CIN], cv[kPxPerThread][CIN];
+  // pixels in pairs on v_pk_fma_f32 / v_pk_add_f32 (the same per-pixel operation chains as the scalar form)
+  static_assert(kPxPerThread == 4, "two pixel pairs");
+  f32x2 t[2][CIN], cv[2][CIN];
 #pragma unroll
   for (int c = 0; c < CIN; ++c) {
     float w[CIN + 1];
 #pragma unroll
     for (int j = 0; j <= CIN; ++j) w[j] = ccm[c * (CIN + 1) + j];
 #pragma unroll
-    for (int q = 0; q < kPxPerThread; ++q) {
-      float h = w[CIN];
+    for (int h = 0; h < 2; ++h) {
+      f32x2 hv = {w[CIN], w[CIN]};
 #pragma unroll
-      for (int j = 0; j < CIN; ++j) h = fmaf(w[j], inf[q * CIN + j], h);
-      t[q][c] = h;
-      cv[q][c] = 0.0f;
+      for (int j = 0; j < CIN; ++j)
+        hv = __builtin_elementwise_fma(f32x2{w[j], w[j]}, f32x2{inf[(2 * h) * CIN + j], inf[(2 * h + 1) * CIN + j]}, hv);
+      t[h][c] = hv;
+      cv[h][c] = f32x2{0.0f, 0.0f};
     }
   }
 #pragma unroll 4
@@ -79,7 +82,11 @@ __device__ __forceinline__ void guide_curves_quad(const GuideNet& gn, const floa
     for (int c = 0; c < CIN; ++c) {
       const float sl = slopes[k * CIN + c], sh = shifts[k * CIN + c];
 #pragma unroll
-      for (int q = 0; q < kPxPerThread; ++q) cv[q][c] = fmaf(sl, fmaxf(t[q][c] - sh, 0.0f), cv[q][c]);
+      for (int h = 0; h < 2; ++h) {
+        const f32x2 d = t[h][c] - f32x2{sh, sh};
+        const f32x2 r = {fmaxf(d.x, 0.0f), fmaxf(d.y, 0.0f)};
+        cv[h][c] = __builtin_elementwise_fma(f32x2{sl, sl}, r, cv[h][c]);
+      }
     }
   }
   float m[CIN + 1];
@@ -89,7 +96,7 @@ __device__ __forceinline__ void guide_curves_quad(const GuideNet& gn, const floa
   for (int q = 0; q < kPxPerThread; ++q) {
     float v = m[CIN];
 #pragma unroll
-    for (int c = 0; c < CIN; ++c) v = fmaf(m[c], cv[q][c], v);
+    for (int c = 0; c < CIN; ++c) v = fmaf(m[c], (q & 1) ? cv[q >> 1][c].y : cv[q >> 1][c].x, v);
     g[q] = fminf(fmaxf(v, 0.0f), 1.0f);  // tf.clip_by_value(guidemap, 0, 1)
   }
 }

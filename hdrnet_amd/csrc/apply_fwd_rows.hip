@@ -314,8 +314,10 @@ bool apply_fwd_nnguide_supported(const ApplyArgs& a, const float* guide_out) {
 hipError_t launch_apply_fwd_nnguide(const ApplyArgs& a, const float* conv1, const float* conv2,
                                     int n_feats, float* guide_out, hipStream_t s,
                                     const char** name) {
-  if (apply_fwd_seg_nnguide_supported(a, guide_out))
-    return launch_apply_fwd_seg_nnguide(a, conv1, conv2, n_feats, guide_out, s, name);
+  if (apply_fwd_seg_nnguide_supported(a, guide_out)) {
+    const hipError_t e = launch_apply_fwd_seg_nnguide(a, conv1, conv2, n_feats, guide_out, s, name);
+    if (e != hipErrorNotSupported) return e;  // (a network too wide for its LDS copy falls through)
+  }
   const GuideNN gn{conv1, conv2, guide_out, n_feats};
   ApplyArgs t = a;
   t.guide = a.input;
@@ -341,8 +343,10 @@ bool apply_fwd_upadd_supported(const ApplyArgs& a, const float* coarse, bool gui
 hipError_t launch_apply_fwd_upadd(const ApplyArgs& a, const float* coarse, int Hc, int Wc,
                                   const float* conv1, const float* conv2, int n_feats,
                                   hipStream_t s, const char** name) {
-  if (apply_fwd_seg_upadd_supported(a, coarse, conv1 != nullptr))
-    return launch_apply_fwd_seg_upadd(a, coarse, Hc, Wc, conv1, conv2, n_feats, s, name);
+  if (apply_fwd_seg_upadd_supported(a, coarse, conv1 != nullptr)) {
+    const hipError_t e = launch_apply_fwd_seg_upadd(a, coarse, Hc, Wc, conv1, conv2, n_feats, s, name);
+    if (e != hipErrorNotSupported) return e;
+  }
   if (conv1) {
     const GuideNN gn{conv1, conv2, nullptr, n_feats};
     ApplyArgs t = a;
