@@ -184,8 +184,10 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   constexpr int CB = C * (int)sizeof(float);
   constexpr int CIN_Q = (APPLY && CIN > 0) ? CIN : 1;
   // chunks of 64 pixels loaded ahead (4: 132 VGPRs, 3 waves / SIMD, 6 % slower; 1 with dinput fused, which
-  // then fits 4 waves / SIMD instead of 3: 113 -> 120 us, the shorter prefetch costs more than the wave buys)
-  constexpr int kBatch = 2;
+  // then fits 4 waves / SIMD instead of 3: 113 -> 120 us, the shorter prefetch costs more than the wave
+  // buys).  A wide BilateralSlice (dout = 48-64 B/px) is the exception: its batch is 26-34 registers, one
+  // chunk ahead brings the pass from 3 to 4 waves / SIMD and 115 -> 110 us at 4K.
+  constexpr int kBatch = (!APPLY && COUT >= 12) ? 1 : 2;
   constexpr int kLoadAux = FUSED ? rows::kAuxNt : 0;  // fused pass is an HBM stream: nontemporal pixel loads
   constexpr int kImg = FUSED ? 2 * 10 * C : 0;  // [x corner][plane 0 .. GD + 1 (GD <= 8)][c]
   constexpr int kSlab = (16 + C) * kTStride + kImg;  // floats per wave: A^T [16][68], V^T [C][68], image
