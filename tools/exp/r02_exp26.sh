@@ -5,7 +5,7 @@ R=$(pwd); O=$R/gpurun_out; mkdir -p $O
 T=$(date +%H%M%S)
 {
 rocminfo 2>/dev/null | grep -i "Uuid" | grep GPU | head -1
-rocm-smi --showpowercap --showperflevel 2>&1 | grep -i "cap\|level" | tr -s ' ' | cut -c1-100
+rocm-smi --showperflevel --showmaxpower 2>&1 | grep -i "level\|max" | tr -s " " | cut -c1-100
 python - <<'PY' &
 import time, torch, sys
 sys.path.insert(0, '.')
