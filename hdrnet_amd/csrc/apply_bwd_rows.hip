@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void apply_vjp_rows_vec4(
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int wave_x0 = xs + kPxPerThread * (int)(threadIdx.x & ~63u);
     const int nvalid = (min(xe, wave_x0 + 64 * kPxPerThread) - wave_x0) * CIN / 4;
-    // write-through buffer stores on a descriptor over exactly this wave's run (rows_common.hip.h)
+    // nontemporal buffer stores on a descriptor over exactly this wave's run (rows_common.hip.h)
     const __amdgpu_buffer_rsrc_t orsrc =
         make_rsrc(dinput + ((size_t)row * W + wave_x0) * CIN, nvalid > 0 ? (unsigned)nvalid * 16u : 0u);
 #pragma unroll

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // write-through buffer stores on a descriptor over exactly this wave's run (rows_common.hip.h)
+  // nontemporal buffer stores on a descriptor over exactly this wave's run (rows_common.hip.h)
   const int nvalid = wave_px * COUT / 4;  // float4s
   const __amdgpu_buffer_rsrc_t orsrc =
       make_rsrc(out + ((size_t)row * W + wave_x0) * COUT, nvalid > 0 ? (unsigned)nvalid * 16u : 0u);

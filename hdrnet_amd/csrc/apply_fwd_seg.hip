@@ -27,11 +27,12 @@
 //     40.8 to 39.4 us per 4K frame, but only as dense per-instruction runs (a per-pixel 48-B
 //     stride re-fetches lines).
 //   * STORES leave through the same slab, transposed to lane-contiguous 16-B runs, as
-//     `buffer_store_dwordx4 ... nt` on a descriptor that covers exactly the row segment (lanes past
-//     the run are dropped by the bounds check -- no predicate).  Plain stores leave up to an L2's
-//     worth of dirty lines for the end-of-kernel write-back; streaming them out is worth 1.5 us per
-//     4K frame and 0.7 us per 1080p frame; write-through (sc0 sc1) is as good on line-aligned
-//     segments and 10 % worse on unaligned ones (rows_common.hip.h; profiles/r02/).
+//     `buffer_store_dwordx4` with a streaming cache policy on a descriptor that covers exactly the
+//     row segment (lanes past the run are dropped by the bounds check -- no predicate).  Plain stores
+//     leave up to an L2's worth of dirty lines for the end-of-kernel write-back; streaming them out is
+//     worth 1.5 us per 4K frame and 0.7 us per 1080p frame.  Write-through (sc0 sc1) is the fastest
+//     where segments are whole 128-B lines and 10 % worse than `nt` where they are not, so the
+//     flavour is chosen per launch (launch_apply_fwd_seg below; rows_common.hip.h; profiles/r02/).
 //   * 3-D launch grid (segment, row, batch): no integer division in the kernel.
 //
 // Numerics: the coordinate and weight expressions of the reference in the reference's order

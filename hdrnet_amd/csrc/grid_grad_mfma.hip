@@ -21,7 +21,9 @@
 // does not overlap with VALU work of any wave on that SIMD (tools/debug/ubench/
 // mfma_valu_overlap.hip: MFMA-only 483 us + VALU-only 469 us -> 919 us interleaved), and the
 // tile is 19 % dense (4 live weights x 12 channels of 16 x 16).  Stage 1 is therefore bound by
-// FP32 issue: 16 MFMA (512 cycles) + ~115 VALU per 64-pixel chunk.
+// FP32 issue: a per-chunk phase trace (tools variant 9, profiles/r02/exp29) shows 866 cycles per
+// 64-pixel chunk per SIMD at the ~1.95 GHz the power manager grants under this load -- 512 of them
+// the 16 MFMAs.
 // The sparse alternative -- a wave-level counting sort of every 64-pixel chunk by z bin, then
 // v_mfma_f32_4x4x1_16B_f32 blocks of (4 weights) x (4 channels) with every MAC live -- was built
 // and measured in round 2 (git history: "dgrid: sorted 4x4x1-MFMA stage 1"; profiles/r02/
@@ -31,16 +33,19 @@
 // rewritten without atomics the issue count equals the dense kernel's, so it was dropped.
 //
 // Stage 1 (grid_grad_stage1): one workgroup of 4 waves owns one x-interval (all pixels with
-//   gx0 == g, g = -1 .. GW-1) of RG consecutive rows; its waves take alternate rows.  Per row a
-//   wave loads the interval's pixels (guide, input, dout: buffer loads, 2 chunks of 64 ahead),
-//   and per chunk each lane stages ITS pixel's operands -- V (dout x [in; 1]) and A (the two x
-//   corners folded into one row where they clamp onto the same column) -- in a private LDS
-//   slab; the wave reads them back as MFMA operands.  The row's 16x16 result is scaled by its
-//   two y weights into three REGISTER tiles (the <= 3 grid rows the group touches); after the
-//   last row the four waves' tiles are added in fixed order and go to the workspace.  No LDS
-//   accumulator, no atomics: the result is deterministic.
+//   gx0 == g, g = -1 .. GW-1) of rg consecutive rows (rg fitted per launch to whole rounds of
+//   resident workgroups, gg_plan); its waves take alternate rows.  Per row a wave loads the
+//   interval's pixels (guide, input, dout: buffer loads, one batch of 2 chunks of 64 ahead), and
+//   per chunk each lane stages ITS pixel's operands -- V (dout x [in; 1]) and A (x corner 0 in rows
+//   0-7, corner 1 in rows 8-15) -- in a private LDS slab; the wave reads them back as MFMA
+//   operands (conflict-free ds_read_b64 pattern).  The row's 16x16 result is scaled by its two y
+//   weights into three REGISTER tiles (the <= 3 grid rows the group touches); after the last row
+//   the four waves' tiles are added in fixed order and go to the workspace.  No LDS accumulator,
+//   no atomics: the result is deterministic.  With dguide / dinput requested (WG / WI) the same
+//   pass also evaluates the per-pixel VJPs from a per-wave coefficient image.
 // Stage 2 (grid_grad_stage2): one workgroup per grid cell adds, in fixed order, the partial
-//   tiles of the row groups and the two intervals that cover it.
+//   tiles of the row groups and the two intervals that cover it (+ the clamp-to-edge halves of the
+//   border intervals).
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
               }
             }
           }
-          {  // write-through buffer stores; descriptors end at the interval, so dead lanes are dropped
+          {  // nontemporal buffer stores; descriptors end at the interval, so dead lanes are dropped
             const unsigned px = (unsigned)(x0 + lane);
             if constexpr (WG) {
               const __amdgpu_buffer_rsrc_t rs = rows::make_rsrc(p.dguide + prow_out, (unsigned)x_hi * 4u);

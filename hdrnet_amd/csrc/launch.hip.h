@@ -118,7 +118,7 @@ hipError_t launch_apply_fwd_rows(const ApplyArgs& a, hipStream_t s, const char**
 hipError_t launch_apply_fwd_variant(const ApplyArgs& a, hipStream_t s, const char** name);
 hipError_t launch_apply_fwd_rows_direct_stores(const ApplyArgs& a, hipStream_t s, const char** name, int which);
 // apply_fwd_seg.hip -- the product forward for 16-B-aligned, W % 4 == 0 inputs: padded LDS image,
-// LDS-DMA nontemporal pixel loads, write-through buffer stores.  launch_apply_fwd_rows routes here
+// LDS-DMA nontemporal pixel loads, streaming (write-through / nontemporal) buffer stores.  launch_apply_fwd_rows routes here
 // when supported (else the scalar kernel of apply_fwd_rows.hip).
 bool apply_fwd_seg_supported(const ApplyArgs& a);
 hipError_t launch_apply_fwd_seg(const ApplyArgs& a, hipStream_t s, const char** name);

@@ -289,9 +289,11 @@ __device__ __forceinline__ void vjp_blend(const float* __restrict__ img, int a00
 // workgroup's run is a whole number of 128-B lines (4K: 768 px x 12 B, 1080p: 960 px x 12 B), but
 // write-through pays for every PARTIAL line at a run boundary -- 4000-px rows cut into 1000-px
 // segments (12 000 B): 64.8 us write-through vs 58.7 us nt vs 63.7 us plain (profiles/r02/
-// exp10_hdrp_flavours.txt) -- so `nt` is the policy the product kernels store with.  A raw buffer
-// descriptor over exactly the run being written also drops out-of-range lanes in hardware (no
-// predicate).
+// exp10_hdrp_flavours.txt) -- so `nt` is the policy the product kernels store with (the forward
+// alone picks write-through per launch where every segment is whole lines, apply_fwd_seg.hip).  For
+// ~2 ms after a kernel that left plain-store dirty lines behind, both run slower (write-through 45-47
+// us, nt 42-43 us at 4K) and then settle (profiles/r02/exp25).  A raw buffer descriptor over exactly
+// the run being written also drops out-of-range lanes in hardware (no predicate).
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 constexpr int kAuxPlain = 0, kAuxNt = 2, kAuxSc1 = 16, kAuxSc0Sc1 = 17;
 constexpr int kAuxStream = kAuxNt;  // the policy the product kernels store with

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void slice_fwd_rows(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // write-through buffer stores on a descriptor over exactly this run (rows_common.hip.h)
+    // nontemporal buffer stores on a descriptor over exactly this run (rows_common.hip.h)
     // (the descriptor ends at the run's last float: the bounds check is per dword, so a final
     //  partial float4 -- possible for C < 4 -- is written up to the run's end and no further)
     const unsigned run_bytes = (unsigned)(min(xe, xk0 + 64) - xk0) * (unsigned)C * 4u;
