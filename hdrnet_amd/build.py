@@ -37,6 +37,7 @@ SOURCES = [
     ("apply_fwd_seg.hip", ["-fno-slp-vectorize"]),
     ("apply_fwd_io.hip", ["-fno-slp-vectorize"]),
     ("apply_bwd_rows.hip", ["-fno-slp-vectorize"]),
+    ("apply_vjp_seg.hip", ["-fno-slp-vectorize"]),
     ("slice_fwd_rows.hip", ["-fno-slp-vectorize"]),
     ("grid_grad_mfma.hip", ["-fno-slp-vectorize"]),
     ("guide_grad.hip", ["-fno-slp-vectorize"]),

@@ -197,6 +197,15 @@ bool apply_vjp_rows_supported(const ApplyGradArgs& a) {
 }
 
 hipError_t launch_apply_vjp_rows(const ApplyGradArgs& a, hipStream_t s, const char** name) {
+#ifdef HDRNET_TOOLS_BUILD
+  const bool round1_kernel = a.variant == 11;  // A/B: the round-1 kernel below
+#else
+  const bool round1_kernel = false;
+#endif
+  if (!round1_kernel && apply_vjp_seg_supported(a)) {
+    const hipError_t e = launch_apply_vjp_seg(a, s, name);
+    if (e != hipErrorNotSupported) return e;
+  }
   VjpShape v{a.grid, a.guide, a.input, a.dout, a.dguide, a.dinput, a.B, a.H, a.W,
              a.GH, a.GW, a.GD, a.Cin, a.Cout, a.Cj};
   Plan pl;

@@ -160,6 +160,9 @@ hipError_t launch_apply_fwd_io(const ApplyIoArgs& a, hipStream_t s, const char**
 // (BilateralSliceApply), dguide (BilateralSlice).  dgrid is not their business.
 bool apply_vjp_rows_supported(const ApplyGradArgs& a);
 hipError_t launch_apply_vjp_rows(const ApplyGradArgs& a, hipStream_t s, const char** name);
+// the same on the product forward's core (apply_vjp_seg.hip); launch_apply_vjp_rows routes here when it applies
+bool apply_vjp_seg_supported(const ApplyGradArgs& a);
+hipError_t launch_apply_vjp_seg(const ApplyGradArgs& a, hipStream_t s, const char** name);
 bool slice_vjp_rows_supported(const SliceGradArgs& a);
 hipError_t launch_slice_vjp_rows(const SliceGradArgs& a, hipStream_t s, const char** name);
 

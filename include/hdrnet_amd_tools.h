@@ -23,6 +23,7 @@
  *             wave, 5 no MFMAs, 6 prologue + epilogue only, 7 = 4 + 5, 8 the launch alone; 9 = the product
  *             pass with per-chunk phase stamps of wave 0 ([task][16][5] clock64 values in the buffer
  *             given to hdrnet_tools_set_trace; tools/exp/r02_exp29.py)
+ *       11    (dgrid == NULL) the round-1 per-pixel VJP kernel (apply_vjp_rows) instead of apply_vjp_seg
  *       HDRNET_GG_RG (environment): rows per workgroup task
  *   - hdrnet_tools_set_trace: device buffer that the trace variants fill with
  *     [workgroup][3] = {start, end in wall_clock64() ticks (100 MHz), XCC id}.
