@@ -117,6 +117,23 @@ def test_backward_vs_oracle_at_config_size(dev, ops, mt_port, name):
         np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5 * scale, err_msg=nm)
 
 
+def test_per_pixel_vjps_without_dgrid_vs_oracle_at_1080p(dev, ops, mt_port):
+    """dguide + dinput with the grid frozen (no dgrid requested): the stand-alone per-pixel kernel on the
+    forward's core, a full 1080p frame against the oracle."""
+    H, W, GH, GW, GD = CONFIGS["1080p (config #2)"]
+    rng = np.random.default_rng(77)
+    grid, guide, inp = frame(rng, H, W, GH, GW, GD)
+    dout = rng.standard_normal((1, H, W, 3)).astype(np.float32)
+    _, wgu, wi = mt_port.bilateral_slice_apply_grad(grid, guide, inp, dout, True)
+    tg = T(grid, dev)
+    tgu, ti = (T(a, dev).requires_grad_(True) for a in (guide, inp))
+    ops.bilateral_slice_apply(tg, tgu, ti, has_offset=True).backward(T(dout, dev))
+    assert ops.last_kernel() == "apply_vjp_seg/vec4", ops.last_kernel()
+    for got, want, nm in ((tgu.grad, wgu, "dguide"), (ti.grad, wi, "dinput")):
+        scale = max(1.0, float(np.abs(want).max()))
+        np.testing.assert_allclose(N(got), want, rtol=1e-4, atol=1e-5 * scale, err_msg=nm)
+
+
 @pytest.mark.parametrize("B,H,W,GH,GW", [(3, 540, 960, 8, 8), (4, 270, 480, 16, 16), (2, 600, 450, 5, 9)])
 def test_batched_backward_vs_oracle_every_gradient_subset(dev, ops, mt_port, B, H, W, GH, GW):
     """The rows-per-task plan of the fused backward depends on the batch, the frame, the grid AND on which
