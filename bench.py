@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- BilateralSliceApply forward throughput on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 4k|1080p|hdrp]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 4k|1080p|1080p_b4|hdrp] [--split rows]
 
 `--gpus N` with N > 1 from a bare shell re-launches itself as N ranks under
 torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1); launched by the driver under
@@ -20,15 +20,16 @@ working set exceeds the 256 MiB Infinity Cache + L2 (232 MB per 4K frame x 3 set
 number is an HBM number, not a cache number; the cache-resident rate is reported separately
 under "extra".
 
-Before the W counted warm-up steps an untimed, disclosed PRE-ROLL (>= 50 ms of launches,
-`preroll_launches` in the JSON) takes the device out of the idle power state, in which the same
-kernel runs ~8 % slower (the ramp takes ~25 ms); and when the timed region is shorter than 10 ms
-(the default 200 steps, or `--steps 20`), where the host-side synchronisation latency would be a
-visible fraction of the wall clock, `value` is computed from the HIP-event time of the region
-instead (`"clock": "events"`).  The K timed launches follow the pre-roll directly.  Under SUSTAINED
-load some boxes alternate between this state and a ~17 % slower one in episodes of 50-200 ms (the
-first 60-100 ms after the load starts; profiles/r02/exp35): the `sustained` block (N = 1) reports
-the mean and the spread of 100-launch windows over a further 0.5 s, next to `value`, never in it.
+Protocol (the same since round 1; round 2's short event-timed default is gone): an untimed, disclosed
+PRE-ROLL (>= 50 ms of launches, `preroll_launches` in the JSON) takes the device out of the idle power
+state (the clock ramp takes ~25 ms), then W warm-up launches, then EXACTLY K launches timed on the WALL
+clock between barrier + torch.cuda.synchronize() pairs -- always the wall clock, whatever K is; `value`
+= MP/s over that region, max over ranks.  Defaults K = 2000, W = 1000 (an 80-ms region starting ~100 ms
+after the load does).  HIP events on the launch stream bracket the same K launches and give the
+`roofline` block its average kernel duration.  Under SUSTAINED load some boxes alternate between a fast
+state and a ~17 % slower one in episodes of 50-200 ms (profiles/r02/exp35): the `sustained` block
+(N = 1) reports the mean and the spread of 100-launch windows over a further 0.5 s, and
+`roofline.frac_sustained` is the roofline fraction at that mean.
 
 Adds to the JSON line:
   roofline     -- algorithmic bytes / average kernel duration (HIP events on the launch
@@ -60,10 +61,12 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s me
 CACHE_BYTES = 256 * 2 ** 20 + 32 * 2 ** 20  # Infinity Cache + aggregate L2
 
 WORKLOADS = {
-    # name: (H, W, GH, GW, GD, description)
-    "4k": (2160, 3840, 16, 16, 8, "BilateralSliceApply fwd 3840x2160 fp32 NHWC, grid 16x16x8x12, batch=1/GPU"),
-    "1080p": (1080, 1920, 16, 16, 8, "BilateralSliceApply fwd 1920x1080 fp32 NHWC, grid 16x16x8x12, batch=1/GPU"),
-    "hdrp": (3000, 4000, 32, 32, 8, "BilateralSliceApply fwd 4000x3000 fp32 NHWC, grid 32x32x8x12, 1 image/GPU"),
+    # name: (B, H, W, GH, GW, GD, description)   B = images per launch (per GPU)
+    "4k": (1, 2160, 3840, 16, 16, 8, "BilateralSliceApply fwd 3840x2160 fp32 NHWC, grid 16x16x8x12, batch=1/GPU"),
+    "1080p": (1, 1080, 1920, 16, 16, 8, "BilateralSliceApply fwd 1920x1080 fp32 NHWC, grid 16x16x8x12, batch=1/GPU"),
+    "1080p_b4": (4, 1080, 1920, 16, 16, 8,
+                 "BilateralSliceApply fwd 4 x 1920x1080 fp32 NHWC per launch (config #4's per-GPU batch), grid 16x16x8x12"),
+    "hdrp": (1, 3000, 4000, 32, 32, 8, "BilateralSliceApply fwd 4000x3000 fp32 NHWC, grid 32x32x8x12, 1 image/GPU"),
 }
 
 
@@ -109,23 +112,23 @@ def measured_traffic(workload, kernel):
                   else "no PMC record for this workload / kernel")
 
 
-def make_sets(dev, nsets, H, W, GH, GW, GD, seed, smooth_guide=False):
+def make_sets(dev, nsets, B, H, W, GH, GW, GD, seed, smooth_guide=False):
     """grid, guide, input ~ U[0,1) (the reference's own test inputs, hdrnet_ops_test.py:283).
     smooth_guide: a luminance-like low-pass ramp + 2 % noise instead (the
     z-gather locality of a real image; neighbouring pixels then share their LDS reads)."""
     gen = torch.Generator(device=dev).manual_seed(seed)
     sets = []
     for i in range(nsets):
-        grid = torch.rand((1, GH, GW, GD, 12), device=dev, generator=gen)
+        grid = torch.rand((B, GH, GW, GD, 12), device=dev, generator=gen)
         if smooth_guide:
             yy = torch.linspace(0, 1, H, device=dev)[:, None]
             xx = torch.linspace(0, 1, W, device=dev)[None, :]
             guide = 0.5 + 0.4 * torch.sin(5.0 * xx + 3.0 * yy + i) * torch.cos(2.0 * yy - xx)
-            guide = (guide + 0.02 * torch.randn((H, W), device=dev, generator=gen)).clamp(0, 1)[None].contiguous()
+            guide = (guide[None] + 0.02 * torch.randn((B, H, W), device=dev, generator=gen)).clamp(0, 1).contiguous()
         else:
-            guide = torch.rand((1, H, W), device=dev, generator=gen)
-        inp = torch.rand((1, H, W, 3), device=dev, generator=gen)
-        out = torch.empty((1, H, W, 3), device=dev)
+            guide = torch.rand((B, H, W), device=dev, generator=gen)
+        inp = torch.rand((B, H, W, 3), device=dev, generator=gen)
+        out = torch.empty((B, H, W, 3), device=dev)
         sets.append((grid, guide, inp, out))
     return sets
 
@@ -133,30 +136,43 @@ def make_sets(dev, nsets, H, W, GH, GW, GD, seed, smooth_guide=False):
 _BOUND = {}
 
 
-def run_steps(lib, sets, dims, stream, n, start=0):
+def run_steps(lib, sets, dims, stream, n, start=0, band=None):
     """n launches through the C-ABI over the rotating buffer sets.  The argument tuples are bound
     once per buffer ring (no tensor attribute look-ups on the launch path): at 1080p the kernel
-    (12.6 us) is shorter than a naive Python launch loop."""
-    key = (id(sets), dims, stream)
-    calls = _BOUND.get(key)
-    if calls is None:
+    (12 us) is shorter than a naive Python launch loop.  The cache is keyed on the buffers' device
+    addresses (and holds the ring), so a recycled `id()` can never alias another ring.
+    band = (y0, rows): launch only that band of every frame through the row-split entry point
+    (hdrnet_bilateral_slice_apply_rows_f32; `--split rows`)."""
+    key = (tuple(t.data_ptr() for st in sets for t in st), dims, stream, band)
+    ent = _BOUND.get(key)
+    if ent is None:
         import ctypes
-        H, W, GH, GW, GD = dims
+        B, H, W, GH, GW, GD = dims
         c_int, c_vp = ctypes.c_int, ctypes.c_void_p
-        fixed = tuple(c_int(v) for v in (1, H, W, GH, GW, GD, 3, 3, 1)) + (c_vp(stream),)
-        calls = [tuple(c_vp(t.data_ptr()) for t in st) + fixed for st in sets]
+        if band is None:
+            fn = lib.hdrnet_bilateral_slice_apply_f32
+            fixed = tuple(c_int(v) for v in (B, H, W, GH, GW, GD, 3, 3, 1)) + (c_vp(stream),)
+            calls = [tuple(c_vp(t.data_ptr()) for t in st) + fixed for st in sets]
+        else:
+            assert B == 1, "--split rows: one frame per launch"
+            y0, rows = band
+            fn = lib.hdrnet_bilateral_slice_apply_rows_f32
+            fixed = tuple(c_int(v) for v in (B, H, y0, rows, W, GH, GW, GD, 3, 3, 1)) + (c_vp(stream),)
+            calls = [(c_vp(g.data_ptr()), c_vp(gu.data_ptr() + 4 * y0 * W), c_vp(i.data_ptr() + 12 * y0 * W),
+                      c_vp(o.data_ptr() + 12 * y0 * W)) + fixed for (g, gu, i, o) in sets]
         _BOUND.clear()
-        _BOUND[key] = calls
+        ent = _BOUND[key] = (fn, calls, sets)  # holds the ring
+    fn, calls, _ = ent
     ns = len(calls)
-    fn = lib.hdrnet_bilateral_slice_apply_f32
     for k in range(start, start + n):
         rc = fn(*calls[k % ns])
         if rc != 0:
-            raise RuntimeError(f"hdrnet_bilateral_slice_apply_f32 rc={rc}: {lib.hdrnet_last_error().decode()}")
+            raise RuntimeError(f"{fn.__name__} rc={rc}: {lib.hdrnet_last_error().decode()}")
 
 
-def timed(lib, sets, dims, stream, steps, dist_on, dev):
-    """Barrier + sync, K launches bracketed by HIP events on the launch stream, sync + barrier."""
+def timed(step_fn, steps, dist_on, dev):
+    """Barrier + sync, K launches (also bracketed by HIP events on the launch stream), sync + barrier.
+    Returns (wall seconds, event seconds)."""
     from hdrnet_amd import dist as hd
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
@@ -165,7 +181,7 @@ def timed(lib, sets, dims, stream, steps, dist_on, dev):
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     ev0.record()
-    run_steps(lib, sets, dims, stream, steps)
+    step_fn(steps, 0)
     ev1.record()
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
@@ -195,13 +211,13 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def sustained(lib, sets, dims, stream, dev, seconds=0.5, window=100):
+def sustained(step_fn, dev, est_us, seconds=0.5, window=100):
     """Mean and spread of the per-launch time over `seconds` of back-to-back launches (event windows)."""
-    n_win = max(4, int(seconds / (window * 40e-6)))
+    n_win = max(4, int(seconds / (window * est_us * 1e-6)))
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_win + 1)]
     ev[0].record()
     for w in range(n_win):
-        run_steps(lib, sets, dims, stream, window, start=w * window)
+        step_fn(window, w * window)
         ev[w + 1].record()
     torch.cuda.synchronize(dev)
     us = [ev[w].elapsed_time(ev[w + 1]) / window * 1e3 for w in range(n_win)]
@@ -228,9 +244,13 @@ def preroll(step_fn, sync_fn, min_seconds=0.05, chunk=64, max_launches=20000):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--workload", default="4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--split", default="images", choices=["images", "rows"],
+                    help="images (default): every rank slices its OWN frames, weak scaling.  rows: every frame "
+                         "is split into N row bands, one per rank (hdrnet_bilateral_slice_apply_rows_f32), strong "
+                         "scaling -- the total work is fixed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extra", action="store_true",
                     help="also time the cache-resident rate and 1080p (same kernel name at other "
@@ -263,45 +283,55 @@ def main():
     from hdrnet_amd import _lib
     lib = _lib.load()  # raises loudly if the HIP library is missing
 
-    H, W, GH, GW, GD, desc = WORKLOADS[args.workload]
-    dims = (H, W, GH, GW, GD)
-    abytes = algorithmic_bytes(1, H, W, GH, GW, GD)
+    B, H, W, GH, GW, GD, desc = WORKLOADS[args.workload]
+    dims = (B, H, W, GH, GW, GD)
+    frame_bytes = algorithmic_bytes(B, H, W, GH, GW, GD)
+    band = None
+    if args.split == "rows":
+        # strong scaling: rank r slices rows [y0, y0 + rows) of EVERY frame; the grid (96 KiB) is replicated
+        y0, y1 = hd.row_range(H, rank, world)
+        band = (y0, y1 - y0)
+    rows_here = band[1] if band else H
+    abytes = algorithmic_bytes(B, rows_here, W, GH, GW, GD)  # per launch on this rank
     nsets = max(3, -(-int(CACHE_BYTES * 1.5) // abytes))
-    sets = make_sets(dev, nsets, H, W, GH, GW, GD, seed=1234 + rank)
+    sets = make_sets(dev, nsets, B, H, W, GH, GW, GD, seed=1234 + (0 if band else rank))
     stream = torch.cuda.current_stream(dev).cuda_stream
 
+    def step(n, k0):
+        run_steps(lib, sets, dims, stream, n, start=k0, band=band)
+
     lib.hdrnet_enable_kernel_names(1)
-    run_steps(lib, sets, dims, stream, 1)
+    step(1, 0)
     kernel = lib.hdrnet_last_kernel().decode()
     lib.hdrnet_enable_kernel_names(0)  # no bookkeeping on the launch path from here on
-    n_pre, pre_s = preroll(lambda n, k0: run_steps(lib, sets, dims, stream, n, start=k0),
-                           lambda: torch.cuda.synchronize(dev))
-    run_steps(lib, sets, dims, stream, args.warmup)
-    wall, gpu_s = timed(lib, sets, dims, stream, args.steps, dist_on, dev)
+    n_pre, pre_s = preroll(step, lambda: torch.cuda.synchronize(dev))
+    step(args.warmup, 0)
+    wall, gpu_s = timed(step, args.steps, dist_on, dev)
 
     wall_max, gpu_max = hd.max_over_ranks([wall, gpu_s], device=dev if backend == "nccl" else torch.device("cpu"))
 
-    mp_per_step = H * W / 1e6
-    # Short regions (< 10 ms): the host's synchronise latency is a visible share of the wall
-    # clock, so the HIP-event time of the region is the clock for `value`; disclosed in "clock".
-    clock = "wall" if wall_max >= 0.010 else "events"
-    t_region = wall_max if clock == "wall" else gpu_max
-    value = world * args.steps * mp_per_step / t_region
+    # `value`: always the wall clock of the K launches (max over ranks).  images: every rank did K frames
+    # of its own; rows: the N ranks together did K frames.
+    mp_per_step = B * H * W / 1e6
+    value = (1 if band else world) * args.steps * mp_per_step / wall_max
     avg_kernel_s = gpu_max / args.steps  # events bracket K back-to-back launches of ONE kernel
     achieved = abytes / avg_kernel_s / 1e9
-    traffic, traffic_note = measured_traffic(args.workload, kernel)
+    traffic, traffic_note = measured_traffic(args.workload, kernel) if not band else (None, "row-split launch")
 
     result = {
         "metric": "megapixels/sec BilateralSliceApply fwd @4K" if args.workload == "4k"
                   else f"megapixels/sec BilateralSliceApply fwd @{args.workload}",
         "value": round(value, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(t_region / args.steps * 1e3, 5),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic", "clock": clock,
+        "warmup": args.warmup, "ms_per_step": round(wall_max / args.steps * 1e3, 5),
+        "higher_is_better": True, "scaling": "strong" if band else "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic", "clock": "wall",
         "preroll_launches": n_pre, "preroll_ms": round(pre_s * 1e3, 1),
-        "config": {"workload": desc, "images_per_gpu_per_step": 1, "layout": "NHWC fp32",
+        "config": {"workload": desc, "images_per_gpu_per_step": B if not band else round(1.0 / world, 4),
+                   "layout": "NHWC fp32",
                    "has_offset": True, "rotating_buffer_sets": nsets,
-                   "working_set_MB": round(nsets * abytes / 1e6, 1), "parallelism": f"image-shard x{world}",
+                   "working_set_MB": round(nsets * frame_bytes / 1e6, 1),
+                   "parallelism": (f"row-split x{world} (one frame over all ranks)" if band
+                                   else f"image-shard x{world}"),
                    "kernel": kernel},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4),
@@ -309,47 +339,33 @@ def main():
                      "traffic_source": (traffic or {}).get("source") or traffic_note,
                      "source_digest": source_digest(),
                      "algorithmic_bytes_per_launch": abytes, "avg_kernel_us": round(avg_kernel_s * 1e6, 3),
-                     "wall_ms_per_step": round(wall_max / args.steps * 1e3, 5),
-                     "timing": "HIP events on the launch stream around the timed region / steps"},
+                     "event_ms_per_step": round(gpu_max / args.steps * 1e3, 5),
+                     "timing": "HIP events on the launch stream around the K timed launches / K"},
     }
 
     if world == 1:
-        # Disclosed next to `value`, never part of it: ~0.5 s of back-to-back launches in 100-launch
-        # HIP-event windows.  Some boxes alternate between a fast and a ~17 % slower state in episodes of
-        # 50-200 ms under sustained load, the first one 60-100 ms after the load starts
-        # (profiles/r02/exp35); K launches right after the pre-roll see the fast state, this block shows
-        # what a long-running caller gets.
-        result["sustained"] = sustained(lib, sets, dims, stream, dev)
+        # ~0.5 s more of back-to-back launches in 100-launch HIP-event windows: what a long-running caller
+        # gets on this box, and how much it wanders (profiles/r02/exp35).
+        sus = sustained(step, dev, est_us=avg_kernel_s * 1e6)
+        result["sustained"] = sus
+        result["roofline"]["frac_sustained"] = round(
+            abytes / (sus["us_per_launch_mean"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
     if rank == 0 and world == 1:
         extra = {}
         if args.extra:
             # cache-resident rate (one buffer set, stays in the 256 MiB Infinity Cache): labelled, not `value`
             one = sets[:1]
             run_steps(lib, one, dims, stream, 10)
-            _, g1 = timed(lib, one, dims, stream, args.steps, False, dev)
+            _, g1 = timed(lambda n, k0: run_steps(lib, one, dims, stream, n, start=k0), args.steps, False, dev)
             extra["cache_resident_MPps"] = round(args.steps * mp_per_step / g1, 1)
             extra["cache_resident_GBps"] = round(abytes * args.steps / g1 / 1e9, 1)
             # same workload with a smooth (image-like) guide instead of U[0,1) noise
-            del one
-            s3 = make_sets(dev, nsets, H, W, GH, GW, GD, seed=77, smooth_guide=True)
-            run_steps(lib, s3, dims, stream, args.warmup)
-            _, g3 = timed(lib, s3, dims, stream, args.steps, False, dev)
+            s3 = make_sets(dev, nsets, B, H, W, GH, GW, GD, seed=77, smooth_guide=True)
+            run_steps(lib, s3, dims, stream, min(args.warmup, 200))
+            _, g3 = timed(lambda n, k0: run_steps(lib, s3, dims, stream, n, start=k0), args.steps, False, dev)
             extra["smooth_guide_avg_kernel_us"] = round(g3 / args.steps * 1e6, 3)
             extra["smooth_guide_hbm_frac"] = round(abytes / (g3 / args.steps) / 1e9 / HBM_PEAK_GBPS, 4)
             del s3
-            if args.workload == "4k":
-                h2, w2, gh2, gw2, gd2, _ = WORKLOADS["1080p"]
-                ab2 = algorithmic_bytes(1, h2, w2, gh2, gw2, gd2)
-                n2 = max(3, -(-int(CACHE_BYTES * 1.5) // ab2))
-                del sets
-                torch.cuda.empty_cache()
-                s2 = make_sets(dev, n2, h2, w2, gh2, gw2, gd2, seed=99)
-                d2 = (h2, w2, gh2, gw2, gd2)
-                run_steps(lib, s2, d2, stream, args.warmup)
-                w_, g2 = timed(lib, s2, d2, stream, args.steps * 2, False, dev)
-                extra["1080p_MPps"] = round(args.steps * 2 * h2 * w2 / 1e6 / w_, 1)
-                extra["1080p_avg_kernel_us"] = round(g2 / (args.steps * 2) * 1e6, 3)
-                extra["1080p_hbm_frac"] = round(ab2 / (g2 / (args.steps * 2)) / 1e9 / HBM_PEAK_GBPS, 4)
         result["extra"] = extra
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(H, W, GH, GW, GD)

@@ -34,6 +34,8 @@ SIGNATURES = {
     "hdrnet_enable_kernel_names": (None, [_I]),
     "hdrnet_bilateral_slice_apply_f32": (_I, [_FP] * 4 + [_I] * 9 + [_VP]),
     "hdrnet_bilateral_slice_apply_f32_ex": (_I, [_FP] * 4 + [_I] * 9 + [_U, _VP]),
+    "hdrnet_bilateral_slice_apply_rows_f32": (_I, [_FP] * 4 + [_I] * 11 + [_VP]),
+    "hdrnet_bilateral_slice_apply_rows_f32_ex": (_I, [_FP] * 4 + [_I] * 11 + [_U, _VP]),
     "hdrnet_bilateral_slice_apply_nnguide_f32": (_I, [_FP] * 6 + [_I] * 10 + [_VP]),
     "hdrnet_bilateral_slice_apply_io_curves": (_I, [_FP] * 3 + [_I] * 10 + [ctypes.c_float, _I] + [_FP] * 4 + [_I, _FP, _VP]),
     "hdrnet_bilateral_slice_apply_upadd_f32": (_I, [_FP] * 4 + [_I, _I, _FP] + [_I] * 9 + [_FP, _FP, _I, _VP]),

@@ -63,12 +63,34 @@ def _deps() -> List[str]:
     return out
 
 
+def source_digest(tools: bool = False) -> str:
+    """sha256 over everything the library is built from: csrc/*, the public header, this file (the
+    flags) and which build it is.  Written next to the .so after a successful link."""
+    import hashlib
+
+    h = hashlib.sha256(b"tools" if tools else b"product")
+    for d in sorted(_deps()):
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _digest_path(tools: bool) -> str:
+    return (TOOLS_LIB_PATH if tools else LIB_PATH) + ".digest"
+
+
 def is_stale(tools: bool = False) -> bool:
+    """True unless the .so exists AND was built from exactly the sources in the tree -- decided from a
+    content digest, not from mtimes (a git checkout or a copy without -t perturbs those)."""
     path = TOOLS_LIB_PATH if tools else LIB_PATH
     if not os.path.exists(path):
         return True
-    t = os.path.getmtime(path)
-    return any(os.path.getmtime(d) > t for d in _deps())
+    try:
+        with open(_digest_path(tools)) as fh:
+            return fh.read().strip() != source_digest(tools)
+    except OSError:
+        return True
 
 
 def _run(cmd: List[str], verbose: bool) -> None:
@@ -100,6 +122,7 @@ def build(force: bool = False, verbose: bool = False, tools: bool = False) -> st
         try:
             if not force and not is_stale(tools):  # another process built it while we waited
                 return lib_path
+            digest = source_digest(tools)  # of the sources as they are read now
             objdir = os.path.join(LIB_DIR, "obj_tools" if tools else "obj")
             os.makedirs(objdir, exist_ok=True)
             tag = ".%d" % os.getpid()
@@ -123,6 +146,9 @@ def build(force: bool = False, verbose: bool = False, tools: bool = False) -> st
                 tmp = lib_path + tag + ".tmp"
                 _run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", tmp, *objs], verbose)
                 os.replace(tmp, lib_path)
+                with open(_digest_path(tools) + tag, "w") as fh:
+                    fh.write(digest + "\n")
+                os.replace(_digest_path(tools) + tag, _digest_path(tools))
             finally:
                 for o in objs:
                     if os.path.exists(o):

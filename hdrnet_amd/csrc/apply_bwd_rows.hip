@@ -186,9 +186,7 @@ bool vjp_plan(const VjpShape& a, Plan* pl) {
 
 // ---- BilateralSliceApply: dguide / dinput -------------------------------------------------
 bool apply_vjp_rows_supported(const ApplyGradArgs& a) {
-  const bool shape = (a.Cin == 3 && a.Cout == 3) || (a.Cin == 3 && a.Cout == 4 && a.has_offset) ||
-                     (a.Cin == 1 && a.Cout == 1) || (a.Cin == 1 && a.Cout == 3 && a.has_offset) ||
-                     (a.Cin == 4 && a.Cout == 4 && a.has_offset);
+  const bool shape = apply_fast_shape(a.Cin, a.Cout, a.has_offset);
   if (!shape) return false;
   VjpShape v{a.grid, a.guide, a.input, a.dout, a.dguide, a.dinput, a.B, a.H, a.W,
              a.GH, a.GW, a.GD, a.Cin, a.Cout, a.Cj};
@@ -212,14 +210,8 @@ hipError_t launch_apply_vjp_rows(const ApplyGradArgs& a, hipStream_t s, const ch
   if (!vjp_plan(v, &pl)) return hipErrorInvalidValue;
   *name = "apply_vjp_rows/vec4";
 #define HDRNET_CASE(CI, CO, OFF) \
-  if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF) return launch_vjp_want<CI, CO, OFF>(v, pl, s)
-  HDRNET_CASE(3, 3, true);
-  HDRNET_CASE(3, 3, false);
-  HDRNET_CASE(3, 4, true);
-  HDRNET_CASE(1, 1, true);
-  HDRNET_CASE(1, 1, false);
-  HDRNET_CASE(1, 3, true);
-  HDRNET_CASE(4, 4, true);
+  if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF) return launch_vjp_want<CI, CO, OFF>(v, pl, s);
+  HDRNET_APPLY_FAST_SHAPES(HDRNET_CASE)
 #undef HDRNET_CASE
   return hipErrorInvalidValue;
 }

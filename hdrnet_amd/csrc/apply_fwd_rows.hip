@@ -359,9 +359,7 @@ hipError_t launch_apply_fwd_upadd(const ApplyArgs& a, const float* coarse, int H
 }
 
 bool apply_fwd_rows_supported(const ApplyArgs& a) {
-  const bool shape = (a.Cin == 3 && a.Cout == 3) || (a.Cin == 3 && a.Cout == 4 && a.has_offset) ||
-                     (a.Cin == 1 && a.Cout == 1) || (a.Cin == 1 && a.Cout == 3 && a.has_offset) ||
-                     (a.Cin == 4 && a.Cout == 4 && a.has_offset);
+  const bool shape = apply_fast_shape(a.Cin, a.Cout, a.has_offset);
   if (!shape) return false;
   // stage_row reads the grid as float4 when C % 4 == 0.
   if ((a.Cout * a.Cj) % 4 == 0 && ((uintptr_t)a.grid & 15u)) return false;
@@ -387,14 +385,8 @@ hipError_t launch_apply_fwd_rows(const ApplyArgs& a, hipStream_t s, const char**
   // scalar kernel (any W / alignment) and the fused guide-network / pyramid instantiations.
   if (!round1_kernel && apply_fwd_seg_supported(a)) return launch_apply_fwd_seg(a, s, name);
 #define HDRNET_CASE(CI, CO, OFF) \
-  if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF) return launch_t<CI, CO, OFF>(a, s, name)
-  HDRNET_CASE(3, 3, true);
-  HDRNET_CASE(3, 3, false);
-  HDRNET_CASE(3, 4, true);
-  HDRNET_CASE(1, 1, true);
-  HDRNET_CASE(1, 1, false);
-  HDRNET_CASE(1, 3, true);
-  HDRNET_CASE(4, 4, true);
+  if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF) return launch_t<CI, CO, OFF>(a, s, name);
+  HDRNET_APPLY_FAST_SHAPES(HDRNET_CASE)
 #undef HDRNET_CASE
   return hipErrorInvalidValue;
 }

@@ -77,6 +77,7 @@ struct SegParams {
   const float* input;
   float* out;
   int H, W, GH, GW, GD;
+  int y0;          // first frame row of a row-split launch (buffers hold rows y0 .. y0 + H - 1); else 0
   int seg;         // pixels per segment, multiple of 4
   int slab_off;    // float offset of the per-wave slabs in dynamic LDS (= size of the image)
   float scale_x, scale_y;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
     }
   }
 
-  stage_image<C>(lds, grid_b, y, cmin, ncols, p.GH, p.GW, p.GD, p.scale_y, p.inv_col, tid, (int)blockDim.x);
+  stage_image<C>(lds, grid_b, y + p.y0, cmin, ncols, p.GH, p.GW, p.GD, p.scale_y, p.inv_col, tid, (int)blockDim.x);
 
   // x-only terms of this thread's 4 pixels
   XTerm xt[kPxPerThread];
@@ -320,10 +321,11 @@ hipError_t launch_seg_t(const ApplyArgs& a, hipStream_t s, long long* trace,
   p.GH = a.GH;
   p.GW = a.GW;
   p.GD = a.GD;
+  p.y0 = a.y0;
   p.seg = g.pl.seg;
   p.slab_off = g.slab_off;
   p.scale_x = (float)a.GW / a.W;
-  p.scale_y = (float)a.GH / a.H;
+  p.scale_y = (float)a.GH / a.frame_rows();
   p.inv_col = 1.0f / (float)(a.GD * (C / VEC));
   p.trace = trace;
   const dim3 grid3((unsigned)g.pl.nseg, (unsigned)a.H, (unsigned)a.B);
@@ -331,11 +333,7 @@ hipError_t launch_seg_t(const ApplyArgs& a, hipStream_t s, long long* trace,
   return hipGetLastError();
 }
 
-bool seg_shape(const ApplyArgs& a) {
-  return (a.Cin == 3 && a.Cout == 3) || (a.Cin == 3 && a.Cout == 4 && a.has_offset) ||
-         (a.Cin == 1 && a.Cout == 1) || (a.Cin == 1 && a.Cout == 3 && a.has_offset) ||
-         (a.Cin == 4 && a.Cout == 4 && a.has_offset);
-}
+bool seg_shape(const ApplyArgs& a) { return apply_fast_shape(a.Cin, a.Cout, a.has_offset); }
 
 #ifdef HDRNET_TOOLS_BUILD
 long long* g_trace = nullptr;  // device buffer of [nblocks][3]
@@ -362,7 +360,7 @@ hipError_t launch_apply_fwd_seg(const ApplyArgs& a, hipStream_t s, const char** 
   *name = "apply_fwd_seg/vec4";
   const SegGeom g = seg_geom(a, true);
   const long long nblocks = (long long)g.pl.nseg * a.H * a.B;
-  const long long one_round = 256LL * (32 / (g.pl.threads / 64));  // workgroups resident on 256 CUs
+  const long long one_round = (long long)num_cus() * (32 / (g.pl.threads / 64));  // workgroups resident at once
   const bool small = 4 * nblocks <= 5 * one_round;
   const bool whole_lines = ((uintptr_t)a.out % 128 == 0) && ((long long)g.pl.seg * a.Cout * 4) % 128 == 0 &&
                            ((long long)a.W * a.Cout * 4) % 128 == 0;
@@ -372,13 +370,7 @@ hipError_t launch_apply_fwd_seg(const ApplyArgs& a, hipStream_t s, const char** 
     if (whole_lines) return launch_seg_t<CI, CO, OFF, kLoadsDmaNt, kStoresBufSc01, false>(a, s, nullptr); \
     return launch_seg_t<CI, CO, OFF, kLoadsDmaNt, kStoresBufNt, false>(a, s, nullptr);               \
   }
-  HDRNET_CASE(3, 3, true)
-  HDRNET_CASE(3, 3, false)
-  HDRNET_CASE(3, 4, true)
-  HDRNET_CASE(1, 1, true)
-  HDRNET_CASE(1, 1, false)
-  HDRNET_CASE(1, 3, true)
-  HDRNET_CASE(4, 4, true)
+  HDRNET_APPLY_FAST_SHAPES(HDRNET_CASE)
 #undef HDRNET_CASE
   return hipErrorInvalidValue;
 }

@@ -204,9 +204,7 @@ hipError_t launch_want(const ApplyGradArgs& a, const VjpGeom& g, hipStream_t s) 
 }  // namespace
 
 bool apply_vjp_seg_supported(const ApplyGradArgs& a) {
-  const bool shape = (a.Cin == 3 && a.Cout == 3) || (a.Cin == 3 && a.Cout == 4 && a.has_offset) ||
-                     (a.Cin == 1 && a.Cout == 1) || (a.Cin == 1 && a.Cout == 3 && a.has_offset) ||
-                     (a.Cin == 4 && a.Cout == 4 && a.has_offset);
+  const bool shape = apply_fast_shape(a.Cin, a.Cout, a.has_offset);
   if (!shape || !a.guide || !a.input || !a.dout) return false;
   if ((a.Cout * a.Cj) % 4 == 0 && ((uintptr_t)a.grid & 15u)) return false;  // stage_image reads float4
   return vjp_geom(a).ok;
@@ -217,14 +215,8 @@ hipError_t launch_apply_vjp_seg(const ApplyGradArgs& a, hipStream_t s, const cha
   if (!g.ok) return hipErrorNotSupported;
   *name = "apply_vjp_seg/vec4";
 #define HDRNET_CASE(CI, CO, OFF) \
-  if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF) return launch_want<CI, CO, OFF>(a, g, s)
-  HDRNET_CASE(3, 3, true);
-  HDRNET_CASE(3, 3, false);
-  HDRNET_CASE(3, 4, true);
-  HDRNET_CASE(1, 1, true);
-  HDRNET_CASE(1, 1, false);
-  HDRNET_CASE(1, 3, true);
-  HDRNET_CASE(4, 4, true);
+  if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF) return launch_want<CI, CO, OFF>(a, g, s);
+  HDRNET_APPLY_FAST_SHAPES(HDRNET_CASE)
 #undef HDRNET_CASE
   return hipErrorInvalidValue;
 }

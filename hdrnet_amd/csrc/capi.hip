@@ -112,13 +112,18 @@ void hdrnet_tools_set_trace(void* device_buf) {
 }
 #endif
 
-int hdrnet_bilateral_slice_apply_f32_ex(const float* grid, const float* guide,
-                                        const float* input, float* out, int B, int H, int W,
-                                        int GH, int GW, int GD, int Cin, int Cout,
-                                        int has_offset, unsigned flags, void* stream) {
+// Forward, whole frames (H_total = rows, y0 = 0) or one row band of every frame.
+static int apply_fwd_impl(const float* grid, const float* guide, const float* input, float* out, int B,
+                          int H_total, int y0, int H, int W, int GH, int GW, int GD, int Cin, int Cout,
+                          int has_offset, unsigned flags, void* stream) {
   using namespace hdrnet_amd;
   if (int rc = check_common(B, H, W, GH, GW, GD)) return rc;
   if (int rc = check_flags(flags)) return rc;
+  if (H_total < 0 || y0 < 0 || (long long)y0 + H > H_total)
+    return fail(HDRNET_INVALID_ARGUMENT, "row band [%d, %d + %d) outside the frame's %d rows", y0, y0, H, H_total);
+  const bool band = y0 != 0 || H != H_total;
+  if (band && variant(flags) != 0)
+    return fail(HDRNET_INVALID_ARGUMENT, "kernel variants take whole frames");
   if (Cin < 0 || Cout <= 0 || Cin + (has_offset ? 1 : 0) <= 0)
     return fail(HDRNET_INVALID_ARGUMENT,
                 "grid should have output_channels * (input_channels%s) channels "
@@ -133,13 +138,17 @@ int hdrnet_bilateral_slice_apply_f32_ex(const float* grid, const float* guide,
     return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
   ApplyArgs a{grid, guide, input, out, B, H, W, GH, GW, GD, Cin, Cout,
               Cin + (has_offset ? 1 : 0), has_offset != 0, variant(flags)};
+  a.y0 = y0;
+  a.H_total = H_total;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool fast_ok = apply_fwd_rows_supported(a);
+  // a row band runs on the row-segment kernel (apply_fwd_seg.hip) or the generic one; whole frames may
+  // also take the scalar row kernel (unaligned buffers, W % 4 != 0)
+  const bool fast_ok = band ? apply_fwd_seg_supported(a) : apply_fwd_rows_supported(a);
   if (family(flags) == HDRNET_KERNEL_FAST && !fast_ok)
     return fail(HDRNET_INVALID_ARGUMENT, "no fast BilateralSliceApply variant for this shape");
   if (family(flags) != HDRNET_KERNEL_GENERIC && fast_ok) {
     const char* name = "";
-    const hipError_t e = launch_apply_fwd_rows(a, s, &name);
+    const hipError_t e = band ? launch_apply_fwd_seg(a, s, &name) : launch_apply_fwd_rows(a, s, &name);
     const int rc = check_launch(e, "BilateralSliceApply");
     if (rc == HDRNET_OK) set_kernel(name);
     return rc;
@@ -147,6 +156,29 @@ int hdrnet_bilateral_slice_apply_f32_ex(const float* grid, const float* guide,
   const int rc = check_launch(launch_apply_fwd_generic(a, s), "BilateralSliceApply");
   if (rc == HDRNET_OK) set_kernel("apply_fwd_generic");
   return rc;
+}
+
+int hdrnet_bilateral_slice_apply_f32_ex(const float* grid, const float* guide,
+                                        const float* input, float* out, int B, int H, int W,
+                                        int GH, int GW, int GD, int Cin, int Cout,
+                                        int has_offset, unsigned flags, void* stream) {
+  return apply_fwd_impl(grid, guide, input, out, B, H, 0, H, W, GH, GW, GD, Cin, Cout, has_offset, flags,
+                        stream);
+}
+
+int hdrnet_bilateral_slice_apply_rows_f32_ex(const float* grid, const float* guide, const float* input,
+                                             float* out, int B, int H_total, int y0, int rows, int W,
+                                             int GH, int GW, int GD, int Cin, int Cout, int has_offset,
+                                             unsigned flags, void* stream) {
+  return apply_fwd_impl(grid, guide, input, out, B, H_total, y0, rows, W, GH, GW, GD, Cin, Cout, has_offset,
+                        flags, stream);
+}
+
+int hdrnet_bilateral_slice_apply_rows_f32(const float* grid, const float* guide, const float* input,
+                                          float* out, int B, int H_total, int y0, int rows, int W, int GH,
+                                          int GW, int GD, int Cin, int Cout, int has_offset, void* stream) {
+  return apply_fwd_impl(grid, guide, input, out, B, H_total, y0, rows, W, GH, GW, GD, Cin, Cout, has_offset,
+                        HDRNET_KERNEL_AUTO, stream);
 }
 
 int hdrnet_bilateral_slice_apply_f32(const float* grid, const float* guide, const float* input,

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kThreads) void apply_fwd_generic(
     const float* __restrict__ grid, const float* __restrict__ guide,
     const float* __restrict__ input, float* __restrict__ out, long long npix, int H,
     int W, int GH, int GW, int GD, int Cin, int Cout, int Cj, float scale_x,
-    float scale_y) {
+    float scale_y, int y0) {
   const long long p = (long long)blockIdx.x * kThreads + threadIdx.x;
   if (p >= npix) return;
   const int x = (int)(p % W);
@@ -88,7 +88,8 @@ __global__ __launch_bounds__(kThreads) void apply_fwd_generic(
   const long long b = p / ((long long)W * H);
   const int C = Cout * Cj;
   const float* gb = grid + b * ((long long)GH * GW * GD * C);
-  const Corners c = make_corners<false>(x, y, guide[p], scale_x, scale_y, GH, GW, GD, C);
+  // y0: first frame row of a row-split launch (0 for whole frames); scale_y is GH / frame height
+  const Corners c = make_corners<false>(x, y + y0, guide[p], scale_x, scale_y, GH, GW, GD, C);
   const float* in = input + p * Cin;
   float* o = out + p * Cout;
   for (int i = 0; i < Cout; ++i) {
@@ -256,7 +257,7 @@ hipError_t launch_apply_fwd_generic(const ApplyArgs& a, hipStream_t s) {
   const long long npix = (long long)a.B * a.H * a.W;
   apply_fwd_generic<<<blocks_for(npix), kThreads, 0, s>>>(
       a.grid, a.guide, a.input, a.out, npix, a.H, a.W, a.GH, a.GW, a.GD, a.Cin, a.Cout,
-      a.Cj, (float)a.GW / a.W, (float)a.GH / a.H);
+      a.Cj, (float)a.GW / a.W, (float)a.GH / a.frame_rows(), a.y0);
   return hipGetLastError();
 }
 

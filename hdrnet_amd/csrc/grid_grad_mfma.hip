@@ -720,17 +720,7 @@ long long resident_slots(Stage1Fn kfn, std::atomic<int>* cache) {
       occ = 1;
     if (cache) cache->store(occ, std::memory_order_relaxed);
   }
-  static std::atomic<int> ncu{0};
-  int n = ncu.load(std::memory_order_relaxed);
-  if (n <= 0) {
-    int dev = 0;
-    n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    ncu.store(n, std::memory_order_relaxed);
-  }
-  return (long long)occ * n;
+  return (long long)occ * rows::num_cus();  // CU count of the CURRENT device (cached per ordinal)
 }
 
 struct GGPtrs {
@@ -769,12 +759,22 @@ hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int G
             : wg ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, true, false>             \
                  : wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, false, CAN_WI>      \
                       : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, false, false>)
+#ifdef HDRNET_TOOLS_BUILD  // the bf16-split contraction is an experiment: not in the product library
       kfn = split ? GG_PICK(true) : GG_PICK(false);
+#else
+      if (split) return hipErrorNotSupported;
+      kfn = GG_PICK(false);
+#endif
 #undef GG_PICK
     } else {
       if (wg || wi) return hipErrorInvalidValue;  // fused VJPs read the coefficient image as float4
+#ifdef HDRNET_TOOLS_BUILD
       kfn = split ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, true>
                   : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false>;
+#else
+      if (split) return hipErrorNotSupported;
+      kfn = (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false>;
+#endif
     }
   }
   GGPlan pl;
@@ -792,9 +792,9 @@ hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int G
   return hipGetLastError();
 }
 
+// the shared fast-shape table (launch.hip.h) restricted to one 16-column MFMA tile
 bool apply_shape_ok(int Cin, int Cout, bool off) {
-  return (Cin == 3 && Cout == 3) || (Cin == 3 && Cout == 4 && off) || (Cin == 1 && Cout == 1) ||
-         (Cin == 1 && Cout == 3 && off) || (Cin == 4 && Cout == 4 && !off);
+  return apply_fast_shape(Cin, Cout, off) && Cout * (Cin + (off ? 1 : 0)) <= 16;
 }
 
 bool slice_c_ok(int C) { return C == 1 || C == 2 || C == 4 || C == 8 || C == 12 || C == 16; }
@@ -826,16 +826,12 @@ static hipError_t apply_gg(const ApplyGradArgs& a, bool fused, hipStream_t s) {
                  fused ? a.dinput : nullptr};
   const bool split = a.variant == 2;
 #define HDRNET_CASE(CI, CO, OFF)                                                                  \
-  if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF)                                         \
-  return gg_launch<CI, CO, OFF, true>(q, a.B, a.H, a.W, a.GH, a.GW, a.GD, a.workspace, a.workspace_bytes, s, split, \
-                                      (a.variant >= 4 && a.variant <= 9) ? a.variant - 3 : 0)
-  HDRNET_CASE(3, 3, true);
-  HDRNET_CASE(3, 3, false);
-  HDRNET_CASE(3, 4, true);
-  HDRNET_CASE(1, 1, true);
-  HDRNET_CASE(1, 1, false);
-  HDRNET_CASE(1, 3, true);
-  HDRNET_CASE(4, 4, false);
+  if constexpr (CO * (CI + (OFF ? 1 : 0)) <= 16) {                                                \
+    if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF)                                       \
+      return gg_launch<CI, CO, OFF, true>(q, a.B, a.H, a.W, a.GH, a.GW, a.GD, a.workspace, a.workspace_bytes, s, \
+                                          split, (a.variant >= 4 && a.variant <= 9) ? a.variant - 3 : 0); \
+  }
+  HDRNET_APPLY_FAST_SHAPES(HDRNET_CASE)
 #undef HDRNET_CASE
   return hipErrorInvalidValue;
 }

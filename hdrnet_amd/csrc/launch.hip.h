@@ -17,6 +17,11 @@ struct ApplyArgs {
   int B, H, W, GH, GW, GD, Cin, Cout, Cj;  // Cj = Cin + has_offset
   bool has_offset;
   int variant;  // 0 = library default; >0 selects a kernel variant (flags bits 8..15)
+  // Row-split launch (hdrnet_bilateral_slice_apply_rows_f32): the buffers hold rows y0 .. y0 + H - 1 of a
+  // frame that is H_total rows high; gyf = (y0 + y + .5) * GH / H_total (bilateral_slice_apply.cc:38,42).
+  // H_total = 0: a whole frame (H_total = H, y0 = 0).
+  int y0 = 0, H_total = 0;
+  int frame_rows() const { return H_total > 0 ? H_total : H; }
 };
 
 // Forward with wire-format conversion and / or the fused guide network (apply_fwd_io.hip).
@@ -101,6 +106,20 @@ struct SliceGradArgs {
   size_t workspace_bytes;
   int variant = 0;  // as ApplyGradArgs
 };
+
+// The (Cin, Cout, has_offset) shapes every fast BilateralSliceApply path specialises -- ONE table for the
+// forward (apply_fwd_seg / apply_fwd_rows), the per-pixel VJPs (apply_vjp_seg / apply_vjp_rows) and the
+// grid VJP (grid_grad_mfma, which additionally needs C = Cout * Cj <= 16, one MFMA tile: (4, 4, offset)
+// has C = 20 and takes the generic dgrid kernel).  X(CIN, COUT, OFFSET).
+#define HDRNET_APPLY_FAST_SHAPES(X) \
+  X(3, 3, true) X(3, 3, false) X(3, 4, true) X(1, 1, true) X(1, 1, false) X(1, 3, true) X(4, 4, true) X(4, 4, false)
+
+inline bool apply_fast_shape(int Cin, int Cout, bool has_offset) {
+#define HDRNET_SHAPE_EQ(CI, CO, OFF) if (Cin == CI && Cout == CO && has_offset == OFF) return true;
+  HDRNET_APPLY_FAST_SHAPES(HDRNET_SHAPE_EQ)
+#undef HDRNET_SHAPE_EQ
+  return false;
+}
 
 // generic_kernels.hip -- any shape, bit-exact vs the reference CPU op.
 hipError_t launch_apply_fwd_generic(const ApplyArgs& a, hipStream_t s);

@@ -49,6 +49,27 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
+def row_range(height: int, rank: int, world: int) -> Tuple[int, int]:
+    """Row band [y0, y1) of a `height`-row frame for `rank` when ONE frame is split over `world` GPUs
+    (the optional intra-image split; hdrnet_ops.bilateral_slice_apply_rows).  The
+    bands are contiguous, balanced (first ranks get the remainder) and cover the frame exactly; the
+    grid (96-384 KiB) is replicated, nothing else is exchanged."""
+    return shard_range(height, rank, world)
+
+
+def gather_rows(local: torch.Tensor, height: int) -> torch.Tensor:
+    """All-gather row bands [B, rows_r, W, C] back into whole frames [B, height, W, C] (tests /
+    validation only; a pipeline that consumes bands never needs it)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    world = dist.get_world_size()
+    parts: List[Optional[torch.Tensor]] = [None] * world
+    dist.all_gather_object(parts, local.cpu())
+    out = torch.cat([p for p in parts if p is not None and p.shape[1] > 0], dim=1)
+    assert out.shape[1] == height
+    return out
+
+
 def barrier() -> None:
     if dist.is_available() and dist.is_initialized():
         dist.barrier()

@@ -34,7 +34,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["bilateral_slice", "bilateral_slice_apply", "bilateral_slice_apply_nnguide",
+__all__ = ["bilateral_slice", "bilateral_slice_apply", "bilateral_slice_apply_rows", "bilateral_slice_apply_nnguide",
            "bilateral_slice_apply_io", "bilateral_slice_apply_curves", "bilateral_slice_apply_upadd", "resize_bilinear", "input_moments",
            "kernel_override", "last_kernel"]
 
@@ -48,8 +48,9 @@ def _flags() -> int:
 @contextlib.contextmanager
 def kernel_override(which: str, variant: int = 0):
     """Force a kernel family inside the block: 'auto' | 'generic' | 'fast' (tests/bench).
-    `variant` > 0 additionally selects one of the benchmark-only forward kernels
-    (csrc/apply_fwd_variants.hip); it is ignored where no such variant exists."""
+    `variant` > 0 selects a benchmark-only kernel of the TOOLS build (csrc/apply_fwd_variants.hip,
+    tools/ab_bench.py); the product library these ops call has no variants and answers any non-zero
+    variant with HDRNET_INVALID_ARGUMENT (raised as HdrnetInvalidArgument)."""
     table = {"auto": _lib.KERNEL_AUTO, "generic": _lib.KERNEL_GENERIC, "fast": _lib.KERNEL_FAST}
     old = _flags()
     _tls.flags = table[which] | ((int(variant) & 0xFF) << 8)
@@ -271,6 +272,32 @@ def bilateral_slice_apply(grid: torch.Tensor, guide: torch.Tensor, input: torch.
     (bilateral_slice_apply_op.cc:382-386)."""
     del name
     return _BilateralSliceApply.apply(grid, guide, input, has_offset)
+
+
+def bilateral_slice_apply_rows(grid: torch.Tensor, guide_rows: torch.Tensor, input_rows: torch.Tensor,
+                               frame_height: int, y0: int, has_offset: bool) -> torch.Tensor:
+    """Row-split ``BilateralSliceApply`` forward (the optional intra-image split):
+    ``guide_rows`` [B, rows, W] and ``input_rows`` [B, rows, W, Cin] hold rows ``y0 .. y0 + rows - 1`` of
+    frames that are ``frame_height`` rows high; the grid is the whole frame's.  The y coordinate is the
+    reference's expression on the frame height (bilateral_slice_apply.cc:38,42), so the bands of any
+    partition (``dist.row_range``), concatenated, equal the whole-frame op bit for bit.  Forward only."""
+    if grid.requires_grad or guide_rows.requires_grad or input_rows.requires_grad:
+        if torch.is_grad_enabled():
+            raise RuntimeError("bilateral_slice_apply_rows is forward-only (inference); detach the operands")
+    B, rows, W, GH, GW, GD, Cin, Cout = _check_apply(grid, guide_rows, input_rows, has_offset)
+    frame_height, y0 = int(frame_height), int(y0)
+    if y0 < 0 or y0 + rows > frame_height:
+        raise ValueError(f"row band [{y0}, {y0 + rows}) outside the frame's {frame_height} rows")
+    grid, guide_rows, input_rows = grid.contiguous(), guide_rows.contiguous(), input_rows.contiguous()
+    out = torch.empty((B, rows, W, Cout), dtype=torch.float32, device=guide_rows.device)
+    lib = _lib.load()
+    with torch.cuda.device(guide_rows.device):
+        rc = lib.hdrnet_bilateral_slice_apply_rows_f32_ex(
+            grid.data_ptr(), guide_rows.data_ptr(), input_rows.data_ptr(), out.data_ptr(),
+            B, frame_height, y0, rows, W, GH, GW, GD, Cin, Cout, int(has_offset), _flags(),
+            _stream(guide_rows.device))
+    _lib.check(rc, "BilateralSliceApplyRows")
+    return out
 
 
 def _check_nnguide(grid, input, guide_conv1, guide_conv2, has_offset):  # noqa: A002

@@ -33,7 +33,10 @@
  *   - work is enqueued asynchronously on `stream` (a hipStream_t passed as
  *     void*; NULL = the null stream) and the call returns without
  *     synchronising, like the reference launchers on device.stream();
- *   - re-entrant and thread-safe: no globals besides a thread-local error text;
+ *   - re-entrant and thread-safe.  Process-wide state: a thread-local error text, the opt-in
+ *     last-kernel name (hdrnet_enable_kernel_names; off by default) and read-mostly caches of device
+ *     facts (compute-unit count per device ordinal, resident workgroups per kernel) -- nothing a
+ *     result depends on;
  *   - never throws, never exits.  Return codes:
  *         HDRNET_OK                0
  *         HDRNET_INVALID_ARGUMENT  1   (TF: errors::InvalidArgument)
@@ -102,6 +105,25 @@ int hdrnet_bilateral_slice_apply_f32_ex(const float* grid, const float* guide,
                                         int H, int W, int GH, int GW, int GD,
                                         int Cin, int Cout, int has_offset,
                                         unsigned flags, void* stream);
+
+/* Row-split forward: ONE frame (or batch of frames) cut into horizontal bands across several GPUs
+ * (the optional intra-image split).  The buffers hold rows y0 .. y0 + rows - 1
+ * only -- guide [B][rows][W], input [B][rows][W][Cin], out [B][rows][W][Cout] -- of frames that are
+ * H_total rows high; the grid is the whole frame's.  The y coordinate keeps the reference's expression
+ * on the FRAME height, gyf = (y0 + y + 0.5) * GH / H_total (hdrnet/ops/bilateral_slice_apply.cc:38,42),
+ * so the bands of any partition, concatenated, equal the whole-frame call bit for bit (same kernel
+ * family).  y0 = 0, rows = H_total is hdrnet_bilateral_slice_apply_f32.  Requires
+ * 0 <= y0, y0 + rows <= H_total.  Forward only: the gradients of a band are the whole-frame VJPs of a
+ * dout that is zero outside the band. */
+int hdrnet_bilateral_slice_apply_rows_f32(const float* grid, const float* guide, const float* input,
+                                          float* out, int B, int H_total, int y0, int rows, int W,
+                                          int GH, int GW, int GD, int Cin, int Cout, int has_offset,
+                                          void* stream);
+
+int hdrnet_bilateral_slice_apply_rows_f32_ex(const float* grid, const float* guide, const float* input,
+                                             float* out, int B, int H_total, int y0, int rows, int W,
+                                             int GH, int GW, int GD, int Cin, int Cout, int has_offset,
+                                             unsigned flags, void* stream);
 
 /* Fused point-wise guide network + BilateralSliceApply forward (inference).
  * guide[b,y,x] = sigmoid(conv2[n] + sum_k conv2[k] * relu(conv1[k][Cin] + sum_j conv1[k][j] * input[b,y,x,j]))

@@ -95,20 +95,23 @@ int oracle_max_threads(void) {
 #define PIX(b, y, x) (((size_t)(b) * H + (y)) * W + (x))
 
 /* hdrnet/ops/bilateral_slice_apply.cc:24-82  BilateralSliceApply */
-void oracle_bilateral_slice_apply(const float* grid, const float* guide,
-                                  const float* input, float* out, int B, int H,
-                                  int W, int GH, int GW, int GD, int Cin,
-                                  int Cout, int has_offset) {
+/* The forward on rows y0 .. y0 + H - 1 of frames that are H_total rows high: the buffers hold the band
+ * only; scale_y (:38) and gyf (:42) are the reference's expressions on the FRAME.  Whole frame:
+ * y0 = 0, H_total = H.  (Checker for hdrnet_bilateral_slice_apply_rows_f32; test infrastructure.) */
+void oracle_bilateral_slice_apply_rows(const float* grid, const float* guide,
+                                       const float* input, float* out, int B, int H_total, int y0,
+                                       int H, int W, int GH, int GW, int GD, int Cin,
+                                       int Cout, int has_offset) {
   const int Cj = Cin + (has_offset ? 1 : 0);
-  const float scale_x = (float)GW / W; /* :37 */
-  const float scale_y = (float)GH / H; /* :38 */
+  const float scale_x = (float)GW / W;       /* :37 */
+  const float scale_y = (float)GH / H_total; /* :38 */
   long long by;
 #pragma omp parallel for schedule(static)
   for (by = 0; by < (long long)B * H; ++by) {
     const int b = (int)(by / H), y = (int)(by % H);
     for (int x = 0; x < W; ++x) {
       const float gxf = (x + 0.5f) * scale_x;         /* :41 */
-      const float gyf = (y + 0.5f) * scale_y;         /* :42 */
+      const float gyf = ((y0 + y) + 0.5f) * scale_y;  /* :42 */
       const float gzf = guide[PIX(b, y, x)] * GD;     /* :44 */
       const int gx0 = (int)floorf(gxf - 0.5f);        /* :46 */
       const int gy0 = (int)floorf(gyf - 0.5f);        /* :47 */
@@ -140,6 +143,14 @@ void oracle_bilateral_slice_apply(const float* grid, const float* guide,
       }
     }
   }
+}
+
+void oracle_bilateral_slice_apply(const float* grid, const float* guide,
+                                  const float* input, float* out, int B, int H,
+                                  int W, int GH, int GW, int GD, int Cin,
+                                  int Cout, int has_offset) {
+  oracle_bilateral_slice_apply_rows(grid, guide, input, out, B, H, 0, H, W, GH, GW, GD, Cin, Cout,
+                                    has_offset);
 }
 
 /* hdrnet/ops/bilateral_slice_apply.cc:84-138  BilateralSliceApplyGridGrad */

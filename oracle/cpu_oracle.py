@@ -102,6 +102,23 @@ class Oracle:
         fn(_p(grid), _p(guide), _p(inp), _p(out), B, H, W, GH, GW, GD, Cin, Cout, int(bool(has_offset)))
         return out
 
+    def bilateral_slice_apply_rows(self, grid, guide_rows, inp_rows, frame_height: int, y0: int,
+                                   has_offset: bool = True) -> np.ndarray:
+        """The forward on rows y0 .. y0 + rows - 1 of frames `frame_height` rows high (port only):
+        the checker for hdrnet_bilateral_slice_apply_rows_f32."""
+        if self.kind != "port":
+            raise NotImplementedError("the reference's op has no row-split form")
+        grid, guide_rows, inp_rows = _f32(grid, "grid"), _f32(guide_rows, "guide"), _f32(inp_rows, "input")
+        B, rows, W, GH, GW, GD, Cin, Cout = self._apply_dims(grid, guide_rows, inp_rows, has_offset)
+        if y0 < 0 or y0 + rows > frame_height:
+            raise ValueError("row band outside the frame")
+        out = np.empty((B, rows, W, Cout), np.float32)
+        if out.size:
+            self.lib.oracle_bilateral_slice_apply_rows(_p(grid), _p(guide_rows), _p(inp_rows), _p(out), B,
+                                                       int(frame_height), int(y0), rows, W, GH, GW, GD, Cin,
+                                                       Cout, int(has_offset))
+        return out
+
     def bilateral_slice_apply_grad(self, grid, guide, inp, dout, has_offset: bool = True,
                                    want=("grid", "guide", "input")):
         grid, guide, inp, dout = (_f32(grid, "grid"), _f32(guide, "guide"),

@@ -79,3 +79,54 @@ def test_shard_range_properties():
     assert shard_range(32, 7, 8) == (28, 32)   # config #4: four per GPU
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+# ---- one frame over N ranks: the row split (optional) ---------------------------
+def _rows_worker(rank, world, port, H, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import oracle
+    from hdrnet_amd import dist as hd
+    hd.init(backend="gloo")
+    rng = np.random.default_rng(77)  # the same frames on every rank
+    B, W = 2, 24
+    grid = rng.random((B, 4, 5, 3, 12), dtype=np.float32)  # replicated (a few hundred KiB at most)
+    guide = rng.random((B, H, W), dtype=np.float32)
+    inp = rng.random((B, H, W, 3), dtype=np.float32)
+    P = oracle.port()
+    P.set_threads(1)
+    y0, y1 = hd.row_range(H, rank, world)
+    band = P.bilateral_slice_apply_rows(grid, guide[:, y0:y1], inp[:, y0:y1], H, y0, True)
+    full = hd.gather_rows(torch.from_numpy(band), H)
+    want = torch.from_numpy(P.bilateral_slice_apply(grid, guide, inp, True))
+    ok = bool(torch.equal(full, want)) and band.shape[1] == y1 - y0  # bit for bit: gyf is the frame's
+    if rank == 0:
+        q.put((ok, (y0, y1)))
+    hd.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("H", [13, 12, 1])
+def test_two_rank_row_split_equals_whole_frame(H):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rows_worker, args=(r, 2, port, H, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    ok, span = q.get()
+    assert ok, span
+
+
+def test_row_range_covers_the_frame():
+    from hdrnet_amd.dist import row_range
+    for H in (0, 1, 7, 1080, 2160, 3000):
+        for world in (1, 2, 4, 8):
+            spans = [row_range(H, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == H
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert row_range(2160, 7, 8) == (1890, 2160)  # 4K over 8 GPUs: 270 rows each

@@ -357,3 +357,23 @@ def test_pointwise_nn_guide_restatement_equals_gpyrnn_frag():
     c2_lit = per_level[2][1].copy()
     c2_lit[16] = per_level[0][1][16]
     np.testing.assert_allclose(oracle.pointwise_nn_guide(px[:1][None], per_level[2][0], c2_lit)[0, 0], lit, atol=2e-6)
+
+
+# ---- the row-split restatement (checker of hdrnet_bilateral_slice_apply_rows_f32) ---------------------
+@pytest.mark.parametrize("cuts", [(0, 17), (0, 5, 17), (0, 1, 2, 9, 9, 17), (0, 16, 17)])
+def test_port_row_bands_concatenate_to_the_pinned_whole_frame(port, cuts):
+    """oracle_bilateral_slice_apply_rows keeps the reference's gyf on the FRAME height
+    (bilateral_slice_apply.cc:38,42): any partition into bands (1-row and empty ones included),
+    concatenated, equals the whole-frame function -- which is pinned to the reference -- bit for bit."""
+    rng = np.random.default_rng(5)
+    B, H, W = 2, 17, 23
+    grid = rng.random((B, 5, 4, 6, 12), dtype=np.float32)
+    guide = (rng.random((B, H, W), dtype=np.float32) * 1.1 - 0.05).astype(np.float32)
+    inp = rng.random((B, H, W, 3), dtype=np.float32)
+    want = port.bilateral_slice_apply(grid, guide, inp, True)
+    bands = [port.bilateral_slice_apply_rows(grid, guide[:, a:b], inp[:, a:b], H, a, True)
+             for a, b in zip(cuts, cuts[1:])]
+    got = np.concatenate(bands, axis=1)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    with pytest.raises(ValueError):
+        port.bilateral_slice_apply_rows(grid, guide[:, :4], inp[:, :4], H, 14, True)
