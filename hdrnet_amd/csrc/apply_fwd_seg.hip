@@ -62,7 +62,14 @@ using namespace rows;
 constexpr int kLoadsLane = 0;      // per-lane 16-B loads of the lane's own 4 pixels
 constexpr int kLoadsNtContig = 1;  // nontemporal, lane-contiguous, transposed through the slab
 constexpr int kLoadsDma = 2;       // LDS-DMA (global_load_lds_dwordx4), default cache policy
-constexpr int kLoadsDmaNt = 3;     // LDS-DMA, nontemporal                         <- product
+constexpr int kLoadsDmaNt = 3;     // LDS-DMA, nontemporal                         <- product (round 2)
+constexpr int kLoadsBufDmaNt = 4;  // LDS-DMA, nontemporal, as buffer_load ... lds: ONE per-lane offset register for
+                                   // all pieces and the run's end enforced by the descriptor (no per-piece
+                                   // clamp + 64-bit address arithmetic)
+
+// Pixel phase: 0 = round 2's (seg_pixel), 1 = lean with the packed blend, 2 = lean with a scalar blend
+// (seg_common.hip.h).
+constexpr int kPixR02 = 0, kPixLean = 1, kPixLeanScalar = 2;
 
 // Output stores (all lane-contiguous 16 B after the per-wave LDS transpose):
 constexpr int kStoresGlobal = 0;   // global_store_dwordx4, predicated on the run length
@@ -78,6 +85,7 @@ struct SegParams {
   float* out;
   int H, W, GH, GW, GD;
   int y0;          // first frame row of a row-split launch (buffers hold rows y0 .. y0 + H - 1); else 0
+  int grid_image;  // floats per image of the grid: GH * GW * GD * C (< 2^31, capi.hip check_common)
   int seg;         // pixels per segment, multiple of 4
   int slab_off;    // float offset of the per-wave slabs in dynamic LDS (= size of the image)
   float scale_x, scale_y;
@@ -101,11 +109,21 @@ __device__ __forceinline__ void dma16(const float* src, float* dst_wave_base) {
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst_wave_base, 16, 0, NT ? 2 : 0);
 }
 
+// N 1-KiB pieces of one buffer: piece K lands at dst_wave_base + 1 KiB * K (the immediate offset of the
+// instruction must be a compile-time constant, hence the recursion).
+template <int K, int N>
+__device__ __forceinline__ void buf_dma_pieces(__amdgpu_buffer_rsrc_t rs, float* dst_wave_base, unsigned voff) {
+  if constexpr (K < N) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst_wave_base + 256 * K), 16, voff, 0, 1024 * K, kAuxNt);
+    buf_dma_pieces<K + 1, N>(rs, dst_wave_base, voff);
+  }
+}
+
 // GUIDE_NN / UPADD: the guide is computed in registers from the input run
 // the wave has just streamed in (no guide DMA: 24 instead of 28 B/px), and / or the coarser pyramid
 // level is up-sampled and added before the store -- HDRNetPointwiseNNGuide / HDRNetGaussianPyrNN.
 template <int CIN, int COUT, bool OFFSET, int LOADS, int STORES, bool TRACE, bool GUIDE_NN = false,
-          bool UPADD = false>
+          bool UPADD = false, int PIX = kPixR02>
 __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
   constexpr int CJ = CIN + (OFFSET ? 1 : 0);
   constexpr int C = COUT * CJ;
@@ -124,7 +142,7 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
   const int xe = min(xs + p.seg, p.W);
   const int y = blockIdx.y;
   const int b = blockIdx.z;
-  const float* grid_b = p.grid + (size_t)b * p.GH * p.GW * p.GD * C;
+  const float* grid_b = p.grid + (size_t)b * (unsigned)p.grid_image;
 
   const int x = xs + kPxPerThread * tid;
   const bool active = x < xe;
@@ -141,7 +159,7 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
   const float gd_f = (float)p.GD, zhi = (float)(p.GD - 1);
 
   // Addressing: a wave-uniform 64-bit segment base (SGPRs) + a 32-bit per-lane element offset.
-  const size_t row = (size_t)b * p.H + y;
+  const size_t row = (unsigned)b * (unsigned)p.H + (unsigned)y;  // B, H <= 65535 (seg_geom)
   const unsigned lpx = kPxPerThread * (unsigned)tid;         // this lane's first pixel in the segment
   const unsigned wpx = kPxPerThread * 64u * (unsigned)wave;  // this wave's first pixel in the segment
   [[maybe_unused]] const float* gseg = GUIDE_NN ? nullptr : p.guide + (row * p.W + xs);
@@ -165,6 +183,18 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
       const int e = lane + 64 * k;
       if (e < wave_px * CIN / 4) iv[k] = load_stream4(iseg + (wpx * CIN + 4u * (unsigned)e));
     }
+  } else if constexpr (LOADS == kLoadsBufDmaNt) {
+    // LDS-DMA through buffer descriptors that end with the wave's run: every piece uses the same
+    // per-lane offset (16 * lane) + an immediate; lanes past the run read zeros (never used).
+    if (wave_px > 0) {
+      const unsigned voff = 16u * (unsigned)lane;
+      if constexpr (!GUIDE_NN) {
+        const __amdgpu_buffer_rsrc_t grs = make_rsrc(gseg + wpx, (unsigned)wave_px * 4u);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(grs, (lptr_t) reinterpret_cast<float*>(gslab), 16, voff, 0, 0, kAuxNt);
+      }
+      const __amdgpu_buffer_rsrc_t irs = make_rsrc(iseg + wpx * CIN, (unsigned)wave_px * (4u * CIN));
+      buf_dma_pieces<0, CIN>(irs, reinterpret_cast<float*>(slab), voff);
+    }
   } else {
     // LDS-DMA: every lane issues (the LDS side is base + 16 * lane); lanes past the run re-read
     // its last float4.  An idle wave issues nothing.
@@ -183,10 +213,18 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
   stage_image<C>(lds, grid_b, y + p.y0, cmin, ncols, p.GH, p.GW, p.GD, p.scale_y, p.inv_col, tid, (int)blockDim.x);
 
   // x-only terms of this thread's 4 pixels
-  XTerm xt[kPxPerThread];
+  constexpr bool LEAN = PIX != kPixR02;
+  XTerm xt[LEAN ? 1 : kPxPerThread];
+  XTermLean xl[LEAN ? kPxPerThread : 1];
   const float xf0 = (float)x + 0.5f;  // (x + k) + 0.5f == xf0 + k exactly (x < 2^23)
+  if constexpr (LEAN) {
+    const float colb_f = (float)colb, xbase_f = (float)(CB - cmin * colb);  // exact: |.| < 2^24
 #pragma unroll
-  for (int k = 0; k < kPxPerThread; ++k) xt[k] = x_term(xf0 + (float)k, p.scale_x, cmin, colb, CB);
+    for (int k = 0; k < kPxPerThread; ++k) xl[k] = x_term_lean(xf0 + (float)k, p.scale_x, colb_f, xbase_f);
+  } else {
+#pragma unroll
+    for (int k = 0; k < kPxPerThread; ++k) xt[k] = x_term(xf0 + (float)k, p.scale_x, cmin, colb, CB);
+  }
 
   __syncthreads();  // image complete; with LDS-DMA in flight the compiler drains vmcnt here too
 
@@ -234,7 +272,10 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
       float in[CIN > 0 ? CIN : 1], o[COUT];
 #pragma unroll
       for (int j = 0; j < CIN; ++j) in[j] = inf[k * CIN + j];
-      seg_pixel<CIN, COUT, OFFSET>(lds, gd_f, zhi, colb, xt[k], gs[k], in, o);
+      if constexpr (LEAN)
+        seg_pixel_lean<CIN, COUT, OFFSET, PIX == kPixLean>(lds, gd_f, zhi, colb, xl[k], gs[k], in, o);
+      else
+        seg_pixel<CIN, COUT, OFFSET>(lds, gd_f, zhi, colb, xt[k], gs[k], in, o);
 #pragma unroll
       for (int i = 0; i < COUT; ++i) of[k * COUT + i] = o[i];
     }
@@ -301,7 +342,7 @@ SegGeom seg_geom(const ApplyArgs& a, bool dma, bool guide_map = true) {
 }
 
 template <int CIN, int COUT, bool OFFSET, int LOADS, int STORES, bool TRACE, bool GUIDE_NN = false,
-          bool UPADD = false>
+          bool UPADD = false, int PIX = kPixR02>
 hipError_t launch_seg_t(const ApplyArgs& a, hipStream_t s, long long* trace,
                         const GuideNN& gn = GuideNN{nullptr, nullptr, nullptr, 0},
                         const UpAdd& up = UpAdd{nullptr, 0, 0, 0.f, 0.f}) {
@@ -322,6 +363,7 @@ hipError_t launch_seg_t(const ApplyArgs& a, hipStream_t s, long long* trace,
   p.GW = a.GW;
   p.GD = a.GD;
   p.y0 = a.y0;
+  p.grid_image = a.GH * a.GW * a.GD * C;
   p.seg = g.pl.seg;
   p.slab_off = g.slab_off;
   p.scale_x = (float)a.GW / a.W;
@@ -329,7 +371,7 @@ hipError_t launch_seg_t(const ApplyArgs& a, hipStream_t s, long long* trace,
   p.inv_col = 1.0f / (float)(a.GD * (C / VEC));
   p.trace = trace;
   const dim3 grid3((unsigned)g.pl.nseg, (unsigned)a.H, (unsigned)a.B);
-  apply_fwd_seg<CIN, COUT, OFFSET, LOADS, STORES, TRACE, GUIDE_NN, UPADD><<<grid3, g.pl.threads, g.lds, s>>>(p);
+  apply_fwd_seg<CIN, COUT, OFFSET, LOADS, STORES, TRACE, GUIDE_NN, UPADD, PIX><<<grid3, g.pl.threads, g.lds, s>>>(p);
   return hipGetLastError();
 }
 
@@ -356,20 +398,30 @@ bool apply_fwd_seg_supported(const ApplyArgs& a) {
   return seg_geom(a, true).ok && seg_geom(a, false).ok;
 }
 
-hipError_t launch_apply_fwd_seg(const ApplyArgs& a, hipStream_t s, const char** name) {
-  *name = "apply_fwd_seg/vec4";
+// The per-launch flavour choice for one shape, with the pixel phase PIX and the DMA form DMAL as parameters
+// (the tools build times the alternatives against each other, launch_apply_fwd_seg_pix).
+template <int CI, int CO, bool OFF, int PIX, int DMAL>
+hipError_t launch_seg_pick(const ApplyArgs& a, hipStream_t s) {
   const SegGeom g = seg_geom(a, true);
   const long long nblocks = (long long)g.pl.nseg * a.H * a.B;
   const long long one_round = (long long)num_cus() * (32 / (g.pl.threads / 64));  // workgroups resident at once
   const bool small = 4 * nblocks <= 5 * one_round;
   const bool whole_lines = ((uintptr_t)a.out % 128 == 0) && ((long long)g.pl.seg * a.Cout * 4) % 128 == 0 &&
                            ((long long)a.W * a.Cout * 4) % 128 == 0;
-#define HDRNET_CASE(CI, CO, OFF)                                                                     \
-  if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF) {                                          \
-    if (small) return launch_seg_t<CI, CO, OFF, kLoadsLane, kStoresBufNt, false>(a, s, nullptr);     \
-    if (whole_lines) return launch_seg_t<CI, CO, OFF, kLoadsDmaNt, kStoresBufSc01, false>(a, s, nullptr); \
-    return launch_seg_t<CI, CO, OFF, kLoadsDmaNt, kStoresBufNt, false>(a, s, nullptr);               \
-  }
+  const GuideNN gn{nullptr, nullptr, nullptr, 0};
+  const UpAdd up{nullptr, 0, 0, 0.f, 0.f};
+  if (small) return launch_seg_t<CI, CO, OFF, kLoadsLane, kStoresBufNt, false, false, false, PIX>(a, s, nullptr, gn, up);
+  if (whole_lines)
+    return launch_seg_t<CI, CO, OFF, DMAL, kStoresBufSc01, false, false, false, PIX>(a, s, nullptr, gn, up);
+  return launch_seg_t<CI, CO, OFF, DMAL, kStoresBufNt, false, false, false, PIX>(a, s, nullptr, gn, up);
+}
+
+constexpr int kProductPix = kPixR02, kProductDma = kLoadsDmaNt;
+
+hipError_t launch_apply_fwd_seg(const ApplyArgs& a, hipStream_t s, const char** name) {
+  *name = "apply_fwd_seg/vec4";
+#define HDRNET_CASE(CI, CO, OFF) \
+  if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF) return launch_seg_pick<CI, CO, OFF, kProductPix, kProductDma>(a, s);
   HDRNET_APPLY_FAST_SHAPES(HDRNET_CASE)
 #undef HDRNET_CASE
   return hipErrorInvalidValue;
@@ -420,6 +472,26 @@ hipError_t launch_apply_fwd_seg_upadd(const ApplyArgs& a, const float* coarse, i
 
 #ifdef HDRNET_TOOLS_BUILD
 void apply_fwd_seg_set_trace(long long* device_buf) { g_trace = device_buf; }
+
+// knob = variant - 60: pixel phase = knob % 4 {0 round 2, 1 lean packed, 2 lean scalar blend}; + 4: the pixel
+// loads as buffer_load ... lds instead of global_load ... lds.  Load / store flavour per launch as the product.
+hipError_t launch_apply_fwd_seg_pix(const ApplyArgs& a, int knob, hipStream_t s, const char** name) {
+  if (!(a.Cin == 3 && a.Cout == 3 && a.has_offset)) return hipErrorNotSupported;
+  static const char* const nm[8] = {"apply_fwd_seg/pix0", "apply_fwd_seg/pix-lean", "apply_fwd_seg/pix-lean-scalar", "",
+                                    "apply_fwd_seg/pix0+bufdma", "apply_fwd_seg/pix-lean+bufdma",
+                                    "apply_fwd_seg/pix-lean-scalar+bufdma", ""};
+  if (knob < 0 || knob >= 8 || (knob & 3) == 3) return hipErrorNotSupported;
+  *name = nm[knob];
+  switch (knob) {
+    case 0: return launch_seg_pick<3, 3, true, kPixR02, kLoadsDmaNt>(a, s);
+    case 1: return launch_seg_pick<3, 3, true, kPixLean, kLoadsDmaNt>(a, s);
+    case 2: return launch_seg_pick<3, 3, true, kPixLeanScalar, kLoadsDmaNt>(a, s);
+    case 4: return launch_seg_pick<3, 3, true, kPixR02, kLoadsBufDmaNt>(a, s);
+    case 5: return launch_seg_pick<3, 3, true, kPixLean, kLoadsBufDmaNt>(a, s);
+    case 6: return launch_seg_pick<3, 3, true, kPixLeanScalar, kLoadsBufDmaNt>(a, s);
+  }
+  return hipErrorNotSupported;
+}
 
 // knob = variant - 20:  0..19 loads = knob % 4 {lane, nt-contig, dma, dma-nt}, stores = knob / 4
 // {global, buffer, buffer nt, buffer sc1, buffer sc0 sc1};  20..39 the same with the timeline trace.

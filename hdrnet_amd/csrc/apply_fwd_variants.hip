@@ -554,6 +554,7 @@ hipError_t launch_apply_fwd_variant(const ApplyArgs& a, hipStream_t s, const cha
   const Plan pl = make_row_plan(a.W, a.GW, aligned);
   if (!pl.vec4) return hipErrorNotSupported;
   if (a.variant >= 20 && a.variant < 60) return launch_apply_fwd_seg_knob(a, a.variant - 20, s, name);
+  if (a.variant >= 60 && a.variant < 68) return launch_apply_fwd_seg_pix(a, a.variant - 60, s, name);
   if (a.variant == kVariantDirectStores) return launch_apply_fwd_rows_direct_stores(a, s, name, 0);
   if (a.variant == kVariantNtLoads) return launch_apply_fwd_rows_direct_stores(a, s, name, 1);
   if (a.Cin == 3 && a.Cout == 3 && a.has_offset) {

@@ -151,6 +151,7 @@ hipError_t launch_apply_fwd_seg_upadd(const ApplyArgs& a, const float* coarse, i
 #ifdef HDRNET_TOOLS_BUILD
 // knob: loads + 4 * stores (+ 20: timeline trace); include/hdrnet_amd_tools.h
 hipError_t launch_apply_fwd_seg_knob(const ApplyArgs& a, int knob, hipStream_t s, const char** name);
+hipError_t launch_apply_fwd_seg_pix(const ApplyArgs& a, int knob, hipStream_t s, const char** name);
 void apply_fwd_seg_set_trace(long long* device_buf);
 void grid_grad_set_trace(long long* device_buf);
 #endif

@@ -80,6 +80,109 @@ __device__ __forceinline__ void seg_pixel(const float* __restrict__ img, float g
   }
 }
 
+// ---- the LEAN pixel phase (round 3) ---------------------------------------------------------------------
+// The same gather / blend / affine with the per-pixel bookkeeping cut down (the pixel phase,
+// not the memory system, is what follows the shader clock in a slow episode):
+//   * x: wx1 = fract(gxf - .5) (one v_fract_f32) instead of floor / +.5 / subtract; equal to the
+//     reference's -((gx0 + .5) - gxf) exactly for gxf >= .5 and to 1 ulp (6e-8) in the first half cell,
+//     where gxf - .5 itself rounds.  wx0 is never formed: w(x0, z) = wz - wz * wx1 (one fma).
+//   * byte addresses are carried as FLOATS (exact: < 2^24): xbp = fma(floor, colb, base), a0 =
+//     cvt(fma(clamp(floor z), CB, xbp)) -- no int multiplies, one conversion per pixel instead of two.
+//   * max(1 - s, 0) is the clamp modifier of the subtraction (1 - s <= 1 always).
+// Everything else -- the rounded products gxf / gzf, the reference's corner-centre expressions for z,
+// v_sqrt_f32 -- is as in seg_pixel above; weights differ from it by <= 1 ulp.
+struct XTermLean {
+  float wx1;   // weight of column gx0 + 1; column gx0 gets 1 - wx1
+  float xbpf;  // byte offset of (column gx0, plane 0 + 1) in the image, as a float
+};
+
+__device__ __forceinline__ XTermLean x_term_lean(float xf, float scale_x, float colb_f, float xbase_f) {
+#pragma clang fp contract(off)
+  XTermLean t;
+  const float gxf = mul_rn(xf, scale_x);
+  const float tx = gxf - 0.5f;
+  t.wx1 = __builtin_amdgcn_fractf(tx);
+  t.xbpf = __builtin_fmaf(floorf(tx), colb_f, xbase_f);
+  return t;
+}
+
+// PK: blend on 2-wide vectors (v_pk_fma_f32) or on scalars (v_fma_f32).
+template <int CIN, int COUT, bool OFFSET, bool PK>
+__device__ __forceinline__ void seg_pixel_lean(const float* __restrict__ img, float gd_f, float zhi, int colb,
+                                               const XTermLean& xt, float g, const float (&in)[CIN > 0 ? CIN : 1],
+                                               float (&out)[COUT]) {
+  constexpr int CJ = CIN + (OFFSET ? 1 : 0);
+  constexpr int C = COUT * CJ;
+  constexpr int CB = C * (int)sizeof(float);
+  float w00, w01, w10, w11;
+  int a0;
+  {
+#pragma clang fp contract(off)
+    const float gzf = mul_rn(g, gd_f);
+    const float fzl = floorf(gzf - 0.5f);
+    // the two taps as a 2-wide vector (corner centres as the reference forms them: (float)gz + 0.5f, gz1 = gz0 + 1)
+    const f32x2 cz = {fzl + 0.5f, (fzl + 1.0f) + 0.5f};
+    const f32x2 gz2 = {gzf, gzf};
+    const f32x2 dz = cz - gz2;
+    const f32x2 eps2 = {kSmoothEps, kSmoothEps};
+    const f32x2 q = __builtin_elementwise_fma(dz, dz, eps2);
+    const float s0 = __builtin_amdgcn_sqrtf(q.x), s1 = __builtin_amdgcn_sqrtf(q.y);
+    // max(1 - s, 0) (numerics.h:108-113) == clamp(1 - s) to [0, 1] since s > 0: folds into the subtraction
+    const f32x2 wz = {__builtin_amdgcn_fmed3f(1.0f - s0, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(1.0f - s1, 0.0f, 1.0f)};
+    const f32x2 wx1 = {xt.wx1, xt.wx1};
+    const f32x2 w1 = wz * wx1;
+    const f32x2 w0 = __builtin_elementwise_fma(-wz, wx1, wz);  // wz * (1 - wx1), one rounding
+    w00 = w0.x; w01 = w0.y; w10 = w1.x; w11 = w1.y;
+    const float izf = __builtin_amdgcn_fmed3f(fzl, -1.0f, zhi);  // wild guides only (NaN -> -1)
+    a0 = (int)__builtin_fmaf(izf, (float)CB, xt.xbpf);
+  }
+  float o[COUT];
+  if constexpr (PK) {
+    CoefVec<C> coef;
+    accum_vec<C, true>(coef, img, a0, w00);
+    accum_vec<C, false>(coef, img, a0 + CB, w01);
+    accum_vec<C, false>(coef, img, a0 + colb, w10);
+    accum_vec<C, false>(coef, img, a0 + colb + CB, w11);
+#pragma unroll
+    for (int i = 0; i < COUT; ++i) {
+      float v = OFFSET ? coef.get(i * CJ + CIN) : 0.0f;
+#pragma unroll
+      for (int j = 0; j < CIN; ++j) v = fmaf(coef.get(i * CJ + j), in[j], v);
+      o[i] = v;
+    }
+  } else {
+    float coef[C];
+    const char* base = reinterpret_cast<const char*>(img) + a0;
+    const float w[4] = {w00, w01, w10, w11};
+    const int off[4] = {0, CB, colb, colb + CB};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      if constexpr (C % 4 == 0) {
+        const f32x4* p4 = reinterpret_cast<const f32x4*>(base + off[v]);
+#pragma unroll
+        for (int q = 0; q < C / 4; ++q) {
+          const f32x4 t = p4[q];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) coef[4 * q + e] = v == 0 ? w[0] * t[e] : fmaf(w[v], t[e], coef[4 * q + e]);
+        }
+      } else {
+        const float* p1 = reinterpret_cast<const float*>(base + off[v]);
+#pragma unroll
+        for (int q = 0; q < C; ++q) coef[q] = v == 0 ? w[0] * p1[q] : fmaf(w[v], p1[q], coef[q]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < COUT; ++i) {
+      float v = OFFSET ? coef[i * CJ + CIN] : 0.0f;
+#pragma unroll
+      for (int j = 0; j < CIN; ++j) v = fmaf(coef[i * CJ + j], in[j], v);
+      o[i] = v;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < COUT; ++i) out[i] = o[i];
+}
+
 // Blend the two grid rows image row y needs into the padded LDS image (see the header comment):
 //   img[j][p][c] = wy0 * grid[gy0c][clamp(cmin + j)][clamp(p - 1)][c] + wy1 * grid[gy1c][...]
 // Work item = one VEC-float element of a source (column, plane) vector (one per thread at 4K; a
@@ -98,8 +201,9 @@ __device__ __forceinline__ void stage_image(float* __restrict__ img, const float
   const float wy1 = tent_weight(gy0 + 1 + 0.5f, gyf);
   const int gy0c = clamp_index(gy0, 0, GH - 1);
   const int gy1c = clamp_index(gy0 + 1, 0, GH - 1);
-  const elem_t* r0 = reinterpret_cast<const elem_t*>(grid_b + (size_t)gy0c * GW * GD * C);
-  const elem_t* r1 = reinterpret_cast<const elem_t*>(grid_b + (size_t)gy1c * GW * GD * C);
+  const unsigned row_floats = (unsigned)(GW * GD * C);  // one image of the grid is < 2^31 floats
+  const elem_t* r0 = reinterpret_cast<const elem_t*>(grid_b + (unsigned)gy0c * row_floats);
+  const elem_t* r1 = reinterpret_cast<const elem_t*>(grid_b + (unsigned)gy1c * row_floats);
   elem_t* d = reinterpret_cast<elem_t*>(img);
   const int per_col = GD * CV;
   const int n = ncols * per_col;

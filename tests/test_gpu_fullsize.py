@@ -22,6 +22,8 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
+from conftest import check_dgrid, check_pixel_grad  # noqa: E402
+
 FWD_RTOL = FWD_ATOL = 1e-5   # required; the 1e-6 bar is reported
 
 
@@ -99,9 +101,9 @@ def test_hdrp_uint16_wire_format_vs_oracle(dev, ops, mt_port):
 
 @pytest.mark.parametrize("name", ["1080p (config #2)", "4K (config #3 hot path)"])
 def test_backward_vs_oracle_at_config_size(dev, ops, mt_port, name):
-    """All three VJPs of a full frame against the oracle's gather-form gradients.  Tolerance: rtol
-    1e-4; atol = 1e-5 x max|want| per tensor (dgrid cells are sums of ~30 000 terms of random sign:
-    the summation-order noise of ANY f32 evaluation is ~1e-6 of the largest cell)."""
+    """All three VJPs of a full frame against the oracle's gather-form gradients.  Tolerances
+    (tests/conftest.py): rtol 1e-4; dgrid atol = 1e-5 x max|want| (cells are sums of ~30 000 terms of
+    random sign), dinput FLAT atol 1e-5, dguide FLAT atol 4e-5 (the reference's own f32 noise is 1.1e-5)."""
     H, W, GH, GW, GD = CONFIGS[name]
     rng = np.random.default_rng(H + 3 * W)
     grid, guide, inp = frame(rng, H, W, GH, GW, GD)
@@ -110,11 +112,9 @@ def test_backward_vs_oracle_at_config_size(dev, ops, mt_port, name):
     tg, tgu, ti = (T(a, dev).requires_grad_(True) for a in (grid, guide, inp))
     ops.bilateral_slice_apply(tg, tgu, ti, has_offset=True).backward(T(dout, dev))
     assert ops.last_kernel() == "apply_bwd_fused/mfma", ops.last_kernel()
-    for got, want, nm in ((tg.grad, wg, "dgrid"), (tgu.grad, wgu, "dguide"), (ti.grad, wi, "dinput")):
-        got = N(got)
-        scale = max(1.0, float(np.abs(want).max()))
-        print(f"{name} {nm}: max|err| = {np.abs(got - want).max():.3e} (scale {scale:.3g})")
-        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5 * scale, err_msg=nm)
+    check_dgrid(N(tg.grad), wg, name)
+    check_pixel_grad(N(tgu.grad), wgu, name, "dguide")
+    check_pixel_grad(N(ti.grad), wi, name, "dinput")
 
 
 def test_per_pixel_vjps_without_dgrid_vs_oracle_at_1080p(dev, ops, mt_port):
@@ -129,9 +129,8 @@ def test_per_pixel_vjps_without_dgrid_vs_oracle_at_1080p(dev, ops, mt_port):
     tgu, ti = (T(a, dev).requires_grad_(True) for a in (guide, inp))
     ops.bilateral_slice_apply(tg, tgu, ti, has_offset=True).backward(T(dout, dev))
     assert ops.last_kernel() == "apply_vjp_seg/vec4", ops.last_kernel()
-    for got, want, nm in ((tgu.grad, wgu, "dguide"), (ti.grad, wi, "dinput")):
-        scale = max(1.0, float(np.abs(want).max()))
-        np.testing.assert_allclose(N(got), want, rtol=1e-4, atol=1e-5 * scale, err_msg=nm)
+    check_pixel_grad(N(tgu.grad), wgu, "vjp_seg 1080p", "dguide")
+    check_pixel_grad(N(ti.grad), wi, "vjp_seg 1080p", "dinput")
 
 
 @pytest.mark.parametrize("B,H,W,GH,GW", [(3, 540, 960, 8, 8), (4, 270, 480, 16, 16), (2, 600, 450, 5, 9)])
@@ -155,12 +154,11 @@ def test_batched_backward_vs_oracle_every_gradient_subset(dev, ops, mt_port, B, 
         kern = ops.last_kernel()
         assert kern == ("apply_bwd_fused/mfma" if (need_guide or need_input) else "grid_grad_mfma"), kern
         got = {"dgrid": tg.grad, "dguide": tgu.grad, "dinput": ti.grad}
-        for nm, g in got.items():
-            if g is None:
-                continue
-            scale = max(1.0, float(np.abs(want[nm]).max()))
-            np.testing.assert_allclose(N(g), want[nm], rtol=1e-4, atol=1e-5 * scale,
-                                       err_msg=f"{nm} (dguide={need_guide}, dinput={need_input})")
+        tag = f"B={B} {H}x{W} (dguide={need_guide}, dinput={need_input})"
+        check_dgrid(N(got["dgrid"]), want["dgrid"], tag)
+        for nm in ("dguide", "dinput"):
+            if got[nm] is not None:
+                check_pixel_grad(N(got[nm]), want[nm], tag, nm)
 
 
 # ---- hdrnet/test/ops_test.py:178-322, the reference's data / optimiser / step counts / thresholds ----

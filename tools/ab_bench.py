@@ -95,10 +95,10 @@ def main():
     dev = torch.device("cuda:0")
     lib = _lib.load_tools()
     lib.hdrnet_enable_kernel_names(1)
-    H, W, GH, GW, GD, desc = WORKLOADS[args.workload]
-    abytes = algorithmic_bytes(1, H, W, GH, GW, GD)
+    B, H, W, GH, GW, GD, desc = WORKLOADS[args.workload]
+    abytes = algorithmic_bytes(B, H, W, GH, GW, GD)
     nsets = max(3, -(-int(CACHE_BYTES * 1.5) // abytes))
-    sets = make_sets(dev, nsets, H, W, GH, GW, GD, 1234)
+    sets = make_sets(dev, nsets, B, H, W, GH, GW, GD, 1234)
     stream = torch.cuda.current_stream(dev).cuda_stream
     variants = [int(v) for v in args.variants.split(",") if v != ""]
 
@@ -107,7 +107,7 @@ def main():
             grid, guide, inp, out = sets[k % nsets]
             rc = lib.hdrnet_bilateral_slice_apply_f32_ex(
                 grid.data_ptr(), guide.data_ptr(), inp.data_ptr(), out.data_ptr(),
-                1, H, W, GH, GW, GD, 3, 3, 1, flags, stream)
+                B, H, W, GH, GW, GD, 3, 3, 1, flags, stream)
             if rc:
                 raise RuntimeError(lib.hdrnet_last_error().decode())
         return fn
@@ -164,12 +164,12 @@ def main():
         med = statistics.median(t)
         print(f"variant {v:3d} {names[v]:34s} median {med:7.2f} us  min {min(t):7.2f} us  "
               f"-> {abytes / med / 1e3:7.1f} GB/s ({abytes / med / 1e3 / 8000 * 100:4.1f}% of 8 TB/s)  "
-              f"{H * W / med:9.0f} MP/s   all: {[round(x, 1) for x in t]}")
+              f"{B * H * W / med:9.0f} MP/s   all: {[round(x, 1) for x in t]}")
         table.append({"variant": v, "name": names[v], "median_us": med, "min_us": min(t), "all_us": t,
                       "max_abs_err_vs_generic": errs[v]})
     if args.yardstick:
-        vol = {"copy(out<-in, 2x100MB)": 2 * 4 * H * W * 3,
-               "elementwise(out=in*a+b, in 133MB out 100MB)": 4 * H * W * 7}
+        vol = {"copy(out<-in, 2x100MB)": 2 * 4 * B * H * W * 3,
+               "elementwise(out=in*a+b, in 133MB out 100MB)": 4 * B * H * W * 7}
         for k, t in yard.items():
             med = statistics.median(t)
             print(f"yardstick {k}: median {med:7.2f} us -> {vol[k] / med / 1e3:7.1f} GB/s")

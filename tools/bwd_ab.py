@@ -45,23 +45,23 @@ def main():
     dev = torch.device("cuda:0")
     lib = _lib.load_tools()
     lib.hdrnet_enable_kernel_names(1)
-    H, W, GH, GW, GD, desc = WORKLOADS[args.workload]
+    B, H, W, GH, GW, GD, desc = WORKLOADS[args.workload]
     Cin, Cout, C = 3, 3, 12
-    npx = H * W
+    npx = B * H * W
     nsets = max(3, -(-int(CACHE_BYTES * 1.5) // (4 * npx * 11)))
     gen = torch.Generator(device=dev).manual_seed(1)
-    S = [dict(grid=torch.rand((1, GH, GW, GD, C), device=dev, generator=gen),
-              guide=torch.rand((1, H, W), device=dev, generator=gen),
-              inp=torch.rand((1, H, W, Cin), device=dev, generator=gen),
-              dout=torch.randn((1, H, W, Cout), device=dev, generator=gen),
-              dgrid=torch.empty((1, GH, GW, GD, C), device=dev),
-              dguide=torch.empty((1, H, W), device=dev),
-              dinput=torch.empty((1, H, W, Cin), device=dev)) for _ in range(nsets)]
-    sl = [torch.randn((1, H, W, C), device=dev, generator=gen) for _ in range(2)]
+    S = [dict(grid=torch.rand((B, GH, GW, GD, C), device=dev, generator=gen),
+              guide=torch.rand((B, H, W), device=dev, generator=gen),
+              inp=torch.rand((B, H, W, Cin), device=dev, generator=gen),
+              dout=torch.randn((B, H, W, Cout), device=dev, generator=gen),
+              dgrid=torch.empty((B, GH, GW, GD, C), device=dev),
+              dguide=torch.empty((B, H, W), device=dev),
+              dinput=torch.empty((B, H, W, Cin), device=dev)) for _ in range(nsets)]
+    sl = [torch.randn((B, H, W, C), device=dev, generator=gen) for _ in range(2)]
     stream = torch.cuda.current_stream(dev).cuda_stream
-    wsb = lib.hdrnet_bilateral_slice_apply_grad_workspace_bytes(1, H, W, GH, GW, GD, Cin, Cout, 1)
+    wsb = lib.hdrnet_bilateral_slice_apply_grad_workspace_bytes(B, H, W, GH, GW, GD, Cin, Cout, 1)
     ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
-    wsb2 = lib.hdrnet_bilateral_slice_grad_workspace_bytes(1, H, W, GH, GW, GD, C)
+    wsb2 = lib.hdrnet_bilateral_slice_grad_workspace_bytes(B, H, W, GH, GW, GD, C)
     ws2 = torch.empty((max(wsb2, 16),), dtype=torch.uint8, device=dev)
 
     def chk(rc):
@@ -76,13 +76,13 @@ def main():
             if case == "sl":
                 chk(lib.hdrnet_bilateral_slice_grad_f32_ex(
                     s["grid"].data_ptr(), s["guide"].data_ptr(), sl[k % 2].data_ptr(), s["dgrid"].data_ptr(),
-                    s["dguide"].data_ptr(), 1, H, W, GH, GW, GD, C, ws2.data_ptr(), wsb2,
+                    s["dguide"].data_ptr(), B, H, W, GH, GW, GD, C, ws2.data_ptr(), wsb2,
                     _lib.KERNEL_AUTO | (variant << 8), stream))
             else:
                 chk(lib.hdrnet_bilateral_slice_apply_grad_f32_ex(
                     s["grid"].data_ptr(), s["guide"].data_ptr(), s["inp"].data_ptr(), s["dout"].data_ptr(),
                     s["dgrid"].data_ptr() if dg else None, s["dguide"].data_ptr() if dgu else None,
-                    s["dinput"].data_ptr() if di else None, 1, H, W, GH, GW, GD, Cin, Cout, 1,
+                    s["dinput"].data_ptr() if di else None, B, H, W, GH, GW, GD, Cin, Cout, 1,
                     ws.data_ptr(), wsb, _lib.KERNEL_AUTO | (variant << 8), stream))
         return fn
 

@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
     import bench
-    H, W, GH, GW, GD, _ = bench.WORKLOADS[args.workload]
+    B, H, W, GH, GW, GD, _ = bench.WORKLOADS[args.workload]
     npx = H * W
     known_rd, known_wr = 4 * npx * 4, 4 * npx * 3
     cf, ncf = counter_mean(args.calib_fetch, "FETCH_SIZE", "apply_fwd_skeleton")
@@ -70,7 +70,7 @@ def main():
                         "fetch_factor": round(kf, 4), "write_factor": round(kw, 4), "launches": [ncf, ncw]},
         "read_bytes": int(round(rd)), "write_bytes": int(round(wr)),
         "bytes_per_launch": int(round(rd + wr)),
-        "algorithmic_bytes_per_launch": bench.algorithmic_bytes(1, H, W, GH, GW, GD),
+        "algorithmic_bytes_per_launch": bench.algorithmic_bytes(B, H, W, GH, GW, GD),
         "launches": [nf, nw], "source_digest": bench.source_digest(),
         "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python bench.py --steps 20 "
                "--warmup 5`; per-launch means; counters (KiB) x 1024 x the factor calibrated on the skeleton's "

@@ -59,30 +59,30 @@ def main():
     lib.hdrnet_enable_kernel_names(1)
     if args.workload == "refbench":
         return refbench(lib, dev, args)
-    H, W, GH, GW, GD, desc = WORKLOADS[args.workload]
+    B, H, W, GH, GW, GD, desc = WORKLOADS[args.workload]
     Cin, Cout, C = 3, 3, 12
-    npx = H * W
-    gridb = 4 * GH * GW * GD * C
+    npx = B * H * W
+    gridb = 4 * B * GH * GW * GD * C
     nsets = max(3, -(-int(CACHE_BYTES * 1.5) // (4 * npx * 11)))
     gen = torch.Generator(device=dev).manual_seed(1)
     S = []
     for _ in range(nsets):
         S.append(dict(
-            grid=torch.rand((1, GH, GW, GD, C), device=dev, generator=gen),
-            guide=torch.rand((1, H, W), device=dev, generator=gen),
-            inp=torch.rand((1, H, W, Cin), device=dev, generator=gen),
-            dout=torch.randn((1, H, W, Cout), device=dev, generator=gen),
-            out=torch.empty((1, H, W, Cout), device=dev),
-            dgrid=torch.empty((1, GH, GW, GD, C), device=dev),
-            dguide=torch.empty((1, H, W), device=dev),
-            dinput=torch.empty((1, H, W, Cin), device=dev)))
+            grid=torch.rand((B, GH, GW, GD, C), device=dev, generator=gen),
+            guide=torch.rand((B, H, W), device=dev, generator=gen),
+            inp=torch.rand((B, H, W, Cin), device=dev, generator=gen),
+            dout=torch.randn((B, H, W, Cout), device=dev, generator=gen),
+            out=torch.empty((B, H, W, Cout), device=dev),
+            dgrid=torch.empty((B, GH, GW, GD, C), device=dev),
+            dguide=torch.empty((B, H, W), device=dev),
+            dinput=torch.empty((B, H, W, Cin), device=dev)))
     # the un-fused slice moves 4*C B/px: two sets suffice to exceed the cache
-    sl = [dict(dout=torch.randn((1, H, W, C), device=dev, generator=gen),
-               out=torch.empty((1, H, W, C), device=dev)) for _ in range(2)]
+    sl = [dict(dout=torch.randn((B, H, W, C), device=dev, generator=gen),
+               out=torch.empty((B, H, W, C), device=dev)) for _ in range(2)]
     stream = torch.cuda.current_stream(dev).cuda_stream
-    wsb = lib.hdrnet_bilateral_slice_apply_grad_workspace_bytes(1, H, W, GH, GW, GD, Cin, Cout, 1)
+    wsb = lib.hdrnet_bilateral_slice_apply_grad_workspace_bytes(B, H, W, GH, GW, GD, Cin, Cout, 1)
     ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
-    wsb2 = lib.hdrnet_bilateral_slice_grad_workspace_bytes(1, H, W, GH, GW, GD, C)
+    wsb2 = lib.hdrnet_bilateral_slice_grad_workspace_bytes(B, H, W, GH, GW, GD, C)
     ws2 = torch.empty((max(wsb2, 16),), dtype=torch.uint8, device=dev)
 
     def chk(rc):
@@ -92,7 +92,7 @@ def main():
     def apply_fwd(k):
         s = S[k % nsets]
         chk(lib.hdrnet_bilateral_slice_apply_f32(s["grid"].data_ptr(), s["guide"].data_ptr(), s["inp"].data_ptr(),
-                                                 s["out"].data_ptr(), 1, H, W, GH, GW, GD, Cin, Cout, 1, stream))
+                                                 s["out"].data_ptr(), B, H, W, GH, GW, GD, Cin, Cout, 1, stream))
 
     conv1 = (torch.randn((16, Cin + 1), device=dev, generator=gen) * 0.8).contiguous()
     conv2 = (torch.randn((17,), device=dev, generator=gen) * 0.5).contiguous()
@@ -101,16 +101,16 @@ def main():
         s = S[k % nsets]
         chk(lib.hdrnet_bilateral_slice_apply_nnguide_f32(
             s["grid"].data_ptr(), s["inp"].data_ptr(), conv1.data_ptr(), conv2.data_ptr(), s["out"].data_ptr(),
-            None, 1, H, W, GH, GW, GD, Cin, Cout, 1, 16, stream))
+            None, B, H, W, GH, GW, GD, Cin, Cout, 1, 16, stream))
 
-    u8 = [dict(inp=torch.randint(0, 256, (1, H, W, 3), device=dev, dtype=torch.uint8),
-               out=torch.empty((1, H, W, 3), device=dev, dtype=torch.uint8)) for _ in range(nsets)]
+    u8 = [dict(inp=torch.randint(0, 256, (B, H, W, 3), device=dev, dtype=torch.uint8),
+               out=torch.empty((B, H, W, 3), device=dev, dtype=torch.uint8)) for _ in range(nsets)]
 
     def apply_io_u8(k, nn=True):
         s, t = S[k % nsets], u8[k % nsets]
         chk(lib.hdrnet_bilateral_slice_apply_io(
             s["grid"].data_ptr(), None if nn else s["guide"].data_ptr(), t["inp"].data_ptr(), t["out"].data_ptr(),
-            1, H, W, GH, GW, GD, 3, 3, 1, 1, 255.0, 1, conv1.data_ptr() if nn else None,
+            B, H, W, GH, GW, GD, 3, 3, 1, 1, 255.0, 1, conv1.data_ptr() if nn else None,
             conv2.data_ptr() if nn else None, 16 if nn else 0, None, stream))
 
     ccm = torch.cat([torch.eye(3, device=dev), torch.zeros((3, 1), device=dev)], 1) + 0.1 * torch.randn((3, 4), device=dev, generator=gen)
@@ -122,52 +122,52 @@ def main():
         s, t = S[k % nsets], u8[k % nsets]
         chk(lib.hdrnet_bilateral_slice_apply_io_curves(
             s["grid"].data_ptr(), (t["inp"] if u8io else s["inp"]).data_ptr(), (t["out"] if u8io else s["out"]).data_ptr(),
-            1, H, W, GH, GW, GD, 3, 3, 1, 1 if u8io else 0, 255.0 if u8io else 1.0, 1 if u8io else 0,
+            B, H, W, GH, GW, GD, 3, 3, 1, 1 if u8io else 0, 255.0 if u8io else 1.0, 1 if u8io else 0,
             ccm.data_ptr(), shifts.data_ptr(), slopes.data_ptr(), mixv.data_ptr(), 16, None, stream))
 
-    coarse = [torch.randn((1, H // 2, W // 2, 3), device=dev, generator=gen) for _ in range(nsets)]
-    half = [torch.empty((1, H // 2, W // 2, 3), device=dev) for _ in range(nsets)]
+    coarse = [torch.randn((B, H // 2, W // 2, 3), device=dev, generator=gen) for _ in range(nsets)]
+    half = [torch.empty((B, H // 2, W // 2, 3), device=dev) for _ in range(nsets)]
 
     def apply_upadd(k, nn=True):
         s = S[k % nsets]
         chk(lib.hdrnet_bilateral_slice_apply_upadd_f32(
             s["grid"].data_ptr(), None if nn else s["guide"].data_ptr(), s["inp"].data_ptr(),
-            coarse[k % nsets].data_ptr(), H // 2, W // 2, s["out"].data_ptr(), 1, H, W, GH, GW, GD, 3, 3, 1,
+            coarse[k % nsets].data_ptr(), H // 2, W // 2, s["out"].data_ptr(), B, H, W, GH, GW, GD, 3, 3, 1,
             conv1.data_ptr() if nn else None, conv2.data_ptr() if nn else None, 16 if nn else 0, stream))
 
     def resize_half(k):
         chk(lib.hdrnet_resize_bilinear_f32(S[k % nsets]["inp"].data_ptr(), half[k % nsets].data_ptr(),
-                                           1, H, W, H // 2, W // 2, 3, stream))
+                                           B, H, W, H // 2, W // 2, 3, stream))
 
     def apply_bwd(k, dg=True, dgu=True, di=True, variant=0):
         s = S[k % nsets]
         chk(lib.hdrnet_bilateral_slice_apply_grad_f32_ex(
             s["grid"].data_ptr(), s["guide"].data_ptr(), s["inp"].data_ptr(), s["dout"].data_ptr(),
             s["dgrid"].data_ptr() if dg else None, s["dguide"].data_ptr() if dgu else None,
-            s["dinput"].data_ptr() if di else None, 1, H, W, GH, GW, GD, Cin, Cout, 1,
+            s["dinput"].data_ptr() if di else None, B, H, W, GH, GW, GD, Cin, Cout, 1,
             ws.data_ptr(), wsb, _lib.KERNEL_AUTO | (variant << 8), stream))
 
     u16 = None
     if args.workload == "hdrp":
-        u16 = [torch.randint(0, 32768, (1, H, W, 3), device=dev, dtype=torch.int32).to(torch.uint16)
+        u16 = [torch.randint(0, 32768, (B, H, W, 3), device=dev, dtype=torch.int32).to(torch.uint16)
                for _ in range(nsets)]
 
     def apply_io_u16(k):
         s = S[k % nsets]
         chk(lib.hdrnet_bilateral_slice_apply_io(
             s["grid"].data_ptr(), s["guide"].data_ptr(), u16[k % nsets].data_ptr(), s["out"].data_ptr(),
-            1, H, W, GH, GW, GD, 3, 3, 1, 2, 32767.0, 0, None, None, 0, None, stream))
+            B, H, W, GH, GW, GD, 3, 3, 1, 2, 32767.0, 0, None, None, 0, None, stream))
 
     def slice_fwd(k):
         s, t = S[k % nsets], sl[k % 2]
         chk(lib.hdrnet_bilateral_slice_f32(s["grid"].data_ptr(), s["guide"].data_ptr(), t["out"].data_ptr(),
-                                           1, H, W, GH, GW, GD, C, stream))
+                                           B, H, W, GH, GW, GD, C, stream))
 
     def slice_bwd(k):
         s, t = S[k % nsets], sl[k % 2]
         chk(lib.hdrnet_bilateral_slice_grad_f32(s["grid"].data_ptr(), s["guide"].data_ptr(), t["dout"].data_ptr(),
                                                 s["dgrid"].data_ptr(), s["dguide"].data_ptr(),
-                                                1, H, W, GH, GW, GD, C, ws2.data_ptr(), wsb2, stream))
+                                                B, H, W, GH, GW, GD, C, ws2.data_ptr(), wsb2, stream))
 
     rows = []
 
