@@ -20,12 +20,14 @@ working set exceeds the 256 MiB Infinity Cache + L2 (232 MB per 4K frame x 3 set
 number is an HBM number, not a cache number; the cache-resident rate is reported separately
 under "extra".
 
-Protocol (the same since round 1; round 2's short event-timed default is gone): an untimed, disclosed
-PRE-ROLL (>= 50 ms of launches, `preroll_launches` in the JSON) takes the device out of the idle power
-state (the clock ramp takes ~25 ms), then W warm-up launches, then EXACTLY K launches timed on the WALL
-clock between barrier + torch.cuda.synchronize() pairs -- always the wall clock, whatever K is; `value`
-= MP/s over that region, max over ranks.  Defaults K = 2000, W = 1000 (an 80-ms region starting ~100 ms
-after the load does).  HIP events on the launch stream bracket the same K launches and give the
+Protocol (round 2's short event-timed default is gone): an untimed, disclosed PRE-ROLL (>= 250 ms of
+launches, `preroll_launches` in the JSON) puts the device into its SUSTAINED state -- the clock ramp from
+idle takes ~25 ms, and on many boxes the first slow episode of the power manager arrives 50-100 ms after
+the load starts (profiles/r02/exp35; with a 50-ms pre-roll a K = 20 window sat right on that edge and read
+38.6 or 50 us depending on a few hundred microseconds of host timing, profiles/r03/k20_*.txt) -- then W
+warm-up launches, then EXACTLY K launches timed on the WALL clock between barrier +
+torch.cuda.synchronize() pairs -- always the wall clock, whatever K is; `value` = MP/s over that region,
+max over ranks.  Defaults K = 2000, W = 1000.  HIP events on the launch stream bracket the same K launches and give the
 `roofline` block its average kernel duration.  Under SUSTAINED load some boxes alternate between a fast
 state and a ~17 % slower one in episodes of 50-200 ms (profiles/r02/exp35): the `sustained` block
 (N = 1) reports the mean and the spread of 100-launch windows over a further 0.5 s, and
@@ -179,14 +181,27 @@ def timed(step_fn, steps, dist_on, dev):
     if dist_on:
         hd.barrier()
     torch.cuda.synchronize(dev)
+    trace = os.environ.get("HDRNET_BENCH_TRACE") == "1" and steps <= 64  # diagnostics: per-launch events
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps)] if trace else None
     t0 = time.perf_counter()
     ev0.record()
-    step_fn(steps, 0)
+    if trace:
+        for k in range(steps):
+            step_fn(1, k)
+            evs[k].record()
+    else:
+        step_fn(steps, 0)
     ev1.record()
+    th = time.perf_counter()
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
     if dist_on:
         hd.barrier()
+    if trace:
+        marks = [ev0] + evs
+        print("trace: host loop %.0f us; per-launch us: %s" % (
+            (th - t0) * 1e6, " ".join("%.0f" % (marks[k].elapsed_time(marks[k + 1]) * 1e3) for k in range(steps))),
+            file=sys.stderr)
     return t1 - t0, ev0.elapsed_time(ev1) * 1e-3
 
 
@@ -228,7 +243,7 @@ def sustained(step_fn, dev, est_us, seconds=0.5, window=100):
             "window_launches": window}
 
 
-def preroll(step_fn, sync_fn, min_seconds=0.05, chunk=64, max_launches=20000):
+def preroll(step_fn, sync_fn, min_seconds=0.25, chunk=64, max_launches=100000):
     """Untimed launches until >= min_seconds have passed (device out of the idle power state)."""
     n = 0
     t0 = time.perf_counter()

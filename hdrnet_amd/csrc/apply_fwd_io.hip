@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include <cstdio>
+#include <cstring>
 
 #include "launch.hip.h"
 #include "numerics.hip.h"
@@ -101,9 +102,29 @@ __device__ __forceinline__ void guide_curves_quad(const GuideNet& gn, const floa
   }
 }
 
+// v / wl for an integer sample v, correctly rounded like the IEEE division TF performs
+// (tf.to_float(im) / white_level), in three instructions instead of the ~11 of a general IEEE divide:
+//   q = v * r;  e = fma(-q, wl, v);  q' = fma(e, r, q)      with r = RN(1 / wl) from the host.
+// With a correctly rounded reciprocal, one exact-remainder correction yields RN(v / wl) for every v
+// unless wl's significand is all ones (Markstein, "Computation of elementary functions on the IBM RISC
+// System/6000 processor", 1990, theorem on division by a correctly rounded reciprocal); v <= 65535 and
+// wl in [2^-40, 2^40] keep every intermediate normal.  The host (io_fast_div) checks those conditions and
+// otherwise selects the plain divide; tests/test_gpu_parity.py compares both forms exhaustively over
+// all 65536 sample values for the white levels of hdrnet/data_pipeline.py:202-232,267-274.
+struct WhiteLevel {
+  float wl, rcp;  // rcp = 0: use the IEEE divide
+};
+
+__device__ __forceinline__ float div_white(float v, const WhiteLevel& w) {
+  if (w.rcp == 0.0f) return v / w.wl;  // uniform
+  const float q = v * w.rcp;
+  const float e = __builtin_fmaf(-q, w.wl, v);
+  return __builtin_fmaf(e, w.rcp, q);
+}
+
 // Load 4 pixels x CIN channels of TI starting at element index e0, as floats / white level.
 template <typename TI, int N>
-__device__ __forceinline__ void load_pixels(const TI* __restrict__ src, size_t e0, float wl,
+__device__ __forceinline__ void load_pixels(const TI* __restrict__ src, size_t e0, const WhiteLevel& wl,
                                             float (&dst)[N]) {
   if constexpr (sizeof(TI) == 4) {
 #pragma unroll
@@ -120,7 +141,7 @@ __device__ __forceinline__ void load_pixels(const TI* __restrict__ src, size_t e
       uint32_t v;
       if constexpr (sizeof(TI) == 1) v = (w[q >> 2] >> (8 * (q & 3))) & 0xffu;
       else v = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu;
-      dst[q] = (float)v / wl;  // tf.to_float(im) / white_level, IEEE division as TF
+      dst[q] = div_white((float)v, wl);  // tf.to_float(im) / white_level, rounded as TF's IEEE division
     }
   }
 }
@@ -132,7 +153,10 @@ struct IoParams {
   void* out;
   int H, W, GH, GW, GD;
   int seg, slab_off;
-  float scale_x, scale_y, inv_col, white_level;
+  float scale_x, scale_y, inv_col;
+  WhiteLevel white;
+  int grid_image;  // floats per image of the grid
+  SegTab tab;      // (cmin, ncols) per segment, from the host (seg_common.hip.h)
   GuideNet gn;
 };
 
@@ -150,10 +174,10 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
   const int xe = min(xs + p.seg, p.W);
   const int y = blockIdx.y;
   const int b = blockIdx.z;
-  const float* grid_b = p.grid + (size_t)b * p.GH * p.GW * p.GD * C;
+  const float* grid_b = p.grid + (size_t)b * (unsigned)p.grid_image;
   const int x = xs + kPxPerThread * tid;
   const bool active = x < xe;
-  const size_t row = (size_t)b * p.H + y;
+  const size_t row = (unsigned)b * (unsigned)p.H + (unsigned)y;  // B, H <= 65535 (plan_io)
   const size_t px = row * p.W + x;
   const TI* input = static_cast<const TI*>(p.input);
 
@@ -166,17 +190,19 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
       const float4 g4 = *reinterpret_cast<const float4*>(p.guide + px);
       gs[0] = g4.x; gs[1] = g4.y; gs[2] = g4.z; gs[3] = g4.w;
     }
-    load_pixels<TI, NI>(input, px * CIN, p.white_level, inf);
+    load_pixels<TI, NI>(input, px * CIN, p.white, inf);
   }
 
-  const SegCols sc = seg_cols(xs, xe, p.scale_x);
+  const SegCols sc = seg_cols_tab(p.tab, blockIdx.x, xs, xe, p.scale_x);
   const int colb = (p.GD + 2) * CB;
   const float gd_f = (float)p.GD, zhi = (float)(p.GD - 1);
   stage_image<C>(lds, grid_b, y, sc.cmin, sc.ncols, p.GH, p.GW, p.GD, p.scale_y, p.inv_col, tid, (int)blockDim.x);
-  XTerm xt[kPxPerThread];
+  // the lean pixel phase of the product forward (seg_common.hip.h)
+  XTermLean xt[kPxPerThread];
   const float xf0 = (float)x + 0.5f;
+  const float colb_f = (float)colb, xbase_f = (float)(CB - sc.cmin * colb);
 #pragma unroll
-  for (int k = 0; k < kPxPerThread; ++k) xt[k] = x_term(xf0 + (float)k, p.scale_x, sc.cmin, colb, CB);
+  for (int k = 0; k < kPxPerThread; ++k) xt[k] = x_term_lean(xf0 + (float)k, p.scale_x, colb_f, xbase_f);
   __syncthreads();
 
   float of[NO];
@@ -193,7 +219,7 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
       float in[CIN], o[COUT];
 #pragma unroll
       for (int j = 0; j < CIN; ++j) in[j] = inf[k * CIN + j];
-      seg_pixel<CIN, COUT, OFFSET>(lds, gd_f, zhi, colb, xt[k], gs[k], in, o);
+      seg_pixel_lean<CIN, COUT, OFFSET, true>(lds, gd_f, zhi, colb, xt[k], gs[k], in, o);
 #pragma unroll
       for (int i = 0; i < COUT; ++i) of[k * COUT + i] = o[i];
     }
@@ -237,6 +263,16 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
   }
 }
 
+// Host side of div_white: the reciprocal if the three-instruction form is exact for this white level.
+WhiteLevel io_white_level(float wl) {
+  unsigned bits;
+  memcpy(&bits, &wl, sizeof bits);
+  const bool all_ones = (bits & 0x7fffffu) == 0x7fffffu;
+  const bool in_range = wl >= 0x1p-40f && wl <= 0x1p40f;
+  volatile float r = 1.0f / wl;  // IEEE, correctly rounded
+  return WhiteLevel{wl, (all_ones || !in_range) ? 0.0f : (float)r};
+}
+
 struct IoGeom {
   Plan pl;
   int slab_off;
@@ -267,7 +303,9 @@ hipError_t launch_io(const ApplyIoArgs& a, const Plan&, hipStream_t s) {
   p.scale_x = (float)a.GW / a.W;
   p.scale_y = (float)a.GH / a.H;
   p.inv_col = 1.0f / (float)(a.GD * (C / 4));
-  p.white_level = a.white_level;
+  p.white = io_white_level(a.white_level);
+  p.grid_image = a.GH * a.GW * a.GD * C;
+  p.tab = make_seg_tab(a.W, g.pl.seg, g.pl.nseg, p.scale_x);
   p.gn = GuideNet{a.guide_conv1, a.guide_conv2, a.guide_shifts, a.guide_slopes, a.guide_out, a.n_feats};
   const dim3 grid3((unsigned)g.pl.nseg, (unsigned)a.H, (unsigned)a.B);
   apply_fwd_io_rows<CIN, COUT, OFFSET, GUIDE, TI, TO><<<grid3, g.pl.threads, g.lds, s>>>(p);

@@ -69,7 +69,7 @@ constexpr int kLoadsBufDmaNt = 4;  // LDS-DMA, nontemporal, as buffer_load ... l
 
 // Pixel phase: 0 = round 2's (seg_pixel), 1 = lean with the packed blend, 2 = lean with a scalar blend
 // (seg_common.hip.h).
-constexpr int kPixR02 = 0, kPixLean = 1, kPixLeanScalar = 2;
+constexpr int kPixR02 = 0, kPixLean = 1, kPixLeanScalar = 2, kPixLeanAllScalar = 3;  // 3: z taps scalar too
 
 // Output stores (all lane-contiguous 16 B after the per-wave LDS transpose):
 constexpr int kStoresGlobal = 0;   // global_store_dwordx4, predicated on the run length
@@ -86,6 +86,7 @@ struct SegParams {
   int H, W, GH, GW, GD;
   int y0;          // first frame row of a row-split launch (buffers hold rows y0 .. y0 + H - 1); else 0
   int grid_image;  // floats per image of the grid: GH * GW * GD * C (< 2^31, capi.hip check_common)
+  SegTab tab;      // (cmin, ncols) of every segment of a row, from the host
   int seg;         // pixels per segment, multiple of 4
   int slab_off;    // float offset of the per-wave slabs in dynamic LDS (= size of the image)
   float scale_x, scale_y;
@@ -109,12 +110,13 @@ __device__ __forceinline__ void dma16(const float* src, float* dst_wave_base) {
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst_wave_base, 16, 0, NT ? 2 : 0);
 }
 
-// N 1-KiB pieces of one buffer: piece K lands at dst_wave_base + 1 KiB * K (the immediate offset of the
-// instruction must be a compile-time constant, hence the recursion).
+// N 1-KiB pieces of one buffer: piece K lands at dst_wave_base + 1 KiB * K.  The instruction's immediate
+// offset (a compile-time constant, hence the recursion) is added to the memory address AND to the LDS
+// address (LDS = M0 + offset + 16 * lane), so the LDS base stays the slab's for every piece.
 template <int K, int N>
 __device__ __forceinline__ void buf_dma_pieces(__amdgpu_buffer_rsrc_t rs, float* dst_wave_base, unsigned voff) {
   if constexpr (K < N) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst_wave_base + 256 * K), 16, voff, 0, 1024 * K, kAuxNt);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)dst_wave_base, 16, voff, 0, 1024 * K, kAuxNt);
     buf_dma_pieces<K + 1, N>(rs, dst_wave_base, voff);
   }
 }
@@ -152,9 +154,8 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
   [[maybe_unused]] float4* gslab = slab + SLABW / 4;  // DMA only
 
   // Grid columns of this segment, unclamped: gx0 of the first pixel .. gx0 + 1 of the last.
-  const int cmin = floor_to_int(mul_rn(xs + 0.5f, p.scale_x) - 0.5f);
-  const int cmax = floor_to_int(mul_rn(xe - 1 + 0.5f, p.scale_x) - 0.5f) + 1;
-  const int ncols = cmax - cmin + 1;
+  const SegCols sc = seg_cols_tab(p.tab, blockIdx.x, xs, xe, p.scale_x);
+  const int cmin = sc.cmin, ncols = sc.ncols;
   const int colb = (p.GD + 2) * CB;
   const float gd_f = (float)p.GD, zhi = (float)(p.GD - 1);
 
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
 #pragma unroll
       for (int j = 0; j < CIN; ++j) in[j] = inf[k * CIN + j];
       if constexpr (LEAN)
-        seg_pixel_lean<CIN, COUT, OFFSET, PIX == kPixLean>(lds, gd_f, zhi, colb, xl[k], gs[k], in, o);
+        seg_pixel_lean<CIN, COUT, OFFSET, PIX == kPixLean, PIX != kPixLeanAllScalar>(lds, gd_f, zhi, colb, xl[k], gs[k], in, o);
       else
         seg_pixel<CIN, COUT, OFFSET>(lds, gd_f, zhi, colb, xt[k], gs[k], in, o);
 #pragma unroll
@@ -364,6 +365,7 @@ hipError_t launch_seg_t(const ApplyArgs& a, hipStream_t s, long long* trace,
   p.GD = a.GD;
   p.y0 = a.y0;
   p.grid_image = a.GH * a.GW * a.GD * C;
+  p.tab = make_seg_tab(a.W, g.pl.seg, g.pl.nseg, (float)a.GW / a.W);
   p.seg = g.pl.seg;
   p.slab_off = g.slab_off;
   p.scale_x = (float)a.GW / a.W;
@@ -416,7 +418,11 @@ hipError_t launch_seg_pick(const ApplyArgs& a, hipStream_t s) {
   return launch_seg_t<CI, CO, OFF, DMAL, kStoresBufNt, false, false, false, PIX>(a, s, nullptr, gn, up);
 }
 
-constexpr int kProductPix = kPixR02, kProductDma = kLoadsDmaNt;
+// Round 3 (profiles/r03/ab_variants_4k.txt, two boxes, interleaved): lean pixel phase 40.4 -> 39.6-39.8 us,
+// buffer-form DMA 40.4 -> 39.5 us, both 39.3-39.5 us next to the no-compute skeleton's 39.0; the scalar
+// blend times the same as the packed one (v_pk_fma_f32 issues as two passes on gfx950) with 100 more
+// instructions, so the packed blend stays.
+constexpr int kProductPix = kPixLean, kProductDma = kLoadsBufDmaNt;
 
 hipError_t launch_apply_fwd_seg(const ApplyArgs& a, hipStream_t s, const char** name) {
   *name = "apply_fwd_seg/vec4";
@@ -440,7 +446,7 @@ hipError_t launch_apply_fwd_seg_nnguide(const ApplyArgs& a, const float* conv1, 
   *name = "apply_fwd_seg/vec4+nnguide";
 #define HDRNET_CASE(CI, CO, OFF)                          \
   if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF) \
-    return launch_seg_t<CI, CO, OFF, kLoadsDmaNt, kStoresBufNt, false, true, false>(a, s, nullptr, gn)
+    return launch_seg_t<CI, CO, OFF, kProductDma, kStoresBufNt, false, true, false, kProductPix>(a, s, nullptr, gn)
   HDRNET_CASE(3, 3, true);
   HDRNET_CASE(3, 3, false);
   HDRNET_CASE(1, 1, true);
@@ -462,11 +468,11 @@ hipError_t launch_apply_fwd_seg_upadd(const ApplyArgs& a, const float* coarse, i
   const UpAdd up{coarse, Hc, Wc, resize_scale(Hc, a.H), resize_scale(Wc, a.W)};
   if (conv1) {
     *name = "apply_fwd_seg/vec4+nnguide+upadd";
-    return launch_seg_t<3, 3, true, kLoadsDmaNt, kStoresBufNt, false, true, true>(
+    return launch_seg_t<3, 3, true, kProductDma, kStoresBufNt, false, true, true, kProductPix>(
         a, s, nullptr, GuideNN{conv1, conv2, nullptr, n_feats}, up);
   }
   *name = "apply_fwd_seg/vec4+upadd";
-  return launch_seg_t<3, 3, true, kLoadsDmaNt, kStoresBufNt, false, false, true>(
+  return launch_seg_t<3, 3, true, kProductDma, kStoresBufNt, false, false, true, kProductPix>(
       a, s, nullptr, GuideNN{nullptr, nullptr, nullptr, 0}, up);
 }
 
@@ -477,18 +483,21 @@ void apply_fwd_seg_set_trace(long long* device_buf) { g_trace = device_buf; }
 // loads as buffer_load ... lds instead of global_load ... lds.  Load / store flavour per launch as the product.
 hipError_t launch_apply_fwd_seg_pix(const ApplyArgs& a, int knob, hipStream_t s, const char** name) {
   if (!(a.Cin == 3 && a.Cout == 3 && a.has_offset)) return hipErrorNotSupported;
-  static const char* const nm[8] = {"apply_fwd_seg/pix0", "apply_fwd_seg/pix-lean", "apply_fwd_seg/pix-lean-scalar", "",
-                                    "apply_fwd_seg/pix0+bufdma", "apply_fwd_seg/pix-lean+bufdma",
-                                    "apply_fwd_seg/pix-lean-scalar+bufdma", ""};
-  if (knob < 0 || knob >= 8 || (knob & 3) == 3) return hipErrorNotSupported;
+  static const char* const nm[8] = {"apply_fwd_seg/pix0", "apply_fwd_seg/pix-lean", "apply_fwd_seg/pix-lean-scalar",
+                                    "apply_fwd_seg/pix-lean-allscalar", "apply_fwd_seg/pix0+bufdma",
+                                    "apply_fwd_seg/pix-lean+bufdma", "apply_fwd_seg/pix-lean-scalar+bufdma",
+                                    "apply_fwd_seg/pix-lean-allscalar+bufdma"};
+  if (knob < 0 || knob >= 8) return hipErrorNotSupported;
   *name = nm[knob];
   switch (knob) {
     case 0: return launch_seg_pick<3, 3, true, kPixR02, kLoadsDmaNt>(a, s);
     case 1: return launch_seg_pick<3, 3, true, kPixLean, kLoadsDmaNt>(a, s);
     case 2: return launch_seg_pick<3, 3, true, kPixLeanScalar, kLoadsDmaNt>(a, s);
+    case 3: return launch_seg_pick<3, 3, true, kPixLeanAllScalar, kLoadsDmaNt>(a, s);
     case 4: return launch_seg_pick<3, 3, true, kPixR02, kLoadsBufDmaNt>(a, s);
     case 5: return launch_seg_pick<3, 3, true, kPixLean, kLoadsBufDmaNt>(a, s);
     case 6: return launch_seg_pick<3, 3, true, kPixLeanScalar, kLoadsBufDmaNt>(a, s);
+    case 7: return launch_seg_pick<3, 3, true, kPixLeanAllScalar, kLoadsBufDmaNt>(a, s);
   }
   return hipErrorNotSupported;
 }

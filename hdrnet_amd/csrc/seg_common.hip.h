@@ -106,8 +106,8 @@ __device__ __forceinline__ XTermLean x_term_lean(float xf, float scale_x, float 
   return t;
 }
 
-// PK: blend on 2-wide vectors (v_pk_fma_f32) or on scalars (v_fma_f32).
-template <int CIN, int COUT, bool OFFSET, bool PK>
+// PK: blend on 2-wide vectors (v_pk_fma_f32) or on scalars (v_fma_f32).  PKZ: the same choice for the two z taps.
+template <int CIN, int COUT, bool OFFSET, bool PK, bool PKZ = true>
 __device__ __forceinline__ void seg_pixel_lean(const float* __restrict__ img, float gd_f, float zhi, int colb,
                                                const XTermLean& xt, float g, const float (&in)[CIN > 0 ? CIN : 1],
                                                float (&out)[COUT]) {
@@ -120,19 +120,32 @@ __device__ __forceinline__ void seg_pixel_lean(const float* __restrict__ img, fl
 #pragma clang fp contract(off)
     const float gzf = mul_rn(g, gd_f);
     const float fzl = floorf(gzf - 0.5f);
-    // the two taps as a 2-wide vector (corner centres as the reference forms them: (float)gz + 0.5f, gz1 = gz0 + 1)
-    const f32x2 cz = {fzl + 0.5f, (fzl + 1.0f) + 0.5f};
-    const f32x2 gz2 = {gzf, gzf};
-    const f32x2 dz = cz - gz2;
-    const f32x2 eps2 = {kSmoothEps, kSmoothEps};
-    const f32x2 q = __builtin_elementwise_fma(dz, dz, eps2);
-    const float s0 = __builtin_amdgcn_sqrtf(q.x), s1 = __builtin_amdgcn_sqrtf(q.y);
-    // max(1 - s, 0) (numerics.h:108-113) == clamp(1 - s) to [0, 1] since s > 0: folds into the subtraction
-    const f32x2 wz = {__builtin_amdgcn_fmed3f(1.0f - s0, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(1.0f - s1, 0.0f, 1.0f)};
-    const f32x2 wx1 = {xt.wx1, xt.wx1};
-    const f32x2 w1 = wz * wx1;
-    const f32x2 w0 = __builtin_elementwise_fma(-wz, wx1, wz);  // wz * (1 - wx1), one rounding
-    w00 = w0.x; w01 = w0.y; w10 = w1.x; w11 = w1.y;
+    // corner centres as the reference forms them: (float)gz + 0.5f with gz1 = gz0 + 1
+    const float c0 = fzl + 0.5f, c1 = (fzl + 1.0f) + 0.5f;
+    if constexpr (PKZ) {  // the two taps as a 2-wide vector
+      const f32x2 cz = {c0, c1};
+      const f32x2 gz2 = {gzf, gzf};
+      const f32x2 dz = cz - gz2;
+      const f32x2 eps2 = {kSmoothEps, kSmoothEps};
+      const f32x2 q = __builtin_elementwise_fma(dz, dz, eps2);
+      const float s0 = __builtin_amdgcn_sqrtf(q.x), s1 = __builtin_amdgcn_sqrtf(q.y);
+      // max(1 - s, 0) (numerics.h:108-113) == clamp(1 - s) to [0, 1] since s > 0: folds into the subtraction
+      const f32x2 wz = {__builtin_amdgcn_fmed3f(1.0f - s0, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(1.0f - s1, 0.0f, 1.0f)};
+      const f32x2 wx1 = {xt.wx1, xt.wx1};
+      const f32x2 w1 = wz * wx1;
+      const f32x2 w0 = __builtin_elementwise_fma(-wz, wx1, wz);  // wz * (1 - wx1), one rounding
+      w00 = w0.x; w01 = w0.y; w10 = w1.x; w11 = w1.y;
+    } else {
+      const float dz0 = c0 - gzf, dz1 = c1 - gzf;
+      const float s0 = __builtin_amdgcn_sqrtf(__builtin_fmaf(dz0, dz0, kSmoothEps));
+      const float s1 = __builtin_amdgcn_sqrtf(__builtin_fmaf(dz1, dz1, kSmoothEps));
+      const float wz0 = __builtin_amdgcn_fmed3f(1.0f - s0, 0.0f, 1.0f);
+      const float wz1 = __builtin_amdgcn_fmed3f(1.0f - s1, 0.0f, 1.0f);
+      w10 = wz0 * xt.wx1;
+      w11 = wz1 * xt.wx1;
+      w00 = __builtin_fmaf(-wz0, xt.wx1, wz0);  // wz0 * (1 - wx1), one rounding
+      w01 = __builtin_fmaf(-wz1, xt.wx1, wz1);
+    }
     const float izf = __builtin_amdgcn_fmed3f(fzl, -1.0f, zhi);  // wild guides only (NaN -> -1)
     a0 = (int)__builtin_fmaf(izf, (float)CB, xt.xbpf);
   }
@@ -230,6 +243,38 @@ __device__ __forceinline__ SegCols seg_cols(int xs, int xe, float scale_x) {
   const int cmin = floor_to_int(mul_rn(xs + 0.5f, scale_x) - 0.5f);
   const int cmax = floor_to_int(mul_rn(xe - 1 + 0.5f, scale_x) - 0.5f) + 1;
   return SegCols{cmin, cmax - cmin + 1};
+}
+
+// The same two numbers for every segment of a row, computed ONCE on the host and passed in the kernel
+// arguments (they depend on the segment only; on the device they are ~14 wave-uniform VALU instructions
+// per wave): packed (cmin + 1) | ncols << 16.  Rows of more than kSegTab segments compute them on the device.
+constexpr int kSegTab = 8;
+struct SegTab {
+  unsigned packed[kSegTab];
+  int n;  // 0: no table
+};
+
+inline SegTab make_seg_tab(int W, int seg, int nseg, float scale_x) {
+  SegTab t{};
+  if (nseg > kSegTab) return t;
+  for (int i = 0; i < nseg; ++i) {
+    const int xs = i * seg, xe = (xs + seg < W) ? xs + seg : W;
+    // the device's expressions, each product rounded to float before use (volatile: no contraction)
+    volatile float p0 = ((float)xs + 0.5f) * scale_x;
+    volatile float p1 = ((float)(xe - 1) + 0.5f) * scale_x;
+    const int cmin = (int)floorf(p0 - 0.5f), cmax = (int)floorf(p1 - 0.5f) + 1;
+    t.packed[i] = (unsigned)(cmin + 1) | ((unsigned)(cmax - cmin + 1) << 16);
+  }
+  t.n = nseg;
+  return t;
+}
+
+__device__ __forceinline__ SegCols seg_cols_tab(const SegTab& t, int seg_index, int xs, int xe, float scale_x) {
+  if (t.n > 0) {  // uniform
+    const unsigned v = t.packed[seg_index];
+    return SegCols{(int)(v & 0xffffu) - 1, (int)(v >> 16)};
+  }
+  return seg_cols(xs, xe, scale_x);
 }
 
 }  // namespace rows

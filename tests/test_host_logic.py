@@ -110,3 +110,30 @@ def test_fused_ops_shape_rules_and_no_cpu_path():
         ops.input_moments(x)
     with pytest.raises(TypeError, match="float32"):
         ops.input_moments(x.double())
+
+
+def test_three_instruction_white_level_division_is_ieee_exact():
+    """apply_fwd_io.hip::div_white forms v / white_level as q = v * r; e = fma(-q, wl, v); q' = fma(e, r, q)
+    with r = RN(1 / wl) from the host, claiming the result of the IEEE division TensorFlow performs
+    (hdrnet/data_pipeline.py:202-232, 267-274: tf.to_float(im) / 255, 65535, 32767).  Checked here in exact
+    rational arithmetic (each fma rounded once), against numpy's IEEE float32 division."""
+    from fractions import Fraction
+    import numpy as np
+    f32 = np.float32
+
+    def rn32(fr):  # round-to-nearest-even of an exact rational to float32 (normal range)
+        if fr == 0:
+            return f32(0)
+        c = f32(float(fr))
+        cands = [c, np.nextafter(c, f32(np.inf)), np.nextafter(c, f32(-np.inf))]
+        return min(cands, key=lambda x: (abs(Fraction(float(x)) - fr), int(f32(x).view(np.uint32)) & 1))
+
+    for wl, stride in ((255.0, 1), (65535.0, 13), (32767.0, 11), (1023.0, 97), (100.5, 97), (3.3333, 97)):
+        wl32 = f32(wl)
+        r = f32(1.0) / wl32
+        W, R = Fraction(float(wl32)), Fraction(float(r))
+        top = 256 if wl == 255.0 else 65536
+        for v in range(0, top, stride):
+            q = Fraction(float(rn32(v * R)))
+            e = Fraction(float(rn32(v - q * W)))
+            assert rn32(q + e * R) == f32(v) / wl32, (wl, v)
