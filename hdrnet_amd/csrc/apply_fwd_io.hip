@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
       for (int q = 0; q < NO / 4; ++q) w[q] = 0;
 #pragma unroll
       for (int q = 0; q < NO; ++q) {
-        const float c = fminf(fmaxf(of[q], 0.0f), 1.0f);
+        const float c = __builtin_amdgcn_fmed3f(of[q], 0.0f, 1.0f);  // clip: folds into the affine's last fma (clamp)
         w[q >> 2] |= ((uint32_t)(255.0f * c)) << (8 * (q & 3));
       }
       uint32_t* op = reinterpret_cast<uint32_t*>(static_cast<TO*>(p.out) + px * COUT);

@@ -267,9 +267,16 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   };
   const int nrows = (y_end - (y_first + wave) + kWaves - 1) / kWaves;
   const int nbt = (ABL != 3 && span > 0 && nrows > 0) ? nrows * nbr : 0;  // ABL 3: prologue + epilogue only
-  auto load_batch = [&](int t, Batch& bt) {
-    const int r = t / nbr, bi = t - r * nbr;
-    const int y = y_first + wave + r * kWaves;
+  // (row, batch in row) of the next batch to load / to contract: advanced incrementally -- `t / nbr` is an
+  // integer division by a run-time value, ~20 instructions each on this target
+  int ld_y = y_first + wave, ld_bi = 0;
+  int pr_y = y_first + wave, pr_bi = 0;
+  auto load_batch = [&](Batch& bt) {
+    const int y = ld_y, bi = ld_bi;
+    if (++ld_bi == nbr) {
+      ld_bi = 0;
+      ld_y += kWaves;
+    }
     const size_t prow = ((size_t)b * p.H + y) * p.W;  // wave-uniform
     const __amdgpu_buffer_rsrc_t grs = row_rsrc(p.guide + prow);
     const __amdgpu_buffer_rsrc_t irs = row_rsrc((APPLY && CIN > 0) ? p.input + prow * CIN : p.guide);
@@ -294,9 +301,9 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   // exposed first load of every wave, not a too-short steady-state distance.
   constexpr int kAhead = 1;
   Batch ring[kAhead + 1];
-  if (nbt > 0) load_batch(0, ring[0]);  // issued first: the rest of the prologue runs under its latency
+  if (nbt > 0) load_batch(ring[0]);  // issued first: the rest of the prologue runs under its latency
   if constexpr (kAhead > 1 && ABL != 1 && ABL != 4) {
-    if (nbt > 1) load_batch(1, ring[1]);
+    if (nbt > 1) load_batch(ring[1]);
   }
   // fused: this lane's element of the two grid rows the coefficient image blends.  They change only when
   // gy0 does (once per cell height), so they stay in registers across the wave's rows.
@@ -324,18 +331,29 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
 #pragma unroll
   for (int cb = 0; cb < kXW; ++cb) dxc[cb] = x_offset(x_lo + 64 * cb + lane);
   f32x4 dacc = {0.f, 0.f, 0.f, 0.f}, dacc2 = {0.f, 0.f, 0.f, 0.f};
+  // y terms of the row being contracted (bilateral_slice_apply.cc:42,47,55-56), formed once per row
+  int row_gy0 = 0;
+  float row_wy0 = 0.0f, row_wy1 = 0.0f;
   auto process = [&](int t, const Batch& cur, Batch& refill) {
     if constexpr (ABL != 1 && ABL != 4) {  // (tools ablation 1 / 4: the first batch is all a wave ever loads)
-      if (t + kAhead < nbt) load_batch(t + kAhead, refill);
+      if (t + kAhead < nbt) load_batch(refill);
     }
-    const int r = t / nbr, bi = t - r * nbr;
-    const int y = y_first + wave + r * kWaves;
+    const int y = pr_y, bi = pr_bi;
+    if (++pr_bi == nbr) {
+      pr_bi = 0;
+      pr_y += kWaves;
+    }
     const int xb = x_lo + bi * 64 * kBatch;
+    if (bi == 0) {
+      const float gyf = mul_rn(y + 0.5f, p.scale_y);
+      row_gy0 = floor_to_int(gyf - 0.5f);
+      row_wy0 = tent_weight(row_gy0 + 0.5f, gyf);
+      row_wy1 = tent_weight(row_gy0 + 1 + 0.5f, gyf);
+    }
     if constexpr (FUSED) {
       if (bi == 0) {  // new row: blend its coefficient image (wy folded in, planes padded in z)
-        const float gyf = mul_rn(y + 0.5f, p.scale_y);
-        const int gy0 = floor_to_int(gyf - 0.5f);
-        const float wy0 = tent_weight(gy0 + 0.5f, gyf), wy1 = tent_weight(gy0 + 1 + 0.5f, gyf);
+        const int gy0 = row_gy0;
+        const float wy0 = row_wy0, wy1 = row_wy1;
         if (gy0 != gy0_held) load_grid_rows(gy0);  // wave-uniform; at most once more per wave (rg <= cell height)
         if (lane < nst) {
           const f32x4 v = wy0 * sa + wy1 * sb;
@@ -361,7 +379,9 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
         else if (ci == 2) dx = dxc[2];
         else if (ci == 3) dx = dxc[3];
         else dx = x_offset(x0 + lane);  // only intervals wider than 256 px
-        const float w0 = std_max(1.0f - fabsf(dx), 0.0f), w1 = std_max(1.0f - fabsf(dx + 1.0f), 0.0f);
+        // max(1 - |dx|, 0) == clamp(1 - |dx|) to [0, 1] (the difference never exceeds 1): one instruction
+        const float w0 = __builtin_amdgcn_fmed3f(1.0f - fabsf(dx), 0.0f, 1.0f);
+        const float w1 = __builtin_amdgcn_fmed3f(1.0f - fabsf(dx + 1.0f), 0.0f, 1.0f);
         const float wa = w0, wb = w1;
         // z: only the two corners around gzf carry weight (:121); the outermost half cells are
         // forced to 1 (:122-125).  Two v_sqrt_f32 per pixel (1 ulp; argument >= 1e-8, no
@@ -395,7 +415,8 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
 #pragma unroll
           for (int j = 0; j < CIN_Q; ++j) div[j] = 0.0f;
           {
-            const float wz0 = std_max(1.0f - sza, 0.0f), wz1 = std_max(1.0f - szb, 0.0f);
+            const float wz0 = __builtin_amdgcn_fmed3f(1.0f - sza, 0.0f, 1.0f);  // max(1 - s, 0): s > 0
+            const float wz1 = __builtin_amdgcn_fmed3f(1.0f - szb, 0.0f, 1.0f);
             const float wgt[4] = {wa * wz0, wa * wz1, wb * wz0, wb * wz1};
             const float dwg[4] = {wa * dw0, wa * dw1, wb * dw0, wb * dw1};
             const int off[4] = {a0, a0 + CB, a0 + colb, a0 + colb + CB};
@@ -459,13 +480,14 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
             }
           }
         }
-        float wP = std_max(1.0f - sza, 0.0f);
-        float wQ = std_max(1.0f - szb, 0.0f);
-        const bool lo = gzf < 0.5f, hi = gzf > gd_f - 0.5f;
-        int zP = min(max((int)__builtin_amdgcn_fmed3f(fz, -2.0f, 9.0f), 0), 7), zQ = min(zP + 1, 7);
-        if (lo) { zP = 0; zQ = 1; }
-        if (hi) { zP = p.GD - 1; zQ = (p.GD - 1) ^ 1; }
-        if (lo || hi) { wP = 1.0f; wQ = 0.0f; }
+        // P = (plane of the lower tap, its weight), Q = the upper tap.  In the outermost half cells
+        // (gzf < .5, gzf > GD - .5; :121-125) the one live plane is forced to weight 1: there the lower tap's
+        // clamped plane IS that plane (fz = -1 -> 0; fz >= GD - 1 -> GD - 1) and Q carries weight 0 -- where Q
+        // clamps onto P's slot it is written first, so P's value wins.
+        const bool edge = __builtin_amdgcn_fmed3f(gzf, 0.5f, gd_f - 0.5f) != gzf;
+        const float wP = edge ? 1.0f : __builtin_amdgcn_fmed3f(1.0f - sza, 0.0f, 1.0f);
+        const float wQ = edge ? 0.0f : __builtin_amdgcn_fmed3f(1.0f - szb, 0.0f, 1.0f);
+        const int zP = (int)__builtin_amdgcn_fmed3f(fz, 0.0f, zhi), zQ = min(zP + 1, p.GD - 1);
         float* aP = at + zP * kTStride + lane;
         float* aQ = at + zQ * kTStride + lane;
         auto enc = [](float v) { return SPLIT ? split_pack(v) : v; };
@@ -564,10 +586,8 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
       // last batch of the row: fold the row's 16x16 result, scaled by its two y weights
       // (bilateral_slice_apply.cc:42,47,55-56; weights un-clamped, indices clamped), into the
       // register tiles of the (<= 3) grid rows the group touches.
-      const float gyf = mul_rn(y + 0.5f, p.scale_y);
-      const int gy0 = floor_to_int(gyf - 0.5f);
-      const float wy0 = tent_weight(gy0 + 0.5f, gyf);
-      const float wy1 = tent_weight(gy0 + 1 + 0.5f, gyf);
+      const int gy0 = row_gy0;
+      const float wy0 = row_wy0, wy1 = row_wy1;
       const int rel0 = clamp_index(gy0, 0, p.GH - 1) - gy_base;
       const int rel1 = clamp_index(gy0 + 1, 0, p.GH - 1) - gy_base;
       dacc += dacc2;

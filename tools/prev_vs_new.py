@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Interleaved timing of the gradient (and forward) entry points of TWO builds of the library in one process:
+the tree's libhdrnet_amd.so against a previous build given with --prev (e.g. built from the last commit in a
+scratch worktree and copied to tools/exp/prev/libhdrnet_amd_prev.so -- *.so files are git-ignored but travel
+to the GPU box).  Box-to-box spread is ~5 %, run-to-run drift 1-2 %: a kernel change smaller than that can
+only be measured like this.
+
+    python tools/prev_vs_new.py --prev tools/exp/prev/libhdrnet_amd_prev.so [--workload 4k] [--rounds 7]
+"""
+import argparse
+import ctypes
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from bench import CACHE_BYTES, WORKLOADS  # noqa: E402
+from hdrnet_amd import _lib  # noqa: E402
+
+
+def bind(path):
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _lib.SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            continue  # an older build may lack newer entry points
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--prev", required=True)
+    ap.add_argument("--workload", default="4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--cases", default="fwd,all,gg,g,v,slice_fwd,slice_bwd")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    libs = {"new": _lib.load(), "prev": bind(os.path.abspath(args.prev))}
+    B, H, W, GH, GW, GD, desc = WORKLOADS[args.workload]
+    Cin, Cout, C = 3, 3, 12
+    npx = B * H * W
+    nsets = max(3, -(-int(CACHE_BYTES * 1.5) // (4 * npx * 11)))
+    gen = torch.Generator(device=dev).manual_seed(1)
+    S = [dict(grid=torch.rand((B, GH, GW, GD, C), device=dev, generator=gen),
+              guide=torch.rand((B, H, W), device=dev, generator=gen),
+              inp=torch.rand((B, H, W, Cin), device=dev, generator=gen),
+              dout=torch.randn((B, H, W, Cout), device=dev, generator=gen),
+              out=torch.empty((B, H, W, Cout), device=dev),
+              dgrid=torch.empty((B, GH, GW, GD, C), device=dev),
+              dguide=torch.empty((B, H, W), device=dev),
+              dinput=torch.empty((B, H, W, Cin), device=dev)) for _ in range(nsets)]
+    sl = [dict(dout=torch.randn((B, H, W, C), device=dev, generator=gen),
+               out=torch.empty((B, H, W, C), device=dev)) for _ in range(2)]
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ws, ws2 = {}, {}
+    for k, lib in libs.items():
+        n = lib.hdrnet_bilateral_slice_apply_grad_workspace_bytes(B, H, W, GH, GW, GD, Cin, Cout, 1)
+        ws[k] = torch.empty((max(n, 16),), dtype=torch.uint8, device=dev)
+        n2 = lib.hdrnet_bilateral_slice_grad_workspace_bytes(B, H, W, GH, GW, GD, C)
+        ws2[k] = torch.empty((max(n2, 16),), dtype=torch.uint8, device=dev)
+
+    def make(case, which):
+        lib = libs[which]
+
+        def chk(rc):
+            if rc:
+                raise RuntimeError(lib.hdrnet_last_error().decode())
+
+        if case == "fwd":
+            def fn(k):
+                s = S[k % nsets]
+                chk(lib.hdrnet_bilateral_slice_apply_f32(s["grid"].data_ptr(), s["guide"].data_ptr(), s["inp"].data_ptr(),
+                                                         s["out"].data_ptr(), B, H, W, GH, GW, GD, Cin, Cout, 1, stream))
+            return fn
+        if case == "slice_fwd":
+            def fn(k):
+                s, t = S[k % nsets], sl[k % 2]
+                chk(lib.hdrnet_bilateral_slice_f32(s["grid"].data_ptr(), s["guide"].data_ptr(), t["out"].data_ptr(),
+                                                   B, H, W, GH, GW, GD, C, stream))
+            return fn
+        if case == "slice_bwd":
+            def fn(k):
+                s, t = S[k % nsets], sl[k % 2]
+                chk(lib.hdrnet_bilateral_slice_grad_f32(s["grid"].data_ptr(), s["guide"].data_ptr(), t["dout"].data_ptr(),
+                                                        s["dgrid"].data_ptr(), s["dguide"].data_ptr(), B, H, W, GH, GW, GD,
+                                                        C, ws2[which].data_ptr(), ws2[which].numel(), stream))
+            return fn
+        dg, dgu, di = {"all": (1, 1, 1), "gg": (1, 1, 0), "g": (1, 0, 0), "v": (0, 1, 1)}[case]
+
+        def fn(k):
+            s = S[k % nsets]
+            chk(lib.hdrnet_bilateral_slice_apply_grad_f32(
+                s["grid"].data_ptr(), s["guide"].data_ptr(), s["inp"].data_ptr(), s["dout"].data_ptr(),
+                s["dgrid"].data_ptr() if dg else None, s["dguide"].data_ptr() if dgu else None,
+                s["dinput"].data_ptr() if di else None, B, H, W, GH, GW, GD, Cin, Cout, 1,
+                ws[which].data_ptr(), ws[which].numel(), stream))
+        return fn
+
+    def time_launches(fn, n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for k in range(n):
+            fn(k)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n
+
+    print(f"{desc}; prev = {args.prev}")
+    for case in args.cases.split(","):
+        fns = {w: make(case, w) for w in ("prev", "new")}
+        # same results?  (the new build against the previous one; gradients are deterministic in both)
+        outs = {}
+        for w in ("prev", "new"):
+            for t in ("out", "dgrid", "dguide", "dinput"):
+                S[0][t].fill_(0)
+            fns[w](0)
+            torch.cuda.synchronize()
+            outs[w] = [S[0][t].clone() for t in ("out", "dgrid", "dguide", "dinput")]
+        diff = max(float((a - b).abs().max()) for a, b in zip(outs["prev"], outs["new"]))
+        res = {"prev": [], "new": []}
+        for _ in range(args.rounds):
+            for w in ("prev", "new"):
+                time_launches(fns[w], 20)
+                res[w].append(time_launches(fns[w], args.steps))
+        mp, mn = statistics.median(res["prev"]), statistics.median(res["new"])
+        print(f"{case:10s} prev {mp:7.2f} us (min {min(res['prev']):7.2f})   new {mn:7.2f} us (min {min(res['new']):7.2f})   "
+              f"new / prev = {mn / mp:.3f}   max|new - prev| = {diff:.2e}")
+
+
+if __name__ == "__main__":
+    main()
