@@ -137,8 +137,10 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+// live = false: a descriptor of ZERO records -- a load through it touches no memory and returns 0, but it is
+// still one VMEM instruction (see load_batch: the count of VMEM operations must not depend on the path).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float* base, bool live = true) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, live ? 0x7fffffff : 0, 0x00020000);
 }
 
 // AUX: cache policy (rows_common.hip.h: kAuxNt for data that is read exactly once).
@@ -271,16 +273,21 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   // integer division by a run-time value, ~20 instructions each on this target
   int ld_y = y_first + wave, ld_bi = 0;
   int pr_y = y_first + wave, pr_bi = 0;
-  auto load_batch = [&](Batch& bt) {
+  // `live` = false past the wave's last batch: the loads are still ISSUED (through zero-record descriptors).
+  // s_waitcnt vmcnt(N) takes a compile-time N = the fewest VMEM operations any path can have issued after the
+  // one being waited for; with the refill under `if (t + 1 < nbt)` that minimum was "none", so every chunk
+  // waited for the batch just requested instead of the one requested a batch earlier -- the prefetch never
+  // overlapped anything (profiles/r03/bwd_pmc_before.txt: 42 % of all wave cycles parked at s_waitcnt).
+  auto load_batch = [&](Batch& bt, bool live = true) {
     const int y = ld_y, bi = ld_bi;
     if (++ld_bi == nbr) {
       ld_bi = 0;
       ld_y += kWaves;
     }
     const size_t prow = ((size_t)b * p.H + y) * p.W;  // wave-uniform
-    const __amdgpu_buffer_rsrc_t grs = row_rsrc(p.guide + prow);
-    const __amdgpu_buffer_rsrc_t irs = row_rsrc((APPLY && CIN > 0) ? p.input + prow * CIN : p.guide);
-    const __amdgpu_buffer_rsrc_t drs = row_rsrc(p.dout + prow * COUT);
+    const __amdgpu_buffer_rsrc_t grs = row_rsrc(p.guide + prow, live);
+    const __amdgpu_buffer_rsrc_t irs = row_rsrc((APPLY && CIN > 0) ? p.input + prow * CIN : p.guide, live);
+    const __amdgpu_buffer_rsrc_t drs = row_rsrc(p.dout + prow * COUT, live);
     const int xb = x_lo + bi * 64 * kBatch;
 #pragma unroll
     for (int cb = 0; cb < kBatch; ++cb) {
@@ -301,10 +308,8 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   // exposed first load of every wave, not a too-short steady-state distance.
   constexpr int kAhead = 1;
   Batch ring[kAhead + 1];
-  if (nbt > 0) load_batch(ring[0]);  // issued first: the rest of the prologue runs under its latency
-  if constexpr (kAhead > 1 && ABL != 1 && ABL != 4) {
-    if (nbt > 1) load_batch(ring[1]);
-  }
+  load_batch(ring[0], nbt > 0);  // issued first: the rest of the prologue runs under its latency
+  if constexpr (kAhead > 1 && ABL != 1 && ABL != 4) load_batch(ring[1], nbt > 1);
   // fused: this lane's element of the two grid rows the coefficient image blends.  They change only when
   // gy0 does (once per cell height), so they stay in registers across the wave's rows.
   f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = sa;
@@ -336,8 +341,9 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   float row_wy0 = 0.0f, row_wy1 = 0.0f;
   auto process = [&](int t, const Batch& cur, Batch& refill) {
     if constexpr (ABL != 1 && ABL != 4) {  // (tools ablation 1 / 4: the first batch is all a wave ever loads)
-      if (t + kAhead < nbt) load_batch(refill);
+      load_batch(refill, t + kAhead < nbt);  // always issued (see load_batch)
     }
+    if (t >= nbt) return;  // a padding step of the unrolled ring: it only keeps the VMEM count uniform
     const int y = pr_y, bi = pr_bi;
     if (++pr_bi == nbr) {
       pr_bi = 0;
@@ -398,6 +404,20 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
         // 1-ulp sqrt cannot flip it (sqrt(1.0f) is exact).  The derivative is dz / s with v_rcp_f32.
         const float sza = __builtin_amdgcn_sqrtf(fmaf(dza, dza, kSmoothEps));
         const float szb = __builtin_amdgcn_sqrtf(fmaf(dzb, dzb, kSmoothEps));
+        // U[i] = dout_i * [in; 1]: the rows of V the dgrid contraction stages AND the vectors the fused dguide
+        // contracts with, as column pairs (CJ = 4 shapes; two packed multiplies per output channel)
+        constexpr bool UPAIRS = APPLY && CJ == 4;
+        [[maybe_unused]] f32x2 U01[COUT], U23[COUT];
+        if constexpr (UPAIRS) {
+          const f32x2 i01 = {cur.in[cb][0], CIN > 1 ? cur.in[cb][CIN > 1 ? 1 : 0] : 1.0f};
+          const f32x2 i23 = {CIN > 2 ? cur.in[cb][CIN > 2 ? 2 : 0] : 1.0f, CIN > 3 ? cur.in[cb][CIN > 3 ? 3 : 0] : 1.0f};
+#pragma unroll
+          for (int i = 0; i < COUT; ++i) {
+            const f32x2 di = {cur.d[cb][i], cur.d[cb][i]};
+            U01[i] = i01 * di;
+            U23[i] = i23 * di;
+          }
+        }
         if constexpr (FUSED) {
           // per-pixel VJPs from the row's coefficient image: vectors at (x corner, plane iz + 1 + tap)
           const int iz = (int)__builtin_amdgcn_fmed3f(fz, -1.0f, zhi);
@@ -411,50 +431,62 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
           // vector of corner v = (x corner, z tap):
           //   dguide   = sum_v (wx dw)_v <G_v, U>                 (bilateral_slice_apply.cc:140-206)
           //   dinput_j = sum_v (wx wz)_v sum_i dout_i G_v[i, j]   (:208-259)
-          float dgv = 0.0f, div[CIN_Q];
-#pragma unroll
-          for (int j = 0; j < CIN_Q; ++j) div[j] = 0.0f;
+          float dgv = 0.0f;
+          f32x2 div01 = {0.0f, 0.0f}, div23 = {0.0f, 0.0f};  // dinput columns (0, 1), (2, 3)
           {
             const float wz0 = __builtin_amdgcn_fmed3f(1.0f - sza, 0.0f, 1.0f);  // max(1 - s, 0): s > 0
             const float wz1 = __builtin_amdgcn_fmed3f(1.0f - szb, 0.0f, 1.0f);
             const float wgt[4] = {wa * wz0, wa * wz1, wb * wz0, wb * wz1};
             const float dwg[4] = {wa * dw0, wa * dw1, wb * dw0, wb * dw1};
             const int off[4] = {a0, a0 + CB, a0 + colb, a0 + colb + CB};
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-              float G[C];
+            auto read_corner = [&](int v, f32x4 (&dst)[C / 4]) {
               const f32x4* gp4 = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(img) + off[v]);
 #pragma unroll
-              for (int q = 0; q < C / 4; ++q) {
-                const f32x4 t = gp4[q];
-                G[4 * q] = t.x; G[4 * q + 1] = t.y; G[4 * q + 2] = t.z; G[4 * q + 3] = t.w;
-              }
+              for (int q = 0; q < C / 4; ++q) dst[q] = gp4[q];
+            };
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              // this corner's vector: rows i of [COUT][CJ = 4] are the float4s Gc[i] (APPLY), or C / 4 float4s (slice).
+              // With dinput fused the corners are kept apart (sched_barrier below): all four hoisted need 144
+              // VGPRs = 3 waves per SIMD; two in flight (the next one's reads under this one's math) measured
+              // no faster than one (profiles/r03/bwd_prev_vs_new_*.txt).
+              f32x4 Gc[C / 4];
+              read_corner(v, Gc);
+              // Packed (v_pk_fma_f32) contractions: 35 fewer VALU instructions per chunk at the same time (a packed
+              // FMA issues as two passes on gfx950: profiles/r03/bwd_step_r03j_*.txt) -- kept for the shorter code.
               if constexpr (WG) {
-                float sdot = 0.0f;
+                f32x2 acc = {0.0f, 0.0f};
                 if constexpr (APPLY) {
+                  static_assert(CJ == 4, "fused apply shapes have 4 grid columns per output channel");
 #pragma unroll
-                  for (int i = 0; i < COUT; ++i) {
-                    float e = OFFSET ? G[i * CJ + CIN] : 0.0f;
-#pragma unroll
-                    for (int j = 0; j < CIN; ++j) e = fmaf(G[i * CJ + j], cur.in[cb][j < CIN ? j : 0], e);
-                    sdot = fmaf(e, cur.d[cb][i], sdot);
+                  for (int i = 0; i < COUT; ++i) {  // <G[i, :], dout_i * [in; 1]> two columns at a time
+                    acc = __builtin_elementwise_fma(f32x2{Gc[i].x, Gc[i].y}, U01[i], acc);
+                    acc = __builtin_elementwise_fma(f32x2{Gc[i].z, Gc[i].w}, U23[i], acc);
                   }
                 } else {
 #pragma unroll
-                  for (int c = 0; c < C; ++c) sdot = fmaf(G[c], cur.d[cb][c], sdot);
+                  for (int q = 0; q < C / 4; ++q) {
+                    acc = __builtin_elementwise_fma(f32x2{Gc[q].x, Gc[q].y}, f32x2{cur.d[cb][4 * q], cur.d[cb][4 * q + 1]}, acc);
+                    acc = __builtin_elementwise_fma(f32x2{Gc[q].z, Gc[q].w}, f32x2{cur.d[cb][4 * q + 2], cur.d[cb][4 * q + 3]}, acc);
+                  }
                 }
-                dgv = fmaf(dwg[v], sdot, dgv);
+                dgv = fmaf(dwg[v], acc.x + acc.y, dgv);
               }
               if constexpr (WI) {
+                // t_j = sum_i G[i, j] dout_i: columns (0, 1) packed, column 2 (and 3 for CIN = 4) beside them
+                f32x2 t01 = {0.0f, 0.0f}, t23 = {0.0f, 0.0f};
 #pragma unroll
-                for (int j = 0; j < CIN; ++j) {
-                  float t = 0.0f;
-#pragma unroll
-                  for (int i = 0; i < COUT; ++i) t = fmaf(G[i * CJ + j], cur.d[cb][i], t);
-                  div[j] = fmaf(wgt[v], t, div[j]);
+                for (int i = 0; i < COUT; ++i) {
+                  const f32x2 di = {cur.d[cb][i], cur.d[cb][i]};
+                  t01 = __builtin_elementwise_fma(f32x2{Gc[i].x, Gc[i].y}, di, t01);
+                  if constexpr (CIN > 3) t23 = __builtin_elementwise_fma(f32x2{Gc[i].z, Gc[i].w}, di, t23);
+                  else if constexpr (CIN > 2) t23.x = fmaf(Gc[i].z, cur.d[cb][i], t23.x);
                 }
-                // one corner's coefficient vector in registers at a time (all four hoisted: 144 VGPRs, 3 waves)
-                __builtin_amdgcn_sched_barrier(0);
+                const f32x2 wv = {wgt[v], wgt[v]};
+                div01 = __builtin_elementwise_fma(wv, t01, div01);
+                if constexpr (CIN > 3) div23 = __builtin_elementwise_fma(wv, t23, div23);
+                else if constexpr (CIN > 2) div23.x = fmaf(wgt[v], t23.x, div23.x);
+                __builtin_amdgcn_sched_barrier(0);  // ... and the corner after next is not hoisted above this one
               }
             }
           }
@@ -467,15 +499,16 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
             if constexpr (WI) {
               const __amdgpu_buffer_rsrc_t rs = rows::make_rsrc(p.dinput + prow_out * CIN, (unsigned)x_hi * (4u * CIN));
               if constexpr (CIN == 3) {
-                const u32x3 v = {__float_as_uint(div[0]), __float_as_uint(div[1]), __float_as_uint(div[2])};
+                const u32x3 v = {__float_as_uint(div01.x), __float_as_uint(div01.y), __float_as_uint(div23.x)};
                 __builtin_amdgcn_raw_buffer_store_b96(v, rs, px * 12u, 0, rows::kAuxStream);
               } else if constexpr (CIN == 4) {
-                const u32x4 v = {__float_as_uint(div[0]), __float_as_uint(div[1]), __float_as_uint(div[2]), __float_as_uint(div[3])};
+                const u32x4 v = {__float_as_uint(div01.x), __float_as_uint(div01.y), __float_as_uint(div23.x), __float_as_uint(div23.y)};
                 __builtin_amdgcn_raw_buffer_store_b128(v, rs, px * 16u, 0, rows::kAuxStream);
               } else {
+                const float dv[4] = {div01.x, div01.y, div23.x, div23.y};
 #pragma unroll
                 for (int j = 0; j < CIN; ++j)
-                  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(div[j]), rs, (px * CIN + j) * 4u, 0, rows::kAuxStream);
+                  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dv[j]), rs, (px * CIN + j) * 4u, 0, rows::kAuxStream);
               }
             }
           }
@@ -496,7 +529,15 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
         aP[0] = enc(w0 * wP);
         aP[8 * kTStride] = enc(w1 * wP);
         // V^T[c][px]: dout x [in; 1] (slice: dout)
-        if constexpr (APPLY) {
+        if constexpr (UPAIRS) {
+#pragma unroll
+          for (int i = 0; i < COUT; ++i) {
+            vt[(i * CJ + 0) * kTStride + lane] = enc(U01[i].x);
+            vt[(i * CJ + 1) * kTStride + lane] = enc(U01[i].y);
+            vt[(i * CJ + 2) * kTStride + lane] = enc(U23[i].x);
+            vt[(i * CJ + 3) * kTStride + lane] = enc(U23[i].y);
+          }
+        } else if constexpr (APPLY) {
 #pragma unroll
           for (int i = 0; i < COUT; ++i) {
 #pragma unroll
@@ -605,13 +646,13 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   } else if constexpr (kAhead == 1) {
     for (int t = 0; t < nbt; t += 2) {
       process(t, ring[0], ring[1]);
-      if (t + 1 < nbt) process(t + 1, ring[1], ring[0]);
+      process(t + 1, ring[1], ring[0]);
     }
   } else {
     for (int t = 0; t < nbt; t += 3) {
       process(t, ring[0], ring[2]);
-      if (t + 1 < nbt) process(t + 1, ring[1], ring[0]);
-      if (t + 2 < nbt) process(t + 2, ring[2], ring[1]);
+      process(t + 1, ring[1], ring[0]);
+      process(t + 2, ring[2], ring[1]);
     }
   }
   // Sum the four waves' register tiles in fixed order (wave 0 + 1 + 2 + 3) through LDS -- the
