@@ -767,6 +767,23 @@ bool gg_plan(int B, int H, int W, int GH, int GW, int GD, int C, long long slots
   return true;
 }
 
+// Workspace bound for a shape, whatever gradients the call will ask for: the launch plans its rows per task
+// from the resident-workgroup count of the kernel variant it picks (occupancy x CUs of the current device);
+// a variant's occupancy is 1 .. 8 workgroups per CU (8 waves per SIMD, 4-wave workgroups), so the largest
+// plan over those eight counts bounds every launch.  (Round 2 returned the plan for the smallest rows-per-
+// task any launch may pick -- 28 MB at 4K where a launch uses 7, hundreds of MB for batched training.)
+bool gg_ws_bound(int B, int H, int W, int GH, int GW, int GD, int C, size_t* bytes) {
+  size_t worst = 0;
+  const long long cus = rows::num_cus();
+  for (int occ = 1; occ <= 8; ++occ) {
+    GGPlan pl;
+    if (!gg_plan(B, H, W, GH, GW, GD, C, occ * cus, &pl)) return false;
+    if (pl.ws_bytes > worst) worst = pl.ws_bytes;
+  }
+  *bytes = worst;
+  return true;
+}
+
 long long* g_gg_trace = nullptr;  // tools: phase-trace buffer (grid_grad_set_trace)
 
 // Workgroups of `kfn` resident on the device at once (occupancy x CUs).  Queried once per kernel.
@@ -868,17 +885,17 @@ void grid_grad_set_trace(long long* device_buf) { g_gg_trace = device_buf; }
 
 size_t apply_grid_grad_mfma_workspace(int B, int H, int W, int GH, int GW, int GD, int Cin, int Cout,
                                       bool has_offset) {
-  GGPlan pl;
+  size_t bytes = 0;
   if (!apply_shape_ok(Cin, Cout, has_offset)) return 0;
-  if (!gg_plan(B, H, W, GH, GW, GD, Cout * (Cin + (has_offset ? 1 : 0)), 0, &pl)) return 0;
-  return pl.ws_bytes;
+  if (!gg_ws_bound(B, H, W, GH, GW, GD, Cout * (Cin + (has_offset ? 1 : 0)), &bytes)) return 0;
+  return bytes;
 }
 
 bool apply_grid_grad_mfma_supported(const ApplyGradArgs& a) {
-  GGPlan pl;
+  size_t bytes = 0;
   return apply_shape_ok(a.Cin, a.Cout, a.has_offset) &&
-         gg_plan(a.B, a.H, a.W, a.GH, a.GW, a.GD, a.Cout * a.Cj, 0, &pl) && a.workspace != nullptr &&
-         a.workspace_bytes >= pl.ws_bytes;
+         gg_ws_bound(a.B, a.H, a.W, a.GH, a.GW, a.GD, a.Cout * a.Cj, &bytes) && a.workspace != nullptr &&
+         a.workspace_bytes >= bytes;
 }
 
 // variant (tools A/B): 2 = bf16-split contraction.  fused: also write a.dguide / a.dinput.
@@ -916,15 +933,15 @@ hipError_t launch_apply_bwd_fused(const ApplyGradArgs& a, hipStream_t s, const c
 }
 
 size_t slice_grid_grad_mfma_workspace(int B, int H, int W, int GH, int GW, int GD, int C) {
-  GGPlan pl;
-  if (!slice_c_ok(C) || !gg_plan(B, H, W, GH, GW, GD, C, 0, &pl)) return 0;
-  return pl.ws_bytes;
+  size_t bytes = 0;
+  if (!slice_c_ok(C) || !gg_ws_bound(B, H, W, GH, GW, GD, C, &bytes)) return 0;
+  return bytes;
 }
 
 bool slice_grid_grad_mfma_supported(const SliceGradArgs& a) {
-  GGPlan pl;
-  return slice_c_ok(a.C) && gg_plan(a.B, a.H, a.W, a.GH, a.GW, a.GD, a.C, 0, &pl) &&
-         a.workspace != nullptr && a.workspace_bytes >= pl.ws_bytes;
+  size_t bytes = 0;
+  return slice_c_ok(a.C) && gg_ws_bound(a.B, a.H, a.W, a.GH, a.GW, a.GD, a.C, &bytes) &&
+         a.workspace != nullptr && a.workspace_bytes >= bytes;
 }
 
 static hipError_t slice_gg(const SliceGradArgs& a, bool fused, hipStream_t s) {

@@ -133,7 +133,7 @@ def load_tf_variables(model, variables: Dict[str, np.ndarray]) -> None:
             a = _to_torch(np.asarray(variables[_key(variables, name)], dtype=np.float32), kind)
             if tuple(a.shape) != tuple(t.shape):
                 raise ValueError(f"{name}: TensorFlow shape maps to {a.shape}, the module has {tuple(t.shape)}")
-            t.copy_(torch.from_numpy(np.ascontiguousarray(a)).to(t.device))
+            t.copy_(torch.from_numpy(np.ascontiguousarray(a)).reshape(t.shape).to(t.device))  # (0-d stays 0-d)
 
 
 def export_tf_variables(model) -> Dict[str, np.ndarray]:

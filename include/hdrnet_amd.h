@@ -242,10 +242,13 @@ int hdrnet_bilateral_slice_apply_io(const float* grid, const float* guide, const
                                     int n_feats, float* guide_out, void* stream);
 
 /* Scratch (bytes) the grad entry point wants for its deterministic two-stage
- * grid-gradient reduction; 0 is a legal answer.  The caller passes a device
- * buffer of at least this size as `workspace` (contents undefined on entry and
- * exit).  With workspace == NULL the library falls back to float atomics
- * (correct, summation order not reproducible run to run). */
+ * grid-gradient reduction (partial tiles; no atomics anywhere); 0 is a legal answer
+ * (no fast grid-gradient for the shape).  The caller passes a device buffer of at
+ * least this size as `workspace` (contents undefined on entry and exit).  The size is
+ * the bound over the launch plans of the CURRENT device (rows per task are fitted to
+ * its compute-unit count): query it with the device current that the call will run on.
+ * With workspace == NULL or too small the grid gradient runs on the generic gather
+ * kernel instead (bit-exact to the reference CPU code, two orders of magnitude slower). */
 size_t hdrnet_bilateral_slice_apply_grad_workspace_bytes(int B, int H, int W,
                                                          int GH, int GW, int GD,
                                                          int Cin, int Cout,

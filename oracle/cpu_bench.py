@@ -130,8 +130,13 @@ def run(H, W, GH, GW, GD, budget_s=8.0, procs=None):
     res["host_cpus"] = ncpu
     legs = {}
     try:
-        p = procs or max(1, min(ncpu, 64))
+        # capped at 64 whole-image processes: each takes ~16 s of CPU and ~0.7 GB at 4K; 256 of them would not
+        # fit the "default bench.py finishes within minutes" budget.  The cap is stated in the leg.
+        cap = 64
+        p = procs or max(1, min(ncpu, cap))
         legs["reference_nproc"] = leg_nproc(H, W, GH, GW, GD, p)
+        legs["reference_nproc"]["cap"] = (f"{p} of {ncpu} host CPUs used (capped at {cap} processes to bound run time "
+                                          "and memory)" if p < ncpu else f"all {ncpu} host CPUs used")
     except Exception as e:  # noqa: BLE001
         legs["reference_nproc"] = {"error": str(e)}
     try:

@@ -560,7 +560,7 @@ def test_tf_variable_mapping_round_trips(cls):
     TensorFlow dump is what test_tf_fixture_parity checks, when fixtures exist.)"""
     from hdrnet_amd import tf_import
     torch.manual_seed(3)
-    a = getattr(models, cls)().eval()
+    a = getattr(models, cls)(dict(batch_norm=True)).eval()
     with torch.no_grad():  # non-trivial statistics / curve parameters
         for m in a.modules():
             if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
@@ -582,7 +582,7 @@ def test_tf_variable_mapping_round_trips(cls):
         assert v["inference/guide/level_2/conv2/weights:0"].shape == (1, 1, 16, 1)
         assert v["inference/coefficients/prediction/conv1/weights:0"].shape == (1, 1, 64, 8 * 9 * 4)
     torch.manual_seed(99)
-    b = getattr(models, cls)().eval()
+    b = getattr(models, cls)(dict(batch_norm=True)).eval()
     tf_import.load_tf_variables(b, v)
     lo = torch.rand(1, 256, 256, 3)
     with torch.no_grad():
@@ -616,7 +616,7 @@ def test_tf_fixture_parity(cls):
     from hdrnet_amd import tf_import
     with np.load(path) as z:
         fx = {k: z[k] for k in z.files}
-    m = getattr(models, cls)().eval()
+    m = getattr(models, cls)(dict(batch_norm=True)).eval()  # the parameters tools/export_tf_fixtures.py builds with
     m.fuse_guide = False
     tf_import.load_tf_variables(m, {k[len("var/"):]: a for k, a in fx.items() if k.startswith("var/")})
     lo, hi = torch.from_numpy(fx["lowres_input"]), torch.from_numpy(fx["fullres_input"])
