@@ -34,13 +34,23 @@
 //     where segments are whole 128-B lines and 10 % worse than `nt` where they are not, so the
 //     flavour is chosen per launch (launch_apply_fwd_seg below; rows_common.hip.h; profiles/r02/).
 //   * 3-D launch grid (segment, row, batch): no integer division in the kernel.
+//   * ROUND 3 -- a shorter pixel phase (it, not the memory system, is what follows the shader clock when the
+//     power manager throttles: profiles/r02/slow_box, r03/): the LEAN per-pixel code of seg_common.hip.h
+//     (v_fract x weight, float byte addresses, clamp-modifier tents), the pixel runs fetched as
+//     `buffer_load_dwordx4 ... lds` (one per-lane offset register for all four 1-KiB pieces, the run's end
+//     enforced by the descriptor instead of four clamps + 64-bit address adds), the segment's grid-column
+//     window from a host-side table in the kernel arguments, 32-bit row arithmetic.  349 -> ~300 VALU
+//     instructions executed per wave (static: 351 incl. the un-tabled fall-back), 40.4 -> 39.4 us interleaved
+//     on two boxes, the no-compute skeleton at 39.0 (profiles/r03/ab_variants_4k_*.txt).  A scalar blend
+//     (v_fma_f32 instead of v_pk_fma_f32: +96 instructions) times the same -- the packed form stays.
 //
 // Numerics: the coordinate and weight expressions of the reference in the reference's order
-// (products (x+.5)*scale_x, guide*GD explicitly rounded, see numerics.hip.h: mul_rn); the only
-// re-association is wy folded into the LDS image.  max(.,0) of the x tent is dropped (floor()
-// keeps both corners within one cell), v_sqrt_f32 (1 ulp) stands in for sqrtf; differences stay
-// at the 1e-7 level (tests/test_gpu_parity.py holds rtol = atol = 1e-5 and reports the
-// reference's own 1e-6 bar).
+// (products (x+.5)*scale_x, guide*GD explicitly rounded, see numerics.hip.h: mul_rn); wy is folded
+// into the LDS image, the x weights come as wx1 = fract(gxf - .5) and w(x0, .) = wz - wz * wx1 (exact
+// but for 1 ulp in the first half cell), max(., 0) of the z tent is the clamp of the subtraction,
+// v_sqrt_f32 (1 ulp) stands in for sqrtf; differences stay at the 1e-7 level (tests/test_gpu_parity.py
+// and test_gpu_fullsize.py hold rtol = atol = 1e-5 against the oracle and report the reference's own
+// 1e-6 bar: worst / bar <= 0.25 at every config size).
 //
 // The TOOLS build (HDRNET_TOOLS_BUILD) also instantiates the load / store flavours this design
 // was chosen against (per-lane loads, nontemporal lane-contiguous register loads, plain DMA; plain /

@@ -32,6 +32,21 @@
 // atomics (ds_add_f32) retire ~1 lane per 2.7 cycles: 389 us vs 80 us.  Even with the flush
 // rewritten without atomics the issue count equals the dense kernel's, so it was dropped.
 //
+// ROUND 3 (profiles/r03/bwd_*.txt): PMC passes put the pass at (4 N_valu + 32 N_mfma) / SIMDs cycles at the
+// ~1.95 GHz granted under this load + 9 us of launches / stage 2 -- every VALU instruction of a wave costs
+// about four cycles of its SIMD here, and the "memory wait" that the loads-once ablation seemed to show is
+// mostly the higher clock of a run that draws no HBM power (2.3 vs 1.95 GHz).  So the round removed
+// instructions: the run-time integer divisions of the batch cursors (~20 instructions each, twice per batch),
+// compare + select tents (now the clamp modifier), the edge-cell select chain, per-row y terms formed three
+// times; it made the VMEM count the same on every path so that the prefetched batch really stays in flight
+// (s_waitcnt vmcnt takes a compile-time count: with the refill under `if (t + 1 < nbt)` it had been waiting
+// for the batch just requested), and packed the fused VJP's contractions.  dgrid 72.3 -> 64.9 us, dgrid +
+// dguide 90.9 -> 87.4, all three 110.6 -> 109.7 (interleaved with the previous build, same box; results
+// bit-identical until the packed VJP).  Stage 2 is 5.6 us of device time per call and there is no gap
+// between the two kernels (profiles/r03/bwd_kernel_stats.csv; the 8-9 us of the "launches alone" ablation
+// is the HOST's two launches of empty kernels): folding it into the last-arriving workgroup of stage 1
+// would need zero-initialised or epoch-tagged counters in a caller-owned workspace, for <= 5 %; not done.
+//
 // Stage 1 (grid_grad_stage1): one workgroup of 4 waves owns one x-interval (all pixels with
 //   gx0 == g, g = -1 .. GW-1) of rg consecutive rows (rg fitted per launch to whole rounds of
 //   resident workgroups, gg_plan); its waves take alternate rows.  Per row a wave loads the
