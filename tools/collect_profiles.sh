@@ -1,19 +1,23 @@
 #!/bin/bash
-# Collects the round's evidence on an MI355X box into gpurun_out/profiles/ (copy what you want judged
-# into profiles/rNN/).  Two calls, each on a fresh box, from the repo root:
-#   gpurun --timeout 600 -- 'bash tools/collect_profiles.sh pmc'      counters -> traffic.json; copy it to
+# Collects a round's evidence on an MI355X box into gpurun_out/profiles/ (copy what you want judged into
+# profiles/rNN/).  Two calls, each on a fresh box, from the repo root:
+#   gpurun --timeout 600  -- 'bash tools/collect_profiles.sh pmc'     counters -> traffic.json; copy it to
 #                                                                     profiles/rNN/ BEFORE the second call
-#   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh timing'  every timing, on a box no counter
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh timing'  every timing, on a box no counter
 #                                                                     session has touched (timings taken
 #                                                                     after rocprofv3 --pmc passes on the
 #                                                                     same box were intermittently 5 us
 #                                                                     slower: profiles/r02/README.md)
+# Optional: a previous build of the library (e.g. round 2's, built from that commit in a scratch worktree and
+# copied to tools/exp/prev/libhdrnet_amd_r02.so -- *.so files are git-ignored but travel to the GPU box) is
+# timed interleaved with the tree's build (tools/prev_vs_new.py).
 set -u
 R=$(pwd)
 O=$R/gpurun_out/profiles
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 MODE=${1:-timing}
+PREV=$R/tools/exp/prev/libhdrnet_amd_r02.so
 if [ "$MODE" = pmc ]; then
 # 1. HBM traffic of the forward kernel: separate --pmc passes (never combined with trace domains), each
 #    with a calibration twin on the memory skeleton (known byte count, same access widths)
@@ -22,11 +26,17 @@ rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o p --output-format csv -- python $R
 rocprofv3 --pmc FETCH_SIZE -d $O/cal_fetch -o p --output-format csv -- python $R/tools/ab_bench.py --variants 106 --rounds 1 --steps 20 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/cal_write -o p --output-format csv -- python $R/tools/ab_bench.py --variants 106 --rounds 1 --steps 20 > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -d $O/pmc_sq -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
-python $R/tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_sq --match apply_fwd > $O/fwd_pmc.txt 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD -d $O/pmc_sq2 -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+python $R/tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_sq2 --match apply_fwd > $O/fwd_pmc.txt 2>&1
 python $R/tools/pmc_summary.py $O/cal_fetch $O/cal_write --match skeleton > $O/fwd_pmc_calibration.txt 2>&1
 python $R/tools/make_traffic.py --fetch $O/pmc_fetch --write $O/pmc_write --calib-fetch $O/cal_fetch --calib-write $O/cal_write --workload 4k --out $O/traffic.json > $O/traffic.log 2>&1
-rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/cal_fetch $O/cal_write
-tail -3 $O/fwd_pmc.txt; tail -25 $O/traffic.log
+# the fused gradient pass: where its waves spend their cycles
+CMD="python $R/tools/bwd_ab.py --rounds 1 --steps 5 --cases g,gg,all --variants 0"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA -d $O/b1 -o p --output-format csv -- $CMD > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $O/b2 -o p --output-format csv -- $CMD > /dev/null 2>&1
+python $R/tools/pmc_summary.py $O/b1 $O/b2 --match grid_grad_stage1 > $O/bwd_pmc.txt 2>&1
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_sq2 $O/cal_fetch $O/cal_write $O/b1 $O/b2
+tail -40 $O/fwd_pmc.txt; tail -25 $O/traffic.log
 exit 0
 fi
 # 2. the default bench command, un-profiled and under rocprofv3 --kernel-trace --stats
@@ -35,22 +45,29 @@ python $R/bench.py > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats -d $O/stats -o fwd --output-format csv -- python $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
 grep '^{"metric' $O/bench_under_rocprof.log > $O/bench_under_rocprof.json
 find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/fwd_kernel_stats.csv \;
-python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_steps20.json 2>> $O/bench.err
+rm -rf $O/stats
+for i in 1 2 3; do python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline; done > $O/bench_steps20.txt 2>> $O/bench.err
 python $R/bench.py --workload 1080p --no-cpu-baseline > $O/bench_1080p.json 2>> $O/bench.err
+python $R/bench.py --workload 1080p_b4 --no-cpu-baseline > $O/bench_1080p_b4.json 2>> $O/bench.err
 python $R/bench.py --workload hdrp --no-cpu-baseline > $O/bench_hdrp.json 2>> $O/bench.err
-for i in 1 2 3 4 5; do python $R/bench.py --no-cpu-baseline; done > $O/bench_repeat.txt 2>> $O/bench.err
-# 3. every entry point, all sizes; A/B of the forward variants; end-to-end configs
+for i in 1 2 3; do python $R/bench.py --no-cpu-baseline; done > $O/bench_repeat.txt 2>> $O/bench.err
+# 3. every entry point, all sizes; A/B of the forward variants; this build vs the previous round's; end to end
 cd $R
 python tools/op_bench.py --tools --workload 4k --json $O/ops_4k.json > $O/ops_4k.txt 2>&1
 python tools/op_bench.py --tools --workload 1080p --json $O/ops_1080p.json > $O/ops_1080p.txt 2>&1
+python tools/op_bench.py --workload 1080p_b4 --json $O/ops_1080p_b4.json > $O/ops_1080p_b4.txt 2>&1
 python tools/op_bench.py --workload hdrp --json $O/ops_hdrp.json > $O/ops_hdrp.txt 2>&1
 python tools/op_bench.py --workload refbench --json $O/ops_refbench.json > $O/ops_refbench.txt 2>&1
-python tools/ab_bench.py --variants 0,19,8,20,23,27,28,30,31,35,39,105,106 --rounds 5 --steps 100 --trace 23,31 > $O/ab_variants_4k.txt 2>&1
-python tools/ab_bench.py --workload 1080p --variants 0,19,23,28,31,39,105,106 --rounds 5 --steps 400 --trace 31 > $O/ab_variants_1080p.txt 2>&1
-python tools/ab_bench.py --workload hdrp --variants 0,19,23,31,39 --rounds 5 --steps 100 > $O/ab_variants_hdrp.txt 2>&1
+python tools/ab_bench.py --variants 0,31,60,61,62,63,64,65,66,67,105,106 --rounds 9 --steps 200 --trace 31 > $O/ab_variants_4k.txt 2>&1
+python tools/ab_bench.py --workload 1080p --variants 0,23,28,31,60,61,62,106 --rounds 7 --steps 400 > $O/ab_variants_1080p.txt 2>&1
+python tools/ab_bench.py --workload hdrp --variants 0,23,31,39,62,66 --rounds 5 --steps 100 > $O/ab_variants_hdrp.txt 2>&1
+if [ -f $PREV ]; then
+  python tools/prev_vs_new.py --prev $PREV --workload 4k > $O/r02_vs_r03_4k.txt 2>&1
+  python tools/prev_vs_new.py --prev $PREV --workload 1080p --steps 150 > $O/r02_vs_r03_1080p.txt 2>&1
+  python tools/prev_vs_new.py --prev $PREV --workload hdrp > $O/r02_vs_r03_hdrp.txt 2>&1
+fi
 python tools/bwd_ab.py --rounds 5 --steps 50 --cases all,gg,g,sl,v --variants 0,2,3,4,5,6,7,8 > $O/bwd_ab_4k.txt 2>&1
 python tools/bwd_ab.py --workload 1080p --rounds 5 --steps 100 --cases all,gg,g,sl,v --variants 0,3 > $O/bwd_ab_1080p.txt 2>&1
 python tools/e2e_bench.py > $O/e2e.txt 2>&1
-rm -rf $O/stats
 ls -la $O
 cat $O/bench.json

@@ -40,13 +40,15 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--cases", default="fwd,all,gg,g,v,slice_fwd,slice_bwd")
+    ap.add_argument("--nsets", type=int, default=0, help="buffer sets to rotate over (default: enough to exceed the "
+                    "Infinity Cache; 1 = cache-resident, for telling memory time from issue time)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     libs = {"new": _lib.load(), "prev": bind(os.path.abspath(args.prev))}
     B, H, W, GH, GW, GD, desc = WORKLOADS[args.workload]
     Cin, Cout, C = 3, 3, 12
     npx = B * H * W
-    nsets = max(3, -(-int(CACHE_BYTES * 1.5) // (4 * npx * 11)))
+    nsets = args.nsets or max(3, -(-int(CACHE_BYTES * 1.5) // (4 * npx * 11)))
     gen = torch.Generator(device=dev).manual_seed(1)
     S = [dict(grid=torch.rand((B, GH, GW, GD, C), device=dev, generator=gen),
               guide=torch.rand((B, H, W), device=dev, generator=gen),
