@@ -193,6 +193,11 @@ def timed(step_fn, steps, dist_on, dev):
         step_fn(steps, 0)
     ev1.record()
     th = time.perf_counter()
+    # The closing synchronize is entered with the work already done: a blocking wait wakes up 30-60 us late,
+    # which is 5 % of a 20-launch region (profiles/r03/bench_steps20.txt: 41.5 us wall vs 38.9 us events per
+    # launch); polling the closing event first costs one core for the length of the region.
+    while not ev1.query():
+        pass
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
     if dist_on:
