@@ -58,7 +58,7 @@
 //   the four waves' tiles are added in fixed order and go to the workspace.  No LDS accumulator,
 //   no atomics: the result is deterministic.  With dguide / dinput requested (WG / WI) the same
 //   pass also evaluates the per-pixel VJPs from a per-wave coefficient image.
-// Stage 2 (grid_grad_stage2): one workgroup per grid cell adds, in fixed order, the partial
+// Stage 2 (grid_grad_stage2): one workgroup per grid column (all planes) adds, in fixed order, the partial
 //   tiles of the row groups and the two intervals that cover it (+ the clamp-to-edge halves of the
 //   border intervals).
 #include <hip/hip_runtime.h>
@@ -689,44 +689,50 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
   }
 }
 
-// Stage 2.  One 256-thread workgroup per grid cell (b, gy, gx, gz): lane (part, c) adds the
-// partial tiles of row groups yg = yg_lo + part, +16, ... for channel c -- for each group the
-// interval g = gx (its x-corner-0 row) and the interval g = gx - 1 (its x-corner-1 row) --
-// then the 16 partial sums per channel are added in fixed order.  Reads are 64-B runs (the 16
-// channels of one tile row); the result is deterministic.
-__global__ __launch_bounds__(256) void grid_grad_stage2(const float* __restrict__ partial,
+// Stage 2.  One 512-thread workgroup per grid column (b, gy, gx) -- a 3-D launch grid, no index divisions:
+// lane (part, z, c) adds the partial tiles of row groups yg = yg_lo + part, + 4, ... for plane z, channel c --
+// for each group the interval g = gx (its x-corner-0 rows) and the interval g = gx - 1 (its x-corner-1 rows) --
+// then the 4 partial sums are added in fixed order.  A wave reads 256-B runs (4 planes x 16 channels of one tile);
+// the result is deterministic.  (Round 2: one 256-thread workgroup per (column, plane), 16 parts: 5.6 us of device
+// time per call at 4K, profiles/r03/bwd_kernel_stats.csv.)
+constexpr int kS2Parts = 4;
+__global__ __launch_bounds__(512) void grid_grad_stage2(const float* __restrict__ partial,
                                                         float* __restrict__ dgrid, int GH, int GW,
                                                         int GD, int C, int rg, int nyg,
                                                         float scale_y) {
-  __shared__ float red[16][17];
-  const int c = threadIdx.x & 15, part = threadIdx.x >> 4;
-  const long long cell = blockIdx.x;  // ((b * GH + gy) * GW + gx) * GD + z
-  const int z = (int)(cell % GD);
-  const int gx = (int)((cell / GD) % GW);
-  const int gy = (int)((cell / ((long long)GD * GW)) % GH);
-  const long long b = cell / ((long long)GD * GW * GH);
+  __shared__ float red[kS2Parts][8 * 16 + 1];
+  const int c = threadIdx.x & 15, z = (threadIdx.x >> 4) & 7, part = threadIdx.x >> 7;
+  const int gx = blockIdx.x, gy = blockIdx.y;
+  const long long b = blockIdx.z;
   const int nint = GW + 1;
   // Conservative window of row groups that can touch gy; exact membership is `rel`.
   const int yg_lo = max(0, (int)floorf((gy - 2.0f) / scale_y) / rg - 1);
   const int yg_hi = min(nyg, (int)ceilf((gy + 2.5f) / scale_y) / rg + 2);
   float s = 0.0f;
-  for (int yg = yg_lo + part; yg < yg_hi; yg += 16) {
-    const int rel = gy - gy_base_of(yg * rg, scale_y, GH);
-    if (rel < 0 || rel > 2) continue;
-    const size_t t0 = ((size_t)b * nyg + yg) * nint;
-    s += partial[(t0 + gx + 1) * kTileFloats + (rel * 16 + z) * 16 + c];
-    s += partial[(t0 + gx) * kTileFloats + (rel * 16 + 8 + z) * 16 + c];
-    // clamp-to-edge: interval g = -1's corner 0 and interval g = GW - 1's corner 1 land on the edge columns
-    if (gx == 0) s += partial[t0 * kTileFloats + (rel * 16 + z) * 16 + c];
-    if (gx == GW - 1) s += partial[(t0 + GW) * kTileFloats + (rel * 16 + 8 + z) * 16 + c];
+  if (z < GD) {
+    for (int yg = yg_lo + part; yg < yg_hi; yg += kS2Parts) {
+      const int rel = gy - gy_base_of(yg * rg, scale_y, GH);
+      if (rel < 0 || rel > 2) continue;
+      const size_t t0 = ((size_t)b * nyg + yg) * nint;
+      float v0 = partial[(t0 + gx + 1) * kTileFloats + (rel * 16 + z) * 16 + c];
+      float v1 = partial[(t0 + gx) * kTileFloats + (rel * 16 + 8 + z) * 16 + c];
+      // clamp-to-edge: interval g = -1's corner 0 and interval g = GW - 1's corner 1 land on the edge columns
+      float v2 = 0.0f, v3 = 0.0f;
+      if (gx == 0) v2 = partial[t0 * kTileFloats + (rel * 16 + z) * 16 + c];
+      if (gx == GW - 1) v3 = partial[(t0 + GW) * kTileFloats + (rel * 16 + 8 + z) * 16 + c];
+      s += v0;
+      s += v1;
+      if (gx == 0) s += v2;
+      if (gx == GW - 1) s += v3;
+    }
   }
-  red[part][c] = s;
+  red[part][z * 16 + c] = s;
   __syncthreads();
-  if (part == 0 && c < C) {
-    float t = red[0][c];
+  if (part == 0 && z < GD && c < C) {
+    float t = red[0][z * 16 + c];
 #pragma unroll
-    for (int q = 1; q < 16; ++q) t += red[q][c];
-    dgrid[cell * C + c] = t;
+    for (int q = 1; q < kS2Parts; ++q) t += red[q][z * 16 + c];
+    dgrid[((((size_t)b * GH + gy) * GW + gx) * GD + z) * C + c] = t;
   }
 }
 
@@ -777,7 +783,7 @@ bool gg_plan(int B, int H, int W, int GH, int GW, int GD, int C, long long slots
   pl->rg = rg;
   pl->nyg = (H + rg - 1) / rg;
   pl->ntasks = cols * pl->nyg;
-  if (pl->ntasks > 0x7fffffffLL || (long long)B * GH * GW * GD > 0x7fffffffLL || pl->nyg > 65535 || B > 65535) return false;
+  if (pl->ntasks > 0x7fffffffLL || (long long)B * GH * GW * GD > 0x7fffffffLL || pl->nyg > 65535 || B > 65535 || GH > 65535) return false;
   pl->ws_bytes = (size_t)pl->ntasks * kTileFloats * sizeof(float);
   return true;
 }
@@ -879,9 +885,8 @@ hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int G
   kfn<<<nblocks, kWaves * 64, 0, s>>>(p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  const long long ncell = (long long)B * GH * GW * GD;
-  grid_grad_stage2<<<(unsigned)ncell, 256, 0, s>>>(static_cast<const float*>(ws), q.dgrid, GH, GW, GD,
-                                                   C, pl.rg, pl.nyg, (float)GH / H);
+  grid_grad_stage2<<<dim3((unsigned)GW, (unsigned)GH, (unsigned)B), 512, 0, s>>>(
+      static_cast<const float*>(ws), q.dgrid, GH, GW, GD, C, pl.rg, pl.nyg, (float)GH / H);
   return hipGetLastError();
 }
 
