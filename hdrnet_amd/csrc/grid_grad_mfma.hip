@@ -46,6 +46,14 @@
 // between the two kernels (profiles/r03/bwd_kernel_stats.csv; the 8-9 us of the "launches alone" ablation
 // is the HOST's two launches of empty kernels): folding it into the last-arriving workgroup of stage 1
 // would need zero-initialised or epoch-tagged counters in a caller-owned workspace, for <= 5 %; not done.
+// Late in the round the fused VJPs went from the four-corner form to an x-lerped one: the coefficient image
+// keeps column g and the DIFFERENCE to column g + 1, so a z tap's blended vector is one FMA per coefficient
+// and dguide / dinput contract two vectors per pixel instead of four (2 (2 C + 3 CIN) FMAs instead of
+// 4 (C + 3 CIN): -23 VALU instructions per chunk with dinput fused), one vector of a tap read ahead at a time
+// to stay within 4 waves per SIMD; s and 1 / s of the smoothed |dz| from one v_rsq_f32; 24-bit multiplies
+// for the LDS / pixel offsets (v_mad_u64_u32 and v_mul_lo_u32 are quarter-rate).  All three 108.1 -> 104.5 /
+// 109.5 -> 107.9 us at 4K on two boxes, 36.3 -> 34.3 / 34.6 -> 33.6 at 1080p (interleaved, profiles/r03/
+// bwd_step_r03k_*.txt); dgrid alone and dgrid + dguide unchanged within 1 %.
 //
 // Stage 1 (grid_grad_stage1): one workgroup of 4 waves owns one x-interval (all pixels with
 //   gx0 == g, g = -1 .. GW-1) of rg consecutive rows (rg fitted per launch to whole rounds of
@@ -196,7 +204,8 @@ constexpr int kTStride = 68;  // floats per operand row: 64 pixels + 4 (16-B ali
 // each row from grid rows it prefetched with the row's first pixel batch.  The z tent and its
 // derivative share one v_sqrt_f32 per tap with the dgrid weights.
 template <int CIN, int COUT, bool OFFSET, bool APPLY, bool SPLIT, bool WG = false, bool WI = false, int ABL = 0>
-__global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
+__global__ __launch_bounds__(kWaves * 64)
+__attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET ? 1 : 0) : 1) <= 12) ? 4 : 1))) void grid_grad_stage1(GGParams p) {
   constexpr int CJ = APPLY ? CIN + (OFFSET ? 1 : 0) : 1;
   constexpr int C = COUT * CJ;
   static_assert(C <= 16, "one 16-column MFMA tile");
@@ -312,8 +321,10 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
       // nontemporal only where ONE instruction covers the wave's whole run of a tensor (<= 16 B per
       // pixel): an nt line is not kept for a second instruction touching it (profiles/r01, r02/exp6)
       buf_load<1, kLoadAux>(grs, px * 4u, &bt.g[cb]);
-      if constexpr (APPLY && CIN > 0) buf_load<CIN, (CIN <= 4 ? kLoadAux : 0)>(irs, px * (4u * CIN), bt.in[cb]);
-      buf_load<COUT, (COUT <= 4 ? kLoadAux : 0)>(drs, px * (4u * COUT), bt.d[cb]);
+      // (24-bit multiplies -- pixel and plane indices are far below 2^24: v_mul_u32_u24 / v_mad_u32_u24 are
+      //  full-rate, the 32-bit v_mul_lo_u32 / v_mad_u64_u32 the compiler picks otherwise quarter-rate)
+      if constexpr (APPLY && CIN > 0) buf_load<CIN, (CIN <= 4 ? kLoadAux : 0)>(irs, __umul24(px, 4u * CIN), bt.in[cb]);
+      buf_load<COUT, (COUT <= 4 ? kLoadAux : 0)>(drs, __umul24(px, 4u * COUT), bt.d[cb]);
     }
   };
 
@@ -376,8 +387,16 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
         const int gy0 = row_gy0;
         const float wy0 = row_wy0, wy1 = row_wy1;
         if (gy0 != gy0_held) load_grid_rows(gy0);  // wave-uniform; at most once more per wave (rg <= cell height)
+        // column g + 1 is stored as its difference to column g (the lane GD * C4 below holds that element)
+        f32x4 v = wy0 * sa + wy1 * sb;
+        {
+          const int partner = max(lane - p.GD * C4, 0);
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = __shfl(v[e], partner);
+          if (st_col == 1) v = v - o;
+        }
         if (lane < nst) {
-          const f32x4 v = wy0 * sa + wy1 * sb;
           f32x4* d4 = reinterpret_cast<f32x4*>(img);
           d4[st_dst] = v;
           if (st_z == 0) d4[st_dst - C4] = v;
@@ -403,7 +422,7 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
         // max(1 - |dx|, 0) == clamp(1 - |dx|) to [0, 1] (the difference never exceeds 1): one instruction
         const float w0 = __builtin_amdgcn_fmed3f(1.0f - fabsf(dx), 0.0f, 1.0f);
         const float w1 = __builtin_amdgcn_fmed3f(1.0f - fabsf(dx + 1.0f), 0.0f, 1.0f);
-        const float wa = w0, wb = w1;
+        [[maybe_unused]] const float wb = w1;
         // z: only the two corners around gzf carry weight (:121); the outermost half cells are
         // forced to 1 (:122-125).  Two v_sqrt_f32 per pixel (1 ulp; argument >= 1e-8, no
         // denormals; a weight moves by <= 6e-8, far below the summation noise of a 30 000-term
@@ -417,8 +436,14 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
         // the reference's `abs_dx > 1 ? 0 : dx / abs_dx` (numerics.h:116-126) takes its zero branch
         // only for wild guides whose f32 offsets round to 2; for every guide with an exact gzf a
         // 1-ulp sqrt cannot flip it (sqrt(1.0f) is exact).  The derivative is dz / s with v_rcp_f32.
-        const float sza = __builtin_amdgcn_sqrtf(fmaf(dza, dza, kSmoothEps));
-        const float szb = __builtin_amdgcn_sqrtf(fmaf(dzb, dzb, kSmoothEps));
+        // With dguide fused the smoothed |dz| and its reciprocal (the derivative is dz / s) come from ONE
+        // v_rsq_f32 per tap -- s = q * rsq(q), 1.5 ulp instead of v_sqrt_f32's 1 -- instead of a v_sqrt_f32 and a
+        // v_rcp_f32 (each a quarter-rate instruction); rsq(1.0f) is exact, so is s there.
+        const float qza = fmaf(dza, dza, kSmoothEps), qzb = fmaf(dzb, dzb, kSmoothEps);
+        [[maybe_unused]] const float rza = WG ? __builtin_amdgcn_rsqf(qza) : 0.0f;
+        [[maybe_unused]] const float rzb = WG ? __builtin_amdgcn_rsqf(qzb) : 0.0f;
+        const float sza = WG ? qza * rza : __builtin_amdgcn_sqrtf(qza);
+        const float szb = WG ? qzb * rzb : __builtin_amdgcn_sqrtf(qzb);
         // U[i] = dout_i * [in; 1]: the rows of V the dgrid contraction stages AND the vectors the fused dguide
         // contracts with, as column pairs (CJ = 4 shapes; two packed multiplies per output channel)
         constexpr bool UPAIRS = APPLY && CJ == 4;
@@ -436,10 +461,14 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
         if constexpr (FUSED) {
           // per-pixel VJPs from the row's coefficient image: vectors at (x corner, plane iz + 1 + tap)
           const int iz = (int)__builtin_amdgcn_fmed3f(fz, -1.0f, zhi);
-          const int a0 = (iz + 1) * CB;
+          const int a0 = (int)__umul24((unsigned)(iz + 1), (unsigned)CB);
           // GD * SmoothedLerpWeightGrad (:186-187); the s > 1 branch binds only for wild guides (see above)
-          const float dw0 = (sza > 1.0f) ? 0.0f : gd_f * (dza * __builtin_amdgcn_rcpf(sza));
-          const float dw1 = (szb > 1.0f) ? 0.0f : gd_f * (dzb * __builtin_amdgcn_rcpf(szb));
+          // (the branch is taken on q = s^2: sqrt is monotone and sqrt(1.0f) == 1.0f, so q > 1 <=> the reference's
+          //  correctly rounded s > 1 except for q within 2 ulp above 1, which no guide produces -- dz is an exact
+          //  difference in [-1, 1] or, for wild guides, +-2 and beyond -- while q * rsq(q) may round to 1 + ulp
+          //  for q just BELOW 1, i.e. a guide within 1e-7 of a cell boundary: ~16 pixels of a random 4K frame)
+          const float dw0 = (qza > 1.0f) ? 0.0f : gd_f * (dza * (WG ? rza : __builtin_amdgcn_rcpf(sza)));
+          const float dw1 = (qzb > 1.0f) ? 0.0f : gd_f * (dzb * (WG ? rzb : __builtin_amdgcn_rcpf(szb)));
           // Direct form (no 2 x C blended-coefficient accumulators: 4 scalars instead of 24 registers
           // live, which is what keeps this kernel at 4 waves per SIMD).  With U[c] = dout_i * [in; 1]_j
           // -- the SAME per-pixel products the dgrid contraction uses -- and G_v the coefficient
@@ -449,60 +478,59 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
           float dgv = 0.0f;
           f32x2 div01 = {0.0f, 0.0f}, div23 = {0.0f, 0.0f};  // dinput columns (0, 1), (2, 3)
           {
-            const float wz0 = __builtin_amdgcn_fmed3f(1.0f - sza, 0.0f, 1.0f);  // max(1 - s, 0): s > 0
-            const float wz1 = __builtin_amdgcn_fmed3f(1.0f - szb, 0.0f, 1.0f);
-            const float wgt[4] = {wa * wz0, wa * wz1, wb * wz0, wb * wz1};
-            const float dwg[4] = {wa * dw0, wa * dw1, wb * dw0, wb * dw1};
-            const int off[4] = {a0, a0 + CB, a0 + colb, a0 + colb + CB};
-            auto read_corner = [&](int v, f32x4 (&dst)[C / 4]) {
-              const f32x4* gp4 = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(img) + off[v]);
+            // The image holds column g and the DIFFERENCE to column g + 1, so the x blend of a z tap is one FMA
+            // per coefficient -- G_t = A_t + w1 (B_t - A_t); the two x weights sum to 1 up to rounding (w0 =
+            // 1 - |dx|, w1 = 1 - |dx + 1|, dx in (-1, 0]; bilateral_slice_apply.cc:58-68), so this moves a
+            // coefficient by <= 1 ulp of max(|A|, |B|).  Then, with U[c] = dout_i * [in; 1]_j -- the SAME
+            // per-pixel products the dgrid contraction uses -- per tap t:
+            //   dguide   += dw_t <G_t, U>                 (bilateral_slice_apply.cc:140-206)
+            //   dinput_j += wz_t sum_i dout_i G_t[i, j]   (:208-259)
+            // 2 x (C + C + 3 CIN) FMAs per pixel instead of the four-corner form's 4 x (C + 3 CIN).
+            const float wzt[2] = {__builtin_amdgcn_fmed3f(1.0f - sza, 0.0f, 1.0f),   // max(1 - s, 0): s > 0
+                                  __builtin_amdgcn_fmed3f(1.0f - szb, 0.0f, 1.0f)};
+            const float dwt[2] = {dw0, dw1};
+            const f32x4 wx1 = {wb, wb, wb, wb};
+            // One float4 of a tap at a time (row i of [COUT][CJ = 4] for APPLY, channels 4 q .. 4 q + 3 for a
+            // slice), the next one's two reads issued under this one's math: a whole tap in registers (A and the
+            // difference: 2 C floats) costs the fourth wave per SIMD.  Tap 1's vectors follow tap 0's in the image.
+            constexpr int NQ = C / 4, NS = 2 * NQ;
+            const char* ibase = reinterpret_cast<const char*>(img) + a0;
+            f32x4 nA = *reinterpret_cast<const f32x4*>(ibase), nD = *reinterpret_cast<const f32x4*>(ibase + colb);
+            f32x2 acc = {0.0f, 0.0f}, t01 = {0.0f, 0.0f}, t23 = {0.0f, 0.0f};
 #pragma unroll
-              for (int q = 0; q < C / 4; ++q) dst[q] = gp4[q];
-            };
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-              // this corner's vector: rows i of [COUT][CJ = 4] are the float4s Gc[i] (APPLY), or C / 4 float4s (slice).
-              // With dinput fused the corners are kept apart (sched_barrier below): all four hoisted need 144
-              // VGPRs = 3 waves per SIMD; two in flight (the next one's reads under this one's math) measured
-              // no faster than one (profiles/r03/bwd_prev_vs_new_*.txt).
-              f32x4 Gc[C / 4];
-              read_corner(v, Gc);
-              // Packed (v_pk_fma_f32) contractions: 35 fewer VALU instructions per chunk at the same time (a packed
-              // FMA issues as two passes on gfx950: profiles/r03/bwd_step_r03j_*.txt) -- kept for the shorter code.
+            for (int st = 0; st < NS; ++st) {
+              const int t = st / NQ, q = st % NQ;
+              const f32x4 G = __builtin_elementwise_fma(wx1, nD, nA);
+              if (st + 1 < NS) {
+                nA = *reinterpret_cast<const f32x4*>(ibase + (st + 1) * 16);
+                nD = *reinterpret_cast<const f32x4*>(ibase + colb + (st + 1) * 16);
+              }
+              if (q == 0) acc = t01 = t23 = f32x2{0.0f, 0.0f};
               if constexpr (WG) {
-                f32x2 acc = {0.0f, 0.0f};
-                if constexpr (APPLY) {
+                if constexpr (APPLY) {  // <G[i, :], dout_i * [in; 1]> two columns at a time
                   static_assert(CJ == 4, "fused apply shapes have 4 grid columns per output channel");
-#pragma unroll
-                  for (int i = 0; i < COUT; ++i) {  // <G[i, :], dout_i * [in; 1]> two columns at a time
-                    acc = __builtin_elementwise_fma(f32x2{Gc[i].x, Gc[i].y}, U01[i], acc);
-                    acc = __builtin_elementwise_fma(f32x2{Gc[i].z, Gc[i].w}, U23[i], acc);
-                  }
+                  acc = __builtin_elementwise_fma(f32x2{G.x, G.y}, U01[q], acc);
+                  acc = __builtin_elementwise_fma(f32x2{G.z, G.w}, U23[q], acc);
                 } else {
-#pragma unroll
-                  for (int q = 0; q < C / 4; ++q) {
-                    acc = __builtin_elementwise_fma(f32x2{Gc[q].x, Gc[q].y}, f32x2{cur.d[cb][4 * q], cur.d[cb][4 * q + 1]}, acc);
-                    acc = __builtin_elementwise_fma(f32x2{Gc[q].z, Gc[q].w}, f32x2{cur.d[cb][4 * q + 2], cur.d[cb][4 * q + 3]}, acc);
-                  }
+                  acc = __builtin_elementwise_fma(f32x2{G.x, G.y}, f32x2{cur.d[cb][4 * q], cur.d[cb][4 * q + 1]}, acc);
+                  acc = __builtin_elementwise_fma(f32x2{G.z, G.w}, f32x2{cur.d[cb][4 * q + 2], cur.d[cb][4 * q + 3]}, acc);
                 }
-                dgv = fmaf(dwg[v], acc.x + acc.y, dgv);
+                if (q == NQ - 1) dgv = fmaf(dwt[t], acc.x + acc.y, dgv);
               }
               if constexpr (WI) {
                 // t_j = sum_i G[i, j] dout_i: columns (0, 1) packed, column 2 (and 3 for CIN = 4) beside them
-                f32x2 t01 = {0.0f, 0.0f}, t23 = {0.0f, 0.0f};
-#pragma unroll
-                for (int i = 0; i < COUT; ++i) {
-                  const f32x2 di = {cur.d[cb][i], cur.d[cb][i]};
-                  t01 = __builtin_elementwise_fma(f32x2{Gc[i].x, Gc[i].y}, di, t01);
-                  if constexpr (CIN > 3) t23 = __builtin_elementwise_fma(f32x2{Gc[i].z, Gc[i].w}, di, t23);
-                  else if constexpr (CIN > 2) t23.x = fmaf(Gc[i].z, cur.d[cb][i], t23.x);
+                const f32x2 di = {cur.d[cb][q], cur.d[cb][q]};
+                t01 = __builtin_elementwise_fma(f32x2{G.x, G.y}, di, t01);
+                if constexpr (CIN > 3) t23 = __builtin_elementwise_fma(f32x2{G.z, G.w}, di, t23);
+                else if constexpr (CIN > 2) t23.x = fmaf(G.z, cur.d[cb][q], t23.x);
+                if (q == NQ - 1) {
+                  const f32x2 wv = {wzt[t], wzt[t]};
+                  div01 = __builtin_elementwise_fma(wv, t01, div01);
+                  if constexpr (CIN > 3) div23 = __builtin_elementwise_fma(wv, t23, div23);
+                  else if constexpr (CIN > 2) div23.x = fmaf(wzt[t], t23.x, div23.x);
                 }
-                const f32x2 wv = {wgt[v], wgt[v]};
-                div01 = __builtin_elementwise_fma(wv, t01, div01);
-                if constexpr (CIN > 3) div23 = __builtin_elementwise_fma(wv, t23, div23);
-                else if constexpr (CIN > 2) div23.x = fmaf(wgt[v], t23.x, div23.x);
-                __builtin_amdgcn_sched_barrier(0);  // ... and the corner after next is not hoisted above this one
               }
+              __builtin_amdgcn_sched_barrier(0);  // keeps the read-ahead at one vector
             }
           }
           {  // nontemporal buffer stores; descriptors end at the interval, so dead lanes are dropped
@@ -515,7 +543,7 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
               const __amdgpu_buffer_rsrc_t rs = rows::make_rsrc(p.dinput + prow_out * CIN, (unsigned)x_hi * (4u * CIN));
               if constexpr (CIN == 3) {
                 const u32x3 v = {__float_as_uint(div01.x), __float_as_uint(div01.y), __float_as_uint(div23.x)};
-                __builtin_amdgcn_raw_buffer_store_b96(v, rs, px * 12u, 0, rows::kAuxStream);
+                __builtin_amdgcn_raw_buffer_store_b96(v, rs, __umul24(px, 12u), 0, rows::kAuxStream);
               } else if constexpr (CIN == 4) {
                 const u32x4 v = {__float_as_uint(div01.x), __float_as_uint(div01.y), __float_as_uint(div23.x), __float_as_uint(div23.y)};
                 __builtin_amdgcn_raw_buffer_store_b128(v, rs, px * 16u, 0, rows::kAuxStream);
@@ -523,7 +551,7 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
                 const float dv[4] = {div01.x, div01.y, div23.x, div23.y};
 #pragma unroll
                 for (int j = 0; j < CIN; ++j)
-                  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dv[j]), rs, (px * CIN + j) * 4u, 0, rows::kAuxStream);
+                  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dv[j]), rs, (__umul24(px, CIN) + j) * 4u, 0, rows::kAuxStream);
               }
             }
           }
@@ -536,8 +564,8 @@ __global__ __launch_bounds__(kWaves * 64) void grid_grad_stage1(GGParams p) {
         const float wP = edge ? 1.0f : __builtin_amdgcn_fmed3f(1.0f - sza, 0.0f, 1.0f);
         const float wQ = edge ? 0.0f : __builtin_amdgcn_fmed3f(1.0f - szb, 0.0f, 1.0f);
         const int zP = (int)__builtin_amdgcn_fmed3f(fz, 0.0f, zhi), zQ = min(zP + 1, p.GD - 1);
-        float* aP = at + zP * kTStride + lane;
-        float* aQ = at + zQ * kTStride + lane;
+        float* aP = at + __umul24((unsigned)zP, (unsigned)kTStride) + lane;
+        float* aQ = at + __umul24((unsigned)zQ, (unsigned)kTStride) + lane;
         auto enc = [](float v) { return SPLIT ? split_pack(v) : v; };
         aQ[0] = enc(w0 * wQ);
         aQ[8 * kTStride] = enc(w1 * wQ);
