@@ -34,8 +34,9 @@
 //     where segments are whole 128-B lines and 10 % worse than `nt` where they are not, so the
 //     flavour is chosen per launch (launch_apply_fwd_seg below; rows_common.hip.h; profiles/r02/).
 //   * 3-D launch grid (segment, row, batch): no integer division in the kernel.
-//   * ROUND 3 -- a shorter pixel phase (it, not the memory system, is what follows the shader clock when the
-//     power manager throttles: profiles/r02/slow_box, r03/): the LEAN per-pixel code of seg_common.hip.h
+//   * ROUND 3 -- a shorter pixel phase (it, not the memory system, is what slows down in the power management's
+//     slow state -- at an unchanged REPORTED clock: profiles/r03/power/summary.txt; the kernel runs at the
+//     1400-W package cap, 1.74-1.9 GHz): the LEAN per-pixel code of seg_common.hip.h
 //     (v_fract x weight, float byte addresses, clamp-modifier tents), the pixel runs fetched as
 //     `buffer_load_dwordx4 ... lds` (one per-lane offset register for all four 1-KiB pieces, the run's end
 //     enforced by the descriptor instead of four clamps + 64-bit address adds), the segment's grid-column
