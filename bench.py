@@ -231,21 +231,75 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def sustained(step_fn, dev, est_us, seconds=0.5, window=100):
+class _PowerProbe:
+    """Shader clock and socket power of one GPU through librocm_smi64 (one sysfs read per call).  Reported beside
+    the sustained block because this kernel runs at the package power cap (profiles/r03/power/):
+    the numbers say which regime the box was in.  Every failure (no library, no permission) just drops the block."""
+
+    def __init__(self, index):
+        import ctypes
+
+        class Freq(ctypes.Structure):
+            _fields_ = [("has_deep_sleep", ctypes.c_bool), ("num_supported", ctypes.c_uint32),
+                        ("current", ctypes.c_uint32), ("frequency", ctypes.c_uint64 * 33)]
+
+        self.ct = ctypes
+        self.lib = ctypes.CDLL("librocm_smi64.so" if not os.path.exists("/opt/rocm/lib/librocm_smi64.so")
+                               else "/opt/rocm/lib/librocm_smi64.so")
+        if self.lib.rsmi_init(ctypes.c_uint64(0)):
+            raise RuntimeError("rsmi_init failed")
+        self.i = ctypes.c_uint32(index)
+        self.f, self.p, self.t = Freq(), ctypes.c_uint64(0), ctypes.c_int(0)
+        self.sclk, self.power = [], []
+
+    def cap_w(self):
+        cap = self.ct.c_uint64(0)
+        return None if self.lib.rsmi_dev_power_cap_get(self.i, 0, self.ct.byref(cap)) else cap.value / 1e6
+
+    def sample(self):
+        if not self.lib.rsmi_dev_gpu_clk_freq_get(self.i, 0, self.ct.byref(self.f)) and self.f.current < 33:
+            self.sclk.append(self.f.frequency[self.f.current] / 1e6)
+        if not self.lib.rsmi_dev_power_get(self.i, self.ct.byref(self.p), self.ct.byref(self.t)):
+            self.power.append(self.p.value / 1e6)
+
+    def summary(self):
+        if not self.sclk or not self.power:
+            return None
+        return {"socket_w_mean": round(sum(self.power) / len(self.power), 1), "socket_w_max": round(max(self.power), 1),
+                "cap_w": self.cap_w(), "sclk_mhz_mean": round(sum(self.sclk) / len(self.sclk)),
+                "sclk_mhz_min": round(min(self.sclk)), "sclk_mhz_max": round(max(self.sclk)),
+                "samples": len(self.power), "how": "librocm_smi64, read by the launching thread every 4 windows"}
+
+
+def sustained(step_fn, dev, est_us, seconds=0.5, window=100, smi_index=None):
     """Mean and spread of the per-launch time over `seconds` of back-to-back launches (event windows)."""
     n_win = max(4, int(seconds / (window * est_us * 1e-6)))
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_win + 1)]
+    probe = None
+    if smi_index is not None:
+        try:
+            probe = _PowerProbe(smi_index)
+        except Exception:  # noqa: BLE001
+            probe = None
     ev[0].record()
     for w in range(n_win):
         step_fn(window, w * window)
         ev[w + 1].record()
+        if probe and w % 4 == 3 and w > n_win // 10:  # the device is busy from the first window on (the host
+            try:                                        # runs ahead of it); two sysfs reads every 4 windows
+                probe.sample()
+            except Exception:  # noqa: BLE001
+                probe = None
     torch.cuda.synchronize(dev)
     us = [ev[w].elapsed_time(ev[w + 1]) / window * 1e3 for w in range(n_win)]
     lo = min(us)
-    return {"launches": n_win * window, "us_per_launch_mean": round(sum(us) / len(us), 3),
-            "window_us_min": round(lo, 3), "window_us_max": round(max(us), 3),
-            "slow_window_fraction": round(sum(1 for x in us if x > 1.08 * lo) / len(us), 3),
-            "window_launches": window}
+    out = {"launches": n_win * window, "us_per_launch_mean": round(sum(us) / len(us), 3),
+           "window_us_min": round(lo, 3), "window_us_max": round(max(us), 3),
+           "slow_window_fraction": round(sum(1 for x in us if x > 1.08 * lo) / len(us), 3),
+           "window_launches": window}
+    if probe and probe.summary():
+        out["power"] = probe.summary()
+    return out
 
 
 def preroll(step_fn, sync_fn, min_seconds=0.25, chunk=64, max_launches=100000):
@@ -366,7 +420,7 @@ def main():
     if world == 1:
         # ~0.5 s more of back-to-back launches in 100-launch HIP-event windows: what a long-running caller
         # gets on this box, and how much it wanders (profiles/r02/exp35).
-        sus = sustained(step, dev, est_us=avg_kernel_s * 1e6)
+        sus = sustained(step, dev, est_us=avg_kernel_s * 1e6, smi_index=dev.index or 0)
         result["sustained"] = sus
         result["roofline"]["frac_sustained"] = round(
             abytes / (sus["us_per_launch_mean"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
