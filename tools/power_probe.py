@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--metrics", action="store_true", help="also read gpu_metrics (amdsmi) once per window")
     ap.add_argument("--dump-keys", action="store_true")
+    ap.add_argument("--grad", action="store_true", help="the gradient entry point instead of the forward variants")
     ap.add_argument("--pattern", default="", help="e.g. 0,0,0,106: one continuous run, windows cycling through these variants")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -164,6 +165,50 @@ def main():
                           f"(min {min(r[1] for r in sel):.2f}, max {max(r[1] for r in sel):.2f})   sclk {mean([r[2] for r in sel]):.0f} MHz   "
                           f"power {mean([r[3] for r in sel]):.0f} W")
         print("  timeline (variant:us): " + " ".join(f"{r[0]}:{r[1]:.1f}" for r in rows[:160]))
+        return
+    if args.grad:
+        # the gradient entry point (product library): all three gradients, dgrid + dguide, dgrid alone
+        plib = _lib.load()
+        Cin, Cout, C = 3, 3, 12
+        gen = torch.Generator(device=dev).manual_seed(1)
+        G = [dict(dout=torch.randn((B, H, W, Cout), device=dev, generator=gen),
+                  dgrid=torch.empty((B, GH, GW, GD, C), device=dev), dguide=torch.empty((B, H, W), device=dev),
+                  dinput=torch.empty((B, H, W, Cin), device=dev)) for _ in range(nsets)]
+        n = plib.hdrnet_bilateral_slice_apply_grad_workspace_bytes(B, H, W, GH, GW, GD, Cin, Cout, 1)
+        ws = torch.empty((max(n, 16),), dtype=torch.uint8, device=dev)
+        for case, (dg, dgu, di) in (("all three", (1, 1, 1)), ("dgrid + dguide", (1, 1, 0)), ("dgrid", (1, 0, 0))):
+            def fn(k):
+                grid, guide, inp, _ = sets[k % nsets]
+                g = G[k % nsets]
+                rc = plib.hdrnet_bilateral_slice_apply_grad_f32(
+                    grid.data_ptr(), guide.data_ptr(), inp.data_ptr(), g["dout"].data_ptr(),
+                    g["dgrid"].data_ptr() if dg else None, g["dguide"].data_ptr() if dgu else None,
+                    g["dinput"].data_ptr() if di else None, B, H, W, GH, GW, GD, Cin, Cout, 1,
+                    ws.data_ptr(), ws.numel(), stream)
+                if rc:
+                    raise RuntimeError(plib.hdrnet_last_error().decode())
+            evs = [torch.cuda.Event(enable_timing=True)]
+            evs[0].record()
+            rows, k, done = [], 0, 0
+            t_start = time.perf_counter()
+            while time.perf_counter() - t_start < args.seconds:
+                for _ in range(args.window // 2):
+                    fn(k)
+                    k += 1
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                evs.append(e)
+                if len(evs) - 1 - done > 2:
+                    evs[done + 1].synchronize()
+                    rows.append((evs[done].elapsed_time(evs[done + 1]) * 1e3 / (args.window // 2), smi.sclk_mhz(), smi.power_w()))
+                    done += 1
+            torch.cuda.synchronize()
+            rows = rows[len(rows) // 10:]
+            mean = lambda a: sum(a) / len(a)
+            print(f"apply grad, {case:15s} {mean([r[0] for r in rows]):7.2f} us (windows {min(r[0] for r in rows):.2f}-{max(r[0] for r in rows):.2f})"
+                  f"   sclk {mean([r[1] for r in rows]):.0f} MHz ({min(r[1] for r in rows):.0f}-{max(r[1] for r in rows):.0f})"
+                  f"   power {mean([r[2] for r in rows]):.0f} W ({min(r[2] for r in rows):.0f}-{max(r[2] for r in rows):.0f})")
+            time.sleep(0.3)
         return
     record = {}
     for rep in range(args.repeat):
