@@ -61,6 +61,35 @@ class Smi:
         return float("nan") if rc else self.t.value / 1e3
 
 
+class EffClk:
+    """One sleeping wave per window on a second stream, started by the window's opening event: shader-clock ticks
+    (clock64) per 100-MHz wall-clock tick = the clock the CU really ran at, whatever the firmware reports."""
+
+    def __init__(self, dev, max_windows=4096, iters=700):
+        path = os.path.join(ROOT, "tools", "debug", "ubench", "bin", "libclkprobe.so")
+        self.lib = ctypes.CDLL(path)
+        self.lib.clk_probe_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        self.out = torch.zeros((max_windows, 2), dtype=torch.int64, device=dev)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.iters = iters
+        self.n = 0
+
+    def start(self, opening_event):
+        if self.n >= self.out.shape[0]:
+            return
+        self.stream.wait_event(opening_event)
+        rc = self.lib.clk_probe_launch(self.out[self.n].data_ptr(), self.iters, self.stream.cuda_stream)
+        if rc:
+            raise RuntimeError(f"clk_probe_launch -> {rc}")
+        self.n += 1
+
+    def mhz(self):
+        torch.cuda.synchronize()
+        o = self.out[:self.n].cpu().tolist()
+        self.n = 0
+        return [100.0 * c / w if w else float("nan") for c, w in o]
+
+
 class Metrics:
     """gpu_metrics through the amdsmi python package that ships with ROCm (per-XCD clocks, throttler residencies)."""
 
@@ -89,6 +118,8 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--metrics", action="store_true", help="also read gpu_metrics (amdsmi) once per window")
     ap.add_argument("--dump-keys", action="store_true")
+    ap.add_argument("--effclk", action="store_true",
+                    help="count the EFFECTIVE shader clock beside every window (tools/debug/ubench/clk_probe.hip on a second stream)")
     ap.add_argument("--grad", action="store_true", help="the gradient entry point instead of the forward variants")
     ap.add_argument("--pattern", default="", help="e.g. 0,0,0,106: one continuous run, windows cycling through these variants")
     args = ap.parse_args()
@@ -130,8 +161,11 @@ def main():
         k = 0
         done = 0
         t_start = time.perf_counter()
+        eff = EffClk(dev) if args.effclk else None
         while time.perf_counter() - t_start < args.seconds:
             fn = fns[pat[(len(evs) - 1) % len(pat)]]
+            if eff:
+                eff.start(evs[-1])
             for _ in range(args.window):
                 fn(k)
                 k += 1
@@ -144,6 +178,9 @@ def main():
                              smi.sclk_mhz(), smi.power_w()))
                 done += 1
         torch.cuda.synchronize()
+        if eff:
+            em = eff.mhz()
+            rows = [r + (em[i] if i < len(em) else float("nan"),) for i, r in enumerate(rows)]
         rows = rows[len(rows) // 10:]
         mean = lambda a: (sum(a) / len(a)) if a else float("nan")
         lead = pat[0]
@@ -163,7 +200,9 @@ def main():
                 if sel:
                     print(f"  variant {v:3d} in {st_name}: {len(sel):4d} windows  {mean([r[1] for r in sel]):6.2f} us "
                           f"(min {min(r[1] for r in sel):.2f}, max {max(r[1] for r in sel):.2f})   sclk {mean([r[2] for r in sel]):.0f} MHz   "
-                          f"power {mean([r[3] for r in sel]):.0f} W")
+                          f"power {mean([r[3] for r in sel]):.0f} W"
+                          + (f"   EFFECTIVE clock {mean([r[4] for r in sel]):.0f} MHz ({min(r[4] for r in sel):.0f}-{max(r[4] for r in sel):.0f})"
+                             if len(sel[0]) > 4 else ""))
         print("  timeline (variant:us): " + " ".join(f"{r[0]}:{r[1]:.1f}" for r in rows[:160]))
         return
     if args.grad:
@@ -211,6 +250,7 @@ def main():
             time.sleep(0.3)
         return
     record = {}
+    eff = EffClk(dev) if args.effclk else None
     for rep in range(args.repeat):
         for v in [int(x) for x in args.variants.split(",")]:
             fn = launcher(_lib.KERNEL_FAST | (v << 8))
@@ -226,6 +266,8 @@ def main():
             t_start = time.perf_counter()
             done = 0
             while True:
+                if eff:
+                    eff.start(evs[-1])
                 for _ in range(args.window):
                     fn(k)
                     k += 1
@@ -243,6 +285,16 @@ def main():
                     break
             torch.cuda.synchronize()
             temp = smi.hotspot_c()
+            if eff:
+                em = eff.mhz()[:len(rows)]
+                cut = len(rows) // 10
+                usw = [r[1] for r in rows[cut:]]
+                lim = 1.05 * min(usw)
+                ef = [m for m, u in zip(em[cut:], usw) if u <= lim]
+                es = [m for m, u in zip(em[cut:], usw) if u > lim]
+                mean_ = lambda a: (sum(a) / len(a)) if a else float("nan")
+                print(f"            EFFECTIVE clock (counted): fast windows {mean_(ef):.0f} MHz ({min(ef):.0f}-{max(ef):.0f})"
+                      + (f", slow windows {mean_(es):.0f} MHz ({min(es):.0f}-{max(es):.0f})" if es else ""))
             if met:
                 m_end = met.read()
                 cut = len(rows) // 10
