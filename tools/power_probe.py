@@ -67,6 +67,10 @@ class EffClk:
 
     def __init__(self, dev, max_windows=4096, iters=700):
         path = os.path.join(ROOT, "tools", "debug", "ubench", "bin", "libclkprobe.so")
+        if not os.path.exists(path):  # built artefacts are not in the history: make it (hipcc is in the image)
+            import subprocess
+            subprocess.run(["make", "-C", os.path.dirname(os.path.dirname(path)), "bin/libclkprobe.so"], check=True,
+                           stdout=subprocess.DEVNULL)
         self.lib = ctypes.CDLL(path)
         self.lib.clk_probe_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         self.out = torch.zeros((max_windows, 2), dtype=torch.int64, device=dev)
