@@ -430,10 +430,16 @@ hipError_t launch_seg_pick(const ApplyArgs& a, hipStream_t s) {
 }
 
 // Round 3 (profiles/r03/ab_variants_4k.txt, two boxes, interleaved): lean pixel phase 40.4 -> 39.6-39.8 us,
-// buffer-form DMA 40.4 -> 39.5 us, both 39.3-39.5 us next to the no-compute skeleton's 39.0; the scalar
-// blend times the same as the packed one (v_pk_fma_f32 issues as two passes on gfx950) with 100 more
-// instructions, so the packed blend stays.
-constexpr int kProductPix = kPixLean, kProductDma = kLoadsBufDmaNt;
+// buffer-form DMA 40.4 -> 39.5 us, both 39.3-39.5 us next to the no-compute skeleton's 39.0.  The SCALAR blend
+// (v_fma_f32 for v_pk_fma_f32: 100 more instructions, bit-identical results) times the same as the packed one on
+// steady boxes (a v_pk_fma_f32 issues as two passes on gfx950) and is the product because of the other boxes:
+// where the power management falls into its high-clock state -- the compute side power-braked, 45-47 us per
+// frame (profiles/r03/power/summary.txt) -- it spends less time there: 42.7 vs 44.6 us mean over four
+// alternations on one such box, 41.4-41.5 vs 44.5-47.5 on two others, equal on a fourth (power/scalar_blend.txt).
+constexpr int kProductPix = kPixLeanScalar, kProductDma = kLoadsBufDmaNt;
+// The guide-network forwards are VALU-bound (16 features x 5 operations per pixel on top of the pixel phase): there
+// the 100 extra instructions of the scalar blend cost 0.7-4 % (power/scalar_blend.txt), so they keep the packed one.
+constexpr int kGuideNNPix = kPixLean;
 
 hipError_t launch_apply_fwd_seg(const ApplyArgs& a, hipStream_t s, const char** name) {
   *name = "apply_fwd_seg/vec4";
@@ -457,7 +463,7 @@ hipError_t launch_apply_fwd_seg_nnguide(const ApplyArgs& a, const float* conv1, 
   *name = "apply_fwd_seg/vec4+nnguide";
 #define HDRNET_CASE(CI, CO, OFF)                          \
   if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF) \
-    return launch_seg_t<CI, CO, OFF, kProductDma, kStoresBufNt, false, true, false, kProductPix>(a, s, nullptr, gn)
+    return launch_seg_t<CI, CO, OFF, kProductDma, kStoresBufNt, false, true, false, kGuideNNPix>(a, s, nullptr, gn)
   HDRNET_CASE(3, 3, true);
   HDRNET_CASE(3, 3, false);
   HDRNET_CASE(1, 1, true);
@@ -479,7 +485,7 @@ hipError_t launch_apply_fwd_seg_upadd(const ApplyArgs& a, const float* coarse, i
   const UpAdd up{coarse, Hc, Wc, resize_scale(Hc, a.H), resize_scale(Wc, a.W)};
   if (conv1) {
     *name = "apply_fwd_seg/vec4+nnguide+upadd";
-    return launch_seg_t<3, 3, true, kProductDma, kStoresBufNt, false, true, true, kProductPix>(
+    return launch_seg_t<3, 3, true, kProductDma, kStoresBufNt, false, true, true, kGuideNNPix>(
         a, s, nullptr, GuideNN{conv1, conv2, nullptr, n_feats}, up);
   }
   *name = "apply_fwd_seg/vec4+upadd";

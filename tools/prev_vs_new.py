@@ -60,6 +60,11 @@ def main():
               dinput=torch.empty((B, H, W, Cin), device=dev)) for _ in range(nsets)]
     sl = [dict(dout=torch.randn((B, H, W, C), device=dev, generator=gen),
                out=torch.empty((B, H, W, C), device=dev)) for _ in range(2)]
+    conv1 = (torch.randn((16, Cin + 1), device=dev, generator=gen) * 0.8).contiguous()
+    conv2 = (torch.randn((17,), device=dev, generator=gen) * 0.5).contiguous()
+    u8 = [dict(inp=torch.randint(0, 256, (B, H, W, 3), device=dev, dtype=torch.uint8),
+               out=torch.empty((B, H, W, 3), device=dev, dtype=torch.uint8)) for _ in range(nsets)]
+    coarse = [torch.randn((B, H // 2, W // 2, 3), device=dev, generator=gen) for _ in range(nsets)]
     stream = torch.cuda.current_stream(dev).cuda_stream
     ws, ws2 = {}, {}
     for k, lib in libs.items():
@@ -93,6 +98,30 @@ def main():
                 chk(lib.hdrnet_bilateral_slice_grad_f32(s["grid"].data_ptr(), s["guide"].data_ptr(), t["dout"].data_ptr(),
                                                         s["dgrid"].data_ptr(), s["dguide"].data_ptr(), B, H, W, GH, GW, GD,
                                                         C, ws2[which].data_ptr(), ws2[which].numel(), stream))
+            return fn
+        if case == "nn":  # guide network fused into the forward
+            def fn(k):
+                s = S[k % nsets]
+                chk(lib.hdrnet_bilateral_slice_apply_nnguide_f32(
+                    s["grid"].data_ptr(), s["inp"].data_ptr(), conv1.data_ptr(), conv2.data_ptr(), s["out"].data_ptr(),
+                    None, B, H, W, GH, GW, GD, Cin, Cout, 1, 16, stream))
+            return fn
+        if case in ("u8", "u8nn"):  # u8 in -> (guide map | guide network) -> u8 out
+            nn = case == "u8nn"
+
+            def fn(k):
+                s, t = S[k % nsets], u8[k % nsets]
+                chk(lib.hdrnet_bilateral_slice_apply_io(
+                    s["grid"].data_ptr(), None if nn else s["guide"].data_ptr(), t["inp"].data_ptr(), t["out"].data_ptr(),
+                    B, H, W, GH, GW, GD, 3, 3, 1, 1, 255.0, 1, conv1.data_ptr() if nn else None,
+                    conv2.data_ptr() if nn else None, 16 if nn else 0, None, stream))
+            return fn
+        if case == "upadd":
+            def fn(k):
+                s = S[k % nsets]
+                chk(lib.hdrnet_bilateral_slice_apply_upadd_f32(
+                    s["grid"].data_ptr(), s["guide"].data_ptr(), s["inp"].data_ptr(), coarse[k % nsets].data_ptr(),
+                    H // 2, W // 2, s["out"].data_ptr(), B, H, W, GH, GW, GD, 3, 3, 1, None, None, 0, stream))
             return fn
         dg, dgu, di = {"all": (1, 1, 1), "gg": (1, 1, 0), "g": (1, 0, 0), "v": (0, 1, 1)}[case]
 
