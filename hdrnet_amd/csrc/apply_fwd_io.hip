@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
   if (active) {
     if constexpr (GUIDE != kGuideMap) {
       if constexpr (GUIDE == kGuideNN)
-        guide_nn_quad<CIN>(GuideNN{p.gn.conv1, p.gn.conv2, nullptr, p.gn.n}, inf, gs);
+        guide_nn_quad<CIN>(GuideNN{p.gn.conv1, p.gn.conv2, p.gn.guide_out, p.gn.n}, inf, gs);  // (writes nothing itself)
       else
         guide_curves_quad<CIN>(p.gn, inf, gs);
       if (p.gn.guide_out) *reinterpret_cast<float4*>(p.gn.guide_out + px) = make_float4(gs[0], gs[1], gs[2], gs[3]);

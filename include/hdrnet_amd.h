@@ -128,7 +128,9 @@ int hdrnet_bilateral_slice_apply_rows_f32_ex(const float* grid, const float* gui
 /* Fused point-wise guide network + BilateralSliceApply forward (inference).
  * guide[b,y,x] = sigmoid(conv2[n] + sum_k conv2[k] * relu(conv1[k][Cin] + sum_j conv1[k][j] * input[b,y,x,j]))
  * is computed in registers and sliced immediately; it is written to `guide_out` [B][H][W] only if
- * that pointer is non-NULL.  This is HDRNetPointwiseNNGuide._guide (hdrnet/models.py:203-210) with
+ * that pointer is non-NULL.  With `guide_out` the sigmoid is expf + an IEEE divide (the copy feeds a
+ * backward pass, which is sensitive to the guide's last bit); without it, v_exp_f32 + v_rcp_f32
+ * (<= 2 ulp of the guide) -- the two calls' outputs agree to ~1e-6 of their scale, not bit for bit.  This is HDRNetPointwiseNNGuide._guide (hdrnet/models.py:203-210) with
  * batch-norm folded, in the parameter layout hdrnet/bin/freeze_graph.py:170-184 exports
  * (guide_conv1.bin = [n][Cin+1], guide_conv2.bin = [n+1]) -- the fusion the reference's GL
  * renderer performs (benchmark/assets/gpyrnn.frag:42-63, benchmark/src/renderer.cc:119-171).
