@@ -50,6 +50,53 @@ class GraphedInference:
         return self.static_output
 
 
+class FramePipeline:
+    """Independent frames round-robin over ``depth`` HIP streams.
+
+    One launch of the 4K slice-apply spends ~5 us filling the memory pipeline and ~6 us draining it; on ONE stream
+    consecutive launches are serialised, so every frame pays both.  The frames of a stream of images are
+    independent: with two streams the next frame's fill runs under the previous frame's drain -- 39.9 -> 36.9 us per
+    4K frame, 11.6 -> 9.5 (two streams) / 8.6 us (three) per 1080p frame for the bare op
+    (``tools/two_stream_probe.py``, profiles/r03/two_streams.txt).  ``make_lane()`` builds one lane's callable (for
+    a whole model: a ``GraphedInference`` with its own static buffers); ``submit(*inputs)`` runs the next lane on
+    its stream and returns a ticket; ``result(ticket)`` makes the CALLER's current stream wait for that frame and
+    returns its output (valid until the lane is submitted to again, ``depth`` frames later).
+    """
+
+    def __init__(self, make_lane, depth: int = 2, device=None):
+        if depth < 1:
+            raise ValueError("depth >= 1")
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        self.lanes = []
+        for st in self.streams:  # build (and, for graphs, capture) every lane under its own stream
+            st.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(st):
+                self.lanes.append(make_lane())
+        self.done = [torch.cuda.Event() for _ in range(depth)]
+        self.outputs = [None] * depth
+        self.next = 0
+
+    def submit(self, *inputs: torch.Tensor) -> int:
+        lane = self.next
+        self.next = (lane + 1) % len(self.lanes)
+        st = self.streams[lane]
+        st.wait_stream(torch.cuda.current_stream(st.device))  # the inputs were produced on the caller's stream
+        with torch.cuda.stream(st):
+            self.outputs[lane] = self.lanes[lane](*inputs)
+            self.done[lane].record(st)
+        return lane
+
+    def result(self, ticket: int):
+        cur = torch.cuda.current_stream(self.streams[ticket].device)
+        cur.wait_event(self.done[ticket])
+        out = self.outputs[ticket]
+        for t in (out if isinstance(out, (tuple, list)) else (out,)):
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(cur)  # allocated on the lane's stream, read on the caller's: keep the allocator honest
+        return out
+
+
 class GraphedTrainStep:
     """One training step -- forward, loss, backward through the HIP VJPs, (at world size 1) the
     optimizer update -- captured into a hipGraph and replayed per batch.

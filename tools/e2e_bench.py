@@ -56,8 +56,22 @@ def main():
         graphed = GraphedInference(m, [low, full])
         t_graph = timeit(lambda: graphed(graphed.static_inputs[0], graphed.static_inputs[1]), args.steps)
         assert torch.allclose(graphed(low, full), m(low, full), rtol=1e-5, atol=1e-5)
+        # independent frames round-robin over 2 / 3 streams (runtime.FramePipeline), each lane its own captured graph
+        from hdrnet_amd.runtime import FramePipeline
+        t_pipe = {}
+        for depth in (2, 3):
+            pipe = FramePipeline(lambda: GraphedInference(m, [low, full]), depth=depth)
+            lanes = pipe.lanes
+
+            def frame():
+                lane = pipe.next
+                pipe.submit(lanes[lane].static_inputs[0], lanes[lane].static_inputs[1])
+
+            t_pipe[depth] = timeit(frame, args.steps)
     mp = 2160 * 3840 / 1e6
     print(f"config #3  (hipGraph replay of the whole inference): {t_graph * 1e3:.3f} ms/frame = {mp / t_graph:.0f} MP/s")
+    print(f"config #3  the same, frames round-robin over 2 / 3 streams: {t_pipe[2] * 1e3:.3f} / {t_pipe[3] * 1e3:.3f} ms/frame"
+          f" = {mp / t_pipe[2]:.0f} / {mp / t_pipe[3]:.0f} MP/s")
     print(f"config #3  HDRNetPointwiseNNGuide 3840x2160 b=1: {t_all * 1e3:.3f} ms/frame = {mp / t_all:.0f} MP/s "
           f"(coefficients {t_coef * 1e3:.3f} ms, guide net {t_guide * 1e3:.3f} ms, slice-apply {t_slice * 1e3:.3f} ms)")
 
