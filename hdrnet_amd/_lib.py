@@ -77,6 +77,7 @@ _tools_lib: Optional[ctypes.CDLL] = None
 # Symbols only the tools build exports (include/hdrnet_amd_tools.h).
 TOOLS_SIGNATURES = {
     "hdrnet_tools_set_trace": (None, [_VP]),
+    "hdrnet_tools_set_knob": (None, [ctypes.c_int, ctypes.c_int]),
 }
 
 

@@ -89,6 +89,40 @@ constexpr int kStoresBufSc1 = 3;   // ... sc1 (write-through: the line does not 
 constexpr int kStoresBufSc01 = 4;  // ... sc0 sc1
 // (1 = buffer_store_dwordx4 with the default policy)
 
+// ---- ticketed tail (SCHED = 1) ----------------------------------------------------------------------------
+// The launch grid is flat: workgroups 0 .. S-1 run task = blockIdx.x; the E workgroups behind them draw ONE
+// ticket each for the remaining D tasks (E > D: an XCD that is ahead reaches its ticketed workgroups earlier and
+// takes more than an eighth of them; a workgroup whose ticket is past its pool's tasks exits).
+//
+// Device-scope atomics are the scarce resource here: one word serves ~60-90 returning atomics per us on this
+// fabric and the requests queued on it hold up the memory channel they sit on (round 4, gpurun_out/r04a: a
+// `done` word incremented by every ticketed workgroup stretched a 39-us launch to 55-95 us).  So: kPools
+// counter words, each on a line of its own 4.25 KiB apart; a ticketed workgroup draws exactly ONCE, from the pool
+// of its position (the 8 consecutive workgroups the dispatcher spreads over the 8 XCDs share a pool, the next 8
+// take the next pool: every pool is drawn by all XCDs alike); dynamic task j belongs to pool j % kPools.  Every
+// pool receives exactly E / kPools draws per launch -- the workgroup that draws the last one zeroes the word: a
+// launch finds the words zero and leaves them zero, with no second counter.
+// CONTRACT: two launches that use the same counter block must not execute concurrently.
+constexpr int kPools = 32;
+constexpr int kPoolStride = 1088;  // unsigned per pool (4352 B)
+constexpr unsigned kNoTask = 0xffffffffu;
+constexpr size_t kSchedWords = (size_t)kPools * kPoolStride;
+
+struct DynSched {
+  unsigned* ctr;  // [kPools][kPoolStride]: word 0 of pool p = its tickets
+  unsigned S, D, E;  // E % (8 * kPools) == 0
+  unsigned nseg, nseg_magic, h_magic;  // t / nseg = umulhi(t, nseg_magic), r / H = umulhi(r, h_magic)
+};
+
+__device__ __forceinline__ unsigned dyn_draw(const DynSched& d, unsigned i) {
+  const unsigned pool = (i >> 3) & (kPools - 1);
+  unsigned* w = d.ctr + pool * kPoolStride;
+  const unsigned per = (d.D + kPools - 1 - pool) / kPools;  // tasks j < D with j % kPools == pool
+  const unsigned t = __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t == d.E / kPools - 1) __hip_atomic_store(w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the pool's last draw
+  return t < per ? d.S + t * kPools + pool : kNoTask;
+}
+
 struct SegParams {
   const float* grid;
   const float* guide;
@@ -105,6 +139,7 @@ struct SegParams {
   long long* trace;  // TRACE: [nblocks][3] wall-clock ticks (start, end), XCC id; else unused
   GuideNN gn;        // GUIDE_NN: the folded point-wise guide network (rows_common.hip.h)
   UpAdd up;          // UPADD: the coarser pyramid level to up-sample and add
+  DynSched dyn;      // SCHED != 0: flat launch grid with a ticketed tail (below)
 };
 
 template <int STORES>
@@ -135,26 +170,23 @@ __device__ __forceinline__ void buf_dma_pieces(__amdgpu_buffer_rsrc_t rs, float*
 // GUIDE_NN / UPADD: the guide is computed in registers from the input run
 // the wave has just streamed in (no guide DMA: 24 instead of 28 B/px), and / or the coarser pyramid
 // level is up-sampled and added before the store -- HDRNetPointwiseNNGuide / HDRNetGaussianPyrNN.
-template <int CIN, int COUT, bool OFFSET, int LOADS, int STORES, bool TRACE, bool GUIDE_NN = false,
-          bool UPADD = false, int PIX = kPixR02>
-__global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
+template <int CIN, int COUT, bool OFFSET, int LOADS, int STORES, bool TRACE, bool GUIDE_NN, bool UPADD, int PIX>
+__device__ __forceinline__ void seg_task(const SegParams& p, float* __restrict__ lds, const int segi, const int y,
+                                         const int b, [[maybe_unused]] const size_t trace_slot) {
   constexpr int CJ = CIN + (OFFSET ? 1 : 0);
   constexpr int C = COUT * CJ;
   constexpr int CB = C * (int)sizeof(float);
   constexpr int SLABW = 64 * kPxPerThread * (CIN > COUT ? CIN : COUT);  // floats: in / out run of a wave
   constexpr bool DMA = LOADS >= kLoadsDma;
   constexpr int SLAB = SLABW + ((DMA && !GUIDE_NN) ? 64 * kPxPerThread : 0);  // + the guide run
-  extern __shared__ __attribute__((aligned(16))) float lds[];
 
   long long t_start = 0;
   if constexpr (TRACE) t_start = wall_clock64();
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (SGPR)
-  const int xs = blockIdx.x * p.seg;
+  const int xs = segi * p.seg;
   const int xe = min(xs + p.seg, p.W);
-  const int y = blockIdx.y;
-  const int b = blockIdx.z;
   const float* grid_b = p.grid + (size_t)b * (unsigned)p.grid_image;
 
   const int x = xs + kPxPerThread * tid;
@@ -165,7 +197,7 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
   [[maybe_unused]] float4* gslab = slab + SLABW / 4;  // DMA only
 
   // Grid columns of this segment, unclamped: gx0 of the first pixel .. gx0 + 1 of the last.
-  const SegCols sc = seg_cols_tab(p.tab, blockIdx.x, xs, xe, p.scale_x);
+  const SegCols sc = seg_cols_tab(p.tab, segi, xs, xe, p.scale_x);
   const int cmin = sc.cmin, ncols = sc.ncols;
   const int colb = (p.GD + 2) * CB;
   const float gd_f = (float)p.GD, zhi = (float)(p.GD - 1);
@@ -320,10 +352,42 @@ __global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
 
   if constexpr (TRACE) {
     if (tid == 0) {
-      const size_t bid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-      p.trace[3 * bid] = t_start;
-      p.trace[3 * bid + 1] = wall_clock64();
-      p.trace[3 * bid + 2] = __builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0xf;  // HW_REG_XCC_ID
+      p.trace[3 * trace_slot] = t_start;
+      p.trace[3 * trace_slot + 1] = wall_clock64();
+      p.trace[3 * trace_slot + 2] = __builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0xf;  // HW_REG_XCC_ID
+    }
+  }
+}
+
+// SCHED = 0: the 3-D launch grid (segment, row, image) -- one task per workgroup, no index arithmetic.
+// SCHED = 1: a FLAT grid whose last workgroups take their task from ticket counters (DynSched): the XCDs of a
+//            launch do not finish together (1350 workgroups each at 4K, ends 2-3.4 us apart: the last 1 % of the
+//            workgroups retires over the last 2 us of a 39-us launch, profiles/r03/ab_variants_4k.txt), and a
+//            statically assigned tail cannot move to the XCDs that are ahead.
+template <int CIN, int COUT, bool OFFSET, int LOADS, int STORES, bool TRACE, bool GUIDE_NN = false,
+          bool UPADD = false, int PIX = kPixR02, int SCHED = 0>
+__global__ __launch_bounds__(256) void apply_fwd_seg(const SegParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if constexpr (SCHED == 0) {
+    seg_task<CIN, COUT, OFFSET, LOADS, STORES, TRACE, GUIDE_NN, UPADD, PIX>(
+        p, lds, blockIdx.x, blockIdx.y, blockIdx.z,
+        ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+  } else {
+    __shared__ unsigned s_task;
+    const DynSched& d = p.dyn;
+    unsigned t = blockIdx.x;
+    const bool dynamic = t >= d.S;  // uniform
+    if (dynamic) {
+      if (threadIdx.x == 0) s_task = dyn_draw(d, t - d.S);
+      __syncthreads();
+      t = s_task;
+    }
+    if (t != kNoTask) {
+      const unsigned r = __umulhi(t, d.nseg_magic);  // t / nseg: row index over all images
+      const unsigned segi = t - r * d.nseg;
+      const unsigned b = __umulhi(r, d.h_magic);     // r / H
+      const unsigned y = r - b * (unsigned)p.H;
+      seg_task<CIN, COUT, OFFSET, LOADS, STORES, TRACE, GUIDE_NN, UPADD, PIX>(p, lds, (int)segi, (int)y, (int)b, t);
     }
   }
 }
@@ -353,15 +417,45 @@ SegGeom seg_geom(const ApplyArgs& a, bool dma, bool guide_map = true) {
   return g;
 }
 
+#ifdef HDRNET_TOOLS_BUILD
+// Experiment knobs of the tools build (hdrnet_tools_set_knob): 0 extra dynamic LDS bytes per workgroup (caps the
+// workgroups per CU), 1 D = ticketed tasks, 2 surplus workgroups E - D.
+int g_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+unsigned* g_sched_words = nullptr;  // kSchedWords zeroed words, allocated on first use
+#endif
+
+inline unsigned div_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / d) + 1u; }
+
+// Flat-grid schedule of M tasks with a ticketed tail of D tasks served by E workgroups.  False: the task count is
+// out of the magic division's exact range (the caller launches the 3-D grid instead).
+inline bool make_dyn_sched(DynSched& d, unsigned* words, long long M, int nseg, int H, long long D, long long E) {
+  const long long dmax = nseg > H ? nseg : H;
+  if (M <= 0 || M * dmax >= (1ll << 32) || M + E >= (1ll << 31) || nseg < 2 || H < 2) return false;
+  if (D > M) D = M;
+  E = (E + 8 * kPools - 1) / (8 * kPools) * (8 * kPools);
+  if (D == 0) E = 0;
+  d.ctr = words;
+  d.S = (unsigned)(M - D);
+  d.D = (unsigned)D;
+  d.E = (unsigned)E;
+  d.nseg = (unsigned)nseg;
+  d.nseg_magic = div_magic((unsigned)nseg);
+  d.h_magic = div_magic((unsigned)H);
+  return true;
+}
+
 template <int CIN, int COUT, bool OFFSET, int LOADS, int STORES, bool TRACE, bool GUIDE_NN = false,
-          bool UPADD = false, int PIX = kPixR02>
+          bool UPADD = false, int PIX = kPixR02, int SCHED = 0>
 hipError_t launch_seg_t(const ApplyArgs& a, hipStream_t s, long long* trace,
                         const GuideNN& gn = GuideNN{nullptr, nullptr, nullptr, 0},
-                        const UpAdd& up = UpAdd{nullptr, 0, 0, 0.f, 0.f}) {
+                        const UpAdd& up = UpAdd{nullptr, 0, 0, 0.f, 0.f}, const DynSched* dyn = nullptr) {
   constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
   constexpr int VEC = (C % 4 == 0) ? 4 : 1;
-  const SegGeom g = seg_geom(a, LOADS >= kLoadsDma, !GUIDE_NN);
+  SegGeom g = seg_geom(a, LOADS >= kLoadsDma, !GUIDE_NN);
   if (!g.ok) return hipErrorNotSupported;
+#ifdef HDRNET_TOOLS_BUILD
+  g.lds += (size_t)g_knob[0];
+#endif
   SegParams p;
   p.gn = gn;
   p.up = up;
@@ -383,8 +477,16 @@ hipError_t launch_seg_t(const ApplyArgs& a, hipStream_t s, long long* trace,
   p.scale_y = (float)a.GH / a.frame_rows();
   p.inv_col = 1.0f / (float)(a.GD * (C / VEC));
   p.trace = trace;
-  const dim3 grid3((unsigned)g.pl.nseg, (unsigned)a.H, (unsigned)a.B);
-  apply_fwd_seg<CIN, COUT, OFFSET, LOADS, STORES, TRACE, GUIDE_NN, UPADD, PIX><<<grid3, g.pl.threads, g.lds, s>>>(p);
+  if constexpr (SCHED != 0) {
+    if (!dyn) return hipErrorInvalidValue;
+    p.dyn = *dyn;
+    apply_fwd_seg<CIN, COUT, OFFSET, LOADS, STORES, TRACE, GUIDE_NN, UPADD, PIX, SCHED>
+        <<<dim3(p.dyn.S + p.dyn.E), g.pl.threads, g.lds, s>>>(p);
+  } else {
+    p.dyn = DynSched{};
+    const dim3 grid3((unsigned)g.pl.nseg, (unsigned)a.H, (unsigned)a.B);
+    apply_fwd_seg<CIN, COUT, OFFSET, LOADS, STORES, TRACE, GUIDE_NN, UPADD, PIX><<<grid3, g.pl.threads, g.lds, s>>>(p);
+  }
   return hipGetLastError();
 }
 
@@ -495,6 +597,50 @@ hipError_t launch_apply_fwd_seg_upadd(const ApplyArgs& a, const float* coarse, i
 
 #ifdef HDRNET_TOOLS_BUILD
 void apply_fwd_seg_set_trace(long long* device_buf) { g_trace = device_buf; }
+void apply_fwd_seg_set_knob(int idx, int value) {
+  if (idx >= 0 && idx < 8) g_knob[idx] = value;
+}
+
+// variants 70 / 71 (71: with the timeline trace): the product flavour on the flat grid with a ticketed tail;
+// knobs 1, 2 = D, surplus.
+hipError_t launch_apply_fwd_seg_dyn(const ApplyArgs& a, bool trace, hipStream_t s, const char** name) {
+  if (!(a.Cin == 3 && a.Cout == 3 && a.has_offset)) return hipErrorNotSupported;
+  if (trace && !g_trace) return hipErrorInvalidValue;
+  if (!g_sched_words) {
+    if (hipMalloc(&g_sched_words, kSchedWords * sizeof(unsigned)) != hipSuccess) return hipErrorOutOfMemory;
+    if (hipMemset(g_sched_words, 0, kSchedWords * sizeof(unsigned)) != hipSuccess) return hipErrorUnknown;
+  }
+  const SegGeom g = seg_geom(a, true);
+  if (!g.ok) return hipErrorNotSupported;
+  const long long M = (long long)g.pl.nseg * a.H * a.B;
+  const long long D = g_knob[1] < M ? g_knob[1] : M;
+  DynSched d;
+  if (!make_dyn_sched(d, g_sched_words, M, g.pl.nseg, a.H, D, D + g_knob[2])) return hipErrorNotSupported;
+  const GuideNN gn{nullptr, nullptr, nullptr, 0};
+  const UpAdd up{nullptr, 0, 0, 0.f, 0.f};
+  static char namebuf[96];
+  snprintf(namebuf, sizeof namebuf, "apply_fwd_seg/dyn D=%u E=%u", d.D, d.E);
+  *name = namebuf;
+  const bool whole_lines = ((uintptr_t)a.out % 128 == 0) && ((long long)g.pl.seg * a.Cout * 4) % 128 == 0 &&
+                           ((long long)a.W * a.Cout * 4) % 128 == 0;
+  if (trace) {
+    return whole_lines ? launch_seg_t<3, 3, true, kLoadsBufDmaNt, kStoresBufSc01, true, false, false, kPixLeanScalar, 1>(a, s, g_trace, gn, up, &d)
+                       : launch_seg_t<3, 3, true, kLoadsBufDmaNt, kStoresBufNt, true, false, false, kPixLeanScalar, 1>(a, s, g_trace, gn, up, &d);
+  }
+  return whole_lines ? launch_seg_t<3, 3, true, kLoadsBufDmaNt, kStoresBufSc01, false, false, false, kPixLeanScalar, 1>(a, s, nullptr, gn, up, &d)
+                     : launch_seg_t<3, 3, true, kLoadsBufDmaNt, kStoresBufNt, false, false, false, kPixLeanScalar, 1>(a, s, nullptr, gn, up, &d);
+}
+
+// variant 72: the product kernel (3-D grid) with the timeline trace -- the static twin of 71.
+hipError_t launch_apply_fwd_seg_product_trace(const ApplyArgs& a, hipStream_t s, const char** name) {
+  if (!(a.Cin == 3 && a.Cout == 3 && a.has_offset) || !g_trace) return hipErrorNotSupported;
+  const SegGeom g = seg_geom(a, true);
+  const bool whole_lines = ((uintptr_t)a.out % 128 == 0) && ((long long)g.pl.seg * a.Cout * 4) % 128 == 0 &&
+                           ((long long)a.W * a.Cout * 4) % 128 == 0;
+  *name = "apply_fwd_seg/product+trace";
+  return whole_lines ? launch_seg_t<3, 3, true, kLoadsBufDmaNt, kStoresBufSc01, true, false, false, kPixLeanScalar>(a, s, g_trace)
+                     : launch_seg_t<3, 3, true, kLoadsBufDmaNt, kStoresBufNt, true, false, false, kPixLeanScalar>(a, s, g_trace);
+}
 
 // knob = variant - 60: pixel phase = knob % 4 {0 round 2, 1 lean packed, 2 lean scalar blend}; + 4: the pixel
 // loads as buffer_load ... lds instead of global_load ... lds.  Load / store flavour per launch as the product.

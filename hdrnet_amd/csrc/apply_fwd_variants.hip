@@ -13,6 +13,7 @@
 //   101      memory skeleton: the product kernel's loads / stores / launch shape, no slicing
 //   103-105  memory skeletons with lane-contiguous accesses on {both, loads only, stores only}
 //   106      103 with nontemporal input loads (the shipped kernel's access pattern)
+//   107      an EMPTY kernel launched with the product's geometry (dispatch + inter-kernel gap alone)
 //
 // Skeletons do NOT compute the op (their name says ABLATION); the others are checked for
 // parity by tests/test_gpu_parity.py like the product kernel.
@@ -31,6 +32,13 @@ constexpr int kVariantWave = 2;
 constexpr int kVariantStream = 3;  // .. 6
 constexpr int kVariantDirectStores = 7;
 constexpr int kVariantNtLoads = 8;
+
+// Variant 107: a launch of the product's geometry (workgroups, threads, LDS per workgroup) that does nothing --
+// what a launch costs before it moves a byte: dispatch of every workgroup + the gap between dependent kernels.
+__global__ __launch_bounds__(256) void apply_fwd_empty(float* out) {
+  extern __shared__ float lds_empty[];
+  if (out == nullptr) lds_empty[threadIdx.x] = 0.f;  // never taken; keeps the LDS allocation
+}
 
 // ---- memory skeletons ---------------------------------------------------------------------
 // MODE 1: thread = 4 consecutive pixels, exactly the product kernel's global accesses.
@@ -538,6 +546,14 @@ hipError_t launch_variant_t(const ApplyArgs& a, const Plan& pl, hipStream_t s, c
         apply_fwd_skeleton<6><<<nblocks, pl.threads, 0, s>>>(a.guide, a.input, a.out, a.H, a.W, pl.nseg, pl.seg);
         *name = "ABLATION/skeleton nt-ld-contig st-contig";
         return hipGetLastError();
+      case 107: {
+        // LDS per workgroup as the product kernel's: padded image + one (guide + in / out) slab per wave
+        const size_t lds = ((size_t)round_up(((pl.seg - 1) * a.GW / a.W + 4) * (a.GD + 2) * C, 4) +
+                            (size_t)(pl.threads / 64) * 64 * kPxPerThread * 4) * sizeof(float);
+        apply_fwd_empty<<<nblocks, pl.threads, lds, s>>>(a.out);
+        *name = "ABLATION/empty launch, product geometry";
+        return hipGetLastError();
+      }
       default:
         break;
     }
@@ -555,6 +571,8 @@ hipError_t launch_apply_fwd_variant(const ApplyArgs& a, hipStream_t s, const cha
   if (!pl.vec4) return hipErrorNotSupported;
   if (a.variant >= 20 && a.variant < 60) return launch_apply_fwd_seg_knob(a, a.variant - 20, s, name);
   if (a.variant >= 60 && a.variant < 68) return launch_apply_fwd_seg_pix(a, a.variant - 60, s, name);
+  if (a.variant == 70 || a.variant == 71) return launch_apply_fwd_seg_dyn(a, a.variant == 71, s, name);
+  if (a.variant == 72) return launch_apply_fwd_seg_product_trace(a, s, name);
   if (a.variant == kVariantDirectStores) return launch_apply_fwd_rows_direct_stores(a, s, name, 0);
   if (a.variant == kVariantNtLoads) return launch_apply_fwd_rows_direct_stores(a, s, name, 1);
   if (a.Cin == 3 && a.Cout == 3 && a.has_offset) {

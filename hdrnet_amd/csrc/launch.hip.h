@@ -153,6 +153,9 @@ hipError_t launch_apply_fwd_seg_upadd(const ApplyArgs& a, const float* coarse, i
 hipError_t launch_apply_fwd_seg_knob(const ApplyArgs& a, int knob, hipStream_t s, const char** name);
 hipError_t launch_apply_fwd_seg_pix(const ApplyArgs& a, int knob, hipStream_t s, const char** name);
 void apply_fwd_seg_set_trace(long long* device_buf);
+void apply_fwd_seg_set_knob(int idx, int value);
+hipError_t launch_apply_fwd_seg_dyn(const ApplyArgs& a, bool trace, hipStream_t s, const char** name);
+hipError_t launch_apply_fwd_seg_product_trace(const ApplyArgs& a, hipStream_t s, const char** name);
 void grid_grad_set_trace(long long* device_buf);
 #endif
 

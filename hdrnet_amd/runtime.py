@@ -73,7 +73,8 @@ class FramePipeline:
             st.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(st):
                 self.lanes.append(make_lane())
-        self.done = [torch.cuda.Event() for _ in range(depth)]
+        with torch.cuda.device(dev):  # events belong to the device of the streams, whichever device is current
+            self.done = [torch.cuda.Event() for _ in range(depth)]
         self.outputs = [None] * depth
         self.next = 0
 
@@ -82,6 +83,12 @@ class FramePipeline:
         self.next = (lane + 1) % len(self.lanes)
         st = self.streams[lane]
         st.wait_stream(torch.cuda.current_stream(st.device))  # the inputs were produced on the caller's stream
+        for t in inputs:
+            # ... and are READ on the lane's stream: tell the caching allocator, or a caller that drops (or lets go
+            # of) an input right after submit() -- the normal streaming pattern -- gets its block handed out again
+            # on the caller's stream while the lane is still reading it
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(st)
         with torch.cuda.stream(st):
             self.outputs[lane] = self.lanes[lane](*inputs)
             self.done[lane].record(st)

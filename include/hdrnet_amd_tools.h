@@ -15,7 +15,8 @@
  *                stores {0 global, 1 buffer, 2 buffer nt, 3 buffer sc1 (write-through), 4 buffer sc0 sc1}
  *                (31 = the product configuration)
  *       40..59   the same with a per-workgroup timeline trace (hdrnet_tools_set_trace)
- *       101, 103..106  memory skeletons
+ *       60..67   pixel-phase / DMA-form variants of the product kernel; 70 / 71 ticketed tail (knobs 1, 2), 72 product + trace
+ *       101, 103..106  memory skeletons; 107 an empty kernel with the product's launch geometry
  *   - kernel variants of the GRADIENT entry points (HDRNET_VARIANT(n) in the flags of
  *     hdrnet_bilateral_slice{,_apply}_grad_f32_ex; tools/bwd_ab.py times them interleaved):
  *       2  bf16-split contraction (two v_mfma_f32_16x16x32_bf16 per 16 pixels)   3  un-fused kernels
@@ -41,6 +42,12 @@ extern "C" {
 
 /* device_buf: at least 3 * (number of workgroups of the traced launch) int64; NULL disables. */
 void hdrnet_tools_set_trace(void* device_buf);
+
+/* Experiment knobs read by some variants at launch (apply_fwd_seg.hip):
+ *   0  extra dynamic LDS bytes per workgroup (caps the workgroups resident per CU), all apply_fwd_seg variants
+ *   1  variants 70 / 71: D, the number of tasks at the end of the launch that are handed out by ticket
+ *   2  variants 70 / 71: surplus ticketed workgroups (E = D + surplus, rounded up to a multiple of 256) */
+void hdrnet_tools_set_knob(int idx, int value);
 
 #ifdef __cplusplus
 }

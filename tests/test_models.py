@@ -261,6 +261,50 @@ def test_frame_pipeline_matches_sequential():
         FramePipeline(lambda: None, depth=0)
 
 
+@pytest.mark.gpu
+def test_frame_pipeline_inputs_dropped_after_submit():
+    """The streaming pattern FramePipeline is built for: the caller lets go of a frame's inputs right after
+    submit() and allocates the next frame -- the caching allocator would hand the SAME blocks out again on the
+    caller's stream while the lane's stream still reads them unless submit() records the lane's use of them
+    (ADVICE r03).  Big frames (the kernel runs for tens of microseconds), every freed block immediately
+    re-allocated and overwritten with garbage on the caller's stream."""
+    from hdrnet_amd import hdrnet_ops as ops
+    from hdrnet_amd.runtime import FramePipeline
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(11)
+    grid = torch.rand(1, 16, 16, 8, 12, device=dev, generator=gen)
+    H, W, n = 1080, 1920, 12
+    seeds = list(range(100, 100 + n))
+
+    def frame(seed):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        return torch.rand(1, H, W, device=dev, generator=g), torch.rand(1, H, W, 3, device=dev, generator=g)
+
+    want = []
+    for sd in seeds:
+        gu, inp = frame(sd)
+        want.append(ops.bilateral_slice_apply(grid, gu, inp, has_offset=True).cpu())
+        del gu, inp
+    torch.cuda.synchronize()
+    for depth in (2, 3):
+        pipe = FramePipeline(lambda: (lambda g, i: ops.bilateral_slice_apply(grid, g, i, has_offset=True)), depth=depth)
+        got, tickets = [], []
+        for sd in seeds:
+            gu, inp = frame(sd)
+            tickets.append(pipe.submit(gu, inp))
+            ptrs = (gu.data_ptr(), inp.data_ptr())
+            del gu, inp  # back to the allocator while the lane may still be reading them
+            junk = [torch.full((1, H, W), float("nan"), device=dev), torch.full((1, H, W, 3), float("nan"), device=dev)]
+            # with record_stream the allocator must NOT have reused the blocks the lane is still reading
+            del junk, ptrs
+            if len(tickets) == depth:
+                got.append(pipe.result(tickets.pop(0)).cpu())
+        while tickets:
+            got.append(pipe.result(tickets.pop(0)).cpu())
+        for k, (a, b) in enumerate(zip(got, want)):
+            assert torch.equal(a, b), f"depth {depth}: frame {k} corrupted"
+
+
 # ---- training side of the fused guide network (SURVEY.md section 8f row 2, extended to training) ----
 def _torch_guide(inp, conv1, conv2):
     """fp32 torch statement of the folded guide network (hdrnet/models.py:203-210)."""

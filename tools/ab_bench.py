@@ -4,6 +4,11 @@
     python tools/ab_bench.py [--workload 4k] [--variants 0,19,20] [--rounds 5] [--steps 100]
                              [--trace 36,39] [--settle 80] [--out gpurun_out/ab.json]
 
+A variant may carry experiment knobs (include/hdrnet_amd_tools.h: hdrnet_tools_set_knob), written
+`variant@knob=value@knob=value`, e.g. `66@0=8192` (the product flavour with 8 KiB of extra LDS per workgroup) or
+`70@1=2000@2=1200` (ticketed tail of 2000 tasks, 1200 surplus workgroups); the knobs are set before every launch
+batch of that entry and cleared after it.  --trace takes the same syntax (71 = traced twin of 70, 72 of the product).
+
 Uses the TOOLS build of the library (libhdrnet_amd_tools.so, include/hdrnet_amd_tools.h): variant 0
 is the product kernel, the others are documented in that header.  Every round times each variant
 once (HIP events around `steps` back-to-back launches over rotating buffer sets larger than the
@@ -100,7 +105,24 @@ def main():
     nsets = max(3, -(-int(CACHE_BYTES * 1.5) // abytes))
     sets = make_sets(dev, nsets, B, H, W, GH, GW, GD, 1234)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    variants = [int(v) for v in args.variants.split(",") if v != ""]
+    class Spec:
+        """One table entry: a variant number and the knobs to set while it runs."""
+
+        def __init__(self, text):
+            parts = text.split("@")
+            self.v = int(parts[0])
+            self.knobs = [tuple(int(x) for x in kv.split("=")) for kv in parts[1:]]
+            self.key = text
+
+        def __enter__(self):
+            for k, val in self.knobs:
+                lib.hdrnet_tools_set_knob(k, val)
+
+        def __exit__(self, *exc):
+            for k, _ in self.knobs:
+                lib.hdrnet_tools_set_knob(k, 0)
+
+    variants = [Spec(v) for v in args.variants.split(",") if v != ""]
 
     def launcher(flags):
         def fn(k):
@@ -119,32 +141,37 @@ def main():
     names = {}
     errs = {}
     good = []
-    for v in variants:
+    for sp in variants:
+        v = sp.key
         try:
             out.fill_(float("nan"))
-            launcher(_lib.KERNEL_FAST | (v << 8))(0)
-            torch.cuda.synchronize()
+            with sp:
+                launcher(_lib.KERNEL_FAST | (sp.v << 8))(0)
+                launcher(_lib.KERNEL_FAST | (sp.v << 8))(0)  # twice: a variant with launch-to-launch state must leave it clean
+                torch.cuda.synchronize()
             names[v] = lib.hdrnet_last_kernel().decode()
             err = (out - ref).abs().max().item()
+            err = float("inf") if err != err else err  # NaN left in the output: pixels nobody wrote
             errs[v] = err
             ok = (err < 1e-5) or names[v].startswith("ABLATION")
             print(f"variant {v} [{names[v]}]: max|fast - generic| = {err:.3e}{'' if ok else '   <-- WRONG, dropped'}",
                   flush=True)
             if ok:
-                good.append(v)
+                good.append(sp)
         except Exception as e:  # noqa: BLE001
             print(f"variant {v}: FAILED ({e}), dropped", flush=True)
     variants = good
 
-    results = {v: [] for v in variants}
+    results = {sp.key: [] for sp in variants}
     yard = {"copy(out<-in, 2x100MB)": [], "elementwise(out=in*a+b, in 133MB out 100MB)": []}
     for r in range(args.rounds):
-        for v in variants:
-            fn = launcher(_lib.KERNEL_FAST | (v << 8))
+        for sp in variants:
+            fn = launcher(_lib.KERNEL_FAST | (sp.v << 8))
             # settle: cache-policy stores run ~15 % slower for the first ~50 launches after a kernel that left
             # plain-store dirty lines behind (profiles/r02/exp25); a timed window must not start inside that
-            time_launches(fn, args.settle)
-            results[v].append(time_launches(fn, args.steps))
+            with sp:
+                time_launches(fn, args.settle)
+                results[sp.key].append(time_launches(fn, args.steps))
         if args.yardstick:
             def cp(k):
                 sets[k % nsets][3].copy_(sets[k % nsets][2])
@@ -159,10 +186,11 @@ def main():
 
     print(f"\n{desc}; {nsets} rotating sets; algorithmic {abytes / 1e6:.1f} MB/launch")
     table = []
-    for v in variants:
+    for sp in variants:
+        v = sp.key
         t = results[v]
         med = statistics.median(t)
-        print(f"variant {v:3d} {names[v]:34s} median {med:7.2f} us  min {min(t):7.2f} us  "
+        print(f"variant {v:>18s} {names[v]:34s} median {med:7.2f} us  min {min(t):7.2f} us  "
               f"-> {abytes / med / 1e3:7.1f} GB/s ({abytes / med / 1e3 / 8000 * 100:4.1f}% of 8 TB/s)  "
               f"{B * H * W / med:9.0f} MP/s   all: {[round(x, 1) for x in t]}")
         table.append({"variant": v, "name": names[v], "median_us": med, "min_us": min(t), "all_us": t,
@@ -175,21 +203,24 @@ def main():
             print(f"yardstick {k}: median {med:7.2f} us -> {vol[k] / med / 1e3:7.1f} GB/s")
 
     traces = []
-    for v in [int(x) for x in args.trace.split(",") if x != ""]:
-        vt = v + 20 if 20 <= v < 40 else v + 4  # traced twin of the plain variant (hdrnet_amd_tools.h)
+    for sp in [Spec(x) for x in args.trace.split(",") if x != ""]:
+        v = sp.v
+        # (traced, plain) twins (hdrnet_amd_tools.h): 71 / 70 ticketed tail, 72 / 0 the product
+        vt, vp = (v, 70) if v == 71 else (v, 0) if v == 72 else (v + 20, v) if 20 <= v < 40 else (v + 4, v)
         try:
             buf = torch.zeros((1 << 16, 3), dtype=torch.int64, device=dev)
             lib.hdrnet_tools_set_trace(buf.data_ptr())
             fn = launcher(_lib.KERNEL_FAST | (vt << 8))
-            plain = launcher(_lib.KERNEL_FAST | (v << 8))
-            time_launches(plain, 50)  # warm clocks, queue is busy right up to the traced launch
-            fn(1)
-            plain(2)
-            torch.cuda.synchronize()
+            plain = launcher(_lib.KERNEL_FAST | (vp << 8))
+            with sp:
+                time_launches(plain, 50)  # warm clocks, queue is busy right up to the traced launch
+                fn(1)
+                plain(2)
+                torch.cuda.synchronize()
             tr = buf.cpu().numpy()
             tr = tr[tr[:, 0] != 0]
             nm = lib.hdrnet_last_kernel().decode()
-            traces.append(dict(trace_summary(tr, f"variant {v} {nm}"), variant=v))
+            traces.append(dict(trace_summary(tr, f"variant {sp.key} {nm}"), variant=sp.key))
         except Exception as e:  # noqa: BLE001
             print(f"trace variant {v}: FAILED ({e})", flush=True)
         finally:
