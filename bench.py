@@ -2,6 +2,10 @@
 """bench.py -- BilateralSliceApply forward throughput on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 4k|1080p|1080p_b4|hdrp] [--split rows]
+    python bench.py --workload train_1080p_b4 [--gpus N]    BASELINE config #4 as stated: training step, 4 x 1080p per GPU,
+                                                            ONE flat-bucket gradient all-reduce over the N ranks
+    python bench.py --workload hdrp_u16 [--gpus N]          BASELINE config #5 as stated: uint16 / 32767 wire format,
+                                                            4000x3000, grid 32x32x8x12, one image per GPU
 
 `--gpus N` with N > 1 from a bare shell re-launches itself as N ranks under
 torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1); launched by the driver under
@@ -73,6 +77,16 @@ WORKLOADS = {
     "1080p_b4": (4, 1080, 1920, 16, 16, 8,
                  "BilateralSliceApply fwd 4 x 1920x1080 fp32 NHWC per launch (config #4's per-GPU batch), grid 16x16x8x12"),
     "hdrp": (1, 3000, 4000, 32, 32, 8, "BilateralSliceApply fwd 4000x3000 fp32 NHWC, grid 32x32x8x12, 1 image/GPU"),
+}
+
+
+# The two multi-GPU configurations of BASELINE.json AS STATED (configs[3], configs[4]); bench lines of their own
+# (main_train / main_hdrp_u16), never the headline.
+EXTRA_WORKLOADS = {
+    "train_1080p_b4": "training step fwd+bwd+Adam, HDRNetPointwiseNNGuide (batch norm), 4 x 1920x1080 per GPU, "
+                      "gradient all-reduce = ONE flat fp32 bucket (RCCL over xGMI)",
+    "hdrp_u16": "BilateralSliceApply fwd, HDR+ wire format uint16 / 32767 -> fp32, 4000x3000, grid 32x32x8x12, "
+                "1 image/GPU",
 }
 
 
@@ -355,7 +369,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=1000)
-    ap.add_argument("--workload", default="4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="4k", choices=sorted(WORKLOADS) + sorted(EXTRA_WORKLOADS))
     ap.add_argument("--split", default="images", choices=["images", "rows"],
                     help="images (default): every rank slices its OWN frames, weak scaling.  rows: every frame "
                          "is split into N row bands, one per rank (hdrnet_bilateral_slice_apply_rows_f32), strong "
@@ -375,7 +389,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world  # n_gpus is what the process group says
     if args.stub_cpu:
+        if args.workload == "train_1080p_b4":
+            return main_train(args, rank, world, local_rank, stub=True)
         return stub_main(args, rank, world)
+    if args.workload == "train_1080p_b4":
+        return main_train(args, rank, world, local_rank)
+    if args.workload == "hdrp_u16":
+        return main_hdrp_u16(args, rank, world, local_rank)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     # One process per GPU.  (On a box with fewer GPUs than ranks -- the 1-GPU development box -- the
@@ -495,6 +515,169 @@ def main():
         dist.destroy_process_group()
 
 
+
+def _init_ranks(world, local_rank, cpu=False):
+    """One process per GPU (main()'s rules): returns (device, dist_on, backend)."""
+    from hdrnet_amd import dist as hd
+    if cpu:
+        dev, backend = torch.device("cpu"), "gloo"
+    else:
+        if not torch.cuda.is_available():
+            sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+        dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+        torch.cuda.set_device(dev)
+        backend = os.environ.get("HDRNET_BENCH_BACKEND", "nccl")
+    if world > 1:
+        hd.init(backend=backend, device=dev)
+    return dev, world > 1, backend
+
+
+def _finish(result, rank, dist_on):
+    from hdrnet_amd import dist as hd
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist_on:
+        import torch.distributed as dist
+        hd.barrier()
+        dist.destroy_process_group()
+
+
+def main_train(args, rank, world, local_rank, stub=False):
+    """BASELINE config #4 as stated: `Training step fwd+bwd 1920x1080 batch=32, grad all-reduce over 8 x MI355X`
+    = 4 images per GPU.  Every rank runs runtime.GraphedTrainStep on ITS 4 images -- forward, loss and backward
+    through the HIP kernels as one hipGraph whose gradients land in ONE persistent flat fp32 bucket -- then the
+    step's only collective, one in-place all-reduce of that bucket (RCCL over xGMI; nothing at N = 1), then the
+    (fused, capturable) Adam update.  The reference's step: hdrnet/bin/train.py:113-157 (single device).
+    value = whole-job megapixels/s (weak scaling: per-GPU batch fixed).  `allreduce` = the collective alone,
+    timed in a loop of its own after the timed steps.
+    stub (tests, CPU + gloo): the same harness around runtime.TrainStep on a stand-in torch-only model -- the HIP
+    kernels have no CPU path by design."""
+    from hdrnet_amd import dist as hd
+    dev, dist_on, backend = _init_ranks(world, local_rank, cpu=stub)
+    B, H, W = 4, 1080, 1920
+    torch.manual_seed(0)  # identical initial weights on every rank
+    if stub:
+        from hdrnet_amd.runtime import TrainStep
+        model = torch.nn.Sequential(torch.nn.Linear(12, 32), torch.nn.ReLU(), torch.nn.Linear(32, 3))
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+        torch.manual_seed(1234 + rank)
+        inputs, targets = [torch.rand(64, 12)], [torch.rand(64, 3)]
+        step = TrainStep(model, lambda out, tgt: (out - tgt).square().mean(), opt)
+        run = lambda: step(inputs, targets)  # noqa: E731
+        sync = lambda: None  # noqa: E731
+        kernel = "stub (torch-only stand-in model on CPU)"
+    else:
+        from hdrnet_amd import _lib, models
+        from hdrnet_amd.runtime import GraphedTrainStep
+        _lib.load()  # raises loudly if the HIP library is missing
+        model = models.HDRNetPointwiseNNGuide(dict(batch_norm=True)).to(dev).train()
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, capturable=True, fused=True)
+        gen = torch.Generator(device=dev).manual_seed(1234 + rank)  # every rank its own images
+        low = torch.rand((B, 256, 256, 3), device=dev, generator=gen)
+        full = torch.rand((B, H, W, 3), device=dev, generator=gen)
+        target = torch.rand((B, H, W, 3), device=dev, generator=gen)
+        step = GraphedTrainStep(model, lambda out, tgt: (out - tgt).square().mean(), opt, [low, full], [target],
+                                flat_bucket=True)  # the multi-rank structure at every N, N = 1 included
+        run = lambda: step([low, full], [target])  # noqa: E731
+        sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
+        kernel = "hipGraph(fwd + loss + bwd) + flat-bucket all-reduce + fused Adam"
+    for _ in range(args.warmup):
+        run()
+    if dist_on:
+        hd.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    sync()
+    wall = time.perf_counter() - t0
+    if dist_on:
+        hd.barrier()
+    # the collective alone
+    n_ar = max(10, min(200, args.steps))
+    sync()
+    t1 = time.perf_counter()
+    for _ in range(n_ar):
+        step.bucket.allreduce()
+    sync()
+    ar = (time.perf_counter() - t1) / n_ar
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
+    wall_max, ar_max = hd.max_over_ranks([wall, ar], device=red_dev)
+    ms = wall_max / args.steps * 1e3
+    mp = B * H * W / 1e6
+    result = {
+        "metric": "megapixels/sec training step fwd+bwd @1080p, 4 images/GPU (BASELINE config #4)",
+        "value": round(world * args.steps * mp / wall_max, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "clock": "wall",
+        "per_gpu_MPps": round(args.steps * mp / wall_max, 1),
+        "allreduce": {"ms": round(ar_max * 1e3, 4), "share_of_step": round(ar_max * 1e3 / ms, 4),
+                      "bucket_elements": int(step.bucket.flat.numel()), "collectives_per_step": 1 if world > 1 else 0,
+                      "backend": backend if dist_on else None},
+        "config": {"workload": EXTRA_WORKLOADS["train_1080p_b4"], "images_per_gpu_per_step": B,
+                   "global_batch": B * world, "parallelism": f"dp{world} (image shards)", "kernel": kernel},
+    }
+    _finish(result, rank, dist_on)
+
+
+def main_hdrp_u16(args, rank, world, local_rank):
+    """BASELINE config #5 as stated: `HDR+ 16-bit linear 4000x3000, grid 32x32x8x12, batch=8 sharded 1 image/GPU`:
+    every rank slices its own uint16 image -- tf.to_float(im) / 32767 (hdrnet/data_pipeline.py:267-274) fused into the
+    kernel (apply_fwd_io.hip), fp32 guide map in, fp32 out -- no data-path collective.  Algorithmic bytes per pixel:
+    6 (uint16 RGB) + 4 (guide) + 12 (out) = 22."""
+    import ctypes
+    from hdrnet_amd import dist as hd
+    dev, dist_on, backend = _init_ranks(world, local_rank)
+    from hdrnet_amd import _lib
+    lib = _lib.load()
+    B, H, W, GH, GW, GD = 1, 3000, 4000, 32, 32, 8
+    abytes = B * (H * W * 22 + 4 * GH * GW * GD * 12)
+    nsets = max(3, -(-int(CACHE_BYTES * 1.5) // abytes))
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    sets = []
+    for _ in range(nsets):
+        sets.append((torch.rand((B, GH, GW, GD, 12), device=dev, generator=gen),
+                     torch.rand((B, H, W), device=dev, generator=gen),
+                     torch.randint(0, 32768, (B, H, W, 3), device=dev, generator=gen, dtype=torch.int32).to(torch.uint16),
+                     torch.empty((B, H, W, 3), device=dev)))
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    c_int, c_vp, c_f = ctypes.c_int, ctypes.c_void_p, ctypes.c_float
+    fn = lib.hdrnet_bilateral_slice_apply_io
+    calls = [(c_vp(g.data_ptr()), c_vp(gu.data_ptr()), c_vp(i.data_ptr()), c_vp(o.data_ptr())) +
+             tuple(c_int(v) for v in (B, H, W, GH, GW, GD, 3, 3, 1, 2)) + (c_f(32767.0), c_int(0), None, None, c_int(0), None,
+                                                                            c_vp(stream)) for (g, gu, i, o) in sets]
+
+    def step(n, k0):
+        for k in range(k0, k0 + n):
+            if fn(*calls[k % nsets]):
+                raise RuntimeError(lib.hdrnet_last_error().decode())
+
+    lib.hdrnet_enable_kernel_names(1)
+    step(1, 0)
+    kernel = lib.hdrnet_last_kernel().decode()
+    lib.hdrnet_enable_kernel_names(0)
+    n_pre, pre_s = preroll(step, lambda: torch.cuda.synchronize(dev))
+    step(args.warmup, 0)
+    wall, gpu_s = timed(step, args.steps, dist_on, dev)
+    wall_max, gpu_max = hd.max_over_ranks([wall, gpu_s], device=dev if backend == "nccl" else torch.device("cpu"))
+    mp = B * H * W / 1e6
+    avg = gpu_max / args.steps
+    result = {
+        "metric": "megapixels/sec BilateralSliceApply fwd, HDR+ uint16 wire format @4000x3000 (BASELINE config #5)",
+        "value": round(world * args.steps * mp / wall_max, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(wall_max / args.steps * 1e3, 5), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32 (uint16 in)", "data": "synthetic", "clock": "wall",
+        "preroll_launches": n_pre, "preroll_ms": round(pre_s * 1e3, 1), "per_gpu_MPps": round(args.steps * mp / wall_max, 1),
+        "config": {"workload": EXTRA_WORKLOADS["hdrp_u16"], "images_per_gpu_per_step": B, "global_batch": B * world,
+                   "rotating_buffer_sets": nsets, "parallelism": f"image-shard x{world}", "kernel": kernel},
+        "roofline": {"bound": "hbm", "achieved": round(abytes / avg / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(abytes / avg / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": abytes, "avg_kernel_us": round(avg * 1e6, 3),
+                     "timing": "HIP events on the launch stream around the K timed launches / K"},
+    }
+    _finish(result, rank, dist_on)
+
+
 def stub_main(args, rank, world):
     """CPU stand-in for the distributed skeleton of main() (tests/test_bench_launch.py): same
     launch path, barrier, max-over-ranks and JSON line, gloo backend, a sleep as the timed body."""
@@ -509,7 +692,7 @@ def stub_main(args, rank, world):
         hd.barrier()
     (wall_max,) = hd.max_over_ranks([wall], device=torch.device("cpu"))
     if rank == 0:
-        print(json.dumps({"metric": "stub", "value": round(world * args.steps / wall_max, 1), "unit": "steps/s",
+        print(json.dumps({"metric": "stub", "workload": args.workload, "value": round(world * args.steps / wall_max, 1), "unit": "steps/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(wall_max / max(args.steps, 1) * 1e3, 5),
                           "higher_is_better": True, "scaling": "weak"}), flush=True)

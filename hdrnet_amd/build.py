@@ -35,7 +35,9 @@ SOURCES = [
     # (measured: 947 -> 646 ISA lines, 82 -> 55 VGPRs with it off).
     ("apply_fwd_rows.hip", ["-fno-slp-vectorize"]),
     ("apply_fwd_seg.hip", ["-fno-slp-vectorize"]),
-    ("apply_fwd_io.hip", ["-fno-slp-vectorize"]),
+    # + MFMA results in VGPRs (gfx950's register file is unified): the guide network's 4x4x4 blocks are consumed by
+    # the VALU at once, and the AGPR form costs a v_accvgpr_read per element
+    ("apply_fwd_io.hip", ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"]),
     ("apply_bwd_rows.hip", ["-fno-slp-vectorize"]),
     ("apply_vjp_seg.hip", ["-fno-slp-vectorize"]),
     ("slice_fwd_rows.hip", ["-fno-slp-vectorize"]),

@@ -38,6 +38,7 @@ using namespace rows;
 // hdrnet/bin/freeze_graph.py:107-127 exports (guide_ccm_f32_3x4.bin, guide_shifts_f32_16x3.bin,
 // guide_slopes_f32_16x3.bin, guide_mix_matrix_f32_1x4.bin).
 constexpr int kGuideMap = 0, kGuideNN = 1, kGuideCurves = 2;
+constexpr int kGuideCurvesScan = 3;  // the curves guide evaluated knot by knot: more than kCurveMaxKnots knots per channel
 
 struct GuideNet {
   const float* conv1;  // NN: [n][CIN + 1]            curves: ccm [CIN][CIN + 1] (row = output channel)
@@ -52,9 +53,11 @@ typedef __attribute__((address_space(4))) const float cfloat;  // wave-uniform p
 
 // guide = clip(mix[CIN] + sum_c mix[c] * sum_k slopes[k][c] * relu(t_c - shifts[k][c]), 0, 1),
 // t_c = ccm[c][CIN] + sum_j ccm[c][j] * in_j     (models.py:157-188), for a lane's 4 pixels at once: one
-// pass over the knots, every parameter read once through the constant address space.
+// pass over the knots, every parameter read once through the constant address space.  (The SCAN form: 3 operations
+// per knot, channel and pixel -- 144 per pixel for the reference's 16 knots.  Kept for more than kCurveMaxKnots
+// knots; the product path is the table form below.)
 template <int CIN>
-__device__ __forceinline__ void guide_curves_quad(const GuideNet& gn, const float* inf, float (&g)[kPxPerThread]) {
+__device__ __forceinline__ void guide_curves_scan_quad(const GuideNet& gn, const float* inf, float (&g)[kPxPerThread]) {
   cfloat* ccm = (cfloat*)gn.conv1;
   cfloat* mix = (cfloat*)gn.conv2;
   cfloat* shifts = (cfloat*)gn.shifts;
@@ -102,6 +105,289 @@ __device__ __forceinline__ void guide_curves_quad(const GuideNet& gn, const floa
   }
 }
 
+// ---- the curves guide as a sorted piecewise-linear lookup (round 4) --------------------------------------------------
+// sum_k slope_k * relu(t - shift_k) is piecewise linear in t with its breaks at the shifts.  Per workgroup, wave 0
+// sorts each channel's knots (rank by counting; ties by index) and tabulates, for the interval that starts at the
+// i-th smallest knot s_(i):  the knot, the curve's VALUE there  C_i = sum_{r<i} slope_(r) (s_(i) - s_(r))  and its SLOPE
+// from there on  A_i = sum_{r<=i} slope_(r)  (both summed in float64, rounded once).  A pixel then finds its interval
+// with a 4-step binary search over the sorted knots (an implicit tree in LDS, Eytzinger order: node e's children are
+// 2e and 2e + 1) and evaluates  C_i + A_i * max(t - s_(i), 0)  -- anchored at the interval's own knot, so that the
+// result carries one rounding of the curve's value instead of the scan's 16.  15 instead of 48 operations per channel
+// and pixel, 4 ds_read_b32 + 1 ds_read_b128 (conflict-free: <= 16 consecutive dwords / 16-B entries per channel).
+// Left of the smallest knot every relu is zero: leaf 0 holds C = 0 and the max() clamps the distance.
+// Up to kCurveMaxKnots knots per channel (the reference has 16, hdrnet/models.py:150); unused slots are +inf knots
+// with slope 0.  The tables sit at the START of dynamic LDS (compile-time addresses); the coefficient image follows.
+constexpr int kCurveMaxKnots = 16;
+template <int CIN>
+struct CurveTab {
+  static constexpr int kTree = 0;                    // [CIN][16]: node e of channel c at c * 16 + e (e = 1 .. 15)
+  static constexpr int kLeaf = CIN * 16;             // [CIN][16][4]: (knot, value at it, slope after it, 0)
+  static constexpr int kRawS = kLeaf + CIN * 64;     // scratch while building: knots / slopes as given,
+  static constexpr int kRawL = kRawS + CIN * 16;
+  static constexpr int kSortS = kRawL + CIN * 16;    //   ... and sorted
+  static constexpr int kSortL = kSortS + CIN * 16;
+  static constexpr int kFloats = kSortL + CIN * 16;  // 16-B multiple
+};
+
+// Run by the first CIN * 16 lanes of wave 0 (lane = channel * 16 + knot); the caller's workgroup barrier publishes
+// the tables.  CIN * 16 <= 64.
+template <int CIN>
+__device__ __forceinline__ void curves_build_tables(float* __restrict__ tab, const GuideNet& gn, int lane) {
+  static_assert(CIN * 16 <= 64, "one wave builds the tables");
+  typedef CurveTab<CIN> T;
+  const int c = lane >> 4, k = lane & 15;
+  const bool mine = lane < CIN * 16;
+  float s = __builtin_inff(), sl = 0.0f;
+  if (mine && k < gn.n) {
+    s = gn.shifts[k * CIN + c];
+    sl = gn.slopes[k * CIN + c];
+  }
+  if (mine) {
+    tab[T::kRawS + lane] = s;
+    tab[T::kRawL + lane] = sl;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (mine) {
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float sj = tab[T::kRawS + c * 16 + j];
+      rank += (sj < s || (sj == s && j < k)) ? 1 : 0;
+    }
+    tab[T::kSortS + c * 16 + rank] = s;
+    tab[T::kSortL + c * 16 + rank] = sl;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (mine) {
+    const int i = k;
+    const float si = tab[T::kSortS + c * 16 + i];
+    double A = 0.0, Cv = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float sr = tab[T::kSortS + c * 16 + r], lr = tab[T::kSortL + c * 16 + r];
+      if (r < i) Cv += (double)lr * ((double)si - (double)sr);
+      if (r <= i) A += (double)lr;
+    }
+    const bool dead = !(si < __builtin_inff());  // an unused slot (or an infinite / NaN knot): never reached
+    float4 leaf = make_float4(si, (float)Cv, (float)A, 0.0f);
+    if (dead) leaf = make_float4(__builtin_inff(), 0.0f, 0.0f, 0.0f);
+    *reinterpret_cast<float4*>(tab + T::kLeaf + (c * 16 + i) * 4) = leaf;
+    if (i >= 1) {
+      // sorted key j = i - 1 of the 15 search keys s_(1) .. s_(15) -> its Eytzinger node: with t = ctz(j + 1) the node sits
+      // on level 3 - t at position (j + 1) >> (t + 1)
+      const int j1 = i;  // j + 1
+      const int t = __builtin_ctz(j1);
+      const int e = (1 << (3 - t)) + (j1 >> (t + 1));
+      tab[T::kTree + c * 16 + e] = si;
+    }
+  }
+}
+
+template <int CIN>
+__device__ __forceinline__ float curve_lookup(const float* __restrict__ tab, int c, float v) {
+  typedef CurveTab<CIN> T;
+  const float* tree = tab + T::kTree + c * 16;
+  int m = 1;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) m = 2 * m + ((v >= tree[m]) ? 1 : 0);
+  const f32x4 leaf = *reinterpret_cast<const f32x4*>(tab + T::kLeaf + c * 64 + (m - 16) * 4);
+  return __builtin_fmaf(leaf.z, fmaxf(v - leaf.x, 0.0f), leaf.y);
+}
+
+// The guide of a lane's 4 pixels from the tables (same colour matrix / mixing / clip as the scan form).
+template <int CIN>
+__device__ __forceinline__ void guide_curves_quad(const float* __restrict__ tab, const GuideNet& gn, const float* inf,
+                                                  float (&g)[kPxPerThread]) {
+  cfloat* ccm = (cfloat*)gn.conv1;
+  cfloat* mix = (cfloat*)gn.conv2;
+  float w[CIN][CIN + 1], m[CIN + 1];
+#pragma unroll
+  for (int c = 0; c < CIN; ++c) {
+#pragma unroll
+    for (int j = 0; j <= CIN; ++j) w[c][j] = ccm[c * (CIN + 1) + j];
+  }
+#pragma unroll
+  for (int c = 0; c <= CIN; ++c) m[c] = mix[c];
+  float cv[kPxPerThread][CIN];
+#pragma unroll
+  for (int q = 0; q < kPxPerThread; ++q) {
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+      float t = w[c][CIN];
+#pragma unroll
+      for (int j = 0; j < CIN; ++j) t = fmaf(w[c][j], inf[q * CIN + j], t);
+      cv[q][c] = curve_lookup<CIN>(tab, c, t);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kPxPerThread; ++q) {
+    float v = m[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) v = fmaf(m[c], cv[q][c], v);
+    g[q] = fminf(fmaxf(v, 0.0f), 1.0f);  // tf.clip_by_value(guidemap, 0, 1)
+  }
+}
+
+// ---- TOOLS BUILD ONLY (knob 5): the point-wise guide network's hidden layer on the bf16 matrix cores, uint8 input ----
+// Round 4 experiment, bit-level parity green (guide within 1e-6 of the oracle), REJECTED on time:
+// u8 -> guide network -> u8 at 4K 39.5 us on the VALU, 47.2 us with 48 of these matrix instructions per wave (max + fma
+// on the VALU), 53.4 us with 60 (the |h| form below) -- a v_mfma_f32_4x4x4_16B_bf16 costs its SIMD ~25 cycles for 1024
+// multiply-adds, and an f32-accurate product needs three of them (hi / mid / lo of the weight): no faster than the 3
+// VALU FMAs it replaces.  The 16 x 16 x 16 form does 96 useful multiply-adds per cycle, / 3 parts = the VALU's own 32, and
+// needs every pixel's bytes in four lanes (an LDS round trip).  A K = 4 contraction is too small for the matrix cores at
+// f32 accuracy.  profiles/r04/guide_nn_mfma.md.  The product evaluates the network with guide_nn_quad (rows_common.hip.h).
+// h[f] = conv1[f][3] + sum_j conv1[f][j] * (v_j / white) is a 16 x 4 by 4 x pixels contraction.  For UINT8 samples the
+// pixel side is exact in bf16 (integers <= 255; the 1 of the bias column too), so the only thing to split is the
+// weight side: w' = w / white (f32) = hi + mid + lo, three bf16 that carry its 24 significant bits, every product exact in
+// the matrix core's f32 accumulator.  v_mfma_f32_4x4x4_16B_bf16 multiplies sixteen independent 4 x 4 blocks: in block b
+// (lanes 4b .. 4b + 3) lane 4b + i supplies row i of A (feature 4 fg + i: its three weights and its bias, one of the three
+// parts), lane 4b + j supplies column j of B -- ITS OWN pixel's (r, g, b, 1) -- and receives column j of D: the four
+// features of its own pixel.  No cross-lane traffic on the pixel side at all; 3 parts x (n / 4) feature groups
+// matrix instructions per pixel quad-slot replace 3 n VALU FMAs per pixel, and the bf16 pipe runs beside the VALU
+// (the f32 matrix instructions do not: profiles/r01/f_ubench_mfma_valu_overlap.txt).  ReLU, the mixing layer and the
+// sigmoid stay on the VALU.  A operands: prepared once per workgroup by wave 0 in LDS (NnTab), re-read per feature group.
+// Requires n % 4 == 0, n <= 16; other sizes / input types take guide_nn_quad.
+#ifdef HDRNET_TOOLS_BUILD
+constexpr bool kToolsBuild = true;
+#else
+constexpr bool kToolsBuild = false;
+#endif
+typedef short bf16x4_t __attribute__((ext_vector_type(4)));
+struct NnTab {
+  // [feature group 0 .. 3, 4 = the linear row][part][row i][2 dwords = 4 bf16]
+  static constexpr int kWords = 5 * 3 * 4 * 2 + 4;  // + 4 floats of scratch for the linear row; 16-B multiple
+};
+
+__device__ __forceinline__ unsigned bf16_rne_bits(float x) {  // round-to-nearest-even truncation to bf16 (finite x)
+  const unsigned u = __float_as_uint(x);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// w[0 .. 3] -> its three bf16 parts, packed as the A operand's two dwords, at tab[((group * 3 + part) * 4 + row) * 2].
+__device__ __forceinline__ void nn_store_row(unsigned* __restrict__ tab, int group, int row, const float (&w)[4]) {
+  unsigned part[3][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float r = w[k];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const unsigned b = bf16_rne_bits(r);
+      part[q][k] = b;
+      r -= __uint_as_float(b << 16);  // exact: the remainder of a bf16 rounding fits a float
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    unsigned* d = tab + ((group * 3 + q) * 4 + row) * 2;
+    d[0] = part[q][0] | (part[q][1] << 16);
+    d[1] = part[q][2] | (part[q][3] << 16);
+  }
+}
+
+// relu(h) = (h + |h|) / 2:  bias2 + sum_f m_f relu(h_f) = [bias2 + sum_f (m_f / 2) h_f] + sum_f (m_f / 2) |h_f|.  The
+// bracket is affine in the pixel -- ONE more row for the matrix cores (group 4, row 0: L_j = sum_f (m_f / 2) w'_fj,
+// L_3 = bias2 + sum_f (m_f / 2) b_f, summed in float64) -- and the rest is one FMA with the |.| source modifier per
+// feature and pixel: no max, no second accumulation.
+// Run by lanes 0 .. 19 of wave 0: lane < 16 = a feature row, lanes 16 .. 19 = the linear row's four entries.
+__device__ __forceinline__ void nn_build_tables(unsigned* __restrict__ tab, float* __restrict__ lin, const GuideNet& gn,
+                                                float white, int lane) {
+  if (lane < 16) {
+    float w[4] = {0.f, 0.f, 0.f, 0.f};
+    if (lane < gn.n) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) w[j] = gn.conv1[lane * 4 + j] / white;  // (w / white) * v == w * (v / white) to an ulp
+      w[3] = gn.conv1[lane * 4 + 3];
+    }
+    nn_store_row(tab, lane >> 2, lane & 3, w);
+    if (lane >= 1 && lane < 4) {  // rows 1 .. 3 of the linear group: zero
+      const float z[4] = {0.f, 0.f, 0.f, 0.f};
+      nn_store_row(tab, 4, lane, z);
+    }
+  } else if (lane < 20) {
+    const int j = lane - 16;
+    double acc = j == 3 ? (double)gn.conv2[gn.n] : 0.0;
+    for (int f = 0; f < gn.n; ++f) {
+      const float w = j == 3 ? gn.conv1[f * 4 + 3] : gn.conv1[f * 4 + j] / white;
+      acc += 0.5 * (double)gn.conv2[f] * (double)w;
+    }
+    lin[j] = (float)acc;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane == 0) {
+    const float w[4] = {lin[0], lin[1], lin[2], lin[3]};
+    nn_store_row(tab, 4, 0, w);
+  }
+}
+
+// raw: the lane's 12 bytes (4 RGB pixels).  g[q] = the guide of pixel q.
+__device__ __forceinline__ void guide_nn_quad_mfma_u8(const unsigned* __restrict__ tab, const GuideNet& gn,
+                                                      const uint32_t (&raw)[3], int lane, float (&g)[kPxPerThread]) {
+  cfloat* c2 = (cfloat*)gn.conv2;
+  // B operands: bf16(v) is the upper half of float(v) for an integer v <= 255
+  bf16x4_t bq[kPxPerThread];
+#pragma unroll
+  for (int q = 0; q < kPxPerThread; ++q) {
+    float ch[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int byte = 3 * q + c;
+      ch[c] = (float)((raw[byte >> 2] >> (8 * (byte & 3))) & 0xffu);  // v_cvt_f32_ubyteN
+    }
+    const unsigned lo = (__float_as_uint(ch[0]) >> 16) | (__float_as_uint(ch[1]) & 0xffff0000u);
+    const unsigned hi = (__float_as_uint(ch[2]) >> 16) | 0x3f800000u;  // (b, 1.0)
+    bq[q] = __builtin_bit_cast(bf16x4_t, uint2{lo, hi});
+  }
+  const unsigned* arow = tab + (lane & 3) * 2;
+  float acc[kPxPerThread];
+  {  // the affine part: group 4, row 0
+    bf16x4_t a[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) a[q] = __builtin_bit_cast(bf16x4_t, *reinterpret_cast<const uint2*>(arow + (4 * 3 + q) * 8));
+#pragma unroll
+    for (int q = 0; q < kPxPerThread; ++q) {
+      f32x4 h = {0.f, 0.f, 0.f, 0.f};
+      h = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a[2], bq[q], h, 0, 0, 0);
+      h = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a[1], bq[q], h, 0, 0, 0);
+      h = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a[0], bq[q], h, 0, 0, 0);
+      acc[q] = h[0];
+    }
+  }
+  const int ngroups = gn.n >> 2;
+#pragma unroll 1
+  for (int fg = 0; fg < ngroups; ++fg) {
+    bf16x4_t a[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) a[q] = __builtin_bit_cast(bf16x4_t, *reinterpret_cast<const uint2*>(arow + (fg * 3 + q) * 8));
+    float m[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = 0.5f * c2[fg * 4 + i];
+#pragma unroll
+    for (int q = 0; q < kPxPerThread; ++q) {
+      f32x4 h = {0.f, 0.f, 0.f, 0.f};
+      // small terms first: lo, mid, hi
+      h = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a[2], bq[q], h, 0, 0, 0);
+      h = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a[1], bq[q], h, 0, 0, 0);
+      h = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a[0], bq[q], h, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[q] = fmaf(m[i], __builtin_fabsf(h[i]), acc[q]);
+    }
+  }
+  if (gn.guide_out) {  // training forward: tf.nn.sigmoid with an IEEE divide (rows_common.hip.h: guide_nn_quad)
+#pragma unroll
+    for (int q = 0; q < kPxPerThread; ++q) g[q] = 1.0f / (1.0f + expf(-acc[q]));
+  } else {
+#pragma unroll
+    for (int q = 0; q < kPxPerThread; ++q)
+      g[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * acc[q]));
+  }
+}
+
 // v / wl for an integer sample v, correctly rounded like the IEEE division TF performs
 // (tf.to_float(im) / white_level), in three instructions instead of the ~11 of a general IEEE divide:
 //   q = v * r;  e = fma(-q, wl, v);  q' = fma(e, r, q)      with r = RN(1 / wl) from the host.
@@ -125,7 +411,7 @@ __device__ __forceinline__ float div_white(float v, const WhiteLevel& w) {
 // Load 4 pixels x CIN channels of TI starting at element index e0, as floats / white level.
 template <typename TI, int N>
 __device__ __forceinline__ void load_pixels(const TI* __restrict__ src, size_t e0, const WhiteLevel& wl,
-                                            float (&dst)[N]) {
+                                            float (&dst)[N], uint32_t* raw = nullptr) {
   if constexpr (sizeof(TI) == 4) {
 #pragma unroll
     for (int q = 0; q < N; ++q) dst[q] = reinterpret_cast<const float*>(src)[e0 + q];
@@ -136,6 +422,10 @@ __device__ __forceinline__ void load_pixels(const TI* __restrict__ src, size_t e
     const uint32_t* p = reinterpret_cast<const uint32_t*>(src + e0);
 #pragma unroll
     for (int q = 0; q < ND; ++q) w[q] = p[q];
+    if (raw) {
+#pragma unroll
+      for (int q = 0; q < ND; ++q) raw[q] = w[q];
+    }
 #pragma unroll
     for (int q = 0; q < N; ++q) {
       uint32_t v;
@@ -158,6 +448,7 @@ struct IoParams {
   int grid_image;  // floats per image of the grid
   SegTab tab;      // (cmin, ncols) per segment, from the host (seg_common.hip.h)
   GuideNet gn;
+  int nn_mfma;     // tools build, knob 5: the guide network's hidden layer on the matrix cores (uint8 input)
 };
 
 // Geometry, LDS image and pixel core are apply_fwd_seg.hip's (seg_common.hip.h): a workgroup owns a row
@@ -167,7 +458,15 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
   constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
   constexpr int CB = C * (int)sizeof(float);
   constexpr int NI = CIN * kPxPerThread, NO = COUT * kPxPerThread;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds_all[];
+  // curves guide: its lookup tables first (compile-time LDS addresses), the coefficient image behind them
+#ifdef HDRNET_TOOLS_BUILD
+  constexpr bool NN_MFMA = GUIDE == kGuideNN && sizeof(TI) == 1 && CIN == 3;  // experiment: hidden layer on the bf16 matrix cores
+#else
+  constexpr bool NN_MFMA = false;
+#endif
+  constexpr int kTabFloats = (GUIDE == kGuideCurves) ? CurveTab<CIN>::kFloats : NN_MFMA ? NnTab::kWords : 0;
+  float* const lds = lds_all + kTabFloats;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int xs = blockIdx.x * p.seg;
@@ -183,6 +482,7 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
 
   float gs[kPxPerThread] = {0.f, 0.f, 0.f, 0.f};
   float inf[NI];
+  [[maybe_unused]] uint32_t raw[3] = {};
 #pragma unroll
   for (int q = 0; q < NI; ++q) inf[q] = 0.0f;
   if (active) {
@@ -190,9 +490,18 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
       const float4 g4 = *reinterpret_cast<const float4*>(p.guide + px);
       gs[0] = g4.x; gs[1] = g4.y; gs[2] = g4.z; gs[3] = g4.w;
     }
-    load_pixels<TI, NI>(input, px * CIN, p.white, inf);
+    if constexpr (NN_MFMA) load_pixels<TI, NI>(input, px * CIN, p.white, inf, raw);
+    else load_pixels<TI, NI>(input, px * CIN, p.white, inf);
+  }
+  const bool nn_mfma = NN_MFMA && p.nn_mfma && p.gn.n <= 16 && (p.gn.n & 3) == 0;  // uniform
+  if constexpr (NN_MFMA) {
+    if (nn_mfma && wave == 0)
+      nn_build_tables(reinterpret_cast<unsigned*>(lds_all), lds_all + NnTab::kWords - 4, p.gn, p.white.wl, lane);
   }
 
+  if constexpr (GUIDE == kGuideCurves) {
+    if (wave == 0) curves_build_tables<CIN>(lds_all, p.gn, lane);  // published by the barrier below
+  }
   const SegCols sc = seg_cols_tab(p.tab, blockIdx.x, xs, xe, p.scale_x);
   const int colb = (p.GD + 2) * CB;
   const float gd_f = (float)p.GD, zhi = (float)(p.GD - 1);
@@ -208,10 +517,20 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
   float of[NO];
   if (active) {
     if constexpr (GUIDE != kGuideMap) {
-      if constexpr (GUIDE == kGuideNN)
-        guide_nn_quad<CIN>(GuideNN{p.gn.conv1, p.gn.conv2, p.gn.guide_out, p.gn.n}, inf, gs);  // (writes nothing itself)
+      if constexpr (GUIDE == kGuideNN) {
+        bool done = false;
+        if constexpr (NN_MFMA) {
+          if (nn_mfma) {
+            guide_nn_quad_mfma_u8(reinterpret_cast<const unsigned*>(lds_all), p.gn, raw, lane, gs);
+            done = true;
+          }
+        }
+        if (!done) guide_nn_quad<CIN>(GuideNN{p.gn.conv1, p.gn.conv2, p.gn.guide_out, p.gn.n}, inf, gs);  // (writes nothing itself)
+      }
+      else if constexpr (GUIDE == kGuideCurves)
+        guide_curves_quad<CIN>(lds_all, p.gn, inf, gs);
       else
-        guide_curves_quad<CIN>(p.gn, inf, gs);
+        guide_curves_scan_quad<CIN>(p.gn, inf, gs);
       if (p.gn.guide_out) *reinterpret_cast<float4*>(p.gn.guide_out + px) = make_float4(gs[0], gs[1], gs[2], gs[3]);
     }
 #pragma unroll
@@ -279,19 +598,19 @@ struct IoGeom {
   size_t lds;
 };
 
-IoGeom io_geom(int W, int GW, int GD, int C, int Cout) {
+IoGeom io_geom(int W, int GW, int GD, int C, int Cout, int tab_floats = 0) {
   IoGeom g;
   g.pl = make_row_plan(W, GW, true);
   const int max_cols = (int)(((long long)(g.pl.seg - 1) * GW) / W + 4);
   g.slab_off = round_up(max_cols * (GD + 2) * C, 4);
-  g.lds = ((size_t)g.slab_off + (size_t)(g.pl.threads / 64) * 64 * kPxPerThread * Cout) * sizeof(float);
+  g.lds = ((size_t)tab_floats + (size_t)g.slab_off + (size_t)(g.pl.threads / 64) * 64 * kPxPerThread * Cout) * sizeof(float);
   return g;
 }
 
 template <int CIN, int COUT, bool OFFSET, int GUIDE, typename TI, typename TO>
 hipError_t launch_io(const ApplyIoArgs& a, const Plan&, hipStream_t s) {
   constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
-  const IoGeom g = io_geom(a.W, a.GW, a.GD, C, COUT);
+  const IoGeom g = io_geom(a.W, a.GW, a.GD, C, COUT, GUIDE == kGuideCurves ? CurveTab<CIN>::kFloats : (kToolsBuild && GUIDE == kGuideNN) ? NnTab::kWords : 0);
   IoParams p;
   p.grid = a.grid;
   p.guide = a.guide;
@@ -307,6 +626,11 @@ hipError_t launch_io(const ApplyIoArgs& a, const Plan&, hipStream_t s) {
   p.grid_image = a.GH * a.GW * a.GD * C;
   p.tab = make_seg_tab(a.W, g.pl.seg, g.pl.nseg, p.scale_x);
   p.gn = GuideNet{a.guide_conv1, a.guide_conv2, a.guide_shifts, a.guide_slopes, a.guide_out, a.n_feats};
+#ifdef HDRNET_TOOLS_BUILD
+  p.nn_mfma = tools_knob(5);
+#else
+  p.nn_mfma = 0;
+#endif
   const dim3 grid3((unsigned)g.pl.nseg, (unsigned)a.H, (unsigned)a.B);
   apply_fwd_io_rows<CIN, COUT, OFFSET, GUIDE, TI, TO><<<grid3, g.pl.threads, g.lds, s>>>(p);
   return hipGetLastError();
@@ -338,7 +662,7 @@ bool plan_io(const ApplyIoArgs& a, Plan* pl) {
                          (a.input_dtype == 0 ? (uintptr_t)a.input : 0);
   if (bits & 15u) return false;
   if (((uintptr_t)a.input | (uintptr_t)a.out) & 3u) return false;
-  const IoGeom g = io_geom(a.W, a.GW, a.GD, 12, 3);
+  const IoGeom g = io_geom(a.W, a.GW, a.GD, 12, 3, CurveTab<3>::kFloats);  // the largest of the three kernels
   *pl = g.pl;
   if (a.B > 65535 || a.H > 65535 || (long long)a.W * a.Cout * 4 >= (1LL << 31)) return false;
   if ((long long)(g.slab_off) >= (1 << 20)) return false;
@@ -361,7 +685,8 @@ hipError_t launch_apply_fwd_io(const ApplyIoArgs& a, hipStream_t s, const char**
   const int kind = a.guide ? kGuideMap : (a.guide_shifts ? kGuideCurves : kGuideNN);
   snprintf(label, sizeof label, "apply_fwd_io/%s%s", io[a.input_dtype][a.output_dtype], suffix[kind]);
   *name = label;
-  if (kind == kGuideCurves) return dispatch_types<kGuideCurves>(a, pl, s);
+  if (kind == kGuideCurves)
+    return a.n_feats <= kCurveMaxKnots ? dispatch_types<kGuideCurves>(a, pl, s) : dispatch_types<kGuideCurvesScan>(a, pl, s);
   return kind == kGuideNN ? dispatch_types<kGuideNN>(a, pl, s) : dispatch_types<kGuideMap>(a, pl, s);
 }
 

@@ -600,6 +600,7 @@ void apply_fwd_seg_set_trace(long long* device_buf) { g_trace = device_buf; }
 void apply_fwd_seg_set_knob(int idx, int value) {
   if (idx >= 0 && idx < 8) g_knob[idx] = value;
 }
+int tools_knob(int idx) { return idx >= 0 && idx < 8 ? g_knob[idx] : 0; }
 
 // variants 70 / 71 (71: with the timeline trace): the product flavour on the flat grid with a ticketed tail;
 // knobs 1, 2 = D, surplus.

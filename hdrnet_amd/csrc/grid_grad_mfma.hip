@@ -72,6 +72,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 
 #include "launch.hip.h"
@@ -779,6 +780,7 @@ struct GGPlan {
 // R <= 6 whose exact-fit rg fills them best, rg within [4, cell height] (a task's rows may span at most 3
 // clamped grid rows).  slots <= 0: the smallest rg any launch may pick -- the workspace bound.
 constexpr int kMinRg = 4, kMaxRounds = 6;
+constexpr int kMaxOcc = 8;  // workgroups per CU a stage-1 kernel can have (8 waves per SIMD, 4-wave workgroups)
 
 bool gg_plan(int B, int H, int W, int GH, int GW, int GD, int C, long long slots, GGPlan* pl) {
   if (GD > 8 || C > 16 || C < 1) return false;
@@ -822,15 +824,45 @@ bool gg_plan(int B, int H, int W, int GH, int GW, int GD, int C, long long slots
 // plan over those eight counts bounds every launch.  (Round 2 returned the plan for the smallest rows-per-
 // task any launch may pick -- 28 MB at 4K where a launch uses 7, hundreds of MB for batched training.)
 bool gg_ws_bound(int B, int H, int W, int GH, int GW, int GD, int C, size_t* bytes) {
-  size_t worst = 0;
+  // asked for on every backward call (the *_supported checks): the last answer per thread is kept, keyed on the
+  // shape and the CU count it was planned for
+  struct Key {
+    int B, H, W, GH, GW, GD, C;
+    long long cus;
+    bool operator==(const Key& o) const {
+      return B == o.B && H == o.H && W == o.W && GH == o.GH && GW == o.GW && GD == o.GD && C == o.C && cus == o.cus;
+    }
+  };
+  thread_local Key last{};
+  thread_local size_t last_bytes = 0;
+  thread_local bool last_ok = false, have = false;
   const long long cus = rows::num_cus();
-  for (int occ = 1; occ <= 8; ++occ) {
-    GGPlan pl;
-    if (!gg_plan(B, H, W, GH, GW, GD, C, occ * cus, &pl)) return false;
-    if (pl.ws_bytes > worst) worst = pl.ws_bytes;
+  const Key k{B, H, W, GH, GW, GD, C, cus};
+  if (!have || !(last == k)) {
+    size_t worst = 0;
+    bool ok = true;
+    for (int occ = 1; occ <= kMaxOcc && ok; ++occ) {
+      GGPlan pl;
+      ok = gg_plan(B, H, W, GH, GW, GD, C, occ * cus, &pl);
+      if (ok && pl.ws_bytes > worst) worst = pl.ws_bytes;
+    }
+    last = k;
+    last_bytes = worst;
+    last_ok = ok;
+    have = true;
   }
-  *bytes = worst;
-  return true;
+  *bytes = last_bytes;
+  return last_ok;
+}
+
+// The caller's workspace is smaller than this device's bound (queried on another device, or with an older
+// library): the call then runs on the generic gather kernel, ~100x slower.  Say so once instead of silently.
+void warn_small_workspace(size_t have, size_t need) {
+  static std::atomic<bool> said{false};
+  if (have == 0 || said.exchange(true)) return;
+  fprintf(stderr, "hdrnet_amd: gradient workspace of %zu bytes is smaller than the %zu this device needs "
+          "(hdrnet_bilateral_slice*_grad_workspace_bytes, queried with the device current); using the generic "
+          "grid-gradient kernel, which is ~100x slower\n", have, need);
 }
 
 long long* g_gg_trace = nullptr;  // tools: phase-trace buffer (grid_grad_set_trace)
@@ -845,6 +877,7 @@ long long resident_slots(Stage1Fn kfn, std::atomic<int>* cache) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kfn), kWaves * 64, 0) !=
             hipSuccess || occ <= 0)
       occ = 1;
+    if (occ > kMaxOcc) occ = kMaxOcc;  // the workspace bound (gg_ws_bound) covers 1 .. kMaxOcc
     if (cache) cache->store(occ, std::memory_order_relaxed);
   }
   return (long long)occ * rows::num_cus();  // CU count of the CURRENT device (cached per ordinal)
@@ -941,9 +974,11 @@ size_t apply_grid_grad_mfma_workspace(int B, int H, int W, int GH, int GW, int G
 
 bool apply_grid_grad_mfma_supported(const ApplyGradArgs& a) {
   size_t bytes = 0;
-  return apply_shape_ok(a.Cin, a.Cout, a.has_offset) &&
-         gg_ws_bound(a.B, a.H, a.W, a.GH, a.GW, a.GD, a.Cout * a.Cj, &bytes) && a.workspace != nullptr &&
-         a.workspace_bytes >= bytes;
+  if (!apply_shape_ok(a.Cin, a.Cout, a.has_offset) || !gg_ws_bound(a.B, a.H, a.W, a.GH, a.GW, a.GD, a.Cout * a.Cj, &bytes))
+    return false;
+  if (a.workspace != nullptr && a.workspace_bytes >= bytes) return true;
+  warn_small_workspace(a.workspace ? a.workspace_bytes : 0, bytes);
+  return false;
 }
 
 // variant (tools A/B): 2 = bf16-split contraction.  fused: also write a.dguide / a.dinput.
@@ -988,8 +1023,10 @@ size_t slice_grid_grad_mfma_workspace(int B, int H, int W, int GH, int GW, int G
 
 bool slice_grid_grad_mfma_supported(const SliceGradArgs& a) {
   size_t bytes = 0;
-  return slice_c_ok(a.C) && gg_ws_bound(a.B, a.H, a.W, a.GH, a.GW, a.GD, a.C, &bytes) &&
-         a.workspace != nullptr && a.workspace_bytes >= bytes;
+  if (!slice_c_ok(a.C) || !gg_ws_bound(a.B, a.H, a.W, a.GH, a.GW, a.GD, a.C, &bytes)) return false;
+  if (a.workspace != nullptr && a.workspace_bytes >= bytes) return true;
+  warn_small_workspace(a.workspace ? a.workspace_bytes : 0, bytes);
+  return false;
 }
 
 static hipError_t slice_gg(const SliceGradArgs& a, bool fused, hipStream_t s) {

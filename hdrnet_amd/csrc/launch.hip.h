@@ -154,6 +154,7 @@ hipError_t launch_apply_fwd_seg_knob(const ApplyArgs& a, int knob, hipStream_t s
 hipError_t launch_apply_fwd_seg_pix(const ApplyArgs& a, int knob, hipStream_t s, const char** name);
 void apply_fwd_seg_set_trace(long long* device_buf);
 void apply_fwd_seg_set_knob(int idx, int value);
+int tools_knob(int idx);  // experiment knobs of the tools build (include/hdrnet_amd_tools.h)
 hipError_t launch_apply_fwd_seg_dyn(const ApplyArgs& a, bool trace, hipStream_t s, const char** name);
 hipError_t launch_apply_fwd_seg_product_trace(const ApplyArgs& a, hipStream_t s, const char** name);
 void grid_grad_set_trace(long long* device_buf);

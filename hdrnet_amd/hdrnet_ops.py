@@ -625,8 +625,8 @@ def bilateral_slice_apply_io(grid: torch.Tensor, input: torch.Tensor,  # noqa: A
     ``guide_conv2``); or ``guide_curves = (ccm [Cin, Cin+1], shifts [npts, Cin], slopes [npts, Cin],
     mix [Cin+1])``, the standard model's curves guide (hdrnet/models.py:145-190) in the layout
     hdrnet/bin/freeze_graph.py:107-127 exports -- then evaluated in registers, as the reference's
-    standard GL shader does (benchmark/assets/std.frag:36-45).  ``return_guide`` (curves only) also
-    returns the guide map.  No autograd."""
+    standard GL shader does (benchmark/assets/std.frag:36-45).  ``return_guide`` (guide network or curves) also
+    returns the guide map the kernel computed (then with the IEEE sigmoid of a training forward).  No autograd."""
     if input.dim() != 4:
         raise ValueError(f"Input image should be 4D (batch_size, height, width, input_channels), got {tuple(input.shape)}")
     if input.dtype not in _DTYPE_CODE:
@@ -637,8 +637,8 @@ def bilateral_slice_apply_io(grid: torch.Tensor, input: torch.Tensor,  # noqa: A
         if guide is not None or guide_conv1 is not None or guide_conv2 is not None:
             raise ValueError("give exactly one of guide, (guide_conv1, guide_conv2), guide_curves")
         return _apply_io_curves(grid, input, guide_curves, input_white_level, out_dtype, has_offset, return_guide)
-    if return_guide:
-        raise ValueError("return_guide is only available with guide_curves")
+    if return_guide and guide is not None:
+        raise ValueError("return_guide needs a guide computed by the kernel (guide network or guide_curves)")
     if (guide is None) == (guide_conv1 is None or guide_conv2 is None):
         raise ValueError("give either a guide map or both guide_conv1 and guide_conv2")
     if input_white_level is None:
@@ -663,12 +663,13 @@ def bilateral_slice_apply_io(grid: torch.Tensor, input: torch.Tensor,  # noqa: A
     grid, inp = grid.detach().contiguous(), input.detach().contiguous()
     dev = inp.device
     out = torch.empty((B, H, W, Cout), dtype=out_dtype, device=dev)
+    gout = torch.empty((B, H, W), dtype=torch.float32, device=dev) if return_guide else None
     lib = _lib.load()
     with torch.cuda.device(dev):
         rc = lib.hdrnet_bilateral_slice_apply_io(
             grid.data_ptr(), _ptr(guide), inp.data_ptr(), out.data_ptr(), B, H, W, GH, GW, GD, Cin, Cout,
             int(bool(has_offset)), _DTYPE_CODE[input.dtype], float(input_white_level), _DTYPE_CODE[out_dtype],
             _ptr(guide_conv1) if guide is None else None, _ptr(guide_conv2) if guide is None else None,
-            n, None, _stream(dev))
+            n, _ptr(gout), _stream(dev))
     _lib.check(rc, "BilateralSliceApplyIO")
-    return out
+    return (out, gout) if return_guide else out

@@ -104,56 +104,79 @@ class FramePipeline:
         return out
 
 
-class GraphedTrainStep:
-    """One training step -- forward, loss, backward through the HIP VJPs, (at world size 1) the
-    optimizer update -- captured into a hipGraph and replayed per batch.
+class TrainStep:
+    """One training step -- forward, loss, backward, gradient all-reduce across the ranks, optimizer update -- with
+    the gradients kept in ONE persistent flat bucket (``dist.GradBucket``: ``.grad`` of every parameter is a view),
+    so that the step's only collective is one in-place all-reduce (RCCL over xGMI on the node; SURVEY.md section
+    8e) with no per-step flatten / scatter.  Eager; ``GraphedTrainStep`` replays forward + backward from a hipGraph
+    and shares everything after the backward with this class.  The reference's step is the single-device
+    ``sess.run(train_op)`` of ``hdrnet/bin/train.py:113-157``.
 
-    With the guide network fused, a config #4 step (4 x 1080p per GPU) is ~1.7 ms of GPU work
-    behind ~3.7 ms of host-side launches of the coefficient network's small ops; the graph removes
-    the host from the loop.  The reference's equivalent is the TF session running its static
-    training graph (``hdrnet/bin/train.py:156-226``).
+    ``loss_fn(output, *targets) -> scalar``.
+    """
 
-    ``loss_fn(output, *targets) -> scalar``.  ``optimizer`` must be capturable (e.g.
-    ``torch.optim.Adam(..., capturable=True)``).  In a multi-process job (``torch.distributed``
-    initialised, world size > 1) only forward + backward are captured; ``__call__`` then runs the
-    flat-bucket gradient all-reduce (``dist.allreduce_gradients_flat``) and the optimizer step
-    eagerly, so the collective stays outside the graph.
+    def __init__(self, module: torch.nn.Module, loss_fn, optimizer: torch.optim.Optimizer):
+        from . import dist as hd
+        self.module, self.loss_fn, self.optimizer = module, loss_fn, optimizer
+        self._hd = hd
+        self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized() \
+            and torch.distributed.get_world_size() > 1
+        self.bucket = hd.GradBucket(module.parameters())
+
+    def _forward_backward(self, inputs, targets) -> torch.Tensor:
+        self.bucket.zero_()
+        loss = self.loss_fn(self.module(*inputs), *targets)
+        loss.backward()  # accumulates IN PLACE into the bucket's views
+        return loss
+
+    def _after_backward(self) -> None:
+        if self.distributed:
+            self.bucket.allreduce()
+        self.optimizer.step()
+
+    def __call__(self, inputs: Sequence[torch.Tensor], targets: Sequence[torch.Tensor]) -> torch.Tensor:
+        loss = self._forward_backward(list(inputs), list(targets))
+        self._after_backward()
+        return loss
+
+
+class GraphedTrainStep(TrainStep):
+    """``TrainStep`` with forward, loss and backward through the HIP VJPs -- and, at world size 1, the optimizer
+    update too -- captured into a hipGraph and replayed per batch.
+
+    With the guide network fused, a config #4 step (4 x 1080p per GPU) is ~1.5 ms of GPU work behind ~3.7 ms of
+    host-side launches of the coefficient network's small ops; the graph removes the host from the loop.  The
+    reference's equivalent is the TF session running its static training graph (``hdrnet/bin/train.py:156-226``).
+
+    ``optimizer`` must be capturable (e.g. ``torch.optim.Adam(..., capturable=True)``).  In a multi-process job
+    (``torch.distributed`` initialised, world size > 1) the graph ends with the backward: ``__call__`` then runs
+    the ONE in-place all-reduce of the flat gradient bucket and the optimizer step eagerly -- the collective stays
+    outside the graph.  ``flat_bucket=True`` forces that structure at world size 1 as well (bench / tests).
     """
 
     def __init__(self, module: torch.nn.Module, loss_fn, optimizer: torch.optim.Optimizer,
                  example_inputs: Sequence[torch.Tensor], example_targets: Sequence[torch.Tensor],
-                 warmup: int = 3):
-        from . import dist as hd
+                 warmup: int = 3, flat_bucket: bool = False):
         if not all(t.is_cuda for t in list(example_inputs) + list(example_targets)):
             raise RuntimeError("GraphedTrainStep needs device tensors (MI355X)")
-        self.module, self.loss_fn, self.optimizer = module, loss_fn, optimizer
+        super().__init__(module, loss_fn, optimizer)
+        self.split = self.distributed or flat_bucket  # graph = forward + backward only; the rest eager
         self.static_inputs = [t.clone() for t in example_inputs]
         self.static_targets = [t.clone() for t in example_targets]
-        self._hd = hd
-        self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized() \
-            and torch.distributed.get_world_size() > 1
         side = torch.cuda.Stream(device=self.static_inputs[0].device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):  # also materialises the optimizer state before capture
-                self._eager_step()
+                self._forward_backward(self.static_inputs, self.static_targets)
+                self._after_backward()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        self.optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
-            self.static_loss = self.loss_fn(self.module(*self.static_inputs), *self.static_targets)
-            self.static_loss.backward()
-            if not self.distributed:
+            self.static_loss = self._forward_backward(self.static_inputs, self.static_targets)
+            if not self.split:
                 self.optimizer.step()
-
-    def _eager_step(self):
-        self.optimizer.zero_grad(set_to_none=True)
-        loss = self.loss_fn(self.module(*self.static_inputs), *self.static_targets)
-        loss.backward()
-        if self.distributed:
-            self._hd.allreduce_gradients_flat(self.module.parameters())
-        self.optimizer.step()
-        return loss
+        if not self.bucket.attached():
+            raise RuntimeError("a parameter's .grad was re-bound during capture: the flat bucket is detached")
 
     def __call__(self, inputs: Sequence[torch.Tensor], targets: Sequence[torch.Tensor]) -> torch.Tensor:
         for dst, src in zip(self.static_inputs + self.static_targets, list(inputs) + list(targets)):
@@ -161,8 +184,7 @@ class GraphedTrainStep:
                 raise ValueError(f"captured for {tuple(dst.shape)} {dst.dtype}, got {tuple(src.shape)} {src.dtype}")
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
-        self.graph.replay()  # gradients land in the captured .grad buffers
-        if self.distributed:
-            self._hd.allreduce_gradients_flat(self.module.parameters())
-            self.optimizer.step()
+        self.graph.replay()  # gradients land in the flat bucket
+        if self.split:
+            self._after_backward()
         return self.static_loss

@@ -125,15 +125,31 @@ def _key(variables: Dict[str, np.ndarray], name: str) -> str:
     raise KeyError(f"TensorFlow variable '{PREFIX}{name}' not in the fixture / checkpoint dump")
 
 
-def load_tf_variables(model, variables: Dict[str, np.ndarray]) -> None:
+# Entries of a checkpoint / fixture dump that are not model state (hdrnet/bin/train.py:120-160: the optimizer's slots and
+# the step counter; a fixture's own inputs / outputs carry no 'inference/' prefix at all).
+_NOT_MODEL_STATE = ("/Adam", "/Adam_1", "beta1_power", "beta2_power", "global_step", "/ExponentialMovingAverage")
+
+
+def load_tf_variables(model, variables: Dict[str, np.ndarray], strict: bool = True) -> None:
     """Fill ``model`` (HDRNetCurves / HDRNetPointwiseNNGuide / HDRNetGaussianPyrNN) from a dict
-    {TensorFlow variable name: array}; every tensor of the model must be present, shapes must agree."""
+    {TensorFlow variable name: array}; every tensor of the model must be present, shapes must agree.
+    ``strict``: a variable under the graph's ``inference/`` scope that the mapping does NOT consume raises --
+    e.g. ``.../BatchNorm/gamma`` of a checkpoint trained with ``scale=True`` (the reference builds its batch norms
+    without a scale, hdrnet/layers.py:40-58; such a checkpoint would otherwise load silently wrong)."""
+    consumed = set()
     with torch.no_grad():
         for name, t, kind in _all_tensors(model):
-            a = _to_torch(np.asarray(variables[_key(variables, name)], dtype=np.float32), kind)
+            key = _key(variables, name)
+            consumed.add(key)
+            a = _to_torch(np.asarray(variables[key], dtype=np.float32), kind)
             if tuple(a.shape) != tuple(t.shape):
                 raise ValueError(f"{name}: TensorFlow shape maps to {a.shape}, the module has {tuple(t.shape)}")
             t.copy_(torch.from_numpy(np.ascontiguousarray(a)).reshape(t.shape).to(t.device))  # (0-d stays 0-d)
+    extra = sorted(k for k in variables if k not in consumed and (k.startswith(PREFIX) or k.startswith("/" + PREFIX))
+                   and not any(tag in k for tag in _NOT_MODEL_STATE))
+    if extra and strict:
+        raise ValueError("TensorFlow variables the model has no place for (a checkpoint of another architecture / "
+                         f"batch norm with scale=True?): {extra[:8]}{' ...' if len(extra) > 8 else ''}")
 
 
 def export_tf_variables(model) -> Dict[str, np.ndarray]:

@@ -32,6 +32,26 @@ def test_bench_single_rank_needs_no_launcher():
     assert out["n_gpus"] == 1
 
 
+def test_train_workload_two_ranks_gloo():
+    """`--workload train_1080p_b4 --gpus 2` (BASELINE config #4 as stated): the harness -- per-rank train step with the
+    flat gradient bucket, ONE all-reduce per step, max-over-ranks timing, the all-reduce's share -- on CPU / gloo
+    with a stand-in torch-only model (the HIP kernels have no CPU path)."""
+    out = _run(["--gpus", "2", "--workload", "train_1080p_b4"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["unit"] == "MP/s"
+    ar = out["allreduce"]
+    assert ar["collectives_per_step"] == 1 and ar["backend"] == "gloo" and ar["bucket_elements"] == 12 * 32 + 32 + 32 * 3 + 3
+    assert 0 < ar["share_of_step"] < 1.5 and out["config"]["global_batch"] == 8
+    assert abs(out["value"] - 2 * out["per_gpu_MPps"]) <= 0.2
+    one = _run(["--gpus", "1", "--workload", "train_1080p_b4"])
+    assert one["n_gpus"] == 1 and one["allreduce"]["collectives_per_step"] == 0
+
+
+def test_hdrp_u16_workload_launch_path():
+    """`--workload hdrp_u16 --gpus 2`: same self-launch / barrier / max-over-ranks skeleton (the timed body needs the GPU)."""
+    out = _run(["--gpus", "2", "--workload", "hdrp_u16"])
+    assert out["n_gpus"] == 2 and out["workload"] == "hdrp_u16"
+
+
 def test_traffic_record_is_refused_when_sources_differ(tmp_path, monkeypatch):
     import bench
     rec = [{"workload": "4k", "kernel": "k", "bytes_per_launch": 1, "source_digest": "deadbeef"}]

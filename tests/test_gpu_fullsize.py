@@ -237,3 +237,32 @@ def test_jax_twin_equals_op_at_reference_size(dev, ops):
     got = N(ops.bilateral_slice(T(grid, dev), T(guide, dev)))
     assert got.shape == (4, 640, 480, 2)
     np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["1080p (config #2)", "4K (config #3 hot path)"])
+def test_dguide_noise_hip_vs_float64_against_the_reference_s_own(dev, ops, mt_port, name):
+    """tests/conftest.py holds dguide to a flat 4e-5 because the reference's OWN float32 arithmetic is
+    ~1e-5 away from the float64 value of its formulas -- but is the HIP path merely ordered differently, or noisier?
+    Measured here instead of argued: max|HIP - f64| and max|oracle - f64| of dguide (and dinput) on a full frame of the
+    suite's data, for both HIP paths that produce dguide (the fused all-gradients pass and the per-pixel VJP kernel).
+    Required: HIP's distance to the exact value <= 2 x the reference's own."""
+    from oracle.f64_vjps import f64_vjps
+    H, W, GH, GW, GD = CONFIGS[name]
+    rng = np.random.default_rng(H + 3 * W)
+    grid, guide, inp = frame(rng, H, W, GH, GW, GD)
+    dout = rng.standard_normal((1, H, W, 3)).astype(np.float32)
+    _, wgu, wi = mt_port.bilateral_slice_apply_grad(grid, guide, inp, dout, True)
+    dg64, di64 = f64_vjps(grid, guide, inp, dout)
+    ref_g, ref_i = np.abs(wgu - dg64).max(), np.abs(wi - di64).max()
+    tg, tgu, ti = (T(a, dev).requires_grad_(True) for a in (grid, guide, inp))
+    ops.bilateral_slice_apply(tg, tgu, ti, has_offset=True).backward(T(dout, dev))
+    k_all = ops.last_kernel()
+    tgu2, ti2 = (T(a, dev).requires_grad_(True) for a in (guide, inp))
+    ops.bilateral_slice_apply(T(grid, dev), tgu2, ti2, has_offset=True).backward(T(dout, dev))
+    k_px = ops.last_kernel()
+    for label, gu, gi in ((k_all, tgu.grad, ti.grad), (k_px, tgu2.grad, ti2.grad)):
+        hip_g, hip_i = np.abs(N(gu) - dg64).max(), np.abs(N(gi) - di64).max()
+        print(f"{name} [{label}]: dguide |HIP - f64| = {hip_g:.3e}, |reference f32 - f64| = {ref_g:.3e}, ratio {hip_g / ref_g:.2f}; "
+              f"dinput {hip_i:.3e} vs {ref_i:.3e}, ratio {hip_i / ref_i:.2f}; max|dguide| = {np.abs(dg64).max():.3g}")
+        assert hip_g <= 2.0 * ref_g, (label, hip_g, ref_g)
+        assert hip_i <= 2.0 * ref_i + 1e-7, (label, hip_i, ref_i)

@@ -362,6 +362,32 @@ def test_nnguide_fused_matches_composed_oracle(dev, ops, port, shape):
     torch.testing.assert_close(out2, out, rtol=2e-5, atol=2e-5)
 
 
+def test_inference_sigmoid_moves_the_guide_by_at_most_2_ulp(dev, ops):
+    """without a guide copy (inference) the fused guide network takes its sigmoid from v_exp_f32 + v_rcp_f32
+    instead of expf + an IEEE divide -- a documented, deliberate train / infer difference.  This bounds the GUIDE itself,
+    not only the output at 2e-5: with a grid whose only non-zero coefficients are the offsets (z + 0.5) / GD the sliced
+    output IS the guide up to the smoothed tent (d out / d guide = 1), so the two forms' outputs differ by the two
+    sigmoids' difference: <= 2 ulp of a value in (0, 1), i.e. 2.4e-7."""
+    B, H, W, GH, GW, GD, n = 1, 64, 512, 16, 16, 8, 16
+    rng = np.random.default_rng(77)
+    grid6 = np.zeros((B, GH, GW, GD, 3, 4), np.float32)
+    grid6[..., :, 3] = ((np.arange(GD, dtype=np.float32) + 0.5) / GD)[None, None, None, :, None]
+    grid = grid6.reshape(B, GH, GW, GD, 12)
+    inp = rng.random((B, H, W, 3)).astype(np.float32)
+    conv1 = (rng.standard_normal((n, 4)) * 0.8).astype(np.float32)
+    conv2 = (rng.standard_normal(n + 1) * 0.5).astype(np.float32)
+    args = (T(grid, dev), T(inp, dev), T(conv1, dev), T(conv2, dev))
+    out_train, gout = ops.bilateral_slice_apply_nnguide(*args, has_offset=True, return_guide=True)
+    out_infer = ops.bilateral_slice_apply_nnguide(*args, has_offset=True)
+    g = N(gout)
+    assert 0.02 < g.min() and g.max() < 0.98 and g.std() > 0.05  # the sigmoid is exercised over its range
+    d = np.abs(N(out_train) - N(out_infer)).max()
+    print(f"max|out(train sigmoid) - out(inference sigmoid)| = {d:.3e} (2 ulp of 1.0 = 2.4e-7)")
+    assert d <= 2.4e-7
+    # and the slice of that grid really is the guide (so that the bound above is a bound on the guide)
+    np.testing.assert_allclose(N(out_train)[..., 0], np.clip(g, 0.5 / GD, 1 - 0.5 / GD), rtol=0, atol=2e-4)
+
+
 # ---- curves guide (the standard model) fused into slice-apply --------------------------------------
 @pytest.mark.parametrize("in_dtype,out_dtype", [("float32", "float32"), ("uint8", "uint8"), ("uint16", "float32")])
 def test_curves_guide_fused_matches_composed_oracle(dev, ops, port, in_dtype, out_dtype):
@@ -502,6 +528,61 @@ def test_wire_format_forward(dev, ops, port, in_dtype, wl, out_dtype, nn):
         assert not np.any((diff > 0) & ~near_edge)
         assert (diff > 0).mean() < 5e-4
         assert got.min() == 0 and got.max() == 255  # the clip is exercised on both sides
+
+
+@pytest.mark.parametrize("n", [16, 8, 4, 12, 5])
+@pytest.mark.parametrize("out_dtype", ["uint8", "float32"])
+@pytest.mark.parametrize("mfma", [False, True])
+def test_u8_guide_network_guide_itself(dev, ops, port, n, out_dtype, mfma, monkeypatch):
+    """uint8 input + fused guide network: the GUIDE the kernel computes is held to 1e-6 against the numpy restatement
+    of the folded network (the bar of the f32 kernel, test_nnguide_fused_matches_composed_oracle), every byte value
+    0..255 in every channel present.  mfma = True: the round-4 experiment of the TOOLS build (knob 5) -- the hidden
+    layer as bf16-split 4x4x4 matrix instructions (apply_fwd_io.hip: guide_nn_quad_mfma_u8; n % 4 == 0, n <= 16, n = 5
+    falls back to the VALU form) -- parity-green, rejected on time (profiles/r04/guide_nn_mfma.md)."""
+    import oracle
+    from hdrnet_amd import _lib
+    if mfma:
+        tools = _lib.load_tools()
+        monkeypatch.setattr(_lib, "load", lambda: tools)
+        tools.hdrnet_enable_kernel_names(1)
+        tools.hdrnet_tools_set_knob(5, 1)
+    try:
+        B, H, W, GH, GW, GD = 2, 24, 128, 16, 16, 8
+        rng = np.random.default_rng(100 + n)
+        grid6 = np.zeros((B, GH, GW, GD, 3, 4), np.float32)
+        for i in range(3):
+            grid6[..., i, i] = 1.0
+        grid = (grid6 + 0.15 * rng.standard_normal(grid6.shape)).astype(np.float32).reshape(B, GH, GW, GD, 12)
+        raw = rng.integers(0, 256, (B, H, W, 3)).astype(np.uint8)
+        raw[0, 0, :, 0] = np.arange(W) * 2 % 256          # ramps: every byte value in every channel
+        raw[0, 1, :, 1] = (np.arange(W) * 2 + 1) % 256
+        raw[0, 2, :, 2] = np.arange(W) * 2 % 256
+        raw[0, 3, :, :] = 255
+        raw[0, 4, :, :] = 0
+        inp_f = (raw.astype(np.float32) / np.float32(255.0)).astype(np.float32)
+        conv1 = (rng.standard_normal((n, 4)) * 0.8).astype(np.float32)
+        conv2 = (rng.standard_normal(n + 1) * 0.5).astype(np.float32)
+        guide = oracle.pointwise_nn_guide(inp_f, conv1, conv2)
+        want_f = port.bilateral_slice_apply(grid, guide, inp_f, True)
+        kw = dict(input_white_level=255.0, out_dtype=getattr(torch, out_dtype), guide_conv1=T(conv1, dev),
+                  guide_conv2=T(conv2, dev))
+        out, gout = ops.bilateral_slice_apply_io(T(grid, dev), torch.from_numpy(raw).to(dev), return_guide=True, **kw)
+        name = (tools if mfma else _lib.load()).hdrnet_last_kernel().decode()
+        assert name == f"apply_fwd_io/u8->{'u8' if out_dtype == 'uint8' else 'f32'}+nnguide"
+        np.testing.assert_allclose(N(gout), guide, rtol=0, atol=1e-6)
+        # inference form (no guide copy: v_exp / v_rcp sigmoid)
+        out2 = ops.bilateral_slice_apply_io(T(grid, dev), torch.from_numpy(raw).to(dev), **kw)
+        if out_dtype == "float32":
+            np.testing.assert_allclose(N(out), want_f, rtol=2e-5, atol=2e-5)
+            np.testing.assert_allclose(N(out2), want_f, rtol=2e-5, atol=2e-5)
+        else:
+            want_u8 = (np.float32(255.0) * np.clip(want_f, 0, 1)).astype(np.uint8)
+            for got in (N(out), N(out2)):
+                diff = np.abs(got.astype(np.int16) - want_u8.astype(np.int16))
+                assert diff.max() <= 1 and (diff > 0).mean() < 5e-4
+    finally:
+        if mfma:
+            tools.hdrnet_tools_set_knob(5, 0)
 
 
 def test_nnguide_rejects_unsupported(dev, ops):

@@ -3,6 +3,7 @@ rules and error behaviour (hdrnet/hdrnet_ops.py:27-48; bilateral_slice_apply_op.
 bilateral_slice_op.cc:129-147; hdrnet/layers.py:99-148).  Runs without a GPU."""
 import inspect
 
+import numpy as np
 import pytest
 import torch
 
@@ -137,3 +138,92 @@ def test_three_instruction_white_level_division_is_ieee_exact():
             q = Fraction(float(rn32(v * R)))
             e = Fraction(float(rn32(v - q * W)))
             assert rn32(q + e * R) == f32(v) / wl32, (wl, v)
+
+
+# ---- curves guide as a sorted piecewise-linear lookup (apply_fwd_io.hip, round 4) ---------------------------
+def _curve_tables(shifts, slopes):
+    """numpy twin of curves_build_tables for ONE channel: (tree[16], leaf[16][3]) from <= 16 knots -- rank by
+    counting with index tie-break, float64 prefix sums rounded once, Eytzinger tree over the sorted knots 1..15."""
+    n = len(shifts)
+    s = np.full(16, np.inf, np.float32)
+    sl = np.zeros(16, np.float32)
+    s[:n], sl[:n] = shifts, slopes
+    rank = np.array([sum((s[j] < s[k]) or (s[j] == s[k] and j < k) for j in range(16)) for k in range(16)])
+    assert sorted(rank) == list(range(16))
+    ss, ll = np.empty(16, np.float32), np.empty(16, np.float32)
+    ss[rank], ll[rank] = s, sl
+    tree = np.full(16, np.nan, np.float32)
+    leaf = np.zeros((16, 3), np.float32)
+    for i in range(16):
+        if not ss[i] < np.inf:
+            leaf[i] = (np.inf, 0, 0)
+        else:
+            cv = sum(float(ll[r]) * (float(ss[i]) - float(ss[r])) for r in range(i))
+            leaf[i] = (ss[i], np.float32(cv), np.float32(sum(float(ll[r]) for r in range(i + 1))))
+        if i >= 1:
+            t = (i & -i).bit_length() - 1  # ctz
+            tree[(1 << (3 - t)) + (i >> (t + 1))] = ss[i]
+    assert not np.isnan(tree[1:]).any()
+    return tree, leaf
+
+
+def _curve_lookup(tree, leaf, v):
+    v = np.asarray(v, np.float32)
+    m = np.ones(v.shape, np.int64)
+    for _ in range(4):
+        m = 2 * m + (v >= tree[m])
+    lf = leaf[m - 16]
+    with np.errstate(invalid="ignore"):
+        d = np.maximum(v - lf[..., 0], np.float32(0))
+    return (lf[..., 2] * d + lf[..., 1]).astype(np.float32)
+
+
+@pytest.mark.parametrize("case", ["reference-like", "random", "ties", "reversed", "few-knots", "one-knot", "wide"])
+def test_curves_lookup_tables_equal_the_knot_scan(case):
+    """The table form of the curves guide (sorted knots, value + slope per interval, 4-step search) against the
+    reference's knot-by-knot sum (hdrnet/models.py:157-188 as oracle.curves_guide restates it) -- every interval,
+    every knot itself, both sides of every knot, far outside; unsorted / tied / fewer knots."""
+    import oracle
+    rng = np.random.default_rng(sum(map(ord, case)))
+    n = {"few-knots": 5, "one-knot": 1}.get(case, 16)
+    if case == "reference-like":
+        shifts = np.tile(np.linspace(0, 1, n, endpoint=False)[:, None], (1, 3)) + 0.01 * rng.standard_normal((n, 3))
+        slopes = 0.3 * rng.standard_normal((n, 3))
+        slopes[0] += 1.0
+    elif case == "ties":
+        shifts = rng.choice([0.1, 0.25, 0.25, 0.5, 0.5, 0.5, 0.9], (n, 3))
+        slopes = rng.standard_normal((n, 3))
+    elif case == "reversed":
+        shifts = np.tile(np.linspace(1, 0, n)[:, None], (1, 3))
+        slopes = rng.standard_normal((n, 3))
+    elif case == "wide":
+        shifts = 10 * rng.standard_normal((n, 3))
+        slopes = 3 * rng.standard_normal((n, 3))
+    else:
+        shifts = rng.random((n, 3))
+        slopes = rng.standard_normal((n, 3))
+    shifts, slopes = shifts.astype(np.float32), slopes.astype(np.float32)
+    ccm = np.concatenate([np.eye(3), np.zeros((3, 1))], 1).astype(np.float32)  # identity: t = the sample itself
+    lo, hi = float(shifts.min()) - 1, float(shifts.max()) + 1
+    for c in range(3):
+        tree, leaf = _curve_tables(shifts[:, c], slopes[:, c])
+        ks = shifts[:, c]
+        v = np.concatenate([rng.uniform(lo, hi, 4000).astype(np.float32), ks, np.nextafter(ks, np.float32(-np.inf)),
+                            np.nextafter(ks, np.float32(np.inf)), np.float32([lo - 100, hi + 100])])
+        got = _curve_lookup(tree, leaf, v)
+        # the reference's sum, float32 in knot order (what oracle.curves_guide does per channel) and in float64
+        want32 = (slopes[:, c] * np.maximum(v[:, None] - ks, np.float32(0))).sum(-1, dtype=np.float32)
+        want64 = (slopes[:, c].astype(np.float64) * np.maximum(v[:, None].astype(np.float64) - ks, 0)).sum(-1)
+        scale = np.abs(slopes[:, c].astype(np.float64) * np.maximum(v[:, None].astype(np.float64) - ks, 0)).sum(-1) + 1e-30
+        # one rounding of value + slope term against the exact sum; the float32 scan itself is up to ~n ulp away
+        assert np.all(np.abs(got - want64) <= 3 * 2.0 ** -24 * np.maximum(scale, np.abs(want64)) + 1e-30), case
+        assert np.all(np.abs(got - want64) <= np.abs(want32 - want64) + 3 * 2.0 ** -24 * scale + 1e-30), case
+    # and through the whole guide formula, at the GPU test's tolerance
+    x = rng.random((2000, 3)).astype(np.float32)
+    ccm2 = (ccm + 0.2 * rng.standard_normal((3, 4))).astype(np.float32)
+    mix = np.array([0.4, 0.35, 0.25, 0.02], np.float32)
+    if case in ("reference-like", "random", "few-knots"):
+        t = (x @ ccm2[:, :-1].T + ccm2[:, -1]).astype(np.float32)
+        cv = np.stack([_curve_lookup(*_curve_tables(shifts[:, c], slopes[:, c]), t[:, c]) for c in range(3)], -1)
+        g = np.clip((cv @ mix[:-1] + mix[-1]).astype(np.float32), 0, 1)
+        np.testing.assert_allclose(g, oracle.curves_guide(x, ccm2, shifts, slopes, mix), rtol=0, atol=2e-6)

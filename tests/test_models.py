@@ -109,6 +109,101 @@ def _grad_worker(rank, world, port, q):
     torch.distributed.destroy_process_group()
 
 
+def _toy_net():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+
+
+def test_grad_bucket_views_survive_backward_and_step():
+    """dist.GradBucket: every .grad is a view of ONE flat buffer, autograd accumulates into the views in place,
+    zero_() is one memset, and runtime.TrainStep on it takes exactly the steps of the plain torch loop."""
+    from hdrnet_amd import dist as hd
+    from hdrnet_amd.runtime import TrainStep
+    net, ref = _toy_net(), _toy_net()
+    net[0].bias.requires_grad_(False)  # a frozen parameter stays outside the bucket (the models' BN scale)
+    ref[0].bias.requires_grad_(False)
+    opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=0.1)
+    ropt = torch.optim.SGD([p for p in ref.parameters() if p.requires_grad], lr=0.1)
+    step = TrainStep(net, lambda out, tgt: (out - tgt).square().mean(), opt)
+    b = step.bucket
+    assert b.flat.numel() == sum(p.numel() for p in net.parameters() if p.requires_grad) and net[0].bias.grad is None
+    assert b.attached() and not step.distributed
+    torch.manual_seed(1)
+    for _ in range(3):
+        x, y = torch.rand(5, 6), torch.rand(5, 3)
+        loss = step([x], [y])
+        ropt.zero_grad(set_to_none=True)
+        rl = (ref(x) - y).square().mean()
+        rl.backward()
+        ropt.step()
+        assert torch.equal(loss, rl) and b.attached()
+        for p, q in zip(net.parameters(), ref.parameters()):
+            assert torch.equal(p, q)
+            if p.requires_grad:
+                assert torch.equal(p.grad, q.grad)
+    assert b.allreduce() == b.flat.numel()  # no process group: a no-op
+    b.zero_()
+    assert all(float(p.grad.abs().sum()) == 0.0 for p in net.parameters() if p.requires_grad)
+    opt.zero_grad(set_to_none=True)  # what the bucket's user must NOT do: the views are gone
+    assert not b.attached()
+    # a channels_last convolution weight (what the coefficient network's weights are on the GPU): the view takes the
+    # parameter's strides -- autograd's layout contract, and what the fused Adam requires
+    conv = torch.nn.Conv2d(8, 16, 3).to(memory_format=torch.channels_last)
+    cb = hd.GradBucket(conv.parameters())
+    assert conv.weight.grad.stride() == conv.weight.stride() != conv.weight.contiguous().stride()
+    conv(torch.rand(2, 8, 6, 6)).sum().backward()
+    assert cb.attached() and float(cb.flat.abs().sum()) > 0
+
+
+def _train_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from hdrnet_amd import dist as hd
+    from hdrnet_amd.runtime import TrainStep
+    hd.init(backend="gloo")
+    net = _toy_net()  # same weights on every rank
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    step = TrainStep(net, lambda out, tgt: (out - tgt).square().mean(), opt)
+    assert step.distributed
+    torch.manual_seed(100 + rank)  # different data per rank
+    data = [(torch.rand(5, 6), torch.rand(5, 3)) for _ in range(3)]
+    for x, y in data:
+        step([x], [y])
+    gathered = [None] * world
+    torch.distributed.all_gather_object(gathered, data)
+    if rank == 0:
+        # reference: one process, the ranks' losses averaged = the mean gradient
+        ref = _toy_net()
+        ropt = torch.optim.SGD(ref.parameters(), lr=0.1)
+        for k in range(3):
+            ropt.zero_grad(set_to_none=True)
+            (sum((ref(gathered[r][k][0]) - gathered[r][k][1]).square().mean() for r in range(world)) / world).backward()
+            ropt.step()
+        ok = all(torch.allclose(p, r, rtol=1e-5, atol=1e-7) for p, r in zip(net.parameters(), ref.parameters()))
+        q.put((ok, step.bucket.attached(), step.bucket.flat.numel()))
+    hd.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_train_step_distributed_branch_gloo():
+    """runtime.TrainStep at world size 2 (gloo): forward + backward into the flat bucket, ONE in-place all-reduce
+    (averaged), optimizer step -- the parameters follow the single-process run on the union of the ranks' data.
+    GraphedTrainStep shares this code path after its graph replay (runtime.py)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    ok, attached, n = q.get()
+    assert ok and attached and n == 6 * 16 + 16 + 16 * 3 + 3
+
+
 def test_flat_bucket_gradient_allreduce_gloo():
     """The training step's one collective: a single flat fp32 bucket, 2 ranks, gloo."""
     import torch.multiprocessing as mp
@@ -455,6 +550,37 @@ def test_graphed_train_step_matches_eager():
 
 
 @pytest.mark.gpu
+def test_graphed_train_step_split_form_matches_one_graph():
+    """GraphedTrainStep's multi-rank structure -- graph = forward + backward into the flat gradient bucket, then the
+    (here: no-op) all-reduce and the optimizer step outside the graph -- against the one-graph form, same data."""
+    from hdrnet_amd.runtime import GraphedTrainStep
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    low = torch.rand(2, 256, 256, 3, device=dev)
+    full = torch.rand(2, 136, 240, 3, device=dev)
+    target = torch.rand(2, 136, 240, 3, device=dev)
+    m0 = models.HDRNetPointwiseNNGuide(dict(batch_norm=True)).to(dev).train()
+    state = {k: v.clone() for k, v in m0.state_dict().items()}
+    res = []
+    for split in (False, True):
+        m = models.HDRNetPointwiseNNGuide(dict(batch_norm=True)).to(dev).train()
+        m.load_state_dict(state)
+        opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=1e-5)
+        g = GraphedTrainStep(m, lambda out, tgt: (out - tgt).square().mean(), opt, [low, full], [target], warmup=2,
+                             flat_bucket=split)
+        assert g.split == split and g.bucket.attached()
+        for _ in range(3):
+            loss = g([low, full], [target])
+        assert g.bucket.attached()
+        res.append((loss.clone(), {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}))
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-3, atol=1e-6)
+    for n in res[0][1]:
+        d0, d1 = res[0][1][n] - state[n], res[1][1][n] - state[n]
+        scale = d0.abs().max().item()
+        assert scale > 0 and (d0 - d1).abs().max().item() <= 5e-2 * scale, n
+
+
+@pytest.mark.gpu
 def test_pyramid_model_fused_matches_composed():
     """HDRNetGaussianPyrNN inference: the fused path (resize kernel, per-level guide net + slice-apply
     + up-add in one launch) == the composition of the un-fused ops (hdrnet/models.py:213-289)."""
@@ -692,6 +818,18 @@ def test_tf_variable_mapping_round_trips(cls):
     bad["inference/coefficients/global/fc2/weights:0"] = bad["inference/coefficients/global/fc2/weights:0"].T.copy()
     with pytest.raises(ValueError):
         tf_import.load_tf_variables(b, bad)
+    # a variable under inference/ that the mapping has no place for (a batch norm trained with scale=True) is refused;
+    # optimizer slots, the step counter and a fixture's own arrays are not model state
+    extra = dict(v)
+    extra["inference/coefficients/splat/conv2/BatchNorm/gamma:0"] = np.ones(16, np.float32)
+    with pytest.raises(ValueError, match="no place for"):
+        tf_import.load_tf_variables(b, extra)
+    tf_import.load_tf_variables(b, extra, strict=False)
+    ok = dict(v)
+    ok["inference/coefficients/splat/conv1/weights/Adam:0"] = np.zeros((3, 3, 3, 8), np.float32)
+    ok["global_step:0"] = np.zeros((), np.int64)
+    ok["lowres_input"] = np.zeros((1, 256, 256, 3), np.float32)
+    tf_import.load_tf_variables(b, ok)
 
 
 TF_FIXTURES = os.path.join(ROOT, "tests", "golden", "tf")

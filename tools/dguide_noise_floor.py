@@ -25,43 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def f64_vjps(grid, guide, inp, dout):
-    """dguide, dinput in float64; coordinates / tap offsets in float32 as the reference (Cin = Cout = 3, offset)."""
-    f32 = np.float32
-    B, GH, GW, GD, _ = grid.shape
-    _, H, W = guide.shape
-    xs = (np.arange(W, dtype=f32) + f32(0.5)) * (f32(GW) / f32(W))
-    ys = (np.arange(H, dtype=f32) + f32(0.5)) * (f32(GH) / f32(H))
-    gx0 = np.floor(xs - f32(0.5)).astype(np.int64)
-    gy0 = np.floor(ys - f32(0.5)).astype(np.int64)
-    gzf = (guide * f32(GD)).astype(f32)
-    gz0 = np.floor(gzf - f32(0.5)).astype(np.int64)
-    G = grid.astype(np.float64).reshape(B, GH, GW, GD, 3, 4)
-    eps = np.float64(np.float32(1e-8))
-    dg = np.zeros((B, H, W))
-    di = np.zeros((B, H, W, 3))
-    d64 = dout.astype(np.float64)
-    inh = np.concatenate([inp.astype(np.float64), np.ones((B, H, W, 1))], -1)
-    for b in range(B):
-        for dy in (0, 1):
-            gy = gy0 + dy
-            wy = np.maximum(1 - np.abs((gy.astype(f32) + f32(0.5)) - ys).astype(np.float64), 0)
-            gyc = np.clip(gy, 0, GH - 1)
-            for dx in (0, 1):
-                gx = gx0 + dx
-                wx = np.maximum(1 - np.abs((gx.astype(f32) + f32(0.5)) - xs).astype(np.float64), 0)
-                gxc = np.clip(gx, 0, GW - 1)
-                for dz in (0, 1):
-                    gz = gz0[b] + dz
-                    d = ((gz.astype(f32) + f32(0.5)) - gzf[b]).astype(np.float64)
-                    s = np.sqrt(d * d + eps)
-                    dw = np.where(s > 1, 0.0, d / s) * GD   # numerics.h:116-126, x GD (:186)
-                    wz = np.maximum(1 - s, 0)                # numerics.h:108-113
-                    g = G[b][gyc[:, None], gxc[None, :], np.clip(gz, 0, GD - 1)]  # [H, W, 3, 4]
-                    w2 = wy[:, None] * wx[None, :]
-                    dg[b] += np.einsum("hwij,hwj,hwi->hw", g * (w2 * dw)[..., None, None], inh[b], d64[b])
-                    di[b] += np.einsum("hwij,hwi->hwj", (g * (w2 * wz)[..., None, None])[..., :3], d64[b])
-    return dg, di
+from oracle.f64_vjps import f64_vjps  # noqa: E402  (the float64 evaluator lives with the other checkers)
 
 
 def measure(H=540, W=960, seed=7, threads=None):
