@@ -40,10 +40,20 @@
 //     (v_fract x weight, float byte addresses, clamp-modifier tents), the pixel runs fetched as
 //     `buffer_load_dwordx4 ... lds` (one per-lane offset register for all four 1-KiB pieces, the run's end
 //     enforced by the descriptor instead of four clamps + 64-bit address adds), the segment's grid-column
-//     window from a host-side table in the kernel arguments, 32-bit row arithmetic.  349 -> ~300 VALU
-//     instructions executed per wave (static: 351 incl. the un-tabled fall-back), 40.4 -> 39.4 us interleaved
-//     on two boxes, the no-compute skeleton at 39.0 (profiles/r03/ab_variants_4k_*.txt).  A scalar blend
-//     (v_fma_f32 instead of v_pk_fma_f32: +96 instructions) times the same -- the packed form stays.
+//     window from a host-side table in the kernel arguments, 32-bit row arithmetic.  40.4 -> 39.4 us interleaved
+//     on two boxes, the no-compute skeleton at 39.0 (profiles/r03/ab_variants_4k_*.txt).  The BLEND the product
+//     ships is the SCALAR one (kPixLeanScalar: 48 v_fma_f32 per pixel, 419 VALU + 113 SALU instructions per wave;
+//     the packed form, 24 v_pk_fma_f32, is 323 + 114): same time on steady boxes, bit-identical results, less time in
+//     the power manager's braked state on the boxes that fall into it (launch_apply_fwd_seg below).  The guide-network
+//     / wire-format kernels, which are VALU-bound, keep the packed blend.
+//   * ROUND 4 -- the launch shape, measured and left as it is (profiles/r04/fwd_launch_shape/): fewer resident
+//     workgroups shorten a workgroup's life (9 -> 6 per CU: 5.1 -> 4.0 us) and leave the launch where it was (39.4 vs
+//     39.7 us): it is throughput-, not latency-bound; flat 1024-px tasks that ignore rows (1080p: 2025 workgroups for
+//     2048 slots) do not beat row segments in a no-compute skeleton (11.5 vs 11.3 us); a ticketed tail (SCHED = 1 below:
+//     the last ~2000 tasks drawn from counters so that the XCDs finish together) narrows the XCDs' finish from 3.2 to
+//     1.5 us but nets 0.3 us (0.8 %) at 4K and 1.1 us (1.8 %) at 4000x3000 -- tools variants 70 / 71, not the product.
+//     Per launch ~2.5-3 us lie outside the workgroups' span (38.8 us per launch, 35.9 us from the first workgroup's
+//     start to the last one's end): the gap between dependent kernels of one stream.
 //
 // Numerics: the coordinate and weight expressions of the reference in the reference's order
 // (products (x+.5)*scale_x, guide*GD explicitly rounded, see numerics.hip.h: mul_rn); wy is folded
@@ -525,9 +535,14 @@ hipError_t launch_seg_pick(const ApplyArgs& a, hipStream_t s) {
                            ((long long)a.W * a.Cout * 4) % 128 == 0;
   const GuideNN gn{nullptr, nullptr, nullptr, 0};
   const UpAdd up{nullptr, 0, 0, 0.f, 0.f};
-  if (small) return launch_seg_t<CI, CO, OFF, kLoadsLane, kStoresBufNt, false, false, false, PIX>(a, s, nullptr, gn, up);
-  if (whole_lines)
-    return launch_seg_t<CI, CO, OFF, DMAL, kStoresBufSc01, false, false, false, PIX>(a, s, nullptr, gn, up);
+  // The per-launch flavour choice was measured on, and is instantiated for, the shape every BASELINE.json config has
+  // (3 -> 3 with offset); the other fast shapes take the one flavour that is never far off (LDS-DMA loads,
+  // nontemporal stores) -- a third of the instantiations for shapes no config names (hygiene).
+  if constexpr (CI == 3 && CO == 3 && OFF) {
+    if (small) return launch_seg_t<CI, CO, OFF, kLoadsLane, kStoresBufNt, false, false, false, PIX>(a, s, nullptr, gn, up);
+    if (whole_lines)
+      return launch_seg_t<CI, CO, OFF, DMAL, kStoresBufSc01, false, false, false, PIX>(a, s, nullptr, gn, up);
+  }
   return launch_seg_t<CI, CO, OFF, DMAL, kStoresBufNt, false, false, false, PIX>(a, s, nullptr, gn, up);
 }
 

@@ -14,6 +14,7 @@
 //   103-105  memory skeletons with lane-contiguous accesses on {both, loads only, stores only}
 //   106      103 with nontemporal input loads (the shipped kernel's access pattern)
 //   107      an EMPTY kernel launched with the product's geometry (dispatch + inter-kernel gap alone)
+//   108      skeleton 106 on flat 1024-pixel tasks (row boundaries ignored)
 //
 // Skeletons do NOT compute the op (their name says ABLATION); the others are checked for
 // parity by tests/test_gpu_parity.py like the product kernel.
@@ -38,6 +39,38 @@ constexpr int kVariantNtLoads = 8;
 __global__ __launch_bounds__(256) void apply_fwd_empty(float* out) {
   extern __shared__ float lds_empty[];
   if (out == nullptr) lds_empty[threadIdx.x] = 0.f;  // never taken; keeps the LDS allocation
+}
+
+// Variant 108: skeleton 106's accesses on FLAT tasks -- workgroup b moves pixels [1024 b, 1024 b + 1024) of the
+// image taken as one run of B * H * W pixels, whatever rows they fall in: 1920 x 1080 = 2025 four-wave workgroups
+// against the chip's 2048 slots, where row segments need 2160.  What a flattened decomposition of a one-round frame
+// could gain, measured before building it.
+__global__ __launch_bounds__(256) void apply_fwd_skeleton_flat(const float* __restrict__ guide,
+                                                               const float* __restrict__ input,
+                                                               float* __restrict__ out, long long npx) {
+  const long long p0 = (long long)blockIdx.x * 1024;
+  const int n = (int)min((long long)1024, npx - p0);  // pixels of this task (multiple of 4)
+  const int t = threadIdx.x;
+  float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (4 * t < n) g4 = load_stream4(guide + p0 + 4 * t);
+  const float4* ip = reinterpret_cast<const float4*>(input + p0 * 3);
+  float4* op = reinterpret_cast<float4*>(out + p0 * 3);
+  const int nq = n * 3 / 4;
+  float4 v[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int e = t + 256 * k;
+    if (e < nq) v[k] = load_stream4(reinterpret_cast<const float*>(ip + e));
+  }
+  const float gq = g4.x + g4.y + g4.z + g4.w;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int e = t + 256 * k;
+    if (e < nq) {
+      v[k].x *= gq; v[k].y *= gq; v[k].z *= gq; v[k].w *= gq;
+      op[e] = v[k];
+    }
+  }
 }
 
 // ---- memory skeletons ---------------------------------------------------------------------
@@ -546,6 +579,12 @@ hipError_t launch_variant_t(const ApplyArgs& a, const Plan& pl, hipStream_t s, c
         apply_fwd_skeleton<6><<<nblocks, pl.threads, 0, s>>>(a.guide, a.input, a.out, a.H, a.W, pl.nseg, pl.seg);
         *name = "ABLATION/skeleton nt-ld-contig st-contig";
         return hipGetLastError();
+      case 108: {
+        const long long npx = (long long)a.B * a.H * a.W;
+        apply_fwd_skeleton_flat<<<(unsigned)((npx + 1023) / 1024), 256, 0, s>>>(a.guide, a.input, a.out, npx);
+        *name = "ABLATION/skeleton flat 1024-px tasks";
+        return hipGetLastError();
+      }
       case 107: {
         // LDS per workgroup as the product kernel's: padded image + one (guide + in / out) slab per wave
         const size_t lds = ((size_t)round_up(((pl.seg - 1) * a.GW / a.W + 4) * (a.GD + 2) * C, 4) +

@@ -16,7 +16,8 @@
  *                (31 = the product configuration)
  *       40..59   the same with a per-workgroup timeline trace (hdrnet_tools_set_trace)
  *       60..67   pixel-phase / DMA-form variants of the product kernel; 70 / 71 ticketed tail (knobs 1, 2), 72 product + trace
- *       101, 103..106  memory skeletons; 107 an empty kernel with the product's launch geometry
+ *       101, 103..106  memory skeletons; 107 an empty kernel with the product's launch geometry,
+ *                108 skeleton 106 on flat 1024-pixel tasks
  *   - kernel variants of the GRADIENT entry points (HDRNET_VARIANT(n) in the flags of
  *     hdrnet_bilateral_slice{,_apply}_grad_f32_ex; tools/bwd_ab.py times them interleaved):
  *       2  bf16-split contraction (two v_mfma_f32_16x16x32_bf16 per 16 pixels)   3  un-fused kernels

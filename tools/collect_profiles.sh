@@ -17,7 +17,7 @@ O=$R/gpurun_out/profiles
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 MODE=${1:-timing}
-PREV=$R/tools/exp/prev/libhdrnet_amd_r02.so
+PREV=$R/tools/exp/prev/libhdrnet_amd_r03.so
 if [ "$MODE" = pmc ]; then
 # 1. HBM traffic of the forward kernel: separate --pmc passes (never combined with trace domains), each
 #    with a calibration twin on the memory skeleton (known byte count, same access widths)
@@ -35,7 +35,14 @@ CMD="python $R/tools/bwd_ab.py --rounds 1 --steps 5 --cases g,gg,all --variants 
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA -d $O/b1 -o p --output-format csv -- $CMD > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $O/b2 -o p --output-format csv -- $CMD > /dev/null 2>&1
 python $R/tools/pmc_summary.py $O/b1 $O/b2 --match grid_grad_stage1 > $O/bwd_pmc.txt 2>&1
-rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_sq2 $O/cal_fetch $O/cal_write $O/b1 $O/b2
+# the fused-guide / wire-format forwards: every apply_fwd_io instantiation and the guide-network
+# instantiation of apply_fwd_seg that tools/op_bench.py launches at 4K
+CMD="python $R/tools/op_bench.py --workload 4k --steps 5"
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -d $O/g1 -o p --output-format csv -- $CMD > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD -d $O/g2 -o p --output-format csv -- $CMD > /dev/null 2>&1
+python $R/tools/pmc_summary.py $O/g1 $O/g2 --match apply_fwd_io_rows > $O/guide_wire_pmc.txt 2>&1
+python $R/tools/pmc_summary.py $O/g1 $O/g2 --match "false, true, false, 1" >> $O/guide_wire_pmc.txt 2>&1
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_sq2 $O/cal_fetch $O/cal_write $O/b1 $O/b2 $O/g1 $O/g2
 tail -40 $O/fwd_pmc.txt; tail -25 $O/traffic.log
 exit 0
 fi
@@ -50,6 +57,8 @@ for i in 1 2 3; do python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline; d
 python $R/bench.py --workload 1080p --no-cpu-baseline > $O/bench_1080p.json 2>> $O/bench.err
 python $R/bench.py --workload 1080p_b4 --no-cpu-baseline > $O/bench_1080p_b4.json 2>> $O/bench.err
 python $R/bench.py --workload hdrp --no-cpu-baseline > $O/bench_hdrp.json 2>> $O/bench.err
+python $R/bench.py --workload hdrp_u16 > $O/bench_hdrp_u16.json 2>> $O/bench.err
+python $R/bench.py --workload train_1080p_b4 --steps 100 --warmup 20 > $O/bench_train_1080p_b4.json 2>> $O/bench.err
 for i in 1 2 3; do python $R/bench.py --no-cpu-baseline; done > $O/bench_repeat.txt 2>> $O/bench.err
 # 3. every entry point, all sizes; A/B of the forward variants; this build vs the previous round's; end to end
 cd $R
@@ -58,13 +67,12 @@ python tools/op_bench.py --tools --workload 1080p --json $O/ops_1080p.json > $O/
 python tools/op_bench.py --workload 1080p_b4 --json $O/ops_1080p_b4.json > $O/ops_1080p_b4.txt 2>&1
 python tools/op_bench.py --workload hdrp --json $O/ops_hdrp.json > $O/ops_hdrp.txt 2>&1
 python tools/op_bench.py --workload refbench --json $O/ops_refbench.json > $O/ops_refbench.txt 2>&1
-python tools/ab_bench.py --variants 0,31,60,61,62,63,64,65,66,67,105,106 --rounds 9 --steps 200 --trace 31 > $O/ab_variants_4k.txt 2>&1
-python tools/ab_bench.py --workload 1080p --variants 0,23,28,31,60,61,62,106 --rounds 7 --steps 400 > $O/ab_variants_1080p.txt 2>&1
-python tools/ab_bench.py --workload hdrp --variants 0,23,31,39,62,66 --rounds 5 --steps 100 > $O/ab_variants_hdrp.txt 2>&1
+python tools/ab_bench.py --variants 0,65,66,70@1=2048@2=1024,106,108 --rounds 9 --steps 200 --trace 72,71@1=2048@2=1024 > $O/ab_variants_4k.txt 2>&1
+python tools/ab_bench.py --workload 1080p --variants 0,28,31,106,108 --rounds 7 --steps 400 --trace 72 > $O/ab_variants_1080p.txt 2>&1
+python tools/ab_bench.py --workload hdrp --variants 0,31,66,70@1=2048@2=1024,106,108 --rounds 5 --steps 100 > $O/ab_variants_hdrp.txt 2>&1
 if [ -f $PREV ]; then
-  python tools/prev_vs_new.py --prev $PREV --workload 4k > $O/r02_vs_r03_4k.txt 2>&1
-  python tools/prev_vs_new.py --prev $PREV --workload 1080p --steps 150 > $O/r02_vs_r03_1080p.txt 2>&1
-  python tools/prev_vs_new.py --prev $PREV --workload hdrp > $O/r02_vs_r03_hdrp.txt 2>&1
+  python tools/prev_vs_new.py --prev $PREV --workload 4k --cases fwd,nn,u8,u8nn,curves,u8curves,all,gg,g,v,slice_fwd > $O/prev_vs_new_4k.txt 2>&1
+  python tools/prev_vs_new.py --prev $PREV --workload 1080p --steps 150 --cases fwd,u8,u8nn,curves,u8curves,all > $O/prev_vs_new_1080p.txt 2>&1
 fi
 python tools/bwd_ab.py --rounds 5 --steps 50 --cases all,gg,g,sl,v --variants 0,2,3,4,5,6,7,8 > $O/bwd_ab_4k.txt 2>&1
 python tools/bwd_ab.py --workload 1080p --rounds 5 --steps 100 --cases all,gg,g,sl,v --variants 0,3 > $O/bwd_ab_1080p.txt 2>&1

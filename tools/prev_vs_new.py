@@ -62,6 +62,12 @@ def main():
                out=torch.empty((B, H, W, C), device=dev)) for _ in range(2)]
     conv1 = (torch.randn((16, Cin + 1), device=dev, generator=gen) * 0.8).contiguous()
     conv2 = (torch.randn((17,), device=dev, generator=gen) * 0.5).contiguous()
+    ccm = (torch.eye(3, 4, device=dev) + 0.2 * torch.randn((3, 4), device=dev, generator=gen)).contiguous()
+    shifts = (torch.linspace(0, 1, 17, device=dev)[:16, None].repeat(1, 3)
+              + 0.01 * torch.randn((16, 3), device=dev, generator=gen)).contiguous()
+    slopes = (0.3 * torch.randn((16, 3), device=dev, generator=gen)).contiguous()
+    slopes[0] += 1.0
+    mix = torch.tensor([0.4, 0.35, 0.25, 0.02], device=dev)
     u8 = [dict(inp=torch.randint(0, 256, (B, H, W, 3), device=dev, dtype=torch.uint8),
                out=torch.empty((B, H, W, 3), device=dev, dtype=torch.uint8)) for _ in range(nsets)]
     coarse = [torch.randn((B, H // 2, W // 2, 3), device=dev, generator=gen) for _ in range(nsets)]
@@ -115,6 +121,16 @@ def main():
                     s["grid"].data_ptr(), None if nn else s["guide"].data_ptr(), t["inp"].data_ptr(), t["out"].data_ptr(),
                     B, H, W, GH, GW, GD, 3, 3, 1, 1, 255.0, 1, conv1.data_ptr() if nn else None,
                     conv2.data_ptr() if nn else None, 16 if nn else 0, None, stream))
+            return fn
+        if case in ("curves", "u8curves"):  # curves guide fused: f32 -> f32, u8 -> u8
+            u = case == "u8curves"
+
+            def fn(k):
+                s, t = S[k % nsets], u8[k % nsets]
+                chk(lib.hdrnet_bilateral_slice_apply_io_curves(
+                    s["grid"].data_ptr(), (t if u else s)["inp"].data_ptr(), (t if u else s)["out"].data_ptr(),
+                    B, H, W, GH, GW, GD, 3, 3, 1, 1 if u else 0, 255.0 if u else 1.0, 1 if u else 0,
+                    ccm.data_ptr(), shifts.data_ptr(), slopes.data_ptr(), mix.data_ptr(), 16, None, stream))
             return fn
         if case == "upadd":
             def fn(k):
