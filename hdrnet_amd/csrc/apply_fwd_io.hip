@@ -121,7 +121,8 @@ constexpr int kCurveMaxKnots = 16;
 template <int CIN>
 struct CurveTab {
   static constexpr int kTree = 0;                    // [CIN][16]: node e of channel c at c * 16 + e (e = 1 .. 15)
-  static constexpr int kLeaf = CIN * 16;             // [CIN][16][4]: (knot, value at it, slope after it, 0)
+  static constexpr int kLeaf = 64;                   // [CIN][16][4]: (knot, value at it, slope after it, 0); >= 64 floats in,
+                                                     // so that (leaf base - 256 B) stays a non-negative immediate offset
   static constexpr int kRawS = kLeaf + CIN * 64;     // scratch while building: knots / slopes as given,
   static constexpr int kRawL = kRawS + CIN * 16;
   static constexpr int kSortS = kRawL + CIN * 16;    //   ... and sorted
@@ -133,7 +134,7 @@ struct CurveTab {
 // the tables.  CIN * 16 <= 64.
 template <int CIN>
 __device__ __forceinline__ void curves_build_tables(float* __restrict__ tab, const GuideNet& gn, int lane) {
-  static_assert(CIN * 16 <= 64, "one wave builds the tables");
+  static_assert(CIN * 16 <= 64 && CIN * 16 <= CurveTab<CIN>::kLeaf, "one wave builds the tables; the tree fits below the leaves");
   typedef CurveTab<CIN> T;
   const int c = lane >> 4, k = lane & 15;
   const bool mine = lane < CIN * 16;
@@ -190,11 +191,15 @@ __device__ __forceinline__ void curves_build_tables(float* __restrict__ tab, con
 template <int CIN>
 __device__ __forceinline__ float curve_lookup(const float* __restrict__ tab, int c, float v) {
   typedef CurveTab<CIN> T;
-  const float* tree = tab + T::kTree + c * 16;
-  int m = 1;
+  // the walk carries the node's BYTE offset a = 4 * node: a' = 2 a + (v >= key ? 4 : 0) -- compare, select, shift-add --
+  // and the ds_read takes it as it is (the channel's base is the instruction's immediate offset)
+  const char* tree = reinterpret_cast<const char*>(tab + T::kTree + c * 16);
+  unsigned a = 4u;
 #pragma unroll
-  for (int d = 0; d < 4; ++d) m = 2 * m + ((v >= tree[m]) ? 1 : 0);
-  const f32x4 leaf = *reinterpret_cast<const f32x4*>(tab + T::kLeaf + c * 64 + (m - 16) * 4);
+  for (int d = 0; d < 4; ++d) a = (a << 1) + ((v >= *reinterpret_cast<const float*>(tree + a)) ? 4u : 0u);
+  // leaf = node - 16, 16 bytes each: byte offset 4 a - 256
+  const char* leaves = reinterpret_cast<const char*>(tab + T::kLeaf + c * 64) - 256;
+  const f32x4 leaf = *reinterpret_cast<const f32x4*>(leaves + (a << 2));
   return __builtin_fmaf(leaf.z, fmaxf(v - leaf.x, 0.0f), leaf.y);
 }
 
@@ -399,6 +404,7 @@ __device__ __forceinline__ void guide_nn_quad_mfma_u8(const unsigned* __restrict
 // all 65536 sample values for the white levels of hdrnet/data_pipeline.py:202-232,267-274.
 struct WhiteLevel {
   float wl, rcp;  // rcp = 0: use the IEEE divide
+  float inv;      // RN(1 / wl), always: the factor folded into the coefficient image where the input feeds the affine only
 };
 
 __device__ __forceinline__ float div_white(float v, const WhiteLevel& w) {
@@ -409,7 +415,8 @@ __device__ __forceinline__ float div_white(float v, const WhiteLevel& w) {
 }
 
 // Load 4 pixels x CIN channels of TI starting at element index e0, as floats / white level.
-template <typename TI, int N>
+// UNSCALED: the samples as they are, (float)v -- the white level then sits in the coefficient image (stage_image IN_SCALE).
+template <typename TI, int N, bool UNSCALED = false>
 __device__ __forceinline__ void load_pixels(const TI* __restrict__ src, size_t e0, const WhiteLevel& wl,
                                             float (&dst)[N], uint32_t* raw = nullptr) {
   if constexpr (sizeof(TI) == 4) {
@@ -431,7 +438,8 @@ __device__ __forceinline__ void load_pixels(const TI* __restrict__ src, size_t e
       uint32_t v;
       if constexpr (sizeof(TI) == 1) v = (w[q >> 2] >> (8 * (q & 3))) & 0xffu;
       else v = (w[q >> 1] >> (16 * (q & 1))) & 0xffffu;
-      dst[q] = div_white((float)v, wl);  // tf.to_float(im) / white_level, rounded as TF's IEEE division
+      if constexpr (UNSCALED) dst[q] = (float)v;
+      else dst[q] = div_white((float)v, wl);  // tf.to_float(im) / white_level, rounded as TF's IEEE division
     }
   }
 }
@@ -460,13 +468,25 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
   constexpr int NI = CIN * kPxPerThread, NO = COUT * kPxPerThread;
   extern __shared__ __attribute__((aligned(16))) float lds_all[];
   // curves guide: its lookup tables first (compile-time LDS addresses), the coefficient image behind them
+  // Integer samples with a guide MAP: the input is used by the affine only, so the white level goes into the staged
+  // coefficients (coef / wl) * v, and the 12 divisions per lane (3 instructions each) disappear: u8 -> u8 26.7 -> ... us.
+  // (With a guide NETWORK the guide's own input stays v / wl, IEEE-rounded as TensorFlow's division.)
+  constexpr bool FOLD_WL = GUIDE == kGuideMap && sizeof(TI) < 4 && C == 12;
 #ifdef HDRNET_TOOLS_BUILD
   constexpr bool NN_MFMA = GUIDE == kGuideNN && sizeof(TI) == 1 && CIN == 3;  // experiment: hidden layer on the bf16 matrix cores
 #else
   constexpr bool NN_MFMA = false;
 #endif
-  constexpr int kTabFloats = (GUIDE == kGuideCurves) ? CurveTab<CIN>::kFloats : NN_MFMA ? NnTab::kWords : 0;
+  // The curves guide's lookup tables are STATIC LDS: their addresses are compile-time constants, so a table walk's
+  // ds_read takes the walked byte offset as its address register and the table's base as its immediate (behind the
+  // dynamic array's link-time base every step paid a v_add).  The coefficient image and the slabs stay dynamic.
+  constexpr int kTabFloats = NN_MFMA ? NnTab::kWords : 0;
   float* const lds = lds_all + kTabFloats;
+  [[maybe_unused]] float* ctab = nullptr;
+  if constexpr (GUIDE == kGuideCurves) {
+    __shared__ __attribute__((aligned(16))) float curve_tables[CurveTab<CIN>::kFloats];
+    ctab = curve_tables;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int xs = blockIdx.x * p.seg;
@@ -491,7 +511,7 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
       gs[0] = g4.x; gs[1] = g4.y; gs[2] = g4.z; gs[3] = g4.w;
     }
     if constexpr (NN_MFMA) load_pixels<TI, NI>(input, px * CIN, p.white, inf, raw);
-    else load_pixels<TI, NI>(input, px * CIN, p.white, inf);
+    else load_pixels<TI, NI, FOLD_WL>(input, px * CIN, p.white, inf);
   }
   const bool nn_mfma = NN_MFMA && p.nn_mfma && p.gn.n <= 16 && (p.gn.n & 3) == 0;  // uniform
   if constexpr (NN_MFMA) {
@@ -500,12 +520,13 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
   }
 
   if constexpr (GUIDE == kGuideCurves) {
-    if (wave == 0) curves_build_tables<CIN>(lds_all, p.gn, lane);  // published by the barrier below
+    if (wave == 0) curves_build_tables<CIN>(ctab, p.gn, lane);  // published by the barrier below
   }
   const SegCols sc = seg_cols_tab(p.tab, blockIdx.x, xs, xe, p.scale_x);
   const int colb = (p.GD + 2) * CB;
   const float gd_f = (float)p.GD, zhi = (float)(p.GD - 1);
-  stage_image<C>(lds, grid_b, y, sc.cmin, sc.ncols, p.GH, p.GW, p.GD, p.scale_y, p.inv_col, tid, (int)blockDim.x);
+  stage_image<C, FOLD_WL>(lds, grid_b, y, sc.cmin, sc.ncols, p.GH, p.GW, p.GD, p.scale_y, p.inv_col, tid, (int)blockDim.x,
+                          p.white.inv);
   // the lean pixel phase of the product forward (seg_common.hip.h)
   XTermLean xt[kPxPerThread];
   const float xf0 = (float)x + 0.5f;
@@ -528,7 +549,7 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
         if (!done) guide_nn_quad<CIN>(GuideNN{p.gn.conv1, p.gn.conv2, p.gn.guide_out, p.gn.n}, inf, gs);  // (writes nothing itself)
       }
       else if constexpr (GUIDE == kGuideCurves)
-        guide_curves_quad<CIN>(lds_all, p.gn, inf, gs);
+        guide_curves_quad<CIN>(ctab, p.gn, inf, gs);
       else
         guide_curves_scan_quad<CIN>(p.gn, inf, gs);
       if (p.gn.guide_out) *reinterpret_cast<float4*>(p.gn.guide_out + px) = make_float4(gs[0], gs[1], gs[2], gs[3]);
@@ -589,7 +610,7 @@ WhiteLevel io_white_level(float wl) {
   const bool all_ones = (bits & 0x7fffffu) == 0x7fffffu;
   const bool in_range = wl >= 0x1p-40f && wl <= 0x1p40f;
   volatile float r = 1.0f / wl;  // IEEE, correctly rounded
-  return WhiteLevel{wl, (all_ones || !in_range) ? 0.0f : (float)r};
+  return WhiteLevel{wl, (all_ones || !in_range) ? 0.0f : (float)r, (float)r};
 }
 
 struct IoGeom {
@@ -610,7 +631,7 @@ IoGeom io_geom(int W, int GW, int GD, int C, int Cout, int tab_floats = 0) {
 template <int CIN, int COUT, bool OFFSET, int GUIDE, typename TI, typename TO>
 hipError_t launch_io(const ApplyIoArgs& a, const Plan&, hipStream_t s) {
   constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
-  const IoGeom g = io_geom(a.W, a.GW, a.GD, C, COUT, GUIDE == kGuideCurves ? CurveTab<CIN>::kFloats : (kToolsBuild && GUIDE == kGuideNN) ? NnTab::kWords : 0);
+  const IoGeom g = io_geom(a.W, a.GW, a.GD, C, COUT, (kToolsBuild && GUIDE == kGuideNN) ? NnTab::kWords : 0);
   IoParams p;
   p.grid = a.grid;
   p.guide = a.guide;
@@ -662,7 +683,7 @@ bool plan_io(const ApplyIoArgs& a, Plan* pl) {
                          (a.input_dtype == 0 ? (uintptr_t)a.input : 0);
   if (bits & 15u) return false;
   if (((uintptr_t)a.input | (uintptr_t)a.out) & 3u) return false;
-  const IoGeom g = io_geom(a.W, a.GW, a.GD, 12, 3, CurveTab<3>::kFloats);  // the largest of the three kernels
+  const IoGeom g = io_geom(a.W, a.GW, a.GD, 12, 3, CurveTab<3>::kFloats);  // + the curves kernel's static tables: the largest of the kernels
   *pl = g.pl;
   if (a.B > 65535 || a.H > 65535 || (long long)a.W * a.Cout * 4 >= (1LL << 31)) return false;
   if ((long long)(g.slab_off) >= (1 << 20)) return false;

@@ -200,10 +200,15 @@ __device__ __forceinline__ void seg_pixel_lean(const float* __restrict__ img, fl
 //   img[j][p][c] = wy0 * grid[gy0c][clamp(cmin + j)][clamp(p - 1)][c] + wy1 * grid[gy1c][...]
 // Work item = one VEC-float element of a source (column, plane) vector (one per thread at 4K; a
 // rolled loop keeps the kernel at <= 64 VGPRs, i.e. 8 waves per SIMD, for every load flavour).
-template <int C>
+// IN_SCALE (wire formats, apply_fwd_io.hip): the image is staged with the coefficients that MULTIPLY AN INPUT CHANNEL
+// (columns j < 3 of every 3 x 4 affine; C = 12, one float4 = one output row) scaled by `in_scale` = 1 / white level, so
+// that a pixel enters the affine as its raw integer sample: coef * (1 / wl) * v instead of coef * (v / wl), one
+// multiply per staged element instead of a division per sample.
+template <int C, bool IN_SCALE = false>
 __device__ __forceinline__ void stage_image(float* __restrict__ img, const float* __restrict__ grid_b,
                                             int y, int cmin, int ncols, int GH, int GW, int GD,
-                                            float scale_y, float inv_col, int tid, int nthreads) {
+                                            float scale_y, float inv_col, int tid, int nthreads, float in_scale = 1.0f) {
+  static_assert(!IN_SCALE || C == 12, "IN_SCALE: 3 -> 3 with offset, a float4 per output row");
   constexpr int VEC = (C % 4 == 0) ? 4 : 1;
   constexpr int CV = C / VEC;
   typedef float elem_t __attribute__((ext_vector_type(VEC)));
@@ -225,7 +230,12 @@ __device__ __forceinline__ void stage_image(float* __restrict__ img, const float
     const int rem = e - j * per_col;
     const int sc = min(max(cmin + j, 0), GW - 1);
     const int src = sc * per_col + rem;
-    const elem_t v = wy0 * r0[src] + wy1 * r1[src];
+    elem_t v = wy0 * r0[src] + wy1 * r1[src];
+    if constexpr (IN_SCALE) {
+      v[0] *= in_scale;
+      v[1] *= in_scale;
+      v[2] *= in_scale;
+    }
     const int dst = e + CV * (2 * j + 1);  // column j has GD + 2 planes; source plane z is plane z + 1
     d[dst] = v;
     if (rem < CV) d[dst - CV] = v;             // z = 0      -> also plane 0
