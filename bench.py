@@ -375,6 +375,9 @@ def main():
                          "is split into N row bands, one per rank (hdrnet_bilateral_slice_apply_rows_f32), strong "
                          "scaling -- the total work is fixed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true",
+                    help="skip the two-stream `pipelined` block: its overlapping launches have longer per-kernel durations "
+                         "and would be averaged into a rocprofv3 --kernel-trace --stats summary of this command")
     ap.add_argument("--extra", action="store_true",
                     help="also time the cache-resident rate and 1080p (same kernel name at other "
                          "sizes: keep off when collecting rocprofv3 --stats for the roofline line)")
@@ -479,7 +482,7 @@ def main():
         result["sustained"] = sus
         result["roofline"]["frac_sustained"] = round(
             abytes / (sus["us_per_launch_mean"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
-        if band is None:
+        if band is None and not args.no_pipelined:
             # the same frames round-robin on two streams (fill of the next under the drain of the previous): what
             # a pipeline of independent frames gets (runtime.FramePipeline) -- beside the headline, not in it
             us2 = pipelined(lib, sets, dims, dev, nstreams=2)

@@ -49,7 +49,7 @@ fi
 # 2. the default bench command, un-profiled and under rocprofv3 --kernel-trace --stats
 python $R/bench.py > $O/bench.json 2> $O/bench.err
 # the same command under rocprofv3 --kernel-trace --stats (its per-kernel average must agree with the line above)
-rocprofv3 --kernel-trace --stats -d $O/stats -o fwd --output-format csv -- python $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/stats -o fwd --output-format csv -- python $R/bench.py --no-cpu-baseline --no-pipelined > $O/bench_under_rocprof.log 2>&1
 grep '^{"metric' $O/bench_under_rocprof.log > $O/bench_under_rocprof.json
 find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/fwd_kernel_stats.csv \;
 rm -rf $O/stats
