@@ -380,7 +380,7 @@ def test_inference_sigmoid_moves_the_guide_by_at_most_2_ulp(dev, ops):
     out_train, gout = ops.bilateral_slice_apply_nnguide(*args, has_offset=True, return_guide=True)
     out_infer = ops.bilateral_slice_apply_nnguide(*args, has_offset=True)
     g = N(gout)
-    assert g.min() < 0.2 and g.max() > 0.8 and g.std() > 0.05  # the sigmoid is exercised over its range
+    assert g.max() - g.min() > 0.5 and g.std() > 0.05  # the sigmoid is exercised over a wide range
     d = np.abs(N(out_train) - N(out_infer)).max()
     print(f"max|out(train sigmoid) - out(inference sigmoid)| = {d:.3e} (2 ulp of 1.0 = 2.4e-7)")
     assert d <= 2.4e-7
