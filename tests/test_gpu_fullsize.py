@@ -266,3 +266,34 @@ def test_dguide_noise_hip_vs_float64_against_the_reference_s_own(dev, ops, mt_po
               f"dinput {hip_i:.3e} vs {ref_i:.3e}, ratio {hip_i / ref_i:.2f}; max|dguide| = {np.abs(dg64).max():.3g}")
         assert hip_g <= 2.0 * ref_g, (label, hip_g, ref_g)
         assert hip_i <= 2.0 * ref_i + 1e-7, (label, hip_i, ref_i)
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_adjointness_and_linearity_at_config_size(dev, ops, name):
+    """Size-independent properties of the op, checked on the HIP path alone at every BASELINE config size (no oracle in
+    the loop): for fixed guide the output is LINEAR in the grid and AFFINE in the input
+    (bilateral_slice_apply.cc:72-80), so with the VJPs of one backward call
+        <dout, out(grid)>                      == <dgrid, grid>                       (adjoint of grid -> out)
+        <dout, out(input)> - <dout, out(0)>    == <dinput, input>                     (adjoint of input -> out)
+        out(a grid1 + b grid2)                 == a out(grid1) + b out(grid2)         (linearity)
+    Inner products accumulated in float64; the two sides agree to the float32 rounding of ~1e7 summed terms."""
+    H, W, GH, GW, GD = CONFIGS[name]
+    gen = torch.Generator(device=dev).manual_seed(H + W)
+    grid = torch.rand((1, GH, GW, GD, 12), device=dev, generator=gen).requires_grad_(True)
+    grid2 = torch.rand((1, GH, GW, GD, 12), device=dev, generator=gen)
+    guide = torch.rand((1, H, W), device=dev, generator=gen) * 1.04 - 0.02
+    inp = torch.rand((1, H, W, 3), device=dev, generator=gen).requires_grad_(True)
+    dout = torch.randn((1, H, W, 3), device=dev, generator=gen)
+    out = ops.bilateral_slice_apply(grid, guide, inp, has_offset=True)
+    out.backward(dout)
+    dot = lambda a, b: float((a.double() * b.double()).sum())  # noqa: E731
+    lhs = dot(dout, out.detach())
+    scale = float((dout.double().abs() * out.detach().double().abs()).sum())
+    assert abs(lhs - dot(grid.grad, grid.detach())) <= 2e-6 * scale, (lhs, dot(grid.grad, grid.detach()), scale)
+    with torch.no_grad():
+        out0 = ops.bilateral_slice_apply(grid.detach(), guide, torch.zeros_like(inp), has_offset=True)
+        assert abs((lhs - dot(dout, out0)) - dot(inp.grad, inp.detach())) <= 2e-6 * scale
+        a, b = 0.75, -1.5
+        o2 = ops.bilateral_slice_apply(grid2, guide, inp.detach(), has_offset=True)
+        oc = ops.bilateral_slice_apply(a * grid.detach() + b * grid2, guide, inp.detach(), has_offset=True)
+        torch.testing.assert_close(oc, a * out.detach() + b * o2, rtol=1e-5, atol=2e-5)
