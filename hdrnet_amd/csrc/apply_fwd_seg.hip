@@ -46,7 +46,10 @@
 //     the packed form, 24 v_pk_fma_f32, is 323 + 114): same time on steady boxes, bit-identical results, less time in
 //     the power manager's braked state on the boxes that fall into it (launch_apply_fwd_seg below).  The guide-network
 //     / wire-format kernels, which are VALU-bound, keep the packed blend.
-//   * ROUND 4 -- the launch shape, measured and left as it is (profiles/r04/fwd_launch_shape/): fewer resident
+//   * ROUND 4 -- the launch shape (profiles/r04/fwd_launch_shape.md).  ONE thing changed: the resident waves per CU are
+//     CAPPED (resident_cap_lds below: 7 three-wave workgroups per CU instead of the 9 the LDS footprint allows) -- the
+//     same 38-39.5 us per 4K launch on steady boxes, and the end of the power manager's 42-46-us state on the boxes that
+//     had it (profiles/r04/power_state/).  Everything else was measured and left as it is: fewer resident
 //     workgroups shorten a workgroup's life (9 -> 6 per CU: 5.1 -> 4.0 us) and leave the launch where it was (39.4 vs
 //     39.7 us): it is throughput-, not latency-bound; flat 1024-px tasks that ignore rows (1080p: 2025 workgroups for
 //     2048 slots) do not beat row segments in a no-compute skeleton (11.5 vs 11.3 us); a ticketed tail (SCHED = 1 below:
@@ -150,6 +153,10 @@ struct SegParams {
   GuideNN gn;        // GUIDE_NN: the folded point-wise guide network (rows_common.hip.h)
   UpAdd up;          // UPADD: the coarser pyramid level to up-sample and add
   DynSched dyn;      // SCHED != 0: flat launch grid with a ticketed tail (below)
+#ifdef HDRNET_TOOLS_BUILD
+  int stagger, stagger_rows;  // experiment (knob 7): workgroups of the first rows sleep (index % 8) * stagger x 64
+                              // cycles before their pixel phase -- de-synchronises the launch's first round
+#endif
 };
 
 template <int STORES>
@@ -281,6 +288,12 @@ __device__ __forceinline__ void seg_task(const SegParams& p, float* __restrict__
   }
 
   __syncthreads();  // image complete; with LDS-DMA in flight the compiler drains vmcnt here too
+#ifdef HDRNET_TOOLS_BUILD
+  if (p.stagger > 0 && y < p.stagger_rows) {  // uniform
+    const int n = ((y * 5 + segi) & 7) * p.stagger;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+  }
+#endif
 
   // ---- this lane's 4 pixels ---------------------------------------------------------------------
   if constexpr (LOADS == kLoadsNtContig) {
@@ -434,6 +447,28 @@ int g_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 unsigned* g_sched_words = nullptr;  // kSchedWords zeroed words, allocated on first use
 #endif
 
+// RESIDENT-WAVE CAP (round 4).  The kernel needs only ~40 KB of loads in flight per CU to saturate its share of the HBM
+// (Little's law on 26 KB/us per CU and ~1.5 us of fixed latency; 9 -> 7 -> 6 workgroups per CU: 39.4 / 39.3 / 39.7 us
+// per 4K launch, profiles/r04/fwd_launch_shape.md), but what it does with more resident waves matters to the POWER
+// MANAGER: with 27 waves per CU (9 three-wave workgroups, what the LDS footprint allows) a third of the boxes of the
+// pool flip, for 50-200 ms at a time, into a state where the launch takes 42-46 us instead of 39 (higher clock,
+// compute side power-braked: DESIGN.md section 5); with 24 waves the flips become rare, with 21 they are gone --
+// 39.0-39.3 us on the boxes where the uncapped kernel runs 40.6-44.3, and THE SAME 38.0-39.5 us as uncapped on every
+// steady box (20 boxes interleaved, profiles/r04/power_state/).  The cap is a floor on the dynamic LDS a workgroup
+// asks for: the smallest allocation of which kResidentWaves / waves + 1 no longer fit into a CU's 160 KiB.
+inline int resident_cap_wgs(int waves) {
+  // 3-wave workgroups (4K): 7 = 21 waves -- free on steady boxes, no flips.  4-wave workgroups (4 x 1080p, 4000 x 3000;
+  // 7 fit by LDS = 28 waves): 6 = 24 waves costs 0.0-0.2 us per launch, 5 costs 1 us at 4 x 1080p (profiles/r04/
+  // power_state/occ2_*).  Other widths: 21 waves.
+  return waves == 3 ? 7 : waves == 4 ? 6 : waves > 0 ? (21 / waves > 0 ? 21 / waves : 1) : 0;
+}
+inline size_t resident_cap_lds(size_t lds, int threads) {
+  const int wgs = resident_cap_wgs(threads / 64);
+  if (wgs < 1) return lds;
+  const size_t floor_bytes = ((size_t)160 * 1024 / (size_t)(wgs + 1) / 256 + 1) * 256;
+  return lds > floor_bytes ? lds : floor_bytes;
+}
+
 inline unsigned div_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / d) + 1u; }
 
 // Flat-grid schedule of M tasks with a ticketed tail of D tasks served by E workgroups.  False: the task count is
@@ -463,8 +498,13 @@ hipError_t launch_seg_t(const ApplyArgs& a, hipStream_t s, long long* trace,
   constexpr int VEC = (C % 4 == 0) ? 4 : 1;
   SegGeom g = seg_geom(a, LOADS >= kLoadsDma, !GUIDE_NN);
   if (!g.ok) return hipErrorNotSupported;
+  // (not for the per-lane-load flavour, which serves grids of about ONE round of workgroups -- a single 1080p frame:
+  //  there every resident slot counts, 11.7 us uncapped / 12.0 at 7 workgroups per CU / 13.1 at 6;
+  //  nor with the guide network fused: that kernel is VALU-bound and wants its waves, 44.8 -> 48.2 us capped at 4K)
+  if constexpr (LOADS >= kLoadsDma && !GUIDE_NN) g.lds = resident_cap_lds(g.lds, g.pl.threads);
 #ifdef HDRNET_TOOLS_BUILD
-  g.lds += (size_t)g_knob[0];
+  if (g_knob[0] < 0) g.lds = seg_geom(a, LOADS >= kLoadsDma, !GUIDE_NN).lds;  // knob 0 < 0: no cap (round 3's residency)
+  else g.lds += (size_t)g_knob[0];
 #endif
   SegParams p;
   p.gn = gn;
@@ -487,6 +527,10 @@ hipError_t launch_seg_t(const ApplyArgs& a, hipStream_t s, long long* trace,
   p.scale_y = (float)a.GH / a.frame_rows();
   p.inv_col = 1.0f / (float)(a.GD * (C / VEC));
   p.trace = trace;
+#ifdef HDRNET_TOOLS_BUILD
+  p.stagger = g_knob[7];
+  p.stagger_rows = (2304 + g.pl.nseg - 1) / g.pl.nseg;  // the first round of resident workgroups
+#endif
   if constexpr (SCHED != 0) {
     if (!dyn) return hipErrorInvalidValue;
     p.dyn = *dyn;

@@ -45,9 +45,12 @@ extern "C" {
 void hdrnet_tools_set_trace(void* device_buf);
 
 /* Experiment knobs read by some variants at launch (apply_fwd_seg.hip):
- *   0  extra dynamic LDS bytes per workgroup (caps the workgroups resident per CU), all apply_fwd_seg variants
+ *   0  extra dynamic LDS bytes per workgroup (fewer workgroups resident per CU), all apply_fwd_seg variants; -1 = WITHOUT
+ *      the product's resident-wave cap (round 3's residency: 9 three-wave workgroups per CU at 4K)
  *   1  variants 70 / 71: D, the number of tasks at the end of the launch that are handed out by ticket
  *   2  variants 70 / 71: surplus ticketed workgroups (E = D + surplus, rounded up to a multiple of 256)
+ *   7  apply_fwd_seg: the workgroups of the launch's first round sleep (index % 8) * value * 64 cycles before their pixel
+ *      phase (de-synchronises the first round)
  *   5  hdrnet_bilateral_slice_apply_io, uint8 input + guide network: 1 = the hidden layer as bf16-split 4x4x4 matrix
  *      instructions (apply_fwd_io.hip; rejected on time, kept for the record) */
 void hdrnet_tools_set_knob(int idx, int value);
