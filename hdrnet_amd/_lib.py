@@ -46,6 +46,8 @@ SIGNATURES = {
     "hdrnet_curves_guide_grad_f32": (_I, [_FP] * 7 + [_I] + [_FP] * 4 + [ctypes.c_longlong, _I, _I, _VP, _SZ, _VP]),
     "hdrnet_input_moments_workspace_bytes": (_SZ, [ctypes.c_longlong, _I]),
     "hdrnet_input_moments_f32": (_I, [_FP, ctypes.c_longlong, _I, _FP, _FP, _VP, _SZ, _VP]),
+    "hdrnet_coefficients_workspace_bytes": (_SZ, [_VP, _I]),
+    "hdrnet_coefficients_f32": (_I, [_FP, _VP, _FP, _I, _VP, _SZ, _VP]),
     "hdrnet_bilateral_slice_apply_io": (_I, [_FP] * 4 + [_I] * 10 + [ctypes.c_float, _I] + [_FP] * 2 + [_I, _FP, _VP]),
     "hdrnet_bilateral_slice_apply_grad_workspace_bytes": (_SZ, [_I] * 9),
     "hdrnet_bilateral_slice_apply_grad_f32": (_I, [_FP] * 7 + [_I] * 9 + [_VP, _SZ, _VP]),
@@ -56,6 +58,18 @@ SIGNATURES = {
     "hdrnet_bilateral_slice_grad_f32": (_I, [_FP] * 5 + [_I] * 7 + [_VP, _SZ, _VP]),
     "hdrnet_bilateral_slice_grad_f32_ex": (_I, [_FP] * 5 + [_I] * 7 + [_VP, _SZ, _U, _VP]),
 }
+
+
+class CoeffNet(ctypes.Structure):
+    """``hdrnet_coeff_net`` of include/hdrnet_amd.h (the coefficient network's hyper-parameters and parameters)."""
+
+    _fields_ = [("net_input_size", _I), ("spatial_bin", _I), ("luma_bins", _I), ("channel_multiplier", _I),
+                ("n_out", _I), ("n_in", _I), ("n_levels", _I),
+                ("splat_w", _VP * 8), ("splat_b", _VP * 8),
+                ("global_conv_w", _VP * 2), ("global_conv_b", _VP * 2),
+                ("fc_w", _VP * 3), ("fc_b", _VP * 3),
+                ("local_w", _VP * 2), ("local_b", _VP * 2),
+                ("pred_w", _VP), ("pred_b", _VP)]
 
 
 class HdrnetLibraryError(RuntimeError):

@@ -44,6 +44,7 @@ SOURCES = [
     ("grid_grad_mfma.hip", ["-fno-slp-vectorize"]),
     ("guide_grad.hip", ["-fno-slp-vectorize"]),
     ("resize_bilinear.hip", []),
+    ("coeff_net.hip", []),
 ]
 TOOLS_ONLY_SOURCES = [
     ("apply_fwd_variants.hip", ["-fno-slp-vectorize"]),

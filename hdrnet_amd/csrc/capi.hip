@@ -382,6 +382,48 @@ int hdrnet_input_moments_f32(const float* input, long long npx, int Cin, float* 
   return rc;
 }
 
+size_t hdrnet_coefficients_workspace_bytes(const hdrnet_coeff_net* net, int B) {
+  if (!net || B <= 0) return 0;
+  return hdrnet_amd::coefficients_workspace_bytes(*net, B);
+}
+
+int hdrnet_coefficients_f32(const float* lowres, const hdrnet_coeff_net* net, float* coeffs, int B,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  using namespace hdrnet_amd;
+  if (!net) return fail(HDRNET_INVALID_ARGUMENT, "null network description");
+  if (B < 0) return fail(HDRNET_INVALID_ARGUMENT, "negative batch (B=%d)", B);
+  if (!coefficients_supported(*net))
+    return fail(HDRNET_INVALID_ARGUMENT,
+                "coefficient network: unsupported hyper-parameters (net_input_size=%d, spatial_bin=%d, luma_bins=%d, "
+                "channel_multiplier=%d, n_out=%d, n_in=%d, n_levels=%d): sizes must be powers of two and "
+                "channel_multiplier * luma_bins / 4 a power of two",
+                net->net_input_size, net->spatial_bin, net->luma_bins, net->channel_multiplier, net->n_out,
+                net->n_in, net->n_levels);
+  if (B == 0) {
+    set_kernel("noop");
+    g_error[0] = '\0';
+    return HDRNET_OK;
+  }
+  int n_ds = 0;
+  for (int v = net->net_input_size / net->spatial_bin; v > 1; v >>= 1) ++n_ds;
+  bool null_param = !net->pred_w || !net->pred_b || !net->local_w[0] || !net->local_w[1] || !net->local_b[0];
+  for (int i = 0; i < n_ds; ++i) null_param = null_param || !net->splat_w[i] || !net->splat_b[i];
+  for (int i = 0; i < 2; ++i) null_param = null_param || !net->global_conv_w[i] || !net->global_conv_b[i];
+  for (int i = 0; i < 3; ++i) null_param = null_param || !net->fc_w[i] || !net->fc_b[i];
+  if (null_param) return fail(HDRNET_INVALID_ARGUMENT, "coefficient network: null parameter");
+  if (!lowres || !coeffs) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  const size_t need = coefficients_workspace_bytes(*net, B);
+  if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15u))
+    return fail(HDRNET_INVALID_ARGUMENT, "coefficient network needs a 16-B aligned workspace of "
+                                         "hdrnet_coefficients_workspace_bytes() = %zu bytes", need);
+  const char* name = "";
+  const int rc = check_launch(launch_coefficients(lowres, *net, coeffs, B, workspace,
+                                                  static_cast<hipStream_t>(stream), &name),
+                              "Coefficients");
+  if (rc == HDRNET_OK) set_kernel(name);
+  return rc;
+}
+
 int hdrnet_bilateral_slice_apply_io(const float* grid, const float* guide, const void* input,
                                     void* out, int B, int H, int W, int GH, int GW, int GD, int Cin,
                                     int Cout, int has_offset, int input_dtype,

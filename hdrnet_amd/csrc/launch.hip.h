@@ -7,6 +7,8 @@
 
 #include <stddef.h>
 
+#include "../../include/hdrnet_amd.h"
+
 namespace hdrnet_amd {
 
 struct ApplyArgs {
@@ -219,5 +221,11 @@ hipError_t launch_curves_grad(const CurvesGradArgs& a, hipStream_t s, const char
 size_t input_moments_workspace_bytes(long long npx, int Cin);
 hipError_t launch_input_moments(const float* input, long long npx, int Cin, float* sums, float* moments,
                                 void* workspace, hipStream_t s, const char** name);
+
+// coeff_net.hip -- the low-resolution coefficient network (hdrnet/models.py:62-142) as inference kernels.
+bool coefficients_supported(const hdrnet_coeff_net& net);
+size_t coefficients_workspace_bytes(const hdrnet_coeff_net& net, int B);  // 0: unsupported hyper-parameters
+hipError_t launch_coefficients(const float* lowres, const hdrnet_coeff_net& net, float* coeffs, int B, void* workspace,
+                               hipStream_t s, const char** name);
 
 }  // namespace hdrnet_amd

@@ -36,7 +36,7 @@ from . import _lib
 
 __all__ = ["bilateral_slice", "bilateral_slice_apply", "bilateral_slice_apply_rows", "bilateral_slice_apply_nnguide",
            "bilateral_slice_apply_io", "bilateral_slice_apply_curves", "bilateral_slice_apply_upadd", "resize_bilinear", "input_moments",
-           "kernel_override", "last_kernel"]
+           "CoefficientWeights", "coefficients", "kernel_override", "last_kernel"]
 
 _tls = threading.local()
 
@@ -492,6 +492,90 @@ def input_moments(input: torch.Tensor):  # noqa: A002
                                           ws.data_ptr(), wbytes, _stream(dev))
     _lib.check(rc, "InputMoments")
     return sums, mom
+
+
+class CoefficientWeights:
+    """The coefficient network's parameters in the layout ``hdrnet_coefficients_f32`` reads
+    (include/hdrnet_amd.h): convolutions ``[Cout][kh][kw][Cin]``, fully connected layers ``[in][out]``,
+    batch norm folded, fp32, contiguous, on one device.  Holds the tensors alive next to the C struct.
+
+    ``params``: net_input_size, spatial_bin, luma_bins, channel_multiplier (hdrnet/bin/train.py:227-236);
+    ``splat`` / ``global_conv`` / ``fc`` / ``local``: lists of ``(weight, bias)`` (bias ``None`` only for the second
+    local conv, the reference's ``use_bias=False``); ``pred``: ``(weight, bias)``.
+    """
+
+    def __init__(self, params, n_out: int, n_in: int, n_levels: int, splat, global_conv, fc, local, pred):
+        self.params = dict(params)
+        self.n_out, self.n_in, self.n_levels = int(n_out), int(n_in), int(n_levels)
+        groups = dict(splat=list(splat), global_conv=list(global_conv), fc=list(fc), local=list(local), pred=[pred])
+        if len(groups["global_conv"]) != 2 or len(groups["fc"]) != 3 or len(groups["local"]) != 2 or not 1 <= len(groups["splat"]) <= 8:
+            raise ValueError("coefficient network: 1-8 splat layers, 2 global convs, 3 fc layers, 2 local convs")
+        self.device = groups["pred"][0][0].device
+        self._keep = []
+
+        def prep(t):
+            if t is None:
+                return None
+            if t.dtype != torch.float32:
+                raise ValueError(f"coefficient network parameters must be float32, got {t.dtype}")
+            if t.device != self.device:
+                raise ValueError("coefficient network parameters must live on one device")
+            t = t.detach().contiguous()
+            self._keep.append(t)
+            return t.data_ptr()
+
+        net = _lib.CoeffNet()
+        net.net_input_size = int(self.params["net_input_size"])
+        net.spatial_bin = int(self.params["spatial_bin"])
+        net.luma_bins = int(self.params["luma_bins"])
+        net.channel_multiplier = int(self.params["channel_multiplier"])
+        net.n_out, net.n_in, net.n_levels = self.n_out, self.n_in, self.n_levels
+        for i, (w, b) in enumerate(groups["splat"]):
+            net.splat_w[i], net.splat_b[i] = prep(w), prep(b)
+        for i, (w, b) in enumerate(groups["global_conv"]):
+            net.global_conv_w[i], net.global_conv_b[i] = prep(w), prep(b)
+        for i, (w, b) in enumerate(groups["fc"]):
+            net.fc_w[i], net.fc_b[i] = prep(w), prep(b)
+        for i, (w, b) in enumerate(groups["local"]):
+            net.local_w[i], net.local_b[i] = prep(w), prep(b)
+        net.pred_w, net.pred_b = prep(pred[0]), prep(pred[1])
+        self.net = net
+        self.n_splat = len(groups["splat"])
+
+    def supported(self, batch: int = 1) -> bool:
+        """False: hyper-parameters outside the kernels' reach (run the stock-op graph instead)."""
+        import ctypes
+        return _lib.load().hdrnet_coefficients_workspace_bytes(ctypes.byref(self.net), int(batch)) > 0
+
+
+def coefficients(lowres_input: torch.Tensor, weights: CoefficientWeights) -> torch.Tensor:
+    """``HDRNetCurves._coefficients`` (hdrnet/models.py:62-142) in inference mode, on the HIP kernels of
+    csrc/coeff_net.hip: ``lowres_input [B, N, N, 3]`` -> ``[B, sb, sb, gd, n_out, n_in]`` (``n_levels`` > 1:
+    ``[n_levels, B, sb, sb, gd, n_out / n_levels, n_in]``, every level's grid contiguous).  No autograd."""
+    import ctypes
+    _require_f32("lowres_input", lowres_input)
+    if lowres_input.dim() != 4 or lowres_input.shape[3] != 3:
+        raise ValueError(f"lowres_input should be [batch, N, N, 3], got {tuple(lowres_input.shape)}")
+    _require_gpu("lowres_input", lowres_input)
+    p = weights.params
+    N, sb, gd = int(p["net_input_size"]), int(p["spatial_bin"]), int(p["luma_bins"])
+    if lowres_input.shape[1] != N or lowres_input.shape[2] != N:
+        raise ValueError(f"lowres_input is {tuple(lowres_input.shape[1:3])}, the network was built for {N} x {N}")
+    if lowres_input.device != weights.device:
+        raise ValueError("lowres_input and the network parameters live on different devices")
+    low = lowres_input.detach().contiguous()
+    B, dev = low.shape[0], low.device
+    L = weights.n_levels
+    shape = (B, sb, sb, gd, weights.n_out // L, weights.n_in)
+    out = torch.empty((L,) + shape if L > 1 else shape, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        wbytes = lib.hdrnet_coefficients_workspace_bytes(ctypes.byref(weights.net), B)
+        ws = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=dev)
+        rc = lib.hdrnet_coefficients_f32(low.data_ptr(), ctypes.byref(weights.net), out.data_ptr(), B,
+                                         ws.data_ptr(), wbytes, _stream(dev))
+    _lib.check(rc, "Coefficients")
+    return out
 
 
 def resize_bilinear(input: torch.Tensor, height: int, width: int) -> torch.Tensor:  # noqa: A002

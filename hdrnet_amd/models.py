@@ -114,6 +114,9 @@ class _Coefficients(nn.Module):
         gd, cm, sb = params["luma_bins"], params["channel_multiplier"], params["spatial_bin"]
         bn = params["batch_norm"]
         self.gd, self.n_out, self.n_in = gd, n_out, n_in
+        self.hyper = dict(net_input_size=params["net_input_size"], spatial_bin=sb, luma_bins=gd, channel_multiplier=cm)
+        self.n_levels = 1  # HDRNetGaussianPyrNN: 3 (the native kernels then write every level's grid contiguous)
+        self._exported = None  # (key, hdrnet_ops.CoefficientWeights)
         n_ds = int(math.log2(params["net_input_size"] / sb))
         splat, cin = [], 3
         for i in range(n_ds):
@@ -134,7 +137,85 @@ class _Coefficients(nn.Module):
         # call converts them (8 extra launches of 67 per inference)
         self.to(memory_format=torch.channels_last)
 
+    # Inference on the HIP kernels of csrc/coeff_net.hip (10 launches instead of ~67 stock-op launches); training
+    # and anything that needs autograd stays on the torch ops below.  ``native = False`` forces the torch ops.
+    native = True
+
+    @staticmethod
+    def _fold(weight: torch.Tensor, bias: Optional[torch.Tensor], bn: Optional["_BN"]):
+        """Batch norm (running statistics) folded into weight / bias, as hdrnet/bin/freeze_graph.py:170-184 folds
+        the guide's: ``w * gamma / sqrt(var + eps)`` per output channel, ``beta - mean * that``."""
+        if bn is None:
+            return weight, bias
+        m = bn.bn
+        inv = torch.rsqrt(m.running_var + m.eps) * m.weight
+        w = weight * inv.reshape(-1, *([1] * (weight.dim() - 1)))
+        b = m.bias - m.running_mean * inv
+        if bias is not None:
+            b = b + bias * inv
+        return w, b
+
+    def exported(self):
+        """The parameters in the layout of ``hdrnet_coefficients_f32`` (include/hdrnet_amd.h): convolutions
+        ``[Cout][kh][kw][Cin]``, fully connected ``[in][out]``, batch norm folded (eval-mode statistics).  Cached;
+        rebuilt when any parameter or buffer was modified in place or replaced."""
+        from . import hdrnet_ops
+        tensors = list(self.parameters()) + list(self.buffers())
+        key = tuple((t.data_ptr(), t._version) for t in tensors) + (self.n_levels,)
+        if self._exported is not None and self._exported[0] == key:
+            return self._exported[1]
+        with torch.no_grad():
+            def conv(layer: _Conv):
+                w, b = self._fold(layer.conv.weight, layer.conv.bias, layer.bn)
+                return w.permute(0, 2, 3, 1).contiguous().float(), (None if b is None else b.contiguous().float())
+
+            def fc(layer: _FC):
+                w, b = self._fold(layer.fc.weight, layer.fc.bias, layer.bn)
+                return w.t().contiguous().float(), b.contiguous().float()
+
+            weights = hdrnet_ops.CoefficientWeights(
+                self.hyper, self.n_out, self.n_in, self.n_levels,
+                splat=[conv(layer) for layer in self.splat],
+                global_conv=[conv(layer) for layer in self.global_conv],
+                fc=[fc(self.fc1), fc(self.fc2), fc(self.fc3)],
+                local=[conv(self.local1), conv(self.local2)],
+                pred=conv(self.pred))
+        # tensors made while a hipGraph is being captured belong to the graph's pool: do not keep them
+        if not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+            self._exported = (key, weights)
+        return weights
+
+    def _use_native(self, lowres_nhwc: torch.Tensor) -> bool:
+        if not (self.native and lowres_nhwc.is_cuda and lowres_nhwc.dtype == torch.float32 and not self.training):
+            return False
+        if torch.is_grad_enabled() and (lowres_nhwc.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return False
+        N = self.hyper["net_input_size"]
+        if lowres_nhwc.dim() != 4 or tuple(lowres_nhwc.shape[1:]) != (N, N, 3):
+            return False
+        return self.exported().supported(max(int(lowres_nhwc.shape[0]), 1))
+
+    def levels(self, lowres_nhwc: torch.Tensor) -> List[torch.Tensor]:
+        """Per pyramid level the 5-D grid ``[B, GH, GW, gd, (n_out / n_levels) * n_in]`` of
+        ``coeffs[:, :, :, :, l*k:(l+1)*k, :]`` (hdrnet/models.py:279), each contiguous."""
+        L = self.n_levels
+        if self._use_native(lowres_nhwc):
+            from . import hdrnet_ops
+            out = hdrnet_ops.coefficients(lowres_nhwc, self.exported())
+            out = out if L > 1 else out[None]
+            return [out[l].reshape(*out.shape[1:5], -1) for l in range(L)]
+        coeffs = self.forward(lowres_nhwc)
+        gs, k = coeffs.shape, self.n_out // L
+        return [coeffs[:, :, :, :, l * k:(l + 1) * k, :].reshape(gs[0], gs[1], gs[2], gs[3], k * gs[5]) for l in range(L)]
+
     def forward(self, lowres_nhwc: torch.Tensor) -> torch.Tensor:
+        if self._use_native(lowres_nhwc):
+            from . import hdrnet_ops
+            out = hdrnet_ops.coefficients(lowres_nhwc, self.exported())
+            if self.n_levels > 1:  # level-major -> the reference's [B, GH, GW, gd, n_out, n_in]
+                L, B, GH, GW, gd, k, n_in = out.shape
+                out = out.permute(1, 2, 3, 4, 0, 5, 6).reshape(B, GH, GW, gd, L * k, n_in)
+            return out
         x = lowres_nhwc.permute(0, 3, 1, 2)  # the convs run NCHW; the tensor is 256 x 256
         splat = self.splat(x)
         g = self.global_conv(splat)
@@ -325,6 +406,10 @@ class HDRNetGaussianPyrNN(HDRNetPointwiseNNGuide):
     n_scales = 3
     n_out, n_in = 9, 4
 
+    def __init__(self, params: Optional[Dict] = None):
+        super().__init__(params)
+        self.coefficients.n_levels = self.n_scales
+
     def _make_guide(self) -> nn.Module:
         return nn.ModuleList([_PointwiseNNGuide(self.params["guide_complexity"]) for _ in range(self.n_scales)])
 
@@ -388,8 +473,7 @@ class HDRNetGaussianPyrNN(HDRNetPointwiseNNGuide):
         the multi-scale input comes from the NHWC resize kernel.  5 launches instead of ~40, and
         no full-resolution intermediate besides the two down-sampled inputs."""
         from . import hdrnet_ops
-        coeffs = self.coefficients(lowres_input)
-        gs = coeffs.shape
+        grids = self.coefficients.levels(lowres_input)
         lvls: List[torch.Tensor] = [fullres_input]
         h, w = fullres_input.shape[1:3]
         for _ in range(self.n_scales - 1):
@@ -397,7 +481,7 @@ class HDRNetGaussianPyrNN(HDRNetPointwiseNNGuide):
             lvls.append(hdrnet_ops.resize_bilinear(lvls[-1], h, w))
         current = None
         for il, (lvl, gnet) in enumerate(reversed(list(zip(lvls, self.guide)))):  # models.py:278
-            c = coeffs[:, :, :, :, il * 3:(il + 1) * 3, :].reshape(gs[0], gs[1], gs[2], gs[3], 12)
+            c = grids[il]
             conv1, conv2 = gnet.folded()
             if current is None:
                 current = hdrnet_ops.bilateral_slice_apply_nnguide(c, lvl, conv1, conv2, has_offset=True)

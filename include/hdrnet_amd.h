@@ -301,6 +301,52 @@ int hdrnet_bilateral_slice_grad_f32_ex(const float* grid, const float* guide,
                                        void* workspace, size_t workspace_bytes,
                                        unsigned flags, void* stream);
 
+/* ---- The low-resolution coefficient network: the caller of the hot path ----
+ *
+ * HDRNetCurves._coefficients (hdrnet/models.py:62-142; layer wrappers hdrnet/layers.py:25-93) in inference
+ * mode: lowres [B][N][N][3] fp32 -> the bilateral grid [B][sb][sb][gd][n_out][n_in] the slice-apply entry points
+ * read (the unroll of models.py:134-138: prediction channel (j*n_out + i)*gd + z -> [.., z, i, j]).
+ *   splat       n_ds = log2(N / sb) stride-2 3x3 convs, padding SAME, ReLU; layer i has cm * 2^i * gd channels
+ *   global      two stride-2 3x3 convs (8*cm*gd channels, ReLU), (h, w, c) flattening, fc 32*cm*gd (ReLU),
+ *               fc 16*cm*gd (ReLU), fc 8*cm*gd
+ *   local       3x3 conv (ReLU), 3x3 conv (no bias, no activation), both 8*cm*gd channels
+ *   fusion      relu(local + global), then the 1x1 prediction conv to gd*n_out*n_in channels
+ * Ten launches on `stream`, no host synchronisation, deterministic.
+ *
+ * Parameters (device pointers, fp32, 16-B aligned), batch norm already FOLDED into weight and bias the way
+ * hdrnet/bin/freeze_graph.py:170-184 folds the guide's (w * gamma / sqrt(var + eps), beta - mean * that):
+ *   convolutions  [Cout][kh][kw][Cin] -- the TensorFlow variable [kh][kw][Cin][Cout] with Cout moved to the front
+ *                 (= a torch Conv2d weight in channels_last memory order); bias [Cout], NULL = none
+ *   fc layers     [in][out], TensorFlow's own layout; bias [out]
+ * n_levels > 1 (HDRNetGaussianPyrNN: n_out = 9, n_levels = 3) writes the output level-major,
+ * [n_levels][B][sb][sb][gd][n_out / n_levels][n_in] -- each level's grid contiguous, as the per-level
+ * slice-applies of models.py:277-289 (coeffs[:, :, :, :, 3*l : 3*l + 3, :]) need it.
+ * Supported: N, sb powers of two, N / sb in [2, 256], cm * gd a multiple of 4 with cm * gd / 4 a power of two;
+ * hdrnet_coefficients_workspace_bytes returns 0 otherwise (run the stock-op graph instead). */
+typedef struct hdrnet_coeff_net {
+  int net_input_size;     /* N */
+  int spatial_bin;        /* sb: the grid is sb x sb cells */
+  int luma_bins;          /* gd */
+  int channel_multiplier; /* cm */
+  int n_out, n_in;        /* 3, 4 (pyramid model: 9, 4) */
+  int n_levels;           /* 1 (pyramid model: 3) */
+  const float* splat_w[8];
+  const float* splat_b[8];
+  const float* global_conv_w[2];
+  const float* global_conv_b[2];
+  const float* fc_w[3];
+  const float* fc_b[3];
+  const float* local_w[2];
+  const float* local_b[2]; /* local_b[1] = NULL: the reference's use_bias=False (models.py:113-115) */
+  const float* pred_w;
+  const float* pred_b;
+} hdrnet_coeff_net;
+
+size_t hdrnet_coefficients_workspace_bytes(const hdrnet_coeff_net* net, int B);
+
+int hdrnet_coefficients_f32(const float* lowres, const hdrnet_coeff_net* net, float* coeffs, int B,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

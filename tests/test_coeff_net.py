@@ -1,0 +1,241 @@
+"""The low-resolution coefficient network on the HIP kernels of csrc/coeff_net.hip (SURVEY.md section 8f row 1:
+the caller of the hot path, hdrnet/models.py:62-142) against the torch restatement of the same graph
+(hdrnet_amd/models.py: _Coefficients), evaluated in float64 on the CPU.
+
+CPU part: the exported parameter layout (conv [Cout][kh][kw][Cin], fc [in][out], batch norm folded) reproduces the
+module; workspace sizes and argument validation of the C-ABI entry points (no GPU call).
+GPU part (-m gpu): the kernels themselves, over the hyper-parameters of hdrnet/bin/train.py:227-236.
+"""
+import copy
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hdrnet_amd import models
+
+
+def randomize(module, seed=0):
+    """Move every parameter and batch-norm statistic off its initial value (zero biases, unit variances)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if p.dim() == 1 and "bn.weight" not in name:
+                p.copy_(0.2 * torch.randn(p.shape, generator=g))
+        for name, b in module.named_buffers():
+            if name.endswith("running_mean"):
+                b.copy_(0.3 * torch.randn(b.shape, generator=g))
+            elif name.endswith("running_var"):
+                b.copy_(0.5 + torch.rand(b.shape, generator=g))
+    return module
+
+
+def evaluate_exported(w, low):
+    """The network evaluated from the EXPORTED arrays with plain torch ops -- the layout contract of
+    include/hdrnet_amd.h (hdrnet_coeff_net) spelled out."""
+    keep = iter(w._keep)
+
+    def take(has_bias=True):
+        wt = next(keep)
+        return wt, (next(keep) if has_bias else None)
+
+    def conv(x, wt, b, stride, relu):
+        k = wt.shape[1]
+        x = models.tf_same_pad(x, k, stride)
+        y = F.conv2d(x, wt.permute(0, 3, 1, 2), b, stride=stride)  # [Cout][kh][kw][Cin] -> OIHW
+        return F.relu(y) if relu else y
+
+    x = low.permute(0, 3, 1, 2)
+    for _ in range(w.n_splat):
+        wt, b = take()
+        x = conv(x, wt, b, 2, True)
+    g = x
+    for _ in range(2):
+        wt, b = take()
+        g = conv(g, wt, b, 2, True)
+    g = g.permute(0, 2, 3, 1).reshape(g.shape[0], -1)
+    for i in range(3):
+        wt, b = take()
+        g = g @ wt + b  # [in][out]
+        if i < 2:
+            g = F.relu(g)
+    wt, b = take()
+    loc = conv(x, wt, b, 1, True)
+    wt, b = take(has_bias=False)
+    loc = conv(loc, wt, None, 1, False)
+    fusion = F.relu(loc + g[:, :, None, None])
+    wt, b = take()
+    pred = conv(fusion, wt, b, 1, False)
+    B, _, GH, GW = pred.shape
+    gd = w.params["luma_bins"]
+    pred = pred.reshape(B, w.n_in, w.n_out, gd, GH, GW)
+    return pred.permute(0, 4, 5, 3, 2, 1).contiguous()
+
+
+@pytest.mark.parametrize("bn", [False, True])
+def test_exported_layout_reproduces_the_module(bn):
+    torch.manual_seed(3)
+    m = randomize(models.HDRNetCurves(dict(batch_norm=bn, net_input_size=64, spatial_bin=8)).eval()).double()
+    net = m.coefficients
+    low = torch.rand(2, 64, 64, 3, dtype=torch.float64)
+    with torch.no_grad():
+        want = net(low)
+        w = copy.deepcopy(net).float().exported()
+        # the exported arrays are float32; evaluate them in float64
+        w._keep = [t.double() for t in w._keep]
+        got = evaluate_exported(w, low)
+    assert got.shape == want.shape == (2, 8, 8, 8, 3, 4)
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6), float((got - want).abs().max())
+
+
+def test_export_cache_follows_the_parameters():
+    m = models.HDRNetCurves(dict(net_input_size=64, spatial_bin=8)).eval()
+    net = m.coefficients
+    a = net.exported()
+    assert net.exported() is a
+    with torch.no_grad():
+        net.pred.conv.bias.add_(1.0)
+    b = net.exported()
+    assert b is not a
+    assert torch.equal(b._keep[-1], net.pred.conv.bias)
+
+
+def test_workspace_and_validation_without_gpu():
+    from hdrnet_amd import _lib
+    lib = _lib.load()
+    w = models.HDRNetPointwiseNNGuide().eval().coefficients.exported()
+    # 128^2*8 + 64^2*16 + 32^2*32 + 16^2*64 (splat) + 2 * 16^2*64 (local) + 8^2*64 + 4^2*64 (global convs)
+    # + fc partial sums 64*256 + 16*128 + 8*64, floats per image
+    per_image = 131072 + 65536 + 32768 + 16384 + 2 * 16384 + 4096 + 1024 + 16384 + 2048 + 512
+    assert lib.hdrnet_coefficients_workspace_bytes(ctypes.byref(w.net), 1) == 4 * per_image
+    assert lib.hdrnet_coefficients_workspace_bytes(ctypes.byref(w.net), 3) == 12 * per_image
+    assert lib.hdrnet_coefficients_workspace_bytes(ctypes.byref(w.net), 0) == 0
+    assert lib.hdrnet_coefficients_workspace_bytes(None, 1) == 0
+    # luma_bins = 6: channel groups of 6, 12, ... are not whole power-of-two float4 groups -> unsupported
+    w6 = models.HDRNetPointwiseNNGuide(dict(luma_bins=6)).eval().coefficients.exported()
+    assert not w6.supported(1)
+    assert lib.hdrnet_coefficients_f32(None, ctypes.byref(w6.net), None, 1, None, 0, None) == 1
+    assert b"unsupported hyper-parameters" in lib.hdrnet_last_error()
+    assert lib.hdrnet_coefficients_f32(None, None, None, 1, None, 0, None) == 1
+    assert lib.hdrnet_coefficients_f32(None, ctypes.byref(w.net), None, 1, None, 0, None) == 1
+    assert b"null buffer" in lib.hdrnet_last_error()
+    assert lib.hdrnet_coefficients_f32(None, ctypes.byref(w.net), None, 0, None, 0, None) == 0  # empty batch: no-op
+    # a missing parameter is an argument error, not a crash
+    net = _lib.CoeffNet.from_buffer_copy(w.net)
+    net.fc_w[1] = None
+    assert lib.hdrnet_coefficients_f32(None, ctypes.byref(net), None, 1, None, 0, None) == 1
+    assert b"null parameter" in lib.hdrnet_last_error()
+
+
+def test_cpu_module_never_takes_the_native_path():
+    m = models.HDRNetCurves(dict(net_input_size=64, spatial_bin=8)).eval()
+    low = torch.rand(1, 64, 64, 3)
+    with torch.no_grad():
+        assert not m.coefficients._use_native(low)
+        assert m.coefficients(low).shape == (1, 8, 8, 8, 3, 4)
+
+
+# ---------------------------------------------------------------------------------------------------- GPU
+
+CASES = {
+    "default": (models.HDRNetPointwiseNNGuide, dict(), 1),
+    "batch3": (models.HDRNetPointwiseNNGuide, dict(), 3),
+    "batch_norm": (models.HDRNetPointwiseNNGuide, dict(batch_norm=True), 2),
+    "curves": (models.HDRNetCurves, dict(batch_norm=True), 1),
+    "pyramid": (models.HDRNetGaussianPyrNN, dict(), 2),
+    "grid32": (models.HDRNetPointwiseNNGuide, dict(spatial_bin=32), 1),      # config #5's 32 x 32 grid: 3 splat layers
+    "input512": (models.HDRNetPointwiseNNGuide, dict(net_input_size=512), 1),  # 5 splat layers, 256 splat channels... no: 128
+    "bins4": (models.HDRNetPointwiseNNGuide, dict(luma_bins=4), 1),           # 4, 8, 16, 32 channels
+    "cm2": (models.HDRNetPointwiseNNGuide, dict(channel_multiplier=2), 1),    # 16 ... 128 channels: four staged chunks
+    "grid8": (models.HDRNetPointwiseNNGuide, dict(spatial_bin=8, net_input_size=128), 1),  # global path 4 -> 2 cells
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_native_coefficients_vs_float64(case):
+    cls, params, B = CASES[case]
+    torch.manual_seed(11)
+    m = randomize(cls(params).eval(), seed=5)
+    N = m.params["net_input_size"]
+    low = torch.rand(B, N, N, 3)
+    with torch.no_grad():
+        ref = copy.deepcopy(m.coefficients).double()(low.double())
+        cpu32 = m.coefficients(low)
+        md = m.to("cuda:0")
+        net = md.coefficients
+        assert net._use_native(low.cuda())
+        got = net(low.cuda())
+        net.native = False
+        stock = net(low.cuda())
+        net.native = True
+    assert got.shape == ref.shape
+    scale = float(ref.abs().max())
+    err = float((got.cpu().double() - ref).abs().max())
+    err_stock = float((stock.cpu().double() - ref).abs().max())
+    err_cpu = float((cpu32.double() - ref).abs().max())
+    print(f"{case}: |coeffs| <= {scale:.3g}; native {err:.3g}, stock GPU ops {err_stock:.3g}, torch CPU f32 {err_cpu:.3g} from float64")
+    assert err <= 2e-6 * scale + 2.0 * max(err_stock, err_cpu), (err, err_stock, err_cpu, scale)
+    assert err <= 1e-5 * scale
+
+
+@pytest.mark.gpu
+def test_native_levels_are_the_reference_slices():
+    torch.manual_seed(2)
+    m = randomize(models.HDRNetGaussianPyrNN().eval(), seed=9).to("cuda:0")
+    low = torch.rand(2, 256, 256, 3, device="cuda:0")
+    with torch.no_grad():
+        coeffs = m.coefficients(low)  # [B, GH, GW, gd, 9, 4]
+        lv = m.coefficients.levels(low)
+    assert coeffs.shape == (2, 16, 16, 8, 9, 4) and len(lv) == 3
+    for il in range(3):
+        want = coeffs[:, :, :, :, 3 * il:3 * il + 3, :].reshape(2, 16, 16, 8, 12)
+        assert lv[il].is_contiguous() and torch.equal(lv[il], want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls", [models.HDRNetCurves, models.HDRNetPointwiseNNGuide, models.HDRNetGaussianPyrNN])
+def test_model_inference_native_vs_stock_coefficients(cls):
+    torch.manual_seed(4)
+    m = randomize(cls(dict(batch_norm=True)).eval(), seed=1).to("cuda:0")
+    low = torch.rand(1, 256, 256, 3, device="cuda:0")
+    full = torch.rand(1, 272, 480, 3, device="cuda:0")
+    with torch.no_grad():
+        got = m(low, full)
+        m.coefficients.native = False
+        want = m(low, full)
+        m.coefficients.native = True
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-4), float((got - want).abs().max())
+
+
+@pytest.mark.gpu
+def test_native_coefficients_under_hipgraph_and_determinism():
+    from hdrnet_amd.runtime import GraphedInference
+    torch.manual_seed(6)
+    m = randomize(models.HDRNetPointwiseNNGuide().eval(), seed=2).to("cuda:0")
+    low = torch.rand(1, 256, 256, 3, device="cuda:0")
+    full = torch.rand(1, 272, 480, 3, device="cuda:0")
+    with torch.no_grad():
+        a = m.coefficients(low)
+        b = m.coefficients(low)
+        assert torch.equal(a, b)  # fixed summation order, no atomics
+        eager = m(low, full)
+        g = GraphedInference(m, [low, full])
+        low2 = torch.rand_like(low)
+        out = g(low2, full).clone()
+        want = m(low2, full)
+    assert torch.equal(out, want)
+    assert not torch.equal(out, eager)
+
+
+@pytest.mark.gpu
+def test_training_mode_and_autograd_stay_on_the_stock_ops():
+    m = models.HDRNetPointwiseNNGuide(dict(batch_norm=True)).to("cuda:0")
+    low = torch.rand(2, 256, 256, 3, device="cuda:0")
+    m.train()
+    assert not m.coefficients._use_native(low)
+    m.eval()
+    assert not m.coefficients._use_native(low)  # grad mode on, parameters require grad
+    with torch.no_grad():
+        assert m.coefficients._use_native(low)

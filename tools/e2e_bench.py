@@ -68,8 +68,23 @@ def main():
                 pipe.submit(lanes[lane].static_inputs[0], lanes[lane].static_inputs[1])
 
             t_pipe[depth] = timeit(frame, args.steps)
+        # the coefficient network alone: HIP kernels (csrc/coeff_net.hip) vs the stock PyTorch-ROCm ops, eager and
+        # as a hipGraph; then the whole inference with the stock-op network for comparison
+        net = m.coefficients
+        gn = GraphedInference(net, [low])
+        t_coef_graph = timeit(lambda: gn(gn.static_inputs[0]), args.steps * 5)
+        net.native = False
+        t_coef_stock = timeit(lambda: net(low), args.steps)
+        gs = GraphedInference(net, [low])
+        t_coef_stock_graph = timeit(lambda: gs(gs.static_inputs[0]), args.steps * 5)
+        graphed_stock = GraphedInference(m, [low, full])
+        t_graph_stock = timeit(lambda: graphed_stock(graphed_stock.static_inputs[0], graphed_stock.static_inputs[1]), args.steps)
+        net.native = True
     mp = 2160 * 3840 / 1e6
-    print(f"config #3  (hipGraph replay of the whole inference): {t_graph * 1e3:.3f} ms/frame = {mp / t_graph:.0f} MP/s")
+    print(f"coefficient network 256x256 b=1: HIP kernels {t_coef * 1e6:.1f} us eager / {t_coef_graph * 1e6:.1f} us as a hipGraph; "
+          f"stock ops {t_coef_stock * 1e6:.1f} us eager / {t_coef_stock_graph * 1e6:.1f} us as a hipGraph")
+    print(f"config #3  (hipGraph replay of the whole inference): {t_graph * 1e3:.3f} ms/frame = {mp / t_graph:.0f} MP/s"
+          f"   [with the stock-op coefficient network: {t_graph_stock * 1e3:.3f} ms/frame]")
     print(f"config #3  the same, frames round-robin over 2 / 3 streams: {t_pipe[2] * 1e3:.3f} / {t_pipe[3] * 1e3:.3f} ms/frame"
           f" = {mp / t_pipe[2]:.0f} / {mp / t_pipe[3]:.0f} MP/s")
     print(f"config #3  HDRNetPointwiseNNGuide 3840x2160 b=1: {t_all * 1e3:.3f} ms/frame = {mp / t_all:.0f} MP/s "
