@@ -96,7 +96,7 @@ int variant(unsigned flags) { return (int)((flags >> 8) & 0xffu); }
 
 extern "C" {
 
-int hdrnet_version(void) { return 200; /* 0.2.0: + guide-network VJP, input moments, pyramid level, resize */ }
+int hdrnet_version(void) { return 210; /* 0.2.1: + the coefficient network (hdrnet_coefficients_f32) */ }
 
 const char* hdrnet_last_error(void) { return g_error; }
 
@@ -111,6 +111,7 @@ void hdrnet_tools_set_knob(int idx, int value) { hdrnet_amd::apply_fwd_seg_set_k
 void hdrnet_tools_set_trace(void* device_buf) {
   hdrnet_amd::apply_fwd_seg_set_trace(static_cast<long long*>(device_buf));
   hdrnet_amd::grid_grad_set_trace(static_cast<long long*>(device_buf));
+  hdrnet_amd::coeff_net_set_trace(static_cast<long long*>(device_buf));
 }
 #endif
 

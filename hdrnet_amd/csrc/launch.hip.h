@@ -160,6 +160,7 @@ int tools_knob(int idx);  // experiment knobs of the tools build (include/hdrnet
 hipError_t launch_apply_fwd_seg_dyn(const ApplyArgs& a, bool trace, hipStream_t s, const char** name);
 hipError_t launch_apply_fwd_seg_product_trace(const ApplyArgs& a, hipStream_t s, const char** name);
 void grid_grad_set_trace(long long* device_buf);
+void coeff_net_set_trace(long long* device_buf);
 #endif
 
 // Fused point-wise-NN guide + slice-apply forward (apply_fwd_rows.hip, GUIDE_NN).

@@ -21,6 +21,11 @@ class GraphedInference:
     buffers, replays the graph and returns the static output (valid until the next call).
 
     Shapes are fixed at capture time; a call with different shapes raises ``ValueError``.
+
+    The PARAMETERS are those of capture time: the models keep the derived arrays the kernels read (batch norm folded
+    into the guide and the coefficient network, ``models._Coefficients.exported``) in a cache that the warm-up fills,
+    so the graph holds pointers to them rather than the ~40 launches that derive them.  After changing the module's
+    parameters (an optimizer step, ``load_state_dict``) call ``recapture()``.
     """
 
     def __init__(self, module: torch.nn.Module, example_inputs: Sequence[torch.Tensor], warmup: int = 3):
@@ -28,10 +33,15 @@ class GraphedInference:
             raise RuntimeError("GraphedInference needs device tensors (MI355X)")
         self.module = module.eval()
         self.static_inputs = [t.clone() for t in example_inputs]
+        self.warmup = warmup
+        self.recapture()
+
+    def recapture(self) -> None:
+        """(Re-)capture the graph with the module's current parameters; the static input buffers are kept."""
         side = torch.cuda.Stream(device=self.static_inputs[0].device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.no_grad(), torch.cuda.stream(side):
-            for _ in range(warmup):  # library loading, allocator warm-up, kernel selection
+            for _ in range(self.warmup):  # library loading, allocator warm-up, kernel selection, derived-array caches
                 self.module(*self.static_inputs)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()

@@ -99,6 +99,33 @@ def test_export_cache_follows_the_parameters():
     b = net.exported()
     assert b is not a
     assert torch.equal(b._keep[-1], net.pred.conv.bias)
+    assert b._keep[-1].data_ptr() != net.pred.conv.bias.data_ptr()  # a snapshot, not an alias
+
+
+def test_guide_fold_caches_follow_the_parameters():
+    """Inference reuses the folded guide parameters (no re-fold launches per frame) until a parameter changes."""
+    m = randomize(models.HDRNetPointwiseNNGuide(dict(batch_norm=True)).eval(), seed=3)
+    a = m.guide.folded()
+    assert m.guide.folded() is a
+    with torch.no_grad():
+        m.guide.bn.running_mean.add_(0.5)
+    b = m.guide.folded()
+    assert b is not a and not torch.equal(a[0], b[0])
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    state["guide.w2"] = state["guide.w2"] * 2
+    m.load_state_dict(state)
+    c = m.guide.folded()
+    assert torch.equal(c[1][:-1], 2 * b[1][:-1])
+    # with autograd the fold stays attached to the parameters (and is not cached)
+    d = m.guide.folded(detach=False)
+    assert d[0].requires_grad and m.guide.folded() is c
+    mc = models.HDRNetCurves().eval()
+    e = mc.guide.exported()
+    assert mc.guide.exported() is e
+    with torch.no_grad():
+        mc.guide.slopes.mul_(1.5)
+    f = mc.guide.exported()
+    assert f is not e and torch.equal(f[2], mc.guide.slopes.t())
 
 
 def test_workspace_and_validation_without_gpu():
@@ -106,8 +133,8 @@ def test_workspace_and_validation_without_gpu():
     lib = _lib.load()
     w = models.HDRNetPointwiseNNGuide().eval().coefficients.exported()
     # 128^2*8 + 64^2*16 + 32^2*32 + 16^2*64 (splat) + 2 * 16^2*64 (local) + 8^2*64 + 4^2*64 (global convs)
-    # + fc partial sums 64*256 + 16*128 + 8*64, floats per image
-    per_image = 131072 + 65536 + 32768 + 16384 + 2 * 16384 + 4096 + 1024 + 16384 + 2048 + 512
+    # + fc partial sums 64*256 (fc1) + 16*128 (fc2), floats per image
+    per_image = 131072 + 65536 + 32768 + 16384 + 2 * 16384 + 4096 + 1024 + 16384 + 2048
     assert lib.hdrnet_coefficients_workspace_bytes(ctypes.byref(w.net), 1) == 4 * per_image
     assert lib.hdrnet_coefficients_workspace_bytes(ctypes.byref(w.net), 3) == 12 * per_image
     assert lib.hdrnet_coefficients_workspace_bytes(ctypes.byref(w.net), 0) == 0
@@ -145,7 +172,7 @@ CASES = {
     "curves": (models.HDRNetCurves, dict(batch_norm=True), 1),
     "pyramid": (models.HDRNetGaussianPyrNN, dict(), 2),
     "grid32": (models.HDRNetPointwiseNNGuide, dict(spatial_bin=32), 1),      # config #5's 32 x 32 grid: 3 splat layers
-    "input512": (models.HDRNetPointwiseNNGuide, dict(net_input_size=512), 1),  # 5 splat layers, 256 splat channels... no: 128
+    "input512": (models.HDRNetPointwiseNNGuide, dict(net_input_size=512), 1),  # 5 splat layers, up to 128 channels
     "bins4": (models.HDRNetPointwiseNNGuide, dict(luma_bins=4), 1),           # 4, 8, 16, 32 channels
     "cm2": (models.HDRNetPointwiseNNGuide, dict(channel_multiplier=2), 1),    # 16 ... 128 channels: four staged chunks
     "grid8": (models.HDRNetPointwiseNNGuide, dict(spatial_bin=8, net_input_size=128), 1),  # global path 4 -> 2 cells
@@ -225,8 +252,16 @@ def test_native_coefficients_under_hipgraph_and_determinism():
         low2 = torch.rand_like(low)
         out = g(low2, full).clone()
         want = m(low2, full)
-    assert torch.equal(out, want)
-    assert not torch.equal(out, eager)
+        assert torch.equal(out, want)
+        assert not torch.equal(out, eager)
+        # the graph holds the parameters of capture time; recapture() picks up a change
+        m.coefficients.pred.conv.bias.add_(0.25)
+        m.guide.b2.add_(0.5)
+        stale = g(low2, full).clone()
+        assert torch.equal(stale, want)
+        g.recapture()
+        fresh = g(low2, full).clone()
+        assert torch.equal(fresh, m(low2, full)) and not torch.equal(fresh, want)
 
 
 @pytest.mark.gpu

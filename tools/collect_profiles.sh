@@ -77,6 +77,8 @@ fi
 python tools/bwd_ab.py --rounds 5 --steps 50 --cases all,gg,g,sl,v --variants 0,2,3,4,5,6,7,8 > $O/bwd_ab_4k.txt 2>&1
 python tools/bwd_ab.py --workload 1080p --rounds 5 --steps 100 --cases all,gg,g,sl,v --variants 0,3 > $O/bwd_ab_1080p.txt 2>&1
 python tools/e2e_bench.py > $O/e2e.txt 2>&1
+# the coefficient network's launches, per-workgroup timeline (tools build)
+python tools/coeff_trace.py > $O/coeff_trace.txt 2>&1
 # socket power / shader clock beside the forward and its no-compute skeleton; skeleton windows inside the product's run
 python tools/power_probe.py --metrics --variants 0,106,0 --seconds 2 2>&1 | grep -v amdgpu.ids > $O/power_probe.txt
 python tools/power_probe.py --pattern 0,0,0,106 --seconds 3 2>&1 | grep -v amdgpu.ids | cut -c1-1600 > $O/power_pattern.txt
