@@ -96,16 +96,36 @@ def algorithmic_bytes(B, H, W, GH, GW, GD, Cin=3, Cout=3, has_offset=True):
     return 4 * B * (H * W * (1 + Cin + Cout) + GH * GW * GD * Cout * Cj)
 
 
+# The translation units the measured forward kernel and its C-ABI entry point are compiled from; the digest follows
+# their quoted #includes.  (Until late in round 4 the digest covered every file under csrc/, so adding an unrelated
+# kernel file -- the coefficient network -- invalidated a traffic record of an unchanged forward.)
+DIGEST_UNITS = ("apply_fwd_seg.hip", "apply_fwd_rows.hip", "generic_kernels.hip", "capi.hip")
+
+
 def source_digest():
-    """sha256 over the kernel sources (hdrnet_amd/csrc/*, sorted): stamps a PMC record with the
-    code it was measured on (the GPU box has no .git)."""
-    import glob
+    """sha256 over the sources the benchmarked forward is built from: DIGEST_UNITS in hdrnet_amd/csrc, the closure of
+    their quoted #includes (csrc/*.h, include/*.h) and hdrnet_amd/build.py (the compiler flags).  Stamps a PMC
+    record with the code it was measured on (the GPU box has no .git)."""
     import hashlib
-    h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "hdrnet_amd", "csrc", "*"))):
-        h.update(os.path.basename(f).encode())
+    import re
+    csrc = os.path.join(ROOT, "hdrnet_amd", "csrc")
+    seen, todo = {}, [os.path.join(csrc, u) for u in DIGEST_UNITS]
+    while todo:
+        f = os.path.normpath(todo.pop())
+        if f in seen or not os.path.exists(f):
+            continue
         with open(f, "rb") as fh:
-            h.update(fh.read())
+            seen[f] = fh.read()
+        for inc in re.findall(rb'^\s*#\s*include\s+"([^"]+)"', seen[f], flags=re.M):
+            todo.append(os.path.join(os.path.dirname(f), inc.decode()))
+    flags = os.path.join(ROOT, "hdrnet_amd", "build.py")
+    if os.path.exists(flags):
+        with open(flags, "rb") as fh:
+            seen[flags] = fh.read()
+    h = hashlib.sha256()
+    for f in sorted(seen, key=lambda x: os.path.relpath(x, ROOT)):
+        h.update(os.path.relpath(f, ROOT).encode())
+        h.update(seen[f])
     return h.hexdigest()[:16]
 
 

@@ -392,7 +392,7 @@ int hdrnet_coefficients_f32(const float* lowres, const hdrnet_coeff_net* net, fl
                             void* workspace, size_t workspace_bytes, void* stream) {
   using namespace hdrnet_amd;
   if (!net) return fail(HDRNET_INVALID_ARGUMENT, "null network description");
-  if (B < 0) return fail(HDRNET_INVALID_ARGUMENT, "negative batch (B=%d)", B);
+  if (B < 0 || B > 65535) return fail(HDRNET_INVALID_ARGUMENT, "batch out of range (B=%d, at most 65535 per call)", B);
   if (!coefficients_supported(*net))
     return fail(HDRNET_INVALID_ARGUMENT,
                 "coefficient network: unsupported hyper-parameters (net_input_size=%d, spatial_bin=%d, luma_bins=%d, "

@@ -566,6 +566,7 @@ bool net_dims(const hdrnet_coeff_net& n, NetDims* d) {
   if (n.net_input_size <= 0 || n.spatial_bin <= 0 || n.luma_bins <= 0 || n.channel_multiplier <= 0) return false;
   if (n.n_out <= 0 || n.n_in <= 0 || n.n_levels <= 0 || n.n_out % n.n_levels != 0) return false;
   if (!pow2(n.net_input_size) || !pow2(n.spatial_bin) || n.spatial_bin > n.net_input_size) return false;
+  if (n.net_input_size > 4096) return false;  // tile counts stay below 2^16 (umulhi divisions), grids below 2^31
   d->N = n.net_input_size; d->sb = n.spatial_bin; d->gd = n.luma_bins; d->cm = n.channel_multiplier;
   d->n_ds = 0;
   for (int v = d->N / d->sb; v > 1; v >>= 1) ++d->n_ds;
@@ -619,7 +620,7 @@ void coeff_net_set_trace(long long* device_buf) { g_coeff_trace = device_buf; }
 
 size_t coefficients_workspace_bytes(const hdrnet_coeff_net& net, int B) {
   NetDims d;
-  if (!net_dims(net, &d) || B <= 0) return 0;
+  if (!net_dims(net, &d) || B <= 0 || B > 65535) return 0;  // the batch is the launch grid's z extent
   return net_workspace(d).total * sizeof(float) * (size_t)B;
 }
 

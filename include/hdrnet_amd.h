@@ -311,7 +311,8 @@ int hdrnet_bilateral_slice_grad_f32_ex(const float* grid, const float* guide,
  *               fc 16*cm*gd (ReLU), fc 8*cm*gd
  *   local       3x3 conv (ReLU), 3x3 conv (no bias, no activation), both 8*cm*gd channels
  *   fusion      relu(local + global), then the 1x1 prediction conv to gd*n_out*n_in channels
- * Ten launches on `stream`, no host synchronisation, deterministic.
+ * Nine launches on `stream` (the convolutions as fp32 matrix-core implicit GEMMs; csrc/coeff_net.hip), no host
+ * synchronisation, no allocation, deterministic (no atomics: two calls give identical bits).
  *
  * Parameters (device pointers, fp32, 16-B aligned), batch norm already FOLDED into weight and bias the way
  * hdrnet/bin/freeze_graph.py:170-184 folds the guide's (w * gamma / sqrt(var + eps), beta - mean * that):
@@ -321,8 +322,9 @@ int hdrnet_bilateral_slice_grad_f32_ex(const float* grid, const float* guide,
  * n_levels > 1 (HDRNetGaussianPyrNN: n_out = 9, n_levels = 3) writes the output level-major,
  * [n_levels][B][sb][sb][gd][n_out / n_levels][n_in] -- each level's grid contiguous, as the per-level
  * slice-applies of models.py:277-289 (coeffs[:, :, :, :, 3*l : 3*l + 3, :]) need it.
- * Supported: N, sb powers of two, N / sb in [2, 256], cm * gd a multiple of 4 with cm * gd / 4 a power of two;
- * hdrnet_coefficients_workspace_bytes returns 0 otherwise (run the stock-op graph instead). */
+ * Supported: N <= 4096 and sb powers of two, N / sb in [2, 256], cm * gd a multiple of 4 with cm * gd / 4 a power of two,
+ * B <= 65535; hdrnet_coefficients_workspace_bytes returns 0 otherwise (run the framework's own graph instead).  The
+ * parameter arrays are read by the launches: keep them alive and unchanged until those have run. */
 typedef struct hdrnet_coeff_net {
   int net_input_size;     /* N */
   int spatial_bin;        /* sb: the grid is sb x sb cells */

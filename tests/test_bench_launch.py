@@ -59,7 +59,10 @@ def test_traffic_record_is_refused_when_sources_differ(tmp_path, monkeypatch):
     d.mkdir(parents=True)
     (d / "traffic.json").write_text(json.dumps(rec))
     os.makedirs(tmp_path / "hdrnet_amd" / "csrc")
-    (tmp_path / "hdrnet_amd" / "csrc" / "a.hip").write_text("x")
+    unit = tmp_path / "hdrnet_amd" / "csrc" / bench.DIGEST_UNITS[0]
+    unit.write_text('#include "common.h"\nx')
+    (tmp_path / "hdrnet_amd" / "csrc" / "common.h").write_text("y")
+    (tmp_path / "hdrnet_amd" / "csrc" / "unrelated.hip").write_text("z")
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     got, why = bench.measured_traffic("4k", "k")
     assert got is None and "other kernel sources" in why
@@ -67,3 +70,9 @@ def test_traffic_record_is_refused_when_sources_differ(tmp_path, monkeypatch):
     (d / "traffic.json").write_text(json.dumps(rec))
     got, why = bench.measured_traffic("4k", "k")
     assert got["bytes_per_launch"] == 1 and why is None
+    # a file outside the forward's include closure does not invalidate the record; one inside it does
+    (tmp_path / "hdrnet_amd" / "csrc" / "unrelated.hip").write_text("changed")
+    assert bench.measured_traffic("4k", "k")[1] is None
+    (tmp_path / "hdrnet_amd" / "csrc" / "common.h").write_text("changed")
+    got, why = bench.measured_traffic("4k", "k")
+    assert got is None and "other kernel sources" in why

@@ -139,6 +139,9 @@ def test_workspace_and_validation_without_gpu():
     assert lib.hdrnet_coefficients_workspace_bytes(ctypes.byref(w.net), 3) == 12 * per_image
     assert lib.hdrnet_coefficients_workspace_bytes(ctypes.byref(w.net), 0) == 0
     assert lib.hdrnet_coefficients_workspace_bytes(None, 1) == 0
+    assert lib.hdrnet_coefficients_workspace_bytes(ctypes.byref(w.net), 65536) == 0  # the batch is a launch-grid extent
+    assert lib.hdrnet_coefficients_f32(None, ctypes.byref(w.net), None, 65536, None, 0, None) == 1
+    assert b"batch out of range" in lib.hdrnet_last_error()
     # luma_bins = 6: channel groups of 6, 12, ... are not whole power-of-two float4 groups -> unsupported
     w6 = models.HDRNetPointwiseNNGuide(dict(luma_bins=6)).eval().coefficients.exported()
     assert not w6.supported(1)
