@@ -402,6 +402,10 @@ def main():
                     help="also time the cache-resident rate and 1080p (same kernel name at other "
                          "sizes: keep off when collecting rocprofv3 --stats for the roofline line)")
     ap.add_argument("--no-extra", action="store_true", help=argparse.SUPPRESS)  # old spelling, no-op
+    ap.add_argument("--no-batch-norm", action="store_true",
+                    help="train_1080p_b4: the model WITHOUT batch norm, as the reference's own script trains it "
+                         "(scripts/ll/train_nn_guide.sh: --nobatch_norm); the default keeps batch norm in training "
+                         "mode, the heavier graph")
     ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)  # tests: gloo + a stub timed body
     args = ap.parse_args()
 
@@ -576,6 +580,7 @@ def main_train(args, rank, world, local_rank, stub=False):
     stub (tests, CPU + gloo): the same harness around runtime.TrainStep on a stand-in torch-only model -- the HIP
     kernels have no CPU path by design."""
     from hdrnet_amd import dist as hd
+    from hdrnet_amd import metrics
     dev, dist_on, backend = _init_ranks(world, local_rank, cpu=stub)
     B, H, W = 4, 1080, 1920
     torch.manual_seed(0)  # identical initial weights on every rank
@@ -585,7 +590,7 @@ def main_train(args, rank, world, local_rank, stub=False):
         opt = torch.optim.Adam(model.parameters(), lr=1e-4)
         torch.manual_seed(1234 + rank)
         inputs, targets = [torch.rand(64, 12)], [torch.rand(64, 3)]
-        step = TrainStep(model, lambda out, tgt: (out - tgt).square().mean(), opt)
+        step = TrainStep(model, lambda out, tgt: metrics.l2_loss(tgt, out), opt)
         run = lambda: step(inputs, targets)  # noqa: E731
         sync = lambda: None  # noqa: E731
         kernel = "stub (torch-only stand-in model on CPU)"
@@ -593,13 +598,13 @@ def main_train(args, rank, world, local_rank, stub=False):
         from hdrnet_amd import _lib, models
         from hdrnet_amd.runtime import GraphedTrainStep
         _lib.load()  # raises loudly if the HIP library is missing
-        model = models.HDRNetPointwiseNNGuide(dict(batch_norm=True)).to(dev).train()
+        model = models.HDRNetPointwiseNNGuide(dict(batch_norm=not args.no_batch_norm)).to(dev).train()
         opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, capturable=True, fused=True)
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)  # every rank its own images
         low = torch.rand((B, 256, 256, 3), device=dev, generator=gen)
         full = torch.rand((B, H, W, 3), device=dev, generator=gen)
         target = torch.rand((B, H, W, 3), device=dev, generator=gen)
-        step = GraphedTrainStep(model, lambda out, tgt: (out - tgt).square().mean(), opt, [low, full], [target],
+        step = GraphedTrainStep(model, lambda out, tgt: metrics.l2_loss(tgt, out), opt, [low, full], [target],
                                 flat_bucket=True)  # the multi-rank structure at every N, N = 1 included
         run = lambda: step([low, full], [target])  # noqa: E731
         sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
@@ -638,7 +643,8 @@ def main_train(args, rank, world, local_rank, stub=False):
                       "bucket_elements": int(step.bucket.flat.numel()), "collectives_per_step": 1 if world > 1 else 0,
                       "backend": backend if dist_on else None},
         "config": {"workload": EXTRA_WORKLOADS["train_1080p_b4"], "images_per_gpu_per_step": B,
-                   "global_batch": B * world, "parallelism": f"dp{world} (image shards)", "kernel": kernel},
+                   "global_batch": B * world, "parallelism": f"dp{world} (image shards)", "kernel": kernel,
+                   "batch_norm": not args.no_batch_norm},
     }
     _finish(result, rank, dist_on)
 

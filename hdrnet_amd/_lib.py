@@ -46,6 +46,8 @@ SIGNATURES = {
     "hdrnet_curves_guide_grad_f32": (_I, [_FP] * 7 + [_I] + [_FP] * 4 + [ctypes.c_longlong, _I, _I, _VP, _SZ, _VP]),
     "hdrnet_input_moments_workspace_bytes": (_SZ, [ctypes.c_longlong, _I]),
     "hdrnet_input_moments_f32": (_I, [_FP, ctypes.c_longlong, _I, _FP, _FP, _VP, _SZ, _VP]),
+    "hdrnet_guide_fold_batch_f32": (_I, [_FP, _FP, ctypes.c_longlong] + [_FP] * 5 + [ctypes.c_double, ctypes.c_double, _I, _I] + [_FP] * 5 + [_VP]),
+    "hdrnet_guide_fold_batch_grad_f32": (_I, [_FP, _FP, ctypes.c_longlong] + [_FP] * 3 + [ctypes.c_double, _I, _I] + [_FP] * 6 + [_VP]),
     "hdrnet_coefficients_workspace_bytes": (_SZ, [_VP, _I]),
     "hdrnet_coefficients_f32": (_I, [_FP, _VP, _FP, _I, _VP, _SZ, _VP]),
     "hdrnet_bilateral_slice_apply_io": (_I, [_FP] * 4 + [_I] * 10 + [ctypes.c_float, _I] + [_FP] * 2 + [_I, _FP, _VP]),

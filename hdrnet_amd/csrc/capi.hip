@@ -383,6 +383,43 @@ int hdrnet_input_moments_f32(const float* input, long long npx, int Cin, float* 
   return rc;
 }
 
+int hdrnet_guide_fold_batch_f32(const float* sums, const float* moments, long long npx, const float* w1,
+                                const float* gamma, const float* beta, const float* w2, const float* b2, double eps,
+                                double momentum, int Cin, int n_feats, float* conv1, float* conv2,
+                                float* running_mean, float* running_var, long long* num_batches_tracked,
+                                void* stream) {
+  using namespace hdrnet_amd;
+  if (npx <= 0 || (Cin != 1 && Cin != 3) || n_feats <= 0)
+    return fail(HDRNET_INVALID_ARGUMENT, "guide fold needs npx > 0, Cin in {1,3}, n_feats > 0 (npx=%lld, Cin=%d, n=%d)",
+                npx, Cin, n_feats);
+  if (!sums || !moments || !w1 || !gamma || !beta || !w2 || !b2 || !conv1 || !conv2 || (!running_mean != !running_var))
+    return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  const int rc = check_launch(launch_guide_fold_batch(sums, moments, npx, w1, gamma, beta, w2, b2, eps, momentum, Cin,
+                                                      n_feats, conv1, conv2, running_mean, running_var,
+                                                      num_batches_tracked, static_cast<hipStream_t>(stream)),
+                              "GuideFoldBatch");
+  if (rc == HDRNET_OK) set_kernel("guide_fold_batch");
+  return rc;
+}
+
+int hdrnet_guide_fold_batch_grad_f32(const float* sums, const float* moments, long long npx, const float* w1,
+                                     const float* gamma, const float* beta, double eps, int Cin, int n_feats,
+                                     const float* dconv1, const float* dconv2, float* dw1, float* dbeta, float* dw2,
+                                     float* db2, void* stream) {
+  using namespace hdrnet_amd;
+  if (npx <= 0 || (Cin != 1 && Cin != 3) || n_feats <= 0)
+    return fail(HDRNET_INVALID_ARGUMENT, "guide fold needs npx > 0, Cin in {1,3}, n_feats > 0 (npx=%lld, Cin=%d, n=%d)",
+                npx, Cin, n_feats);
+  if (!sums || !moments || !w1 || !gamma || !beta || !dconv1 || !dconv2 || !dw1 || !dbeta || !dw2 || !db2)
+    return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  const int rc = check_launch(launch_guide_fold_batch_grad(sums, moments, npx, w1, gamma, beta, eps, Cin, n_feats,
+                                                           dconv1, dconv2, dw1, dbeta, dw2, db2,
+                                                           static_cast<hipStream_t>(stream)),
+                              "GuideFoldBatchGrad");
+  if (rc == HDRNET_OK) set_kernel("guide_fold_batch_grad");
+  return rc;
+}
+
 size_t hdrnet_coefficients_workspace_bytes(const hdrnet_coeff_net* net, int B) {
   if (!net || B <= 0) return 0;
   return hdrnet_amd::coefficients_workspace_bytes(*net, B);

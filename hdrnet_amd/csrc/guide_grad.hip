@@ -399,6 +399,130 @@ hipError_t launch_guide_grad(const GuideGradArgs& a, hipStream_t s, const char**
   return hipErrorInvalidValue;
 }
 
+// Training-mode fold of the guide network's batch norm into its first layer (hdrnet/layers.py:40-58 with
+// is_training=True, folded as hdrnet/bin/freeze_graph.py:170-184 folds the inference statistics): the first
+// convolution is linear, so the batch statistics of its never-materialised output follow from the input's moments,
+//   mean_h = w1^T mean_x,   var_h[k] = w1[:,k]^T Cov_x w1[:,k]   (biased; Cov_x = moments / N - mean_x mean_x^T)
+//   inv = gamma / sqrt(var_h + eps),  conv1[k] = (w1[:,k] * inv, beta[k] - mean_h * inv),  conv2 = (w2, b2)
+// and the running statistics move as tf.contrib.layers.batch_norm / nn.BatchNorm1d move them (unbiased variance).
+// ~100 numbers: as torch ops this was 33 launches forward and 30 backward of a graph-captured training step
+// (profiles/r04/train_step.md); here one thread per feature, float64 arithmetic, one launch each way.
+struct FoldArgs {
+  const float* sums;     // [Cin]
+  const float* moments;  // [Cin][Cin]
+  const float* w1;       // [Cin][n]
+  const float* gamma;    // [n]
+  const float* beta;     // [n]
+  const float* w2;       // [n]
+  const float* b2;       // [1]
+  double npx, eps, momentum;
+  int Cin, n;
+};
+
+template <int CIN>
+__device__ __forceinline__ void fold_stats(const FoldArgs& a, int k, double (&mx)[CIN], double (&cov)[CIN][CIN],
+                                           double (&w)[CIN], double& mean_h, double& var_raw) {
+#pragma unroll
+  for (int i = 0; i < CIN; ++i) mx[i] = (double)a.sums[i] / a.npx;
+#pragma unroll
+  for (int i = 0; i < CIN; ++i) {
+#pragma unroll
+    for (int j = 0; j < CIN; ++j) cov[i][j] = (double)a.moments[i * CIN + j] / a.npx - mx[i] * mx[j];
+  }
+  mean_h = 0.0;
+#pragma unroll
+  for (int i = 0; i < CIN; ++i) {
+    w[i] = (double)a.w1[i * a.n + k];
+    mean_h += mx[i] * w[i];
+  }
+  var_raw = 0.0;
+#pragma unroll
+  for (int i = 0; i < CIN; ++i) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < CIN; ++j) t += cov[i][j] * w[j];
+    var_raw += t * w[i];
+  }
+}
+
+template <int CIN>
+__global__ void guide_fold_batch(const FoldArgs a, float* __restrict__ conv1, float* __restrict__ conv2,
+                                 float* __restrict__ running_mean, float* __restrict__ running_var,
+                                 long long* __restrict__ num_batches_tracked) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0) {
+    conv2[a.n] = a.b2[0];
+    if (num_batches_tracked) num_batches_tracked[0] += 1;
+  }
+  if (k >= a.n) return;
+  double mx[CIN], cov[CIN][CIN], w[CIN], mean_h, var_raw;
+  fold_stats<CIN>(a, k, mx, cov, w, mean_h, var_raw);
+  const double var_h = var_raw > 0.0 ? var_raw : 0.0;
+  if (running_mean) {
+    const double unbias = a.npx / (a.npx > 1.0 ? a.npx - 1.0 : 1.0);
+    running_mean[k] = (float)((1.0 - a.momentum) * (double)running_mean[k] + a.momentum * (double)(float)mean_h);
+    running_var[k] = (float)((1.0 - a.momentum) * (double)running_var[k] + a.momentum * (double)(float)(var_h * unbias));
+  }
+  const double inv = (double)a.gamma[k] / sqrt(var_h + a.eps);
+#pragma unroll
+  for (int j = 0; j < CIN; ++j) conv1[k * (CIN + 1) + j] = (float)(w[j] * inv);
+  conv1[k * (CIN + 1) + CIN] = (float)((double)a.beta[k] - mean_h * inv);
+  conv2[k] = a.w2[k];
+}
+
+// VJP of the fold with respect to w1 [Cin][n], beta [n], w2 [n], b2 (the moments are data, gamma is fixed).
+template <int CIN>
+__global__ void guide_fold_batch_grad(const FoldArgs a, const float* __restrict__ dconv1,
+                                      const float* __restrict__ dconv2, float* __restrict__ dw1,
+                                      float* __restrict__ dbeta, float* __restrict__ dw2, float* __restrict__ db2) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0) db2[0] = dconv2[a.n];
+  if (k >= a.n) return;
+  double mx[CIN], cov[CIN][CIN], w[CIN], mean_h, var_raw;
+  fold_stats<CIN>(a, k, mx, cov, w, mean_h, var_raw);
+  const double var_h = var_raw > 0.0 ? var_raw : 0.0;
+  const double inv = (double)a.gamma[k] / sqrt(var_h + a.eps);
+  const double db = (double)dconv1[k * (CIN + 1) + CIN];
+  double dinv = -db * mean_h;
+#pragma unroll
+  for (int j = 0; j < CIN; ++j) dinv += (double)dconv1[k * (CIN + 1) + j] * w[j];
+  const double dmean = -db * inv;
+  const double dvar = var_raw > 0.0 ? dinv * (-0.5) * inv / (var_h + a.eps) : 0.0;  // clamp_min(0): no gradient below
+#pragma unroll
+  for (int j = 0; j < CIN; ++j) {
+    double cw = 0.0;
+#pragma unroll
+    for (int i = 0; i < CIN; ++i) cw += cov[j][i] * w[i];
+    dw1[j * a.n + k] = (float)((double)dconv1[k * (CIN + 1) + j] * inv + dmean * mx[j] + 2.0 * dvar * cw);
+  }
+  dbeta[k] = (float)db;
+  dw2[k] = dconv2[k];
+}
+
+hipError_t launch_guide_fold_batch(const float* sums, const float* moments, long long npx, const float* w1,
+                                   const float* gamma, const float* beta, const float* w2, const float* b2, double eps,
+                                   double momentum, int Cin, int n, float* conv1, float* conv2, float* running_mean,
+                                   float* running_var, long long* num_batches_tracked, hipStream_t s) {
+  const FoldArgs a{sums, moments, w1, gamma, beta, w2, b2, (double)npx, eps, momentum, Cin, n};
+  const int nb = (n + 63) / 64;
+  if (Cin == 3) guide_fold_batch<3><<<nb, 64, 0, s>>>(a, conv1, conv2, running_mean, running_var, num_batches_tracked);
+  else if (Cin == 1) guide_fold_batch<1><<<nb, 64, 0, s>>>(a, conv1, conv2, running_mean, running_var, num_batches_tracked);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_guide_fold_batch_grad(const float* sums, const float* moments, long long npx, const float* w1,
+                                        const float* gamma, const float* beta, double eps, int Cin, int n,
+                                        const float* dconv1, const float* dconv2, float* dw1, float* dbeta, float* dw2,
+                                        float* db2, hipStream_t s) {
+  const FoldArgs a{sums, moments, w1, gamma, beta, nullptr, nullptr, (double)npx, eps, 0.0, Cin, n};
+  const int nb = (n + 63) / 64;
+  if (Cin == 3) guide_fold_batch_grad<3><<<nb, 64, 0, s>>>(a, dconv1, dconv2, dw1, dbeta, dw2, db2);
+  else if (Cin == 1) guide_fold_batch_grad<1><<<nb, 64, 0, s>>>(a, dconv1, dconv2, dw1, dbeta, dw2, db2);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 size_t input_moments_workspace_bytes(long long npx, int Cin) {
   if (Cin != 1 && Cin != 3) return 0;
   return (size_t)persistent_blocks(npx) * (size_t)(Cin + Cin * Cin) * sizeof(float);

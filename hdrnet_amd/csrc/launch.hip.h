@@ -223,6 +223,16 @@ size_t input_moments_workspace_bytes(long long npx, int Cin);
 hipError_t launch_input_moments(const float* input, long long npx, int Cin, float* sums, float* moments,
                                 void* workspace, hipStream_t s, const char** name);
 
+// guide_grad.hip -- training-mode fold of the guide network's batch norm (statistics from the input's moments) and its VJP.
+hipError_t launch_guide_fold_batch(const float* sums, const float* moments, long long npx, const float* w1,
+                                   const float* gamma, const float* beta, const float* w2, const float* b2, double eps,
+                                   double momentum, int Cin, int n, float* conv1, float* conv2, float* running_mean,
+                                   float* running_var, long long* num_batches_tracked, hipStream_t s);
+hipError_t launch_guide_fold_batch_grad(const float* sums, const float* moments, long long npx, const float* w1,
+                                        const float* gamma, const float* beta, double eps, int Cin, int n,
+                                        const float* dconv1, const float* dconv2, float* dw1, float* dbeta, float* dw2,
+                                        float* db2, hipStream_t s);
+
 // coeff_net.hip -- the low-resolution coefficient network (hdrnet/models.py:62-142) as inference kernels.
 bool coefficients_supported(const hdrnet_coeff_net& net);
 size_t coefficients_workspace_bytes(const hdrnet_coeff_net& net, int B);  // 0: unsupported hyper-parameters

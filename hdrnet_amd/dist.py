@@ -108,9 +108,14 @@ class GradBucket:
     """The training step's gradients as ONE persistent flat fp32 buffer: every parameter's ``.grad`` is a VIEW into
     it, so the step's only collective (~482 k parameters, 1.9 MB) is a single in-place
     all-reduce on the buffer -- no per-step ``cat`` and no per-parameter copy back (what
-    ``allreduce_gradients_flat`` does, ~35 small launches per step).  Autograd accumulates in place into an
-    existing ``.grad``, so the views survive backward; call ``zero_()`` (one memset; capturable in a hipGraph)
-    instead of ``optimizer.zero_grad(set_to_none=True)``, which would drop them.
+    ``allreduce_gradients_flat`` does, ~35 small launches per step).
+
+    Two ways to fill it.  (a) Leave the views bound: autograd accumulates in place into an existing ``.grad``, so the
+    views survive backward -- call ``zero_()`` (one memset) instead of ``optimizer.zero_grad(set_to_none=True)``, which
+    would drop them; costs one ``+=`` launch per parameter inside backward (35 of a graph-captured step's 210 launches,
+    profiles/r04/train_step.md).  (b) ``release()`` before backward (every ``.grad`` = None: autograd then ASSIGNS its
+    gradients, no zeroing and no adds) and ``gather()`` after it: one multi-tensor copy into the flat buffer, the views
+    re-bound.  ``runtime.TrainStep`` does (b).
     """
 
     def __init__(self, params):
@@ -121,6 +126,7 @@ class GradBucket:
         if any(p.device != dev or p.dtype != dt for p in self.params):
             raise ValueError("GradBucket: parameters must share one device and dtype")
         self.flat = torch.zeros(sum(p.numel() for p in self.params), device=dev, dtype=dt)
+        self.views = []
         off = 0
         for p in self.params:
             n = p.numel()
@@ -128,8 +134,29 @@ class GradBucket:
             # the view takes the PARAMETER's strides where it is a dense permutation (channels_last conv weights):
             # autograd's layout contract, and what the fused optimizers insist on
             dense = torch.empty_like(p).stride() == p.stride()  # preserve_format keeps a dense tensor's strides
-            p.grad = seg.as_strided(p.shape, p.stride()) if dense else seg.view_as(p)
+            self.views.append(seg.as_strided(p.shape, p.stride()) if dense else seg.view_as(p))
+            p.grad = self.views[-1]
             off += n
+
+    def release(self) -> None:
+        """Unbind the views (``.grad = None``) so that the next backward assigns its gradients instead of adding them
+        to a zeroed buffer; ``gather()`` brings them into the flat buffer."""
+        for p in self.params:
+            p.grad = None
+
+    def gather(self) -> None:
+        """After a backward that ran on released gradients: copy them into the flat buffer (one multi-tensor launch),
+        zero the segments of parameters that received none, re-bind every ``.grad`` to its view."""
+        dst, src = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(p.grad)
+            p.grad = v
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def attached(self) -> bool:
         """True while every parameter's .grad still is its view of the flat buffer."""

@@ -36,7 +36,7 @@ from . import _lib
 
 __all__ = ["bilateral_slice", "bilateral_slice_apply", "bilateral_slice_apply_rows", "bilateral_slice_apply_nnguide",
            "bilateral_slice_apply_io", "bilateral_slice_apply_curves", "bilateral_slice_apply_upadd", "resize_bilinear", "input_moments",
-           "CoefficientWeights", "coefficients", "kernel_override", "last_kernel"]
+           "CoefficientWeights", "coefficients", "guide_fold_batch", "kernel_override", "last_kernel"]
 
 _tls = threading.local()
 
@@ -492,6 +492,70 @@ def input_moments(input: torch.Tensor):  # noqa: A002
                                           ws.data_ptr(), wbytes, _stream(dev))
     _lib.check(rc, "InputMoments")
     return sums, mom
+
+
+class _GuideFoldBatch(torch.autograd.Function):
+    """Training-mode fold of the guide network's batch norm (``hdrnet_guide_fold_batch_f32`` and its VJP): one launch
+    each way where the same float64 math on ~100 numbers was 33 + 30 torch launches of a graph-captured step."""
+
+    @staticmethod
+    def forward(ctx, w1, beta, w2, b2, gamma, sums, moments, running_mean, running_var, num_batches_tracked,
+                npx, eps, momentum):
+        Cin, n = w1.shape
+        dev = w1.device
+        args = [t.detach().contiguous() for t in (sums, moments, w1, gamma, beta, w2, b2.reshape(1))]
+        conv1 = torch.empty((n, Cin + 1), dtype=torch.float32, device=dev)
+        conv2 = torch.empty((n + 1,), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            rc = lib.hdrnet_guide_fold_batch_f32(
+                args[0].data_ptr(), args[1].data_ptr(), int(npx), args[2].data_ptr(), args[3].data_ptr(),
+                args[4].data_ptr(), args[5].data_ptr(), args[6].data_ptr(), float(eps), float(momentum), Cin, n,
+                conv1.data_ptr(), conv2.data_ptr(), _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked),
+                _stream(dev))
+        _lib.check(rc, "GuideFoldBatch")
+        for t in (running_mean, running_var, num_batches_tracked):
+            if t is not None:  # written through a raw pointer: tell autograd / the fold caches keyed on ._version
+                torch.autograd.graph.increment_version(t)
+        ctx.save_for_backward(*args[:5])
+        ctx.meta = (int(npx), float(eps), Cin, n, b2.shape)
+        return conv1, conv2
+
+    @staticmethod
+    def backward(ctx, dconv1, dconv2):
+        sums, moments, w1, gamma, beta = ctx.saved_tensors
+        npx, eps, Cin, n, b2_shape = ctx.meta
+        dev = w1.device
+        dconv1, dconv2 = dconv1.contiguous(), dconv2.contiguous()
+        dw1 = torch.empty((Cin, n), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((n,), dtype=torch.float32, device=dev)
+        dw2 = torch.empty((n,), dtype=torch.float32, device=dev)
+        db2 = torch.empty((1,), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            rc = lib.hdrnet_guide_fold_batch_grad_f32(
+                sums.data_ptr(), moments.data_ptr(), npx, w1.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, Cin, n,
+                dconv1.data_ptr(), dconv2.data_ptr(), dw1.data_ptr(), dbeta.data_ptr(), dw2.data_ptr(), db2.data_ptr(),
+                _stream(dev))
+        _lib.check(rc, "GuideFoldBatchGrad")
+        return dw1, dbeta, dw2, db2.reshape(b2_shape), None, None, None, None, None, None, None, None, None
+
+
+def guide_fold_batch(w1: torch.Tensor, beta: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, gamma: torch.Tensor,
+                     sums: torch.Tensor, moments: torch.Tensor, npx: int, eps: float, momentum: float = 0.0,
+                     running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None,
+                     num_batches_tracked: Optional[torch.Tensor] = None):
+    """``(conv1 [n, Cin + 1], conv2 [n + 1])``: the point-wise guide network with batch norm in TRAINING mode folded
+    into its first layer, the batch statistics taken from the input's ``(sums, moments)`` (``input_moments``) --
+    ``hdrnet/layers.py:40-58`` with ``is_training=True`` in the export layout of ``freeze_graph.py:170-184``.
+    ``w1`` is ``[Cin, n]``.  Differentiable in ``w1``, ``beta``, ``w2``, ``b2``; moves the running statistics in place."""
+    for name, t in (("w1", w1), ("beta", beta), ("w2", w2), ("b2", b2), ("gamma", gamma), ("sums", sums), ("moments", moments)):
+        _require_f32(name, t)
+        _require_gpu(name, t)
+    if w1.dim() != 2 or w1.shape[0] not in (1, 3):
+        raise ValueError(f"w1 should be [Cin in (1, 3), n_feats], got {tuple(w1.shape)}")
+    return _GuideFoldBatch.apply(w1, beta, w2, b2, gamma, sums, moments, running_mean, running_var,
+                                 num_batches_tracked, npx, eps, momentum)
 
 
 class CoefficientWeights:

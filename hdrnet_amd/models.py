@@ -74,7 +74,10 @@ class _BN(nn.Module):
         self.bn.weight.requires_grad_(False)
 
     def forward(self, x):
-        return self.bn(x)
+        # nn.BatchNorm's own forward also increments num_batches_tracked (a launch per layer and step; the counter only
+        # matters for momentum=None, and TensorFlow's batch_norm has none): the functional form with the same arguments
+        m = self.bn
+        return F.batch_norm(x, m.running_mean, m.running_var, m.weight, m.bias, self.training, m.momentum, m.eps)
 
 
 class _Conv(nn.Module):
@@ -83,14 +86,17 @@ class _Conv(nn.Module):
     def __init__(self, cin, cout, k, stride=1, use_bias=True, batch_norm=False, activation=F.relu):
         super().__init__()
         self.k, self.stride, self.activation = k, stride, activation
-        self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=0, bias=use_bias and not batch_norm)
+        # stride 1, odd kernel: SAME padding is symmetric -- the convolution's own padding, no pad copy (a launch each way)
+        self.own_pad = stride == 1 and k % 2 == 1
+        self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2 if self.own_pad else 0,
+                              bias=use_bias and not batch_norm)
         nn.init.kaiming_normal_(self.conv.weight, mode="fan_in", nonlinearity="relu")  # variance_scaling(2, FAN_IN)
         if self.conv.bias is not None:
             nn.init.zeros_(self.conv.bias)
         self.bn = _BN(cout, 2) if batch_norm else None
 
     def forward(self, x):
-        x = self.conv(tf_same_pad(x, self.k, self.stride))
+        x = self.conv(x if self.own_pad else tf_same_pad(x, self.k, self.stride))
         if self.bn is not None:
             x = self.bn(x)
         return self.activation(x) if self.activation is not None else x
@@ -335,6 +341,15 @@ class _PointwiseNNGuide(nn.Module):
         from the input's first and second moments (``hdrnet_ops.input_moments``) in float64,
         differentiable in w1 / beta / w2 / b2 (the moments are constants: the full-resolution image
         is data).  Updates the running statistics exactly as ``nn.BatchNorm1d`` would."""
+        if sums.is_cuda and self.w1.shape[0] in (1, 3):  # one HIP launch each way instead of ~33 + ~30 torch launches
+            from . import hdrnet_ops
+            return hdrnet_ops.guide_fold_batch(
+                self.w1, self.bn.bias, self.w2, self.b2, self.bn.weight, sums, moments, npx, self.bn.eps,
+                self.bn.momentum, self.bn.running_mean, self.bn.running_var, self.bn.num_batches_tracked)
+        return self._folded_batch_torch(sums, moments, npx)
+
+    def _folded_batch_torch(self, sums: torch.Tensor, moments: torch.Tensor, npx: int):
+        """The same fold as differentiable torch math (the definition the kernel is tested against)."""
         n = float(npx)
         mean_x = sums.double() / n
         cov_x = moments.double() / n - torch.outer(mean_x, mean_x)  # biased

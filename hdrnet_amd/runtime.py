@@ -134,9 +134,10 @@ class TrainStep:
         self.bucket = hd.GradBucket(module.parameters())
 
     def _forward_backward(self, inputs, targets) -> torch.Tensor:
-        self.bucket.zero_()
+        self.bucket.release()  # .grad = None: backward assigns its gradients (no memset, no `+=` launch per parameter)
         loss = self.loss_fn(self.module(*inputs), *targets)
-        loss.backward()  # accumulates IN PLACE into the bucket's views
+        loss.backward()
+        self.bucket.gather()   # one multi-tensor copy into the flat buffer; every .grad is its view again
         return loss
 
     def _after_backward(self) -> None:

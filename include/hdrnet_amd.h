@@ -301,6 +301,25 @@ int hdrnet_bilateral_slice_grad_f32_ex(const float* grid, const float* guide,
                                        void* workspace, size_t workspace_bytes,
                                        unsigned flags, void* stream);
 
+/* Training-mode fold of the guide network's batch norm into its first layer, from the input's moments
+ * (hdrnet_input_moments_f32): the statistics of the first convolution's never-materialised output are
+ *   mean_h = w1^T mean_x,  var_h[k] = w1[:,k]^T Cov_x w1[:,k]  (biased),  inv = gamma / sqrt(var_h + eps)
+ *   conv1[k] = (w1[:,k] * inv, beta[k] - mean_h[k] * inv)  [n][Cin+1],   conv2 = (w2, b2)  [n+1]
+ * -- tf.contrib.layers.batch_norm with is_training=True (hdrnet/layers.py:40-58), folded the way
+ * hdrnet/bin/freeze_graph.py:170-184 folds the inference statistics.  w1 is [Cin][n].  running_mean / running_var
+ * [n] (both or neither) are moved by `momentum` towards the batch statistics (unbiased variance), num_batches_tracked
+ * (may be NULL) is incremented.  float64 arithmetic on the device, one launch; ..._grad_f32 is its VJP with respect
+ * to w1, beta, w2, b2 given dconv1 [n][Cin+1] and dconv2 [n+1] (the moments are data).  Cin in {1, 3}. */
+int hdrnet_guide_fold_batch_f32(const float* sums, const float* moments, long long npx, const float* w1,
+                                const float* gamma, const float* beta, const float* w2, const float* b2,
+                                double eps, double momentum, int Cin, int n_feats, float* conv1, float* conv2,
+                                float* running_mean, float* running_var, long long* num_batches_tracked,
+                                void* stream);
+int hdrnet_guide_fold_batch_grad_f32(const float* sums, const float* moments, long long npx, const float* w1,
+                                     const float* gamma, const float* beta, double eps, int Cin, int n_feats,
+                                     const float* dconv1, const float* dconv2, float* dw1, float* dbeta,
+                                     float* dw2, float* db2, void* stream);
+
 /* ---- The low-resolution coefficient network: the caller of the hot path ----
  *
  * HDRNetCurves._coefficients (hdrnet/models.py:62-142; layer wrappers hdrnet/layers.py:25-93) in inference

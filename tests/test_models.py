@@ -868,3 +868,65 @@ def test_tf_fixture_parity(cls):
         with torch.no_grad():
             got = m.cuda()(lo.cuda(), hi.cuda()).cpu().numpy()
         np.testing.assert_allclose(got, fx["output"], **tol)
+
+
+def test_metrics_match_the_reference_formulas():
+    """hdrnet/metrics.py:8-20: l2_loss = mean(square(target - prediction)), psnr = mean over the batch of
+    -10 / ln 10 * log(mean(square))."""
+    import math
+    from hdrnet_amd import metrics
+    torch.manual_seed(0)
+    t, p = torch.rand(3, 8, 9, 3, dtype=torch.float64), torch.rand(3, 8, 9, 3, dtype=torch.float64, requires_grad=True)
+    want = (t - p).square().mean()
+    got = metrics.l2_loss(t, p)
+    assert torch.allclose(got, want, rtol=1e-12)
+    g1, = torch.autograd.grad(got, p)
+    g2, = torch.autograd.grad(want, p)
+    assert torch.allclose(g1, g2, rtol=1e-12)
+    sq = (t - p.detach()).square().reshape(3, -1).mean(1)
+    assert torch.allclose(metrics.psnr(t, p.detach()), (-10.0 / math.log(10.0) * sq.log()).mean(), rtol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,n", [(3, 16), (3, 8), (1, 4), (3, 16)])
+def test_guide_fold_batch_kernel_equals_the_torch_fold(cin, n):
+    """hdrnet_guide_fold_batch_f32 and its VJP against the differentiable float64 torch math it replaces
+    (_PointwiseNNGuide._folded_batch_torch): values, every parameter gradient, the running statistics."""
+    import copy
+    torch.manual_seed(cin * 100 + n)
+    dev = "cuda:0"
+    g = models._PointwiseNNGuide(n, nchans=cin).to(dev).train()
+    with torch.no_grad():
+        g.bn.bias.normal_(0, 0.3)
+        g.b2.fill_(0.2)
+        g.bn.running_mean.normal_(0, 0.1)
+        g.bn.running_var.uniform_(0.5, 1.5)
+    ref = copy.deepcopy(g)
+    x = torch.rand(5000, cin, device=dev)
+    sums, mom = x.sum(0), x.t() @ x
+    if cin == 3 and n == 8:  # a degenerate feature: zero weights -> zero variance (the clamp's flat side)
+        with torch.no_grad():
+            g.w1[:, 2] = 0
+            ref.w1[:, 2] = 0
+    c1, c2 = g.folded_batch(sums, mom, x.shape[0])
+    r1, r2 = ref._folded_batch_torch(sums, mom, x.shape[0])
+    assert torch.allclose(c1, r1, rtol=1e-6, atol=1e-7) and torch.allclose(c2, r2)
+    assert torch.allclose(g.bn.running_mean, ref.bn.running_mean, rtol=1e-6, atol=1e-8)
+    assert torch.allclose(g.bn.running_var, ref.bn.running_var, rtol=1e-6, atol=1e-8)
+    assert int(g.bn.num_batches_tracked) == int(ref.bn.num_batches_tracked) == 1
+    w1v, w2v = torch.randn_like(c1), torch.randn_like(c2)
+    ((c1 * w1v).sum() + (c2 * w2v).sum()).backward()
+    ((r1 * w1v).sum() + (r2 * w2v).sum()).backward()
+    for (name, p), (_, q) in zip(g.named_parameters(), ref.named_parameters()):
+        if q.grad is None:
+            assert p.grad is None, name
+            continue
+        scale = float(q.grad.abs().max()) + 1e-12
+        assert float((p.grad - q.grad).abs().max()) <= 2e-6 * scale, (name, p.grad, q.grad)
+    # the eval-mode fold cache notices the running statistics the kernel moved
+    g.eval()
+    a = g.folded()
+    g.train()
+    g.folded_batch(sums, mom, x.shape[0])
+    g.eval()
+    assert g.folded() is not a

@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from hdrnet_amd import dist as hd  # noqa: E402
-from hdrnet_amd import models  # noqa: E402
+from hdrnet_amd import metrics, models  # noqa: E402
 
 
 def timeit(fn, steps):
@@ -124,7 +124,7 @@ def main():
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = (mt(low, full) - target).square().mean()
+        loss = metrics.l2_loss(target, mt(low, full))
         loss.backward()
         hd.allreduce_gradients_flat(mt.parameters())
         opt.step()
@@ -145,7 +145,7 @@ def main():
 
     def step_curves():
         optc.zero_grad(set_to_none=True)
-        (mcv(low, full) - target).square().mean().backward()
+        metrics.l2_loss(target, mcv(low, full)).backward()
         optc.step()
 
     t_cs = timeit(step_curves, max(5, args.steps // 2))
@@ -159,7 +159,7 @@ def main():
     from hdrnet_amd.runtime import GraphedTrainStep
     mg = models.HDRNetPointwiseNNGuide(dict(batch_norm=True)).to(dev).train()
     optg = torch.optim.Adam([p for p in mg.parameters() if p.requires_grad], lr=1e-4, capturable=True, fused=True)
-    gstep = GraphedTrainStep(mg, lambda out, tgt: (out - tgt).square().mean(), optg, [low, full], [target])
+    gstep = GraphedTrainStep(mg, lambda out, tgt: metrics.l2_loss(tgt, out), optg, [low, full], [target])
     t_graph = timeit(lambda: gstep([low, full], [target]), max(5, args.steps // 2))
     print(f"config #4  the whole step as one hipGraph: {t_graph * 1e3:.2f} ms/step = "
           f"{B * 1080 * 1920 / 1e6 / t_graph:.0f} MP/s per GPU")
