@@ -50,6 +50,8 @@ SIGNATURES = {
     "hdrnet_guide_fold_batch_grad_f32": (_I, [_FP, _FP, ctypes.c_longlong] + [_FP] * 3 + [ctypes.c_double, _I, _I] + [_FP] * 6 + [_VP]),
     "hdrnet_coefficients_workspace_bytes": (_SZ, [_VP, _I]),
     "hdrnet_coefficients_f32": (_I, [_FP, _VP, _FP, _I, _VP, _SZ, _VP]),
+    "hdrnet_coefficients_grad_workspace_bytes": (_SZ, [_VP, _I]),
+    "hdrnet_coefficients_grad_f32": (_I, [_FP, _VP, _VP, _FP, _VP, _I, _VP, _SZ, _VP]),
     "hdrnet_bilateral_slice_apply_io": (_I, [_FP] * 4 + [_I] * 10 + [ctypes.c_float, _I] + [_FP] * 2 + [_I, _FP, _VP]),
     "hdrnet_bilateral_slice_apply_grad_workspace_bytes": (_SZ, [_I] * 9),
     "hdrnet_bilateral_slice_apply_grad_f32": (_I, [_FP] * 7 + [_I] * 9 + [_VP, _SZ, _VP]),
@@ -68,6 +70,16 @@ class CoeffNet(ctypes.Structure):
     _fields_ = [("net_input_size", _I), ("spatial_bin", _I), ("luma_bins", _I), ("channel_multiplier", _I),
                 ("n_out", _I), ("n_in", _I), ("n_levels", _I),
                 ("splat_w", _VP * 8), ("splat_b", _VP * 8),
+                ("global_conv_w", _VP * 2), ("global_conv_b", _VP * 2),
+                ("fc_w", _VP * 3), ("fc_b", _VP * 3),
+                ("local_w", _VP * 2), ("local_b", _VP * 2),
+                ("pred_w", _VP), ("pred_b", _VP), ("fc_layout", _I)]
+
+
+class CoeffNetGrads(ctypes.Structure):
+    """``hdrnet_coeff_net_grads``: where ``hdrnet_coefficients_grad_f32`` writes the parameter gradients."""
+
+    _fields_ = [("splat_w", _VP * 8), ("splat_b", _VP * 8),
                 ("global_conv_w", _VP * 2), ("global_conv_b", _VP * 2),
                 ("fc_w", _VP * 3), ("fc_b", _VP * 3),
                 ("local_w", _VP * 2), ("local_b", _VP * 2),

@@ -45,6 +45,7 @@ SOURCES = [
     ("guide_grad.hip", ["-fno-slp-vectorize"]),
     ("resize_bilinear.hip", []),
     ("coeff_net.hip", []),
+    ("coeff_net_train.hip", []),
 ]
 TOOLS_ONLY_SOURCES = [
     ("apply_fwd_variants.hip", ["-fno-slp-vectorize"]),

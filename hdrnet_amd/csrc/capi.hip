@@ -462,6 +462,45 @@ int hdrnet_coefficients_f32(const float* lowres, const hdrnet_coeff_net* net, fl
   return rc;
 }
 
+size_t hdrnet_coefficients_grad_workspace_bytes(const hdrnet_coeff_net* net, int B) {
+  if (!net || B <= 0) return 0;
+  return hdrnet_amd::coefficients_grad_workspace_bytes(*net, B);
+}
+
+int hdrnet_coefficients_grad_f32(const float* lowres, const hdrnet_coeff_net* net, const void* forward_workspace,
+                                 const float* dcoeffs, const hdrnet_coeff_net_grads* grads, int B, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  using namespace hdrnet_amd;
+  if (!net || !grads) return fail(HDRNET_INVALID_ARGUMENT, "null network description");
+  const size_t need = B > 0 ? coefficients_grad_workspace_bytes(*net, B) : 0;
+  if (need == 0)
+    return fail(HDRNET_INVALID_ARGUMENT,
+                "coefficient network gradient: unsupported (needs the forward's support, n_levels = 1, fc_layout = 1, "
+                "1 <= B <= 8, 8 * cm * gd <= 256; got B=%d, n_levels=%d, fc_layout=%d)", B, net->n_levels, net->fc_layout);
+  int n_ds = 0;
+  for (int v = net->net_input_size / net->spatial_bin; v > 1; v >>= 1) ++n_ds;
+  bool null_param = !net->pred_w || !net->pred_b || !net->local_w[0] || !net->local_w[1] || !net->local_b[0] ||
+                    !grads->pred_w || !grads->pred_b || !grads->local_w[0] || !grads->local_w[1] || !grads->local_b[0];
+  for (int i = 0; i < n_ds; ++i)
+    null_param = null_param || !net->splat_w[i] || !net->splat_b[i] || !grads->splat_w[i] || !grads->splat_b[i];
+  for (int i = 0; i < 2; ++i)
+    null_param = null_param || !net->global_conv_w[i] || !net->global_conv_b[i] || !grads->global_conv_w[i] ||
+                 !grads->global_conv_b[i];
+  for (int i = 0; i < 3; ++i)
+    null_param = null_param || !net->fc_w[i] || !net->fc_b[i] || !grads->fc_w[i] || !grads->fc_b[i];
+  if (null_param) return fail(HDRNET_INVALID_ARGUMENT, "coefficient network gradient: null parameter");
+  if (!lowres || !forward_workspace || !dcoeffs) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15u))
+    return fail(HDRNET_INVALID_ARGUMENT, "coefficient network gradient needs a 16-B aligned workspace of "
+                                         "hdrnet_coefficients_grad_workspace_bytes() = %zu bytes", need);
+  const char* name = "";
+  const int rc = check_launch(launch_coefficients_grad(lowres, *net, *grads, dcoeffs, B, forward_workspace, workspace,
+                                                       static_cast<hipStream_t>(stream), &name),
+                              "CoefficientsGrad");
+  if (rc == HDRNET_OK) set_kernel(name);
+  return rc;
+}
+
 int hdrnet_bilateral_slice_apply_io(const float* grid, const float* guide, const void* input,
                                     void* out, int B, int H, int W, int GH, int GW, int GD, int Cin,
                                     int Cout, int has_offset, int input_dtype,

@@ -39,6 +39,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/hdrnet_amd.h"
+#include "coeff_net.hip.h"
 #include "launch.hip.h"
 
 namespace hdrnet_amd {
@@ -80,6 +81,7 @@ struct PredExtra {
   int gxS, gK;
   int gd, n_out, n_in, n_levels;
   long long level_stride;
+  int gw_oi;  // gw is [out][in] (a torch Linear weight) instead of TensorFlow's [in][out]
 };
 
 constexpr int kStepRow = 12;  // per wave: 9 steps, their count, 2 pad
@@ -309,7 +311,8 @@ __global__ __launch_bounds__(256) void coeff_conv_mfma(const ConvBatch batch) {
     const bool fast = nk <= 32 && Cin <= 256;
     if (fast) {
 #pragma unroll
-      for (int i2 = 0; i2 < 32; ++i2) w3r[i2] = i2 < nk ? x.gw[(size_t)(kp * nk + i2) * Cin + c] : 0.0f;
+      for (int i2 = 0; i2 < 32; ++i2)
+        w3r[i2] = i2 < nk ? x.gw[x.gw_oi ? (size_t)c * gK + kp * nk + i2 : (size_t)(kp * nk + i2) * Cin + c] : 0.0f;
     }
     float* xg = red;             // [gK]
     float* scratch = red + 512;  // [256]
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(256) void coeff_conv_mfma(const ConvBatch batch) {
     } else {
       for (int c2 = tid; c2 < Cin; c2 += 256) {
         float g = x.gb[c2];
-        for (int k = 0; k < gK; ++k) g = __builtin_fmaf(xg[k], x.gw[(size_t)k * Cin + c2], g);
+        for (int k = 0; k < gK; ++k) g = __builtin_fmaf(xg[k], x.gw[x.gw_oi ? (size_t)c2 * gK + k : (size_t)k * Cin + c2], g);
         gl[c2] = g;
       }
     }
@@ -421,6 +424,7 @@ struct FcParams {
   float* ypart;        // [B][yS][O], yS = gridDim.x
   int xS, xrelu, K, O, kc;
   long long* trace;  // tools build
+  int w_oi;          // w is [O][K] (a torch Linear weight) instead of [K][O]
 };
 
 // y_part[chunk][o] = sum_{k in chunk} x[k] * w[k][o],  x = act(xbias + sum_s xpart[s])
@@ -440,7 +444,8 @@ __global__ __launch_bounds__(256) void coeff_fc(const FcParams p) {
   const int o = blockIdx.y * 256 + tid;
   float wv[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) wv[k] = (o < p.O && k < kn) ? p.w[(size_t)(k0 + k) * p.O + o] : 0.0f;
+  for (int k = 0; k < 16; ++k)
+    wv[k] = (o < p.O && k < kn) ? p.w[p.w_oi ? (size_t)o * p.K + k0 + k : (size_t)(k0 + k) * p.O + o] : 0.0f;
   {
     const int k = tid & 15, r = tid >> 4;  // 16 reducers per input
     float x = 0.0f;
@@ -468,7 +473,6 @@ __global__ __launch_bounds__(256) void coeff_fc(const FcParams p) {
   COEFF_STAMP(3);
 }
 
-constexpr int kFcChunk = 16;
 
 inline int same_pad_before(int in, int out, int k, int s) {  // tf padding='SAME'
   const int total = (out - 1) * s + k - in;
@@ -553,63 +557,6 @@ hipError_t launch_conv_mfma(const ConvBatch& cb_in, int B, hipStream_t s) {
   }
   coeff_conv_mfma<KS, PRED><<<dim3(tiles, groups, (unsigned)B), 256, lds, s>>>(cb);
   return hipGetLastError();
-}
-
-bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
-
-struct NetDims {
-  int N, sb, gd, cm, n_ds, feat, gl, pred;  // feat = splat output channels, gl = 8*cm*gd, pred = gd*n_out*n_in
-  int gside;                                // side of the global path's last conv
-};
-
-bool net_dims(const hdrnet_coeff_net& n, NetDims* d) {
-  if (n.net_input_size <= 0 || n.spatial_bin <= 0 || n.luma_bins <= 0 || n.channel_multiplier <= 0) return false;
-  if (n.n_out <= 0 || n.n_in <= 0 || n.n_levels <= 0 || n.n_out % n.n_levels != 0) return false;
-  if (!pow2(n.net_input_size) || !pow2(n.spatial_bin) || n.spatial_bin > n.net_input_size) return false;
-  if (n.net_input_size > 4096) return false;  // tile counts stay below 2^16 (umulhi divisions), grids below 2^31
-  d->N = n.net_input_size; d->sb = n.spatial_bin; d->gd = n.luma_bins; d->cm = n.channel_multiplier;
-  d->n_ds = 0;
-  for (int v = d->N / d->sb; v > 1; v >>= 1) ++d->n_ds;
-  if (d->n_ds < 1 || d->n_ds > 8) return false;
-  const int base = d->cm * d->gd;  // channels of the first splat layer
-  // every staged layer reads whole float4 channel groups, a power of two of them per pixel (<= 64 channels) or whole
-  // 64-channel chunks
-  if (base % 4 != 0 || !pow2(base / 4)) return false;
-  d->feat = base << (d->n_ds - 1);
-  d->gl = 8 * base;
-  d->pred = d->gd * n.n_out * n.n_in;
-  d->gside = (((d->sb + 1) / 2) + 1) / 2;
-  if ((long long)d->gside * d->gside * d->gl > (1 << 24)) return false;
-  return true;
-}
-
-// Workspace layout (floats per image): the activations of every layer + the fc partial sums.
-struct NetWorkspace {
-  size_t splat[8], local1, local2, g1, g2, fc1, fc2, total;
-  int s1, s2;  // fc K-chunks
-};
-
-NetWorkspace net_workspace(const NetDims& d) {
-  NetWorkspace w{};
-  size_t off = 0;
-  auto take = [&](size_t n) { const size_t o = off; off += (n + 3) & ~(size_t)3; return o; };
-  int side = d.N;
-  for (int i = 0; i < d.n_ds; ++i) {
-    side /= 2;
-    w.splat[i] = take((size_t)side * side * ((d.cm * d.gd) << i));
-  }
-  w.local1 = take((size_t)d.sb * d.sb * d.gl);
-  w.local2 = take((size_t)d.sb * d.sb * d.gl);
-  const int g1side = (d.sb + 1) / 2;
-  w.g1 = take((size_t)g1side * g1side * d.gl);
-  w.g2 = take((size_t)d.gside * d.gside * d.gl);
-  const int K1 = d.gside * d.gside * d.gl;
-  w.s1 = (K1 + kFcChunk - 1) / kFcChunk;
-  w.s2 = (4 * d.gl + kFcChunk - 1) / kFcChunk;
-  w.fc1 = take((size_t)w.s1 * 4 * d.gl);
-  w.fc2 = take((size_t)w.s2 * 2 * d.gl);
-  w.total = off;
-  return w;
 }
 
 }  // namespace
@@ -699,9 +646,9 @@ hipError_t launch_coefficients(const float* lowres, const hdrnet_coeff_net& net,
   float* f2 = buf(ws.fc2);
   {
     auto fc_grid = [&](int chunks, int O) { return dim3((unsigned)chunks, (unsigned)((O + 255) / 256), (unsigned)B); };
-    FcParams p{g2, nullptr, net.fc_w[0], f1, 1, 0, K1, 4 * d.gl, kFcChunk, next_trace()};
+    FcParams p{g2, nullptr, net.fc_w[0], f1, 1, 0, K1, 4 * d.gl, kFcChunk, next_trace(), net.fc_layout};
     coeff_fc<<<fc_grid(ws.s1, 4 * d.gl), 256, 0, s>>>(p);
-    FcParams q{f1, net.fc_b[0], net.fc_w[1], f2, ws.s1, 1, 4 * d.gl, 2 * d.gl, kFcChunk, next_trace()};
+    FcParams q{f1, net.fc_b[0], net.fc_w[1], f2, ws.s1, 1, 4 * d.gl, 2 * d.gl, kFcChunk, next_trace(), net.fc_layout};
     coeff_fc<<<fc_grid(ws.s2, 2 * d.gl), 256, 0, s>>>(q);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -717,6 +664,7 @@ hipError_t launch_coefficients(const float* lowres, const hdrnet_coeff_net& net,
     cb.x.gK = 2 * d.gl;
     cb.x.gw = net.fc_w[2];
     cb.x.gb = net.fc_b[2];
+    cb.x.gw_oi = net.fc_layout;
     cb.x.gd = d.gd;
     cb.x.n_out = net.n_out;
     cb.x.n_in = net.n_in;

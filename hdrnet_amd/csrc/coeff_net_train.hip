@@ -1,0 +1,791 @@
+// Training side of the coefficient network (csrc/coeff_net.hip is its forward): the VJP of
+// `HDRNetCurves._coefficients` (hdrnet/models.py:62-142) with respect to every weight and bias, for the model
+// WITHOUT batch norm -- how the reference's own script trains the guide-network model
+// (scripts/ll/train_nn_guide.sh: --nobatch_norm).  The forward pass is the inference launch sequence; its workspace
+// (every layer's activation, the fully connected layers' partial sums) is what this file reads back.
+//
+// On stock ops the backward of this network is ~75 launches of a graph-captured training step (MIOpen backward-data
+// and backward-weights kernels with their companions, ReLU masks, pad slices, bias reductions), ~0.4 ms of launch
+// latency around a few tens of microseconds of arithmetic (profiles/r04/train_step.md).  Here it is ~26:
+//
+//   coeff_recompute   x1 / x2 (the fully connected layers' activated inputs, from their saved partial sums), the
+//                     global features g, the fusion relu(local + g); the incoming gradient permuted from the unrolled
+//                     grid [.., z, i, j] back to the prediction layer's channel order
+//   coeff_conv_dw     backward-weights of a convolution on the fp32 matrix cores: D[oc][ic] per tap, the contraction
+//                     runs over the PIXELS (4 per v_mfma_f32_16x16x4_f32).  Both operands are plain 4-byte global
+//                     loads in lane order (16 output channels x 4 pixels, 4 pixels x 16 input channels: 64-byte
+//                     runs), 40 per 4 x 4 pixel tile and lane, all in flight one tile ahead of the 36 MFMAs that use
+//                     them; the ReLU mask of the layer's output and the sum of two consumers' gradients are applied
+//                     while loading.  Pixel tiles are dealt to workgroups in chunks; the chunks' partial results are
+//                     summed in fixed order by coeff_reduce_parts (one launch for all layers).  The bias gradient is
+//                     the same kernel's column sum.
+//   coeff_conv_dx     backward-data: a stride-1 convolution of the zero-upsampled (stride 2), masked gradient with the
+//                     flipped filter -- the forward's 4 x 4 x 16 MFMA kernel with the upsampling and the mask folded
+//                     into the LDS staging and the filter read in place ([Cout][kh][kw][Cin]: four 4-byte loads per
+//                     16-channel group instead of one float4; no transposed copy of the weights per step).
+//   coeff_fc_bwd      a fully connected layer: dW, db and dx in one launch.
+//
+// Weights are read and gradients written in the layouts torch holds them in (Conv2d weights in channels_last memory
+// order = [Cout][kh][kw][Cin]; Linear weights [out][in]): the training step moves no parameter data.
+// Deterministic: fixed-order sums, no atomics.
+#include <hip/hip_runtime.h>
+
+#include "coeff_net.hip.h"
+#include "launch.hip.h"
+
+namespace hdrnet_amd {
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kT = 4;          // pixel tile edge (16 pixels = the 16 rows / 4 K-steps of an MFMA tile)
+constexpr int kChunkCh = 64;   // coeff_conv_dx: gradient channels staged at a time
+constexpr int kMaxB = 8;       // coeff_fc_bwd keeps one accumulator per image in registers
+
+// x / d == umulhi(x, magic32(d)) for x < 2^16 and d >= 2; d == 1 has no 32-bit magic number (udiv handles it)
+unsigned magic32(int d) { return d > 1 ? (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d) : 0u; }
+__device__ __forceinline__ int udiv(int x, unsigned mul, int d) { return d == 1 ? x : (int)__umulhi((unsigned)x, mul); }
+
+// ------------------------------------------------------------------------------------------------ backward-weights
+
+struct DwParams {
+  const float* x;      // [B][Hin][Win][Cin]: the layer's forward input
+  const float* dy;     // [B][Hout][Wout][Cout]: gradient of the layer's output (before its ReLU mask)
+  const float* dy2;    // optional second addend (the output feeds two layers), same shape
+  const float* ymask;  // optional: the layer's forward output; the gradient passes where it is > 0
+  float* dw_part;      // [nchunks][Cout][KK][Cin]
+  float* db_part;      // [nchunks][Cout] or null
+  int Hin, Win, Cin, Hout, Wout, Cout, stride, pad_top, pad_left;
+  int tiles_x, tiles_per_image, tiles_total, tiles_per_chunk;
+  unsigned tx_mul, tpi_mul;
+  int ic_blocks;
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void coeff_conv_dw(const DwParams p) {
+  constexpr int KK = KS * KS;
+  __shared__ float red[4 * KK * 4 * 64];
+  __shared__ float bred[4 * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int chunk = blockIdx.x;
+  const int ocb = blockIdx.y / p.ic_blocks, icb = blockIdx.y - ocb * p.ic_blocks;
+  const int oc0 = ocb * 16, ic0 = icb * 16;
+  const int q = lane >> 4, m = lane & 15;  // q: pixel of the K-step (A and B); m: output channel (A) / input channel (B)
+  const bool a_ok = oc0 + m < p.Cout, b_ok = ic0 + m < p.Cin;
+  const int t_end = min((chunk + 1) * p.tiles_per_chunk, p.tiles_total);
+
+  float a_nxt[4], b_nxt[4][KK];
+  const int xrow = p.Win * p.Cin;                       // floats per input row
+  const int mo = a_ok ? m : 0, mi = b_ok ? m : 0;
+  auto fetch = [&](int t) {  // the 4 + 4 * KK operands of tile t, as loads only
+    const int b = udiv(t, p.tpi_mul, p.tiles_per_image);
+    const int r = t - b * p.tiles_per_image;
+    const int ty = udiv(r, p.tx_mul, p.tiles_x), tx = r - ty * p.tiles_x;
+    const int ox = tx * kT + q, oxc = min(ox, p.Wout - 1);
+    const int ix0 = ox * p.stride - p.pad_left;
+    const size_t yimg = (size_t)b * p.Hout * p.Wout * p.Cout + oc0 + mo;
+    const float* dyb = p.dy + yimg;
+    const float* dy2b = p.dy2 ? p.dy2 + yimg : nullptr;
+    const float* ymb = p.ymask ? p.ymask + yimg : nullptr;
+    const float* xb = p.x + (size_t)b * p.Hin * xrow + ic0 + mi;
+    bool xok[KS];
+    int xoff[KS];
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) {
+      const int ix = ix0 + kx;
+      xok[kx] = (unsigned)ix < (unsigned)p.Win && ox < p.Wout && b_ok;
+      xoff[kx] = min(max(ix, 0), p.Win - 1) * p.Cin;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int oy = ty * kT + s;
+      const bool in = oy < p.Hout && ox < p.Wout;
+      const int off = (min(oy, p.Hout - 1) * p.Wout + oxc) * p.Cout;
+      float v = dyb[off];
+      if (dy2b) v += dy2b[off];
+      if (ymb) v = ymb[off] > 0.0f ? v : 0.0f;
+      a_nxt[s] = (in && a_ok) ? v : 0.0f;
+      const int iy0 = oy * p.stride - p.pad_top;
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky) {
+        const int iy = iy0 + ky;
+        const bool yok = (unsigned)iy < (unsigned)p.Hin && oy < p.Hout;
+        const float* xr = xb + min(max(iy, 0), p.Hin - 1) * xrow;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          const float xv = xr[xoff[kx]];
+          b_nxt[s][ky * KS + kx] = (yok && xok[kx]) ? xv : 0.0f;
+        }
+      }
+    }
+  };
+
+  v4f acc[KK];
+#pragma unroll
+  for (int tap = 0; tap < KK; ++tap) acc[tap] = v4f{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.0f;
+  int t = chunk * p.tiles_per_chunk + wave;
+  if (t < t_end) fetch(t);
+  for (; t < t_end; t += 4) {
+    float a_cur[4], b_cur[4][KK];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      a_cur[s] = a_nxt[s];
+#pragma unroll
+      for (int tap = 0; tap < KK; ++tap) b_cur[s][tap] = b_nxt[s][tap];
+    }
+    if (t + 4 < t_end) fetch(t + 4);  // in flight under this tile's MFMAs
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bsum += a_cur[s];
+#pragma unroll
+      for (int tap = 0; tap < KK; ++tap)
+        acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], b_cur[s][tap], acc[tap], 0, 0, 0);
+    }
+  }
+  // D[i = oc][j = ic] per tap: lane holds rows 4 * (lane >> 4) + r, column lane & 15
+#pragma unroll
+  for (int tap = 0; tap < KK; ++tap) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[((wave * KK + tap) * 4 + r) * 64 + lane] = acc[tap][r];
+  }
+  bred[wave * 64 + lane] = bsum;
+  __syncthreads();
+  {
+    const int r = wave;  // thread (wave, lane) finishes row 4 * q + wave, column m of every tap
+    const int oc = oc0 + 4 * q + r, ic = ic0 + m;
+    if (oc < p.Cout && ic < p.Cin) {
+#pragma unroll
+      for (int tap = 0; tap < KK; ++tap) {
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += red[((w * KK + tap) * 4 + r) * 64 + lane];
+        p.dw_part[(((size_t)chunk * p.Cout + oc) * KK + tap) * p.Cin + ic] = v;
+      }
+    }
+  }
+  if (p.db_part && icb == 0 && tid < 16 && oc0 + tid < p.Cout) {
+    float v = 0.0f;
+    for (int w = 0; w < 4; ++w) {
+      for (int qq = 0; qq < 4; ++qq) v += bred[w * 64 + qq * 16 + tid];
+    }
+    p.db_part[(size_t)chunk * p.Cout + oc0 + tid] = v;
+  }
+}
+
+// Sums the chunks' partial results of every layer in one launch: entry e owns blocks [first[e], first[e + 1]).
+constexpr int kMaxParts = 32;
+struct ReduceTab {
+  const float* src[kMaxParts];
+  float* dst[kMaxParts];
+  int n[kMaxParts], nsplit[kMaxParts], first[kMaxParts + 1];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void coeff_reduce_parts(const ReduceTab tab) {
+  __shared__ float red[16][17];
+  int e = 0;
+  while (e + 1 < tab.count && (int)blockIdx.x >= tab.first[e + 1]) ++e;  // uniform
+  // block = 16 consecutive elements x 16 groups of the chunks: every load of the block in flight at once (a loop over
+  // 512 chunks, one load at a time, was 39 us of the step)
+  const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int i = ((int)blockIdx.x - tab.first[e]) * 16 + el;
+  const int n = tab.n[e], ns = tab.nsplit[e];
+  float v = 0.0f;
+  if (i < n) {
+    const float* s = tab.src[e] + i;
+#pragma unroll 8
+    for (int k = g; k < ns; k += 16) v += s[(size_t)k * n];
+  }
+  red[g][el] = v;
+  __syncthreads();
+  if (g == 0 && i < n) {
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][el];
+    tab.dst[e][i] = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- backward-data
+
+struct DxParams {
+  const float* dy;     // [B][Hy][Wy][Cy]: gradient of the layer's output
+  const float* dy2;    // optional second addend
+  const float* ymask;  // optional: the layer's forward output (ReLU mask)
+  const float* w;      // the layer's filter, [Cy][KK][Cx]
+  float* dx;           // [B][Hx][Wx][Cx]
+  int Hy, Wy, Cy, Hx, Wx, Cx;
+  int ups, pad_top, pad_left;  // the gradient upsampled by the forward stride; pad' = KS - 1 - forward pad
+  int tiles_x, tiles, oc_groups;
+  unsigned ti_mul, tx_mul;
+  int c4shift, nchunks;
+  unsigned lds_off[4][12];  // per wave: LDS float offset of each (tap, 16-channel group) step | group << 24; [9] = count
+  unsigned w_off[4][12];    // per wave: filter float offset of the step: (16 g * KK + flipped tap) * Cx
+};
+
+// dx[b, i, :] = sum_taps U[b, i - pad' + tap, :] . w[:, KK - 1 - tap, :],  U = the masked gradient, zero-upsampled.
+// MFMA roles as in coeff_conv_mfma: rows = the tile's 16 pixels of dx, columns = 16 channels of dx (Cx), the k of
+// MFMA e of a 16-channel group of the gradient is channel 16 g + 4 kk + e.
+template <int KS>
+__global__ __launch_bounds__(256) void coeff_conv_dx(const DxParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int KK = KS * KS;
+  constexpr int kMaxSteps = KK;
+  constexpr int TI = (kT - 1) + KS;  // stride 1 over the upsampled gradient
+  constexpr int npix = TI * TI;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned lstep[kMaxSteps], wstep[kMaxSteps];
+#pragma unroll
+  for (int si = 0; si < kMaxSteps; ++si) {
+    lstep[si] = p.lds_off[wave][si];
+    wstep[si] = p.w_off[wave][si];
+  }
+  const int nsw = (int)p.lds_off[wave][9];
+  const int b = blockIdx.z;
+  const int tile = blockIdx.x;
+  const int tyi = udiv(tile, p.tx_mul, p.tiles_x), txi = tile - tyi * p.tiles_x;
+  const int oy0 = tyi * kT, ox0 = txi * kT;
+  const int iy0 = oy0 - p.pad_top, ix0 = ox0 - p.pad_left;  // in the upsampled gradient
+  const int Hu = (p.Hy - 1) * p.ups + 1, Wu = (p.Wy - 1) * p.ups + 1;
+  const int ushift = p.ups >> 1;  // ups in {1, 2}
+  const int Cy = p.Cy, Cx = p.Cx;
+  const int cch = 4 << p.c4shift;
+  const int PS = cch + 4;
+  float* red = lds + npix * PS;  // [4 waves][4][64]
+  const int q = lane >> 4, j = lane & 15;
+  const int n0 = blockIdx.y * 16;
+  const bool qvalid = 4 * q < cch;
+  const bool bvalid = qvalid && n0 + j < Cx;
+  const size_t img = (size_t)b * p.Hy * p.Wy * Cy;
+
+  constexpr int kMaxU = (TI * TI * (kChunkCh / 4) + 255) / 256;
+  const int c4 = tid & ((1 << p.c4shift) - 1), pix0 = tid >> p.c4shift, pstep = 256 >> p.c4shift;
+  const int nU = ((npix << p.c4shift) + 255) >> 8;
+  float4 st[kMaxU], st2[kMaxU], stm[kMaxU];
+  unsigned okbits = 0;
+  auto fetch_tile = [&](int chunk) {
+    okbits = 0;
+#pragma unroll
+    for (int u = 0; u < kMaxU; ++u) {
+      if (u < nU) {  // uniform
+        const int pix = pix0 + u * pstep;
+        const int py = (int)__umulhi((unsigned)pix, p.ti_mul), px = pix - py * TI;
+        const int gy = iy0 + py, gx = ix0 + px;
+        const int gyc = min(max(gy, 0), Hu - 1), gxc = min(max(gx, 0), Wu - 1);
+        const int c = chunk * kChunkCh + 4 * c4;  // the gradient's channel count need not be a multiple of the chunk
+        const bool ok = pix < npix && gy == gyc && gx == gxc && (gy & (p.ups - 1)) == 0 && (gx & (p.ups - 1)) == 0 && c < Cy;
+        const size_t off = img + ((size_t)(gyc >> ushift) * p.Wy + (gxc >> ushift)) * Cy + (c < Cy ? c : 0);
+        st[u] = *reinterpret_cast<const float4*>(p.dy + off);
+        if (p.dy2) st2[u] = *reinterpret_cast<const float4*>(p.dy2 + off);
+        if (p.ymask) stm[u] = *reinterpret_cast<const float4*>(p.ymask + off);
+        okbits |= ok ? (1u << u) : 0u;
+      }
+    }
+  };
+  auto stash_tile = [&]() {
+#pragma unroll
+    for (int u = 0; u < kMaxU; ++u) {
+      const int pix = pix0 + u * pstep;
+      if (u < nU && pix < npix) {
+        float4 v = st[u];
+        if (p.dy2) v = make_float4(v.x + st2[u].x, v.y + st2[u].y, v.z + st2[u].z, v.w + st2[u].w);
+        if (p.ymask) {
+          v.x = stm[u].x > 0.0f ? v.x : 0.0f;
+          v.y = stm[u].y > 0.0f ? v.y : 0.0f;
+          v.z = stm[u].z > 0.0f ? v.z : 0.0f;
+          v.w = stm[u].w > 0.0f ? v.w : 0.0f;
+        }
+        if (!((okbits >> u) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(lds + pix * PS + 4 * c4) = v;
+      }
+    }
+  };
+  // this lane's filter elements: gradient channels 16 g + 4 q + e (rows of [Cy][KK][Cx]), dx channel n0 + j
+  const float* wl = p.w + (size_t)(qvalid ? 4 * q : 0) * KK * Cx + min(n0 + j, Cx - 1);
+  const size_t estride = (size_t)KK * Cx;
+  auto fetch_w = [&](int chunk, float4 (&dst)[kMaxSteps]) {
+#pragma unroll
+    for (int si = 0; si < kMaxSteps; ++si) {
+      if (si < nsw) {  // uniform
+        const int row = chunk * kChunkCh + 16 * (int)(lstep[si] >> 24) + 4 * q;  // first of the lane's 4 filter rows
+        const bool rok = bvalid && row < Cy;
+        const float* ws = wl + (rok ? wstep[si] + (size_t)chunk * kChunkCh * estride : 0);
+        const float4 v = make_float4(ws[0], ws[estride], ws[2 * estride], ws[3 * estride]);
+        dst[si] = rok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  float4 bw[kMaxSteps];
+  fetch_tile(0);
+  fetch_w(0, bw);
+  v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int ti = lane & 15;
+  const float* tl = lds + ((ti >> 2) * TI + (ti & 3)) * PS + (qvalid ? 4 * q : 0);
+  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+    if (chunk > 0) __syncthreads();
+    stash_tile();
+    __syncthreads();
+    float4 bwn[kMaxSteps];
+    if (chunk + 1 < p.nchunks) {
+      fetch_w(chunk + 1, bwn);
+      fetch_tile(chunk + 1);
+    }
+#pragma unroll
+    for (int si = 0; si < kMaxSteps; ++si) {
+      if (si < nsw) {  // uniform
+        float4 x = *reinterpret_cast<const float4*>(tl + (lstep[si] & 0xffffffu));
+        if (!qvalid) x = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, bw[si].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, bw[si].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, bw[si].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, bw[si].w, acc1, 0, 0, 0);
+      }
+    }
+    if (chunk + 1 < p.nchunks) {
+#pragma unroll
+      for (int si = 0; si < kMaxSteps; ++si) bw[si] = bwn[si];
+    }
+  }
+  const v4f acc = acc0 + acc1;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  const int r = wave;
+  float v = red[r * 64 + lane];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) v += red[(w * 4 + r) * 64 + lane];
+  const int i = 4 * q + r, o = n0 + j;
+  const int oy = oy0 + (i >> 2), ox = ox0 + (i & 3);
+  if (o >= Cx || oy >= p.Hx || ox >= p.Wx) return;
+  p.dx[(((size_t)b * p.Hx + oy) * p.Wx + ox) * Cx + o] = v;
+}
+
+// ---------------------------------------------------------------------------------------- fully connected layers
+
+struct FcBwdParams {
+  const float* x;   // [B][K]: the layer's (activated) input
+  const float* dy;  // [B][O]
+  const float* w;   // [O][K]
+  float* dw;        // [O][K]
+  float* db;        // [O]
+  float* dx;        // [B][K] or null
+  int B, K, O, mask_x;  // mask_x: dx passes where x > 0 (the input is a ReLU's output)
+};
+
+// Block = 16 inputs k x 16 parts of the outputs; every (o, k) of dW belongs to exactly one thread.
+__global__ __launch_bounds__(256) void coeff_fc_bwd(const FcBwdParams p) {
+  __shared__ float red[kMaxB][16][17];
+  const int tid = threadIdx.x, kl = tid & 15, op = tid >> 4;
+  const int k = blockIdx.x * 16 + kl;
+  const bool k_ok = k < p.K;
+  float xk[kMaxB], dxp[kMaxB];
+#pragma unroll
+  for (int b = 0; b < kMaxB; ++b) {
+    xk[b] = (b < p.B && k_ok) ? p.x[(size_t)b * p.K + k] : 0.0f;
+    dxp[b] = 0.0f;
+  }
+#pragma unroll 16
+  for (int o = op; o < p.O; o += 16) {
+    const float w = k_ok ? p.w[(size_t)o * p.K + k] : 0.0f;
+    float dwv = 0.0f;
+#pragma unroll
+    for (int b = 0; b < kMaxB; ++b) {
+      if (b < p.B) {
+        const float g = p.dy[(size_t)b * p.O + o];
+        dwv = __builtin_fmaf(g, xk[b], dwv);
+        dxp[b] = __builtin_fmaf(g, w, dxp[b]);
+      }
+    }
+    if (k_ok) p.dw[(size_t)o * p.K + k] = dwv;
+  }
+#pragma unroll
+  for (int b = 0; b < kMaxB; ++b) red[b][op][kl] = dxp[b];
+  __syncthreads();
+  if (p.dx && op < p.B && k_ok) {  // thread (kl, op = image)
+    float v = 0.0f;
+#pragma unroll
+    for (int o2 = 0; o2 < 16; ++o2) v += red[op][o2][kl];
+    const float xv = p.x[(size_t)op * p.K + k];
+    p.dx[(size_t)op * p.K + k] = (p.mask_x && !(xv > 0.0f)) ? 0.0f : v;
+  }
+  if (blockIdx.x == 0) {
+    for (int o = tid; o < p.O; o += 256) {
+      float v = 0.0f;
+      for (int b = 0; b < p.B; ++b) v += p.dy[(size_t)b * p.O + o];
+      p.db[o] = v;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------- what the forward did not keep; permutes
+
+struct RecomputeParams {
+  const float* f1part; int s1;  // fc1's partial sums [B][s1][K2]
+  const float* f2part; int s2;  // fc2's            [B][s2][K3]
+  const float* b1; const float* b2; const float* w3; const float* b3;  // w3 [O3][K3]
+  const float* local2;          // [B][P][O3]
+  const float* dcoeffs;         // [B][P][gd][n_out][n_in]
+  float* x1; float* x2; float* g; float* fusion;  // [B][K2], [B][K3], [B][O3], [B][P][O3]
+  float* dyp;                   // [B][P][gd * n_out * n_in] in the prediction layer's channel order
+  int K2, K3, O3, P, gd, n_out, n_in;
+};
+
+// One workgroup per image (grid.x) and slab of cells (grid.y); every slab re-derives the (tiny) global features.
+__global__ __launch_bounds__(256) void coeff_recompute(const RecomputeParams p) {
+  __shared__ float x2s[512];
+  __shared__ float gs[256];
+  __shared__ float red[256];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const bool first = blockIdx.y == 0;
+  for (int k = tid; k < p.K2 && first; k += 256) {
+    float v = p.b1[k];
+    const float* s = p.f1part + (size_t)b * p.s1 * p.K2 + k;
+#pragma unroll 16
+    for (int i = 0; i < p.s1; ++i) v += s[(size_t)i * p.K2];
+    p.x1[(size_t)b * p.K2 + k] = fmaxf(v, 0.0f);
+  }
+  for (int k = tid; k < p.K3; k += 256) {
+    float v = p.b2[k];
+    const float* s = p.f2part + (size_t)b * p.s2 * p.K3 + k;
+#pragma unroll 16
+    for (int i = 0; i < p.s2; ++i) v += s[(size_t)i * p.K3];
+    v = fmaxf(v, 0.0f);
+    x2s[k] = v;
+    if (first) p.x2[(size_t)b * p.K3 + k] = v;
+  }
+  __syncthreads();
+  // g[c] = b3[c] + sum_k x2[k] w3[c][k]: thread = (channel, K part), the parts summed through LDS
+  const int parts = p.O3 <= 256 ? 256 / p.O3 : 1;  // O3 a power of two
+  for (int c0 = 0; c0 < p.O3; c0 += 256) {
+    const int c = c0 + tid / parts, kp = tid % parts;
+    const int nk = p.K3 / parts;
+    float v = 0.0f;
+    if (c < p.O3) {
+      const float* wr = p.w3 + (size_t)c * p.K3 + kp * nk;
+#pragma unroll 8
+      for (int k = 0; k < nk; ++k) v = __builtin_fmaf(x2s[kp * nk + k], wr[k], v);
+    }
+    red[tid] = v;
+    __syncthreads();
+    if (kp == 0 && c < p.O3) {
+      float t = p.b3[c];
+      for (int k = 0; k < parts; ++k) t += red[tid + k];
+      gs[c] = t;
+      if (first) p.g[(size_t)b * p.O3 + c] = t;
+    }
+    __syncthreads();
+  }
+  const int slabs = gridDim.y, per = (p.P + slabs - 1) / slabs;
+  const int px0 = blockIdx.y * per, px1 = min(px0 + per, p.P);
+  for (int i = px0 * p.O3 + tid; i < px1 * p.O3; i += 256) {
+    const int c = i % p.O3;
+    const size_t off = (size_t)b * p.P * p.O3 + i;
+    p.fusion[off] = fmaxf(p.local2[off] + gs[c], 0.0f);
+  }
+  const int C = p.gd * p.n_out * p.n_in;
+  for (int i = px0 * C + tid; i < px1 * C; i += 256) {
+    const int px = i / C, o = i - px * C;  // o = (j * n_out + ii) * gd + z
+    const int ji = o / p.gd, z = o - ji * p.gd;
+    const int jj = ji / p.n_out, ii = ji - jj * p.n_out;
+    p.dyp[(size_t)b * p.P * C + i] = p.dcoeffs[(((size_t)b * p.P + px) * p.gd + z) * p.n_out * p.n_in + ii * p.n_in + jj];
+  }
+}
+
+// dg_part[b][slab][c] = sum over the slab's 16 cells of df[b][px][c] * (fusion[b][px][c] > 0); dg = sum of the slabs
+// (coeff_slab_sum).  One load round per thread.
+__global__ __launch_bounds__(256) void coeff_masked_colsum(const float* __restrict__ df, const float* __restrict__ fusion,
+                                                          float* __restrict__ dg_part, int P, int C) {
+  const int b = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float v = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int px = slab * 16 + i;
+      if (px < P) {
+        const size_t off = ((size_t)b * P + px) * C + c;
+        v += fusion[off] > 0.0f ? df[off] : 0.0f;
+      }
+    }
+    dg_part[((size_t)b * nslab + slab) * C + c] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void coeff_slab_sum(const float* __restrict__ part, float* __restrict__ dg, int nslab, int C) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float v = 0.0f;
+#pragma unroll 8
+    for (int s = 0; s < nslab; ++s) v += part[((size_t)b * nslab + s) * C + c];
+    dg[(size_t)b * C + c] = v;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------- host
+
+struct Layer {  // one convolution of the network, forward geometry
+  const float* x; const float* y; const float* w;
+  float* dw; float* db;
+  int Hin, Cin, Hout, Cout, ks, stride;
+};
+
+int same_pad_before(int in, int out, int k, int s) {
+  const int total = (out - 1) * s + k - in;
+  return total > 0 ? total / 2 : 0;
+}
+
+struct PartPlan {
+  int tiles_x, tpi, total, tpc, nchunks;
+};
+
+PartPlan part_plan(int B, int Hout, int pairs) {
+  PartPlan pl;
+  pl.tiles_x = (Hout + kT - 1) / kT;
+  pl.tpi = pl.tiles_x * pl.tiles_x;
+  pl.total = pl.tpi * B;
+  // ~256 workgroups per layer at most (one per CU), at least one tile per wave
+  int nchunks = (pl.total + 3) / 4;
+  const int cap = 256 / (pairs > 0 ? pairs : 1) > 1 ? 256 / pairs : 1;
+  if (nchunks > cap) nchunks = cap;
+  pl.tpc = (pl.total + nchunks - 1) / nchunks;
+  pl.nchunks = (pl.total + pl.tpc - 1) / pl.tpc;
+  return pl;
+}
+
+size_t dw_part_floats(int B, const Layer& L) {
+  const int pairs = ((L.Cout + 15) / 16) * ((L.Cin + 15) / 16);
+  const PartPlan pl = part_plan(B, L.Hout, pairs);
+  return (size_t)pl.nchunks * ((size_t)L.Cout * L.ks * L.ks * L.Cin + L.Cout);
+}
+
+hipError_t launch_dw(const Layer& L, int B, const float* dy, const float* dy2, bool mask, float* part, ReduceTab* tab,
+                     hipStream_t s) {
+  const int ocb = (L.Cout + 15) / 16, icb = (L.Cin + 15) / 16;
+  const PartPlan pl = part_plan(B, L.Hout, ocb * icb);
+  DwParams p{};
+  p.x = L.x; p.dy = dy; p.dy2 = dy2; p.ymask = mask ? L.y : nullptr;
+  const size_t nw = (size_t)L.Cout * L.ks * L.ks * L.Cin;
+  p.dw_part = part;
+  p.db_part = L.db ? part + (size_t)pl.nchunks * nw : nullptr;
+  p.Hin = L.Hin; p.Win = L.Hin; p.Cin = L.Cin; p.Hout = L.Hout; p.Wout = L.Hout; p.Cout = L.Cout;
+  p.stride = L.stride;
+  p.pad_top = p.pad_left = same_pad_before(L.Hin, L.Hout, L.ks, L.stride);
+  p.tiles_x = pl.tiles_x; p.tiles_per_image = pl.tpi; p.tiles_total = pl.total; p.tiles_per_chunk = pl.tpc;
+  p.tx_mul = magic32(pl.tiles_x); p.tpi_mul = magic32(pl.tpi);
+  p.ic_blocks = icb;
+  const dim3 grid((unsigned)pl.nchunks, (unsigned)(ocb * icb));
+  if (L.ks == 3) coeff_conv_dw<3><<<grid, 256, 0, s>>>(p);
+  else coeff_conv_dw<1><<<grid, 256, 0, s>>>(p);
+  auto add = [&](const float* src, float* dst, int n) {
+    const int e = tab->count++;
+    tab->src[e] = src; tab->dst[e] = dst; tab->n[e] = n; tab->nsplit[e] = pl.nchunks;
+    tab->first[e + 1] = tab->first[e] + (n + 15) / 16;
+  };
+  add(p.dw_part, L.dw, (int)nw);
+  if (L.db) add(p.db_part, L.db, L.Cout);
+  return hipGetLastError();
+}
+
+hipError_t launch_dx(const Layer& L, int B, const float* dy, const float* dy2, bool mask, float* dx, hipStream_t s) {
+  DxParams p{};
+  p.dy = dy; p.dy2 = dy2; p.ymask = mask ? L.y : nullptr; p.w = L.w; p.dx = dx;
+  p.Hy = p.Wy = L.Hout; p.Cy = L.Cout; p.Hx = p.Wx = L.Hin; p.Cx = L.Cin;
+  p.ups = L.stride;
+  const int pad_f = same_pad_before(L.Hin, L.Hout, L.ks, L.stride);
+  p.pad_top = p.pad_left = L.ks - 1 - pad_f;
+  p.tiles_x = (L.Hin + kT - 1) / kT;
+  p.tiles = p.tiles_x * p.tiles_x;
+  p.oc_groups = (L.Cin + 15) / 16;
+  const int ti = kT - 1 + L.ks;
+  p.ti_mul = magic32(ti);
+  p.tx_mul = magic32(p.tiles_x);
+  const int cmax = L.Cout < kChunkCh ? L.Cout : kChunkCh;  // channels of the widest chunk
+  p.c4shift = 0;
+  while ((4 << p.c4shift) < cmax) ++p.c4shift;  // staged pixel = a power-of-two number of float4 (48 channels: 16)
+  p.nchunks = (L.Cout + kChunkCh - 1) / kChunkCh;  // the last chunk may be partial (a 96-channel prediction layer)
+  const int ps = (4 << p.c4shift) + 4, g16 = (cmax + 15) / 16, kk = L.ks * L.ks;
+  const int nsteps = kk * g16;
+  for (int wv = 0; wv < 4; ++wv) {
+    const int s0 = (wv * nsteps) / 4, s1 = ((wv + 1) * nsteps) / 4;
+    for (int k = 0; k < 12; ++k) p.lds_off[wv][k] = p.w_off[wv][k] = 0;
+    for (int st = s0; st < s1; ++st) {
+      const int tap = st / g16, grp = st - tap * g16;
+      const int ky = tap / L.ks, kx = tap - ky * L.ks;
+      p.lds_off[wv][st - s0] = (unsigned)((ky * ti + kx) * ps + 16 * grp) | ((unsigned)grp << 24);
+      p.w_off[wv][st - s0] = (unsigned)((16 * grp * kk + (kk - 1 - tap)) * L.Cin);
+    }
+    p.lds_off[wv][9] = (unsigned)(s1 - s0);
+  }
+  const size_t lds = ((size_t)ti * ti * ps + 4 * 4 * 64) * sizeof(float);
+  const dim3 grid((unsigned)p.tiles, (unsigned)p.oc_groups, (unsigned)B);
+  if (L.ks == 3) coeff_conv_dx<3><<<grid, 256, lds, s>>>(p);
+  else coeff_conv_dx<1><<<grid, 256, lds, s>>>(p);
+  return hipGetLastError();
+}
+
+struct BwdSpace {  // float offsets into the backward workspace
+  size_t x1, x2, g, fusion, dyp, df, dg, dgp, dx2, dx1, dg2, dl1, dg1, ds4a, ds4b, ds[8], parts, total;
+};
+
+BwdSpace bwd_space(const NetDims& d, const hdrnet_coeff_net& net, int B) {
+  BwdSpace w{};
+  size_t off = 0;
+  auto take = [&](size_t n) { const size_t o = off; off += (n + 3) & ~(size_t)3; return o; };
+  const size_t P = (size_t)d.sb * d.sb;
+  w.x1 = take((size_t)B * 4 * d.gl);
+  w.x2 = take((size_t)B * 2 * d.gl);
+  w.g = take((size_t)B * d.gl);
+  w.fusion = take(B * P * d.gl);
+  w.dyp = take(B * P * d.pred);
+  w.df = take(B * P * d.gl);
+  w.dg = take((size_t)B * d.gl);
+  w.dgp = take((size_t)B * ((P + 15) / 16) * d.gl);
+  w.dx2 = take((size_t)B * 2 * d.gl);
+  w.dx1 = take((size_t)B * 4 * d.gl);
+  const int g1side = (d.sb + 1) / 2;
+  w.dg2 = take((size_t)B * d.gside * d.gside * d.gl);
+  w.dl1 = take(B * P * d.gl);
+  w.dg1 = take((size_t)B * g1side * g1side * d.gl);
+  w.ds4a = take(B * P * d.feat);
+  w.ds4b = take(B * P * d.feat);
+  int side = d.N;
+  for (int i = 0; i + 1 < d.n_ds; ++i) {  // gradients of splat outputs 0 .. n_ds - 2
+    side /= 2;
+    w.ds[i] = take((size_t)B * side * side * ((d.cm * d.gd) << i));
+  }
+  // partial sums of every convolution's weight / bias gradient
+  size_t parts = 0;
+  side = d.N;
+  int cin = 3;
+  for (int i = 0; i < d.n_ds; ++i) {
+    Layer L{nullptr, nullptr, nullptr, nullptr, (float*)1, side, cin, side / 2, (d.cm * d.gd) << i, 3, 2};
+    parts += dw_part_floats(B, L);
+    side /= 2;
+    cin = L.Cout;
+  }
+  Layer l1{nullptr, nullptr, nullptr, nullptr, (float*)1, d.sb, d.feat, d.sb, d.gl, 3, 1};
+  Layer l2{nullptr, nullptr, nullptr, nullptr, nullptr, d.sb, d.gl, d.sb, d.gl, 3, 1};
+  Layer c1{nullptr, nullptr, nullptr, nullptr, (float*)1, d.sb, d.feat, g1side, d.gl, 3, 2};
+  Layer c2{nullptr, nullptr, nullptr, nullptr, (float*)1, g1side, d.gl, d.gside, d.gl, 3, 2};
+  Layer pr{nullptr, nullptr, nullptr, nullptr, (float*)1, d.sb, d.gl, d.sb, d.pred, 1, 1};
+  parts += dw_part_floats(B, l1) + dw_part_floats(B, l2) + dw_part_floats(B, c1) + dw_part_floats(B, c2) + dw_part_floats(B, pr);
+  (void)net;
+  w.parts = take(parts);
+  w.total = off;
+  return w;
+}
+
+bool train_supported(const hdrnet_coeff_net& net, int B, NetDims* d) {
+  if (!net_dims(net, d)) return false;
+  if (B < 1 || B > kMaxB || net.n_levels != 1 || net.fc_layout != 1) return false;
+  if (d->gl > 256) return false;  // coeff_recompute's shared arrays
+  return true;
+}
+
+}  // namespace
+
+size_t coefficients_grad_workspace_bytes(const hdrnet_coeff_net& net, int B) {
+  NetDims d;
+  if (!train_supported(net, B, &d)) return 0;
+  return bwd_space(d, net, B).total * sizeof(float);
+}
+
+// `fwd_ws`: the workspace a forward launch_coefficients() call with the same net and B left behind.
+hipError_t launch_coefficients_grad(const float* lowres, const hdrnet_coeff_net& net, const hdrnet_coeff_net_grads& gr,
+                                    const float* dcoeffs, int B, const void* fwd_ws, void* workspace, hipStream_t s,
+                                    const char** name) {
+  NetDims d;
+  if (!train_supported(net, B, &d)) return hipErrorInvalidValue;
+  *name = "coeff_net_grad";
+  const NetWorkspace fw = net_workspace(d);
+  const float* fbase = static_cast<const float*>(fwd_ws);
+  auto fbuf = [&](size_t off) { return fbase + off * (size_t)B; };
+  const BwdSpace bs = bwd_space(d, net, B);
+  float* base = static_cast<float*>(workspace);
+  auto buf = [&](size_t off) { return base + off; };
+  const int P = d.sb * d.sb, g1side = (d.sb + 1) / 2;
+  const int K1 = d.gside * d.gside * d.gl;
+  hipError_t e;
+
+  // the forward's activations
+  const float* S[8];
+  for (int i = 0; i < d.n_ds; ++i) S[i] = fbuf(fw.splat[i]);
+  const float* L1 = fbuf(fw.local1);
+  const float* L2 = fbuf(fw.local2);
+  const float* G1 = fbuf(fw.g1);
+  const float* G2 = fbuf(fw.g2);
+
+  // ---- what the forward did not keep + the incoming gradient in the prediction layer's channel order
+  {
+    RecomputeParams p{fbuf(fw.fc1), fw.s1, fbuf(fw.fc2), fw.s2, net.fc_b[0], net.fc_b[1], net.fc_w[2], net.fc_b[2], L2,
+                      dcoeffs, buf(bs.x1), buf(bs.x2), buf(bs.g), buf(bs.fusion), buf(bs.dyp),
+                      4 * d.gl, 2 * d.gl, d.gl, P, d.gd, net.n_out, net.n_in};
+    coeff_recompute<<<dim3((unsigned)B, 8), 256, 0, s>>>(p);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  ReduceTab tab{};
+  tab.count = 0;
+  tab.first[0] = 0;
+  float* parts = buf(bs.parts);
+  auto dw = [&](const Layer& L, const float* dy, const float* dy2, bool mask) -> hipError_t {
+    const hipError_t r = launch_dw(L, B, dy, dy2, mask, parts, &tab, s);
+    parts += dw_part_floats(B, L);
+    return r;
+  };
+  // ---- prediction layer (1x1 on the fusion; its own output has no ReLU)
+  const Layer pr{buf(bs.fusion), nullptr, net.pred_w, gr.pred_w, gr.pred_b, d.sb, d.gl, d.sb, d.pred, 1, 1};
+  if ((e = dw(pr, buf(bs.dyp), nullptr, false)) != hipSuccess) return e;
+  if ((e = launch_dx(pr, B, buf(bs.dyp), nullptr, false, buf(bs.df), s)) != hipSuccess) return e;
+  // ---- fusion = relu(local2 + g): d local2 = df masked (applied by the consumers), dg = its sum over the cells
+  {
+    const int nslab = (P + 15) / 16;
+    coeff_masked_colsum<<<dim3((unsigned)B, (unsigned)nslab), 256, 0, s>>>(buf(bs.df), buf(bs.fusion), buf(bs.dgp), P, d.gl);
+    coeff_slab_sum<<<dim3((unsigned)B), 256, 0, s>>>(buf(bs.dgp), buf(bs.dg), nslab, d.gl);
+  }
+  // ---- fully connected layers
+  {
+    FcBwdParams f3{buf(bs.x2), buf(bs.dg), net.fc_w[2], gr.fc_w[2], gr.fc_b[2], buf(bs.dx2), B, 2 * d.gl, d.gl, 1};
+    coeff_fc_bwd<<<dim3((unsigned)((2 * d.gl + 15) / 16)), 256, 0, s>>>(f3);
+    FcBwdParams f2{buf(bs.x1), buf(bs.dx2), net.fc_w[1], gr.fc_w[1], gr.fc_b[1], buf(bs.dx1), B, 4 * d.gl, 2 * d.gl, 1};
+    coeff_fc_bwd<<<dim3((unsigned)((4 * d.gl + 15) / 16)), 256, 0, s>>>(f2);
+    FcBwdParams f1{G2, buf(bs.dx1), net.fc_w[0], gr.fc_w[0], gr.fc_b[0], buf(bs.dg2), B, K1, 4 * d.gl, 0};
+    coeff_fc_bwd<<<dim3((unsigned)((K1 + 15) / 16)), 256, 0, s>>>(f1);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  // ---- local path: local2 (no bias, no ReLU on its own output: the fusion's mask), local1
+  const Layer l2{L1, buf(bs.fusion), net.local_w[1], gr.local_w[1], nullptr, d.sb, d.gl, d.sb, d.gl, 3, 1};
+  if ((e = dw(l2, buf(bs.df), nullptr, true)) != hipSuccess) return e;
+  if ((e = launch_dx(l2, B, buf(bs.df), nullptr, true, buf(bs.dl1), s)) != hipSuccess) return e;
+  const float* feat = S[d.n_ds - 1];
+  const Layer l1{feat, L1, net.local_w[0], gr.local_w[0], gr.local_b[0], d.sb, d.feat, d.sb, d.gl, 3, 1};
+  if ((e = dw(l1, buf(bs.dl1), nullptr, true)) != hipSuccess) return e;
+  if ((e = launch_dx(l1, B, buf(bs.dl1), nullptr, true, buf(bs.ds4a), s)) != hipSuccess) return e;
+  // ---- global path: conv2, conv1
+  const Layer c2{G1, G2, net.global_conv_w[1], gr.global_conv_w[1], gr.global_conv_b[1], g1side, d.gl, d.gside, d.gl, 3, 2};
+  if ((e = dw(c2, buf(bs.dg2), nullptr, true)) != hipSuccess) return e;
+  if ((e = launch_dx(c2, B, buf(bs.dg2), nullptr, true, buf(bs.dg1), s)) != hipSuccess) return e;
+  const Layer c1{feat, G1, net.global_conv_w[0], gr.global_conv_w[0], gr.global_conv_b[0], d.sb, d.feat, g1side, d.gl, 3, 2};
+  if ((e = dw(c1, buf(bs.dg1), nullptr, true)) != hipSuccess) return e;
+  if ((e = launch_dx(c1, B, buf(bs.dg1), nullptr, true, buf(bs.ds4b), s)) != hipSuccess) return e;
+  // ---- splat, last to first; the last layer's gradient is the sum of the two paths'
+  const float* dy = buf(bs.ds4a);
+  const float* dy2 = buf(bs.ds4b);
+  for (int i = d.n_ds - 1; i >= 0; --i) {
+    const int cout = (d.cm * d.gd) << i, cin = i > 0 ? (d.cm * d.gd) << (i - 1) : 3;
+    const int hin = d.N >> i;
+    const Layer L{i > 0 ? S[i - 1] : lowres, S[i], net.splat_w[i], gr.splat_w[i], gr.splat_b[i], hin, cin, hin / 2, cout, 3, 2};
+    if ((e = dw(L, dy, dy2, true)) != hipSuccess) return e;
+    if (i > 0) {
+      if ((e = launch_dx(L, B, dy, dy2, true, buf(bs.ds[i - 1]), s)) != hipSuccess) return e;
+      dy = buf(bs.ds[i - 1]);
+      dy2 = nullptr;
+    }
+  }
+  // ---- the chunks' partial sums of every weight / bias gradient
+  coeff_reduce_parts<<<dim3((unsigned)tab.first[tab.count]), 256, 0, s>>>(tab);
+  return hipGetLastError();
+}
+
+}  // namespace hdrnet_amd

@@ -238,5 +238,10 @@ bool coefficients_supported(const hdrnet_coeff_net& net);
 size_t coefficients_workspace_bytes(const hdrnet_coeff_net& net, int B);  // 0: unsupported hyper-parameters
 hipError_t launch_coefficients(const float* lowres, const hdrnet_coeff_net& net, float* coeffs, int B, void* workspace,
                                hipStream_t s, const char** name);
+// coeff_net_train.hip -- its VJP with respect to the parameters (no batch norm); fwd_ws = the forward's workspace.
+size_t coefficients_grad_workspace_bytes(const hdrnet_coeff_net& net, int B);  // 0: not supported
+hipError_t launch_coefficients_grad(const float* lowres, const hdrnet_coeff_net& net, const hdrnet_coeff_net_grads& gr,
+                                    const float* dcoeffs, int B, const void* fwd_ws, void* workspace, hipStream_t s,
+                                    const char** name);
 
 }  // namespace hdrnet_amd

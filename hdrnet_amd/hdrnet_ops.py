@@ -36,7 +36,8 @@ from . import _lib
 
 __all__ = ["bilateral_slice", "bilateral_slice_apply", "bilateral_slice_apply_rows", "bilateral_slice_apply_nnguide",
            "bilateral_slice_apply_io", "bilateral_slice_apply_curves", "bilateral_slice_apply_upadd", "resize_bilinear", "input_moments",
-           "CoefficientWeights", "coefficients", "guide_fold_batch", "kernel_override", "last_kernel"]
+           "CoefficientWeights", "coefficients", "coefficients_train", "coefficients_train_supported", "guide_fold_batch",
+           "kernel_override", "last_kernel"]
 
 _tls = threading.local()
 
@@ -640,6 +641,114 @@ def coefficients(lowres_input: torch.Tensor, weights: CoefficientWeights) -> tor
                                          ws.data_ptr(), wbytes, _stream(dev))
     _lib.check(rc, "Coefficients")
     return out
+
+
+def _live_net(hyper, n_out: int, n_in: int, params, n_splat: int):
+    """``hdrnet_coeff_net`` over the module's LIVE parameters (no copies): Conv2d weights must be in channels_last memory
+    order (= [Cout][kh][kw][Cin]), Linear weights are taken as they are (fc_layout = 1).  ``params`` in the order
+    splat (w, b) x n_splat, global conv (w, b) x 2, fc (w, b) x 3, local1 (w, b), local2 w, prediction (w, b)."""
+    net = _lib.CoeffNet()
+    net.net_input_size, net.spatial_bin = int(hyper["net_input_size"]), int(hyper["spatial_bin"])
+    net.luma_bins, net.channel_multiplier = int(hyper["luma_bins"]), int(hyper["channel_multiplier"])
+    net.n_out, net.n_in, net.n_levels, net.fc_layout = int(n_out), int(n_in), 1, 1
+    it = iter(params)
+    for i in range(n_splat):
+        net.splat_w[i], net.splat_b[i] = next(it).data_ptr(), next(it).data_ptr()
+    for i in range(2):
+        net.global_conv_w[i], net.global_conv_b[i] = next(it).data_ptr(), next(it).data_ptr()
+    for i in range(3):
+        net.fc_w[i], net.fc_b[i] = next(it).data_ptr(), next(it).data_ptr()
+    net.local_w[0], net.local_b[0] = next(it).data_ptr(), next(it).data_ptr()
+    net.local_w[1] = next(it).data_ptr()
+    net.pred_w, net.pred_b = next(it).data_ptr(), next(it).data_ptr()
+    return net
+
+
+def _params_ok(params) -> bool:
+    for p in params:
+        if p.dtype != torch.float32 or not p.is_cuda:
+            return False
+        if p.dim() == 4:
+            if not p.is_contiguous(memory_format=torch.channels_last):
+                return False
+        elif not p.is_contiguous():
+            return False
+    return True
+
+
+def coefficients_train_supported(hyper, n_out: int, n_in: int, params, n_splat: int, batch: int) -> bool:
+    """True if ``coefficients_train`` can run this network (no batch norm is the caller's business): parameters fp32 on
+    the GPU in torch's own layouts, hyper-parameters and batch within the kernels' reach."""
+    import ctypes
+    params = list(params)
+    if len(params) != 2 * n_splat + 4 + 6 + 2 + 1 + 2 or not _params_ok(params):
+        return False
+    net = _live_net(hyper, n_out, n_in, params, n_splat)
+    return _lib.load().hdrnet_coefficients_grad_workspace_bytes(ctypes.byref(net), int(batch)) > 0
+
+
+class _CoefficientsTrain(torch.autograd.Function):
+    """Forward = the inference launch sequence on the live parameters, its workspace kept; backward =
+    ``hdrnet_coefficients_grad_f32`` (csrc/coeff_net_train.hip)."""
+
+    @staticmethod
+    def forward(ctx, lowres, hyper, n_out, n_in, n_splat, *params):
+        import ctypes
+        low = lowres.detach().contiguous()
+        B, dev = low.shape[0], low.device
+        net = _live_net(hyper, n_out, n_in, params, n_splat)
+        sb, gd = int(hyper["spatial_bin"]), int(hyper["luma_bins"])
+        out = torch.empty((B, sb, sb, gd, n_out, n_in), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            wbytes = lib.hdrnet_coefficients_workspace_bytes(ctypes.byref(net), B)
+            ws = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=dev)
+            rc = lib.hdrnet_coefficients_f32(low.data_ptr(), ctypes.byref(net), out.data_ptr(), B, ws.data_ptr(), wbytes,
+                                             _stream(dev))
+        _lib.check(rc, "Coefficients")
+        ctx.save_for_backward(low, ws, *params)
+        ctx.meta = (dict(hyper), int(n_out), int(n_in), int(n_splat))
+        return out
+
+    @staticmethod
+    def backward(ctx, dcoeffs):
+        import ctypes
+        low, ws = ctx.saved_tensors[:2]
+        params = ctx.saved_tensors[2:]
+        hyper, n_out, n_in, n_splat = ctx.meta
+        B, dev = low.shape[0], low.device
+        net = _live_net(hyper, n_out, n_in, params, n_splat)
+        grads = [torch.empty_like(p) for p in params]  # preserve_format: channels_last weights get channels_last grads
+        gr = _lib.CoeffNetGrads()
+        it = iter(grads)
+        for i in range(n_splat):
+            gr.splat_w[i], gr.splat_b[i] = next(it).data_ptr(), next(it).data_ptr()
+        for i in range(2):
+            gr.global_conv_w[i], gr.global_conv_b[i] = next(it).data_ptr(), next(it).data_ptr()
+        for i in range(3):
+            gr.fc_w[i], gr.fc_b[i] = next(it).data_ptr(), next(it).data_ptr()
+        gr.local_w[0], gr.local_b[0] = next(it).data_ptr(), next(it).data_ptr()
+        gr.local_w[1] = next(it).data_ptr()
+        gr.pred_w, gr.pred_b = next(it).data_ptr(), next(it).data_ptr()
+        dc = dcoeffs.contiguous()
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            wbytes = lib.hdrnet_coefficients_grad_workspace_bytes(ctypes.byref(net), B)
+            ws2 = torch.empty((max(wbytes, 16),), dtype=torch.uint8, device=dev)
+            rc = lib.hdrnet_coefficients_grad_f32(low.data_ptr(), ctypes.byref(net), ws.data_ptr(), dc.data_ptr(),
+                                                  ctypes.byref(gr), B, ws2.data_ptr(), wbytes, _stream(dev))
+        _lib.check(rc, "CoefficientsGrad")
+        return (None, None, None, None, None, *grads)
+
+
+def coefficients_train(lowres_input: torch.Tensor, hyper, n_out: int, n_in: int, params, n_splat: int) -> torch.Tensor:
+    """``HDRNetCurves._coefficients`` (hdrnet/models.py:62-142) WITHOUT batch norm, differentiable in its parameters:
+    forward and backward on the HIP kernels of csrc/coeff_net.hip / coeff_net_train.hip, reading the parameters and
+    writing their gradients in torch's own layouts.  ``lowres_input [B, N, N, 3]`` (no gradient) ->
+    ``[B, sb, sb, gd, n_out, n_in]``."""
+    _require_f32("lowres_input", lowres_input)
+    _require_gpu("lowres_input", lowres_input)
+    return _CoefficientsTrain.apply(lowres_input, hyper, n_out, n_in, n_splat, *params)
 
 
 def resize_bilinear(input: torch.Tensor, height: int, width: int) -> torch.Tensor:  # noqa: A002

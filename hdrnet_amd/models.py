@@ -212,6 +212,40 @@ class _Coefficients(nn.Module):
             return False
         return self.exported().supported(max(int(lowres_nhwc.shape[0]), 1))
 
+    # Training (and any differentiable evaluation) of the network WITHOUT batch norm -- the reference's own training
+    # configuration for the guide-network model (scripts/ll/train_nn_guide.sh) -- on the HIP kernels as well: forward
+    # + backward in ~35 launches instead of ~130 stock-op launches.  With batch norm, or when the input itself needs a
+    # gradient, the torch ops below run.  ``native_training = False`` forces them.
+    native_training = True
+
+    def _train_params(self):
+        convs = list(self.splat) + list(self.global_conv)
+        ps = []
+        for layer in convs:
+            ps += [layer.conv.weight, layer.conv.bias]
+        for layer in (self.fc1, self.fc2, self.fc3):
+            ps += [layer.fc.weight, layer.fc.bias]
+        ps += [self.local1.conv.weight, self.local1.conv.bias, self.local2.conv.weight,
+               self.pred.conv.weight, self.pred.conv.bias]
+        return ps
+
+    def _use_native_training(self, lowres_nhwc: torch.Tensor) -> bool:
+        if not (self.native and self.native_training and lowres_nhwc.is_cuda and lowres_nhwc.dtype == torch.float32):
+            return False
+        if not torch.is_grad_enabled() or lowres_nhwc.requires_grad or self.n_levels != 1:
+            return False
+        if any(m.bn is not None for m in self.modules() if isinstance(m, (_Conv, _FC))):
+            return False
+        N = self.hyper["net_input_size"]
+        if lowres_nhwc.dim() != 4 or tuple(lowres_nhwc.shape[1:]) != (N, N, 3):
+            return False
+        ps = self._train_params()
+        if any(p is None for p in ps) or not any(p.requires_grad for p in ps):
+            return False
+        from . import hdrnet_ops
+        return hdrnet_ops.coefficients_train_supported(self.hyper, self.n_out, self.n_in, ps, len(self.splat),
+                                                       int(lowres_nhwc.shape[0]))
+
     def levels(self, lowres_nhwc: torch.Tensor) -> List[torch.Tensor]:
         """Per pyramid level the 5-D grid ``[B, GH, GW, gd, (n_out / n_levels) * n_in]`` of
         ``coeffs[:, :, :, :, l*k:(l+1)*k, :]`` (hdrnet/models.py:279), each contiguous."""
@@ -226,6 +260,10 @@ class _Coefficients(nn.Module):
         return [coeffs[:, :, :, :, l * k:(l + 1) * k, :].reshape(gs[0], gs[1], gs[2], gs[3], k * gs[5]) for l in range(L)]
 
     def forward(self, lowres_nhwc: torch.Tensor) -> torch.Tensor:
+        if self._use_native_training(lowres_nhwc):
+            from . import hdrnet_ops
+            return hdrnet_ops.coefficients_train(lowres_nhwc, self.hyper, self.n_out, self.n_in, self._train_params(),
+                                                 len(self.splat))
         if self._use_native(lowres_nhwc):
             from . import hdrnet_ops
             out = hdrnet_ops.coefficients(lowres_nhwc, self.exported())

@@ -361,9 +361,37 @@ typedef struct hdrnet_coeff_net {
   const float* local_b[2]; /* local_b[1] = NULL: the reference's use_bias=False (models.py:113-115) */
   const float* pred_w;
   const float* pred_b;
+  int fc_layout; /* 0: fc weights [in][out] (TensorFlow's); 1: [out][in] (a torch Linear weight, as it is) */
 } hdrnet_coeff_net;
 
 size_t hdrnet_coefficients_workspace_bytes(const hdrnet_coeff_net* net, int B);
+
+/* Training side: the VJP of the coefficient network with respect to every weight and bias, for the model WITHOUT batch
+ * norm (how the reference's script trains the guide-network model: scripts/ll/train_nn_guide.sh, --nobatch_norm).
+ * Forward = hdrnet_coefficients_f32 with the parameters AS TORCH HOLDS THEM -- Conv2d weights in channels_last memory
+ * order ([Cout][kh][kw][Cin], the same layout as above) and fc_layout = 1 (Linear weights [out][in]) -- keeping its
+ * workspace: `forward_workspace` here is that buffer, untouched since.  `dcoeffs` is [B][sb][sb][gd][n_out][n_in];
+ * gradients are written (not accumulated) in the parameters' own layouts; local_b[1] is ignored (no such bias).
+ * ~26 launches on `stream`, deterministic.  Supported: what the forward supports, n_levels = 1, fc_layout = 1,
+ * B <= 8, 8 * cm * gd <= 256; hdrnet_coefficients_grad_workspace_bytes returns 0 otherwise. */
+typedef struct hdrnet_coeff_net_grads {
+  float* splat_w[8];
+  float* splat_b[8];
+  float* global_conv_w[2];
+  float* global_conv_b[2];
+  float* fc_w[3];
+  float* fc_b[3];
+  float* local_w[2];
+  float* local_b[2];
+  float* pred_w;
+  float* pred_b;
+} hdrnet_coeff_net_grads;
+
+size_t hdrnet_coefficients_grad_workspace_bytes(const hdrnet_coeff_net* net, int B);
+
+int hdrnet_coefficients_grad_f32(const float* lowres, const hdrnet_coeff_net* net, const void* forward_workspace,
+                                 const float* dcoeffs, const hdrnet_coeff_net_grads* grads, int B, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 
 int hdrnet_coefficients_f32(const float* lowres, const hdrnet_coeff_net* net, float* coeffs, int B,
                             void* workspace, size_t workspace_bytes, void* stream);

@@ -277,3 +277,72 @@ def test_training_mode_and_autograd_stay_on_the_stock_ops():
     assert not m.coefficients._use_native(low)  # grad mode on, parameters require grad
     with torch.no_grad():
         assert m.coefficients._use_native(low)
+
+
+TRAIN_CASES = {
+    "default_b4": (dict(), 4),
+    "default_b1": (dict(), 1),
+    "grid32_b2": (dict(spatial_bin=32), 2),
+    "bins4_b3": (dict(luma_bins=4), 3),
+    "small_b8": (dict(spatial_bin=8, net_input_size=128), 8),
+    "cm2_b2": (dict(channel_multiplier=2), 2),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(TRAIN_CASES))
+def test_native_training_gradients_vs_float64(case):
+    """Forward + backward of the coefficient network (no batch norm) on the HIP kernels against torch autograd over the
+    same module: every parameter gradient, judged against a float64 evaluation on the CPU."""
+    params, B = TRAIN_CASES[case]
+    torch.manual_seed(21)
+    m = randomize(models.HDRNetPointwiseNNGuide(dict(batch_norm=False, **params)), seed=7)
+    N = m.params["net_input_size"]
+    low = torch.rand(B, N, N, 3)
+    ref = copy.deepcopy(m.coefficients).double()
+    out64 = ref(low.double())
+    wts = torch.randn(out64.shape, dtype=torch.float64)
+    (out64 * wts).sum().backward()
+    net = m.coefficients.to("cuda:0")
+    lowd, wd = low.cuda(), wts.float().cuda()
+    assert net._use_native_training(lowd)
+    out = net(lowd)
+    assert out.grad_fn is not None and "CoefficientsTrain" in type(out.grad_fn).__name__
+    (out * wd).sum().backward()
+    native = {n: p.grad.clone() for n, p in net.named_parameters()}
+    for p in net.parameters():
+        p.grad = None
+    net.native_training = False
+    out_t = net(lowd)
+    (out_t * wd).sum().backward()
+    net.native_training = True
+    scale_o = float(out64.abs().max())
+    assert float((out.detach().cpu().double() - out64).abs().max()) <= 1e-5 * scale_o
+    worst = 0.0
+    for (name, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        g64 = q.grad
+        scale = float(g64.abs().max()) + 1e-30
+        e_nat = float((native[name].cpu().double() - g64).abs().max()) / scale
+        e_tor = float((p.grad.cpu().double() - g64).abs().max()) / scale
+        worst = max(worst, e_nat)
+        assert native[name].stride() == p.stride(), name
+        assert e_nat <= 2e-5 + 2.0 * e_tor, (name, e_nat, e_tor)
+    print(f"{case}: worst relative gradient error of the HIP path {worst:.2e}")
+
+
+@pytest.mark.gpu
+def test_native_training_is_deterministic_and_falls_back_with_batch_norm():
+    torch.manual_seed(3)
+    m = randomize(models.HDRNetPointwiseNNGuide(dict(batch_norm=False)), seed=1).to("cuda:0")
+    low = torch.rand(4, 256, 256, 3, device="cuda:0")
+    grads = []
+    for _ in range(2):
+        for p in m.parameters():
+            p.grad = None
+        m.coefficients(low).square().sum().backward()
+        grads.append([p.grad.clone() for p in m.coefficients.parameters()])
+    assert all(torch.equal(a, b) for a, b in zip(*grads))
+    mb = models.HDRNetPointwiseNNGuide(dict(batch_norm=True)).to("cuda:0")
+    assert not mb.coefficients._use_native_training(low)
+    low.requires_grad_(True)
+    assert not m.coefficients._use_native_training(low)  # the input's own gradient: torch ops
