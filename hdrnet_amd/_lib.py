@@ -46,6 +46,9 @@ SIGNATURES = {
     "hdrnet_curves_guide_grad_f32": (_I, [_FP] * 7 + [_I] + [_FP] * 4 + [ctypes.c_longlong, _I, _I, _VP, _SZ, _VP]),
     "hdrnet_input_moments_workspace_bytes": (_SZ, [ctypes.c_longlong, _I]),
     "hdrnet_input_moments_f32": (_I, [_FP, ctypes.c_longlong, _I, _FP, _FP, _VP, _SZ, _VP]),
+    "hdrnet_l2_loss_workspace_bytes": (_SZ, [ctypes.c_longlong]),
+    "hdrnet_l2_loss_f32": (_I, [_FP, _FP, ctypes.c_longlong, _FP, _VP, _SZ, _VP]),
+    "hdrnet_l2_loss_grad_f32": (_I, [_FP, _FP, _FP, ctypes.c_longlong, _FP, _VP]),
     "hdrnet_guide_fold_batch_f32": (_I, [_FP, _FP, ctypes.c_longlong] + [_FP] * 5 + [ctypes.c_double, ctypes.c_double, _I, _I] + [_FP] * 5 + [_VP]),
     "hdrnet_guide_fold_batch_grad_f32": (_I, [_FP, _FP, ctypes.c_longlong] + [_FP] * 3 + [ctypes.c_double, _I, _I] + [_FP] * 6 + [_VP]),
     "hdrnet_coefficients_workspace_bytes": (_SZ, [_VP, _I]),

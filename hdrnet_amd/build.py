@@ -46,6 +46,7 @@ SOURCES = [
     ("resize_bilinear.hip", []),
     ("coeff_net.hip", []),
     ("coeff_net_train.hip", []),
+    ("metrics.hip", []),
 ]
 TOOLS_ONLY_SOURCES = [
     ("apply_fwd_variants.hip", ["-fno-slp-vectorize"]),

@@ -96,7 +96,7 @@ int variant(unsigned flags) { return (int)((flags >> 8) & 0xffu); }
 
 extern "C" {
 
-int hdrnet_version(void) { return 210; /* 0.2.1: + the coefficient network (hdrnet_coefficients_f32) */ }
+int hdrnet_version(void) { return 220; /* 0.2.2: + the coefficient network (inference, gradients), guide fold, l2 loss */ }
 
 const char* hdrnet_last_error(void) { return g_error; }
 
@@ -417,6 +417,36 @@ int hdrnet_guide_fold_batch_grad_f32(const float* sums, const float* moments, lo
                                                            static_cast<hipStream_t>(stream)),
                               "GuideFoldBatchGrad");
   if (rc == HDRNET_OK) set_kernel("guide_fold_batch_grad");
+  return rc;
+}
+
+size_t hdrnet_l2_loss_workspace_bytes(long long n) { return hdrnet_amd::l2_loss_workspace_bytes(n); }
+
+int hdrnet_l2_loss_f32(const float* prediction, const float* target, long long n, float* loss, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+  using namespace hdrnet_amd;
+  if (n <= 0) return fail(HDRNET_INVALID_ARGUMENT, "l2 loss of an empty tensor (n=%lld)", n);
+  if (!prediction || !target || !loss) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  if ((((uintptr_t)prediction | (uintptr_t)target) & 15u) || !workspace || workspace_bytes < l2_loss_workspace_bytes(n))
+    return fail(HDRNET_INVALID_ARGUMENT, "l2 loss needs 16-B aligned tensors and a workspace of "
+                                         "hdrnet_l2_loss_workspace_bytes()");
+  const int rc = check_launch(launch_l2_loss(prediction, target, n, loss, workspace, static_cast<hipStream_t>(stream)),
+                              "L2Loss");
+  if (rc == HDRNET_OK) set_kernel("l2_loss");
+  return rc;
+}
+
+int hdrnet_l2_loss_grad_f32(const float* prediction, const float* target, const float* grad_output, long long n,
+                            float* dprediction, void* stream) {
+  using namespace hdrnet_amd;
+  if (n <= 0) return fail(HDRNET_INVALID_ARGUMENT, "l2 loss of an empty tensor (n=%lld)", n);
+  if (!prediction || !target || !grad_output || !dprediction) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  if (((uintptr_t)prediction | (uintptr_t)target | (uintptr_t)dprediction) & 15u)
+    return fail(HDRNET_INVALID_ARGUMENT, "l2 loss needs 16-B aligned tensors");
+  const int rc = check_launch(launch_l2_loss_grad(prediction, target, grad_output, n, dprediction,
+                                                  static_cast<hipStream_t>(stream)),
+                              "L2LossGrad");
+  if (rc == HDRNET_OK) set_kernel("l2_loss_grad");
   return rc;
 }
 

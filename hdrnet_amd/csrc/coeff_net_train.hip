@@ -174,6 +174,76 @@ __global__ __launch_bounds__(256) void coeff_conv_dw(const DwParams p) {
   }
 }
 
+// Backward-weights of the FIRST splat layer (3x3, stride 2, Cin = 3, Cout <= 9): K = 27 per output channel is no
+// matrix-core shape -- on coeff_conv_dw the 16 x 16 tile is 9 % full and its 40 four-byte gathers per tile and lane
+// make the launch address-bound (36 us at 4 x 128 x 128 output pixels).  Here thread = (output channel, tap x input
+// channel | bias), the 8 x 8 output pixels of a tile and their 17 x 17 x 3 input patch staged in LDS; a thread's 64
+// products per tile read two LDS words each.
+struct DwFirstParams {
+  const float* x;      // [B][Hin][Win][3]
+  const float* dy;     // [B][Hout][Wout][Cout]
+  const float* ymask;  // the layer's output (ReLU mask)
+  float* dw_part;      // [nchunks][Cout][9][3]
+  float* db_part;      // [nchunks][Cout]
+  int Hin, Win, Hout, Wout, Cout, pad_top, pad_left;
+  int tiles_x, tiles_per_image, tiles_total, tiles_per_chunk;
+  unsigned tx_mul, tpi_mul;
+};
+
+__global__ __launch_bounds__(256) void coeff_conv_dw_first(const DwFirstParams p) {
+  constexpr int T8 = 8, TI = 17;
+  __shared__ float xs[TI * TI * 3];
+  __shared__ float ys[T8 * T8 * 9];
+  const int tid = threadIdx.x;
+  const int oc = tid / 28, tt = tid - oc * 28;  // tt < 27: (tap, ic); tt == 27: the bias
+  const bool on = oc < p.Cout;
+  const int tap = tt / 3, ic = tt - tap * 3;
+  const int xoff = tt < 27 ? ((tap / 3) * TI + (tap % 3)) * 3 + ic : 0;
+  const int chunk = blockIdx.x;
+  const int t_end = min((chunk + 1) * p.tiles_per_chunk, p.tiles_total);
+  float acc = 0.0f;
+  for (int t = chunk * p.tiles_per_chunk; t < t_end; ++t) {
+    const int b = udiv(t, p.tpi_mul, p.tiles_per_image);
+    const int r = t - b * p.tiles_per_image;
+    const int ty = udiv(r, p.tx_mul, p.tiles_x), tx = r - ty * p.tiles_x;
+    const int oy0 = ty * T8, ox0 = tx * T8;
+    const int iy0 = oy0 * 2 - p.pad_top, ix0 = ox0 * 2 - p.pad_left;
+    __syncthreads();  // the previous tile has been consumed
+    for (int i = tid; i < TI * TI * 3; i += 256) {
+      const int pix = i / 3, c = i - pix * 3;
+      const int py = pix / TI, px = pix - py * TI;
+      const int gy = iy0 + py, gx = ix0 + px;
+      const bool ok = (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
+      xs[i] = ok ? p.x[(((size_t)b * p.Hin + gy) * p.Win + gx) * 3 + c] : 0.0f;
+    }
+    for (int i = tid; i < T8 * T8 * p.Cout; i += 256) {
+      const int pix = i / p.Cout, c = i - pix * p.Cout;
+      const int oy = oy0 + (pix >> 3), ox = ox0 + (pix & 7);
+      float v = 0.0f;
+      if (oy < p.Hout && ox < p.Wout) {
+        const size_t off = (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + c;
+        v = p.ymask[off] > 0.0f ? p.dy[off] : 0.0f;
+      }
+      ys[pix * 9 + c] = v;
+    }
+    __syncthreads();
+    if (on) {
+      if (tt < 27) {
+#pragma unroll 8
+        for (int pix = 0; pix < T8 * T8; ++pix)
+          acc = __builtin_fmaf(ys[pix * 9 + oc], xs[((pix >> 3) * 2 * TI + (pix & 7) * 2) * 3 + xoff], acc);
+      } else {
+#pragma unroll 8
+        for (int pix = 0; pix < T8 * T8; ++pix) acc += ys[pix * 9 + oc];
+      }
+    }
+  }
+  if (on) {
+    if (tt < 27) p.dw_part[((size_t)chunk * p.Cout + oc) * 27 + tt] = acc;
+    else p.db_part[(size_t)chunk * p.Cout + oc] = acc;
+  }
+}
+
 // Sums the chunks' partial results of every layer in one launch: entry e owns blocks [first[e], first[e + 1]).
 constexpr int kMaxParts = 32;
 struct ReduceTab {
@@ -554,16 +624,53 @@ PartPlan part_plan(int B, int Hout, int pairs) {
   return pl;
 }
 
+PartPlan part_plan_first(int B, int Hout);
+bool first_layer_shape(const Layer& L);
+
 size_t dw_part_floats(int B, const Layer& L) {
   const int pairs = ((L.Cout + 15) / 16) * ((L.Cin + 15) / 16);
   const PartPlan pl = part_plan(B, L.Hout, pairs);
-  return (size_t)pl.nchunks * ((size_t)L.Cout * L.ks * L.ks * L.Cin + L.Cout);
+  int nchunks = pl.nchunks;
+  if (first_layer_shape(L)) nchunks = nchunks > 256 ? nchunks : 256;  // either kernel's chunk count fits
+  return (size_t)nchunks * ((size_t)L.Cout * L.ks * L.ks * L.Cin + L.Cout);
+}
+
+bool first_layer_shape(const Layer& L) { return L.Cin == 3 && L.Cout <= 9 && L.ks == 3 && L.stride == 2; }
+
+PartPlan part_plan_first(int B, int Hout) {  // 8 x 8 pixel tiles, one workgroup per chunk, <= 256 chunks
+  PartPlan pl;
+  pl.tiles_x = (Hout + 7) / 8;
+  pl.tpi = pl.tiles_x * pl.tiles_x;
+  pl.total = pl.tpi * B;
+  int nchunks = pl.total < 256 ? pl.total : 256;
+  pl.tpc = (pl.total + nchunks - 1) / nchunks;
+  pl.nchunks = (pl.total + pl.tpc - 1) / pl.tpc;
+  return pl;
 }
 
 hipError_t launch_dw(const Layer& L, int B, const float* dy, const float* dy2, bool mask, float* part, ReduceTab* tab,
                      hipStream_t s) {
   const int ocb = (L.Cout + 15) / 16, icb = (L.Cin + 15) / 16;
-  const PartPlan pl = part_plan(B, L.Hout, ocb * icb);
+  const bool first = first_layer_shape(L) && !dy2 && mask && L.db;
+  const PartPlan pl = first ? part_plan_first(B, L.Hout) : part_plan(B, L.Hout, ocb * icb);
+  if (first) {
+    DwFirstParams f{};
+    const size_t nw1 = (size_t)L.Cout * 27;
+    f.x = L.x; f.dy = dy; f.ymask = L.y; f.dw_part = part; f.db_part = part + (size_t)pl.nchunks * nw1;
+    f.Hin = f.Win = L.Hin; f.Hout = f.Wout = L.Hout; f.Cout = L.Cout;
+    f.pad_top = f.pad_left = same_pad_before(L.Hin, L.Hout, 3, 2);
+    f.tiles_x = pl.tiles_x; f.tiles_per_image = pl.tpi; f.tiles_total = pl.total; f.tiles_per_chunk = pl.tpc;
+    f.tx_mul = magic32(pl.tiles_x); f.tpi_mul = magic32(pl.tpi);
+    coeff_conv_dw_first<<<dim3((unsigned)pl.nchunks), 256, 0, s>>>(f);
+    auto add1 = [&](const float* src, float* dst, int n) {
+      const int e = tab->count++;
+      tab->src[e] = src; tab->dst[e] = dst; tab->n[e] = n; tab->nsplit[e] = pl.nchunks;
+      tab->first[e + 1] = tab->first[e] + (n + 15) / 16;
+    };
+    add1(f.dw_part, L.dw, (int)nw1);
+    add1(f.db_part, L.db, L.Cout);
+    return hipGetLastError();
+  }
   DwParams p{};
   p.x = L.x; p.dy = dy; p.dy2 = dy2; p.ymask = mask ? L.y : nullptr;
   const size_t nw = (size_t)L.Cout * L.ks * L.ks * L.Cin;

@@ -233,6 +233,13 @@ hipError_t launch_guide_fold_batch_grad(const float* sums, const float* moments,
                                         const float* dconv1, const float* dconv2, float* dw1, float* dbeta, float* dw2,
                                         float* db2, hipStream_t s);
 
+// metrics.hip -- hdrnet/metrics.py's l2 loss and its gradient with respect to the prediction.
+size_t l2_loss_workspace_bytes(long long n);
+hipError_t launch_l2_loss(const float* pred, const float* target, long long n, float* loss, void* workspace,
+                          hipStream_t s);
+hipError_t launch_l2_loss_grad(const float* pred, const float* target, const float* grad_output, long long n,
+                               float* dpred, hipStream_t s);
+
 // coeff_net.hip -- the low-resolution coefficient network (hdrnet/models.py:62-142) as inference kernels.
 bool coefficients_supported(const hdrnet_coeff_net& net);
 size_t coefficients_workspace_bytes(const hdrnet_coeff_net& net, int B);  // 0: unsupported hyper-parameters

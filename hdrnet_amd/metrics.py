@@ -1,8 +1,9 @@
 """Image metrics of the reference's training loop (``hdrnet/metrics.py``), on torch tensors.
 
-``l2_loss`` is what ``hdrnet/bin/train.py:95`` minimises.  It is written with ``F.mse_loss`` -- ONE fused pass forward
-and one backward over the full-resolution batch; the literal ``(target - prediction).square().mean()`` is five
-bandwidth-bound passes over 100 MB each at 4 x 1080p (240 us of a 1.55-ms training step, profiles/r04/train_step.md).
+``l2_loss`` is what ``hdrnet/bin/train.py:95`` minimises.  The literal ``(target - prediction).square().mean()`` is
+five bandwidth-bound passes over 100 MB each at 4 x 1080p (240 us of a 1.55-ms training step); ``F.mse_loss`` still is
+five launches (the squares written out, a zeros_like of the gradient: 143 us); csrc/metrics.hip does it in two
+passes (profiles/r04/train_step.md).
 """
 from __future__ import annotations
 
@@ -14,8 +15,46 @@ import torch.nn.functional as F
 __all__ = ["l2_loss", "psnr"]
 
 
+class _L2Loss(torch.autograd.Function):
+    """``hdrnet_l2_loss_f32`` / ``hdrnet_l2_loss_grad_f32`` (csrc/metrics.hip): two HBM-bound passes."""
+
+    @staticmethod
+    def forward(ctx, prediction, target):
+        from . import _lib
+        p, t = prediction.detach().contiguous(), target.detach().contiguous()
+        dev, n = p.device, p.numel()
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            wbytes = lib.hdrnet_l2_loss_workspace_bytes(n)
+            ws = torch.empty((wbytes,), dtype=torch.uint8, device=dev)
+            rc = lib.hdrnet_l2_loss_f32(p.data_ptr(), t.data_ptr(), n, loss.data_ptr(), ws.data_ptr(), wbytes,
+                                        torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "L2Loss")
+        ctx.save_for_backward(p, t)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        from . import _lib
+        p, t = ctx.saved_tensors
+        dev = p.device
+        g = grad_output.detach().to(torch.float32).reshape(1).contiguous()
+        dpred = torch.empty_like(p)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            rc = lib.hdrnet_l2_loss_grad_f32(p.data_ptr(), t.data_ptr(), g.data_ptr(), p.numel(), dpred.data_ptr(),
+                                             torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "L2LossGrad")
+        return dpred, None
+
+
 def l2_loss(target: torch.Tensor, prediction: torch.Tensor) -> torch.Tensor:
-    """``tf.reduce_mean(tf.square(target - prediction))`` (hdrnet/metrics.py:8-11)."""
+    """``tf.reduce_mean(tf.square(target - prediction))`` (hdrnet/metrics.py:8-11).  On the GPU in fp32 with no
+    gradient wanted for the target: the two-pass HIP kernels; otherwise ``F.mse_loss``."""
+    if (prediction.is_cuda and target.is_cuda and prediction.dtype == torch.float32 and target.dtype == torch.float32
+            and prediction.shape == target.shape and not target.requires_grad and prediction.numel() > 0):
+        return _L2Loss.apply(prediction, target)
     return F.mse_loss(prediction, target)
 
 

@@ -301,6 +301,17 @@ int hdrnet_bilateral_slice_grad_f32_ex(const float* grid, const float* guide,
                                        void* workspace, size_t workspace_bytes,
                                        unsigned flags, void* stream);
 
+/* The training loop's l2 loss (hdrnet/metrics.py:8-11: reduce_mean(square(target - prediction)); minimised by
+ * hdrnet/bin/train.py:95) over n fp32 elements, and its gradient with respect to the prediction:
+ *   loss[0] = sum((prediction - target)^2) / n        (one pass over both tensors + a 2048-element reduction)
+ *   dprediction = (2 / n) * grad_output[0] * (prediction - target)   (grad_output: a DEVICE scalar, the loss's upstream
+ *   gradient -- no host synchronisation).  16-B aligned tensors. */
+size_t hdrnet_l2_loss_workspace_bytes(long long n);
+int hdrnet_l2_loss_f32(const float* prediction, const float* target, long long n, float* loss, void* workspace,
+                       size_t workspace_bytes, void* stream);
+int hdrnet_l2_loss_grad_f32(const float* prediction, const float* target, const float* grad_output, long long n,
+                            float* dprediction, void* stream);
+
 /* Training-mode fold of the guide network's batch norm into its first layer, from the input's moments
  * (hdrnet_input_moments_f32): the statistics of the first convolution's never-materialised output are
  *   mean_h = w1^T mean_x,  var_h[k] = w1[:,k]^T Cov_x w1[:,k]  (biased),  inv = gamma / sqrt(var_h + eps)

@@ -930,3 +930,22 @@ def test_guide_fold_batch_kernel_equals_the_torch_fold(cin, n):
     g.folded_batch(sums, mom, x.shape[0])
     g.eval()
     assert g.folded() is not a
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4, 270, 480, 3), (1, 7, 5, 3), (3, 33, 41, 1)])
+def test_l2_loss_kernels_equal_the_reference_formula(shape):
+    """metrics.l2_loss on the GPU (csrc/metrics.hip) against mean(square(target - prediction)) in float64, values and
+    gradient, including lengths that are not a multiple of 4 and an upstream gradient other than 1."""
+    from hdrnet_amd import metrics
+    torch.manual_seed(5)
+    t = torch.rand(shape, device="cuda:0")
+    p = torch.rand(shape, device="cuda:0", requires_grad=True)
+    loss = metrics.l2_loss(t, p)
+    assert "L2Loss" in type(loss.grad_fn).__name__
+    (loss * 3.5).backward()
+    p64 = p.detach().double().requires_grad_(True)
+    want = (t.double() - p64).square().mean()
+    (want * 3.5).backward()
+    assert abs(float(loss) - float(want)) <= 1e-6 * float(want)
+    assert torch.allclose(p.grad.double(), p64.grad, rtol=1e-5, atol=1e-12)

@@ -59,7 +59,7 @@ python $R/bench.py --workload 1080p_b4 --no-cpu-baseline > $O/bench_1080p_b4.jso
 python $R/bench.py --workload hdrp --no-cpu-baseline > $O/bench_hdrp.json 2>> $O/bench.err
 python $R/bench.py --workload hdrp_u16 > $O/bench_hdrp_u16.json 2>> $O/bench.err
 python $R/bench.py --workload train_1080p_b4 --steps 100 --warmup 20 > $O/bench_train_1080p_b4.json 2>> $O/bench.err
-python $R/bench.py --workload train_1080p_b4 --no-batch-norm --steps 100 --warmup 20 > $O/bench_train_1080p_b4_nobn.json 2>> $O/bench.err
+python $R/bench.py --workload train_1080p_b4 --batch-norm --steps 100 --warmup 20 > $O/bench_train_1080p_b4_batch_norm.json 2>> $O/bench.err
 for i in 1 2 3; do python $R/bench.py --no-cpu-baseline; done > $O/bench_repeat.txt 2>> $O/bench.err
 # 3. every entry point, all sizes; A/B of the forward variants; this build vs the previous round's; end to end
 cd $R

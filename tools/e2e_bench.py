@@ -157,12 +157,17 @@ def main():
 
     # the whole step (fwd + loss + bwd + Adam) as one hipGraph
     from hdrnet_amd.runtime import GraphedTrainStep
-    mg = models.HDRNetPointwiseNNGuide(dict(batch_norm=True)).to(dev).train()
-    optg = torch.optim.Adam([p for p in mg.parameters() if p.requires_grad], lr=1e-4, capturable=True, fused=True)
-    gstep = GraphedTrainStep(mg, lambda out, tgt: metrics.l2_loss(tgt, out), optg, [low, full], [target])
-    t_graph = timeit(lambda: gstep([low, full], [target]), max(5, args.steps // 2))
-    print(f"config #4  the whole step as one hipGraph: {t_graph * 1e3:.2f} ms/step = "
-          f"{B * 1080 * 1920 / 1e6 / t_graph:.0f} MP/s per GPU")
+    t_graph = {}
+    for bn, native in ((True, True), (False, False), (False, True)):
+        mg = models.HDRNetPointwiseNNGuide(dict(batch_norm=bn)).to(dev).train()
+        mg.coefficients.native_training = native
+        optg = torch.optim.Adam([p for p in mg.parameters() if p.requires_grad], lr=1e-4, capturable=True, fused=True)
+        gstep = GraphedTrainStep(mg, lambda out, tgt: metrics.l2_loss(tgt, out), optg, [low, full], [target])
+        t_graph[(bn, native)] = timeit(lambda: gstep([low, full], [target]), max(5, args.steps // 2))
+    t = t_graph[(False, True)]
+    print(f"config #4  the whole step as one hipGraph, no batch norm (the reference's scripts), coefficient network's "
+          f"forward + backward on the HIP kernels: {t * 1e3:.3f} ms/step = {B * 1080 * 1920 / 1e6 / t:.0f} MP/s per GPU;  "
+          f"on stock ops: {t_graph[(False, False)] * 1e3:.3f};  with batch norm (stock ops): {t_graph[(True, True)] * 1e3:.3f}")
 
 
 if __name__ == "__main__":
