@@ -232,8 +232,8 @@ class _Coefficients(nn.Module):
     def _use_native_training(self, lowres_nhwc: torch.Tensor) -> bool:
         if not (self.native and self.native_training and lowres_nhwc.is_cuda and lowres_nhwc.dtype == torch.float32):
             return False
-        if not torch.is_grad_enabled() or lowres_nhwc.requires_grad or self.n_levels != 1:
-            return False
+        if not torch.is_grad_enabled() or lowres_nhwc.requires_grad:
+            return False  # (the pyramid model's 9 x 4 coefficients come out in the reference's order: n_levels plays no role here)
         if any(m.bn is not None for m in self.modules() if isinstance(m, (_Conv, _FC))):
             return False
         N = self.hyper["net_input_size"]

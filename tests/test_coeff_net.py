@@ -280,6 +280,7 @@ def test_training_mode_and_autograd_stay_on_the_stock_ops():
 
 
 TRAIN_CASES = {
+    "pyramid_b2": (dict(_cls="pyramid"), 2),   # 288 prediction channels: four and a half 64-channel chunks
     "default_b4": (dict(), 4),
     "default_b1": (dict(), 1),
     "grid32_b2": (dict(spatial_bin=32), 2),
@@ -295,8 +296,10 @@ def test_native_training_gradients_vs_float64(case):
     """Forward + backward of the coefficient network (no batch norm) on the HIP kernels against torch autograd over the
     same module: every parameter gradient, judged against a float64 evaluation on the CPU."""
     params, B = TRAIN_CASES[case]
+    params = dict(params)
+    cls = models.HDRNetGaussianPyrNN if params.pop("_cls", "") == "pyramid" else models.HDRNetPointwiseNNGuide
     torch.manual_seed(21)
-    m = randomize(models.HDRNetPointwiseNNGuide(dict(batch_norm=False, **params)), seed=7)
+    m = randomize(cls(dict(batch_norm=False, **params)), seed=7)
     N = m.params["net_input_size"]
     low = torch.rand(B, N, N, 3)
     ref = copy.deepcopy(m.coefficients).double()
