@@ -91,7 +91,9 @@ __global__ __launch_bounds__(256) void reduce_partials(const float* __restrict__
 // ---- VJP of the folded guide network ---------------------------------------------------------
 // guide (saved by the forward) gives the sigmoid's derivative without re-running the network's
 // second layer: dacc = dguide * g * (1 - g).
-template <int CIN, int NF, bool ACCUM>
+// DIN: 0 = the input needs no gradient (a training step: the image is data) -- its 3 FMAs per feature and pixel, a
+// fifth of the kernel's arithmetic, are not issued; 1 = store d input; 2 = add to what dinput holds.
+template <int CIN, int NF, int DIN>
 __global__ __launch_bounds__(kThreads, 2) void guide_nn_grad(
     const float* __restrict__ input, const float* __restrict__ guide, const float* __restrict__ dguide,
     const float* __restrict__ conv1, const float* __restrict__ conv2, float* __restrict__ dinput,
@@ -156,12 +158,13 @@ __global__ __launch_bounds__(kThreads, 2) void guide_nn_grad(
 #pragma unroll
         for (int j = 0; j < CIN; ++j) {
           acc[f * CJ + j] = fmaf(dh, in[k][j], acc[f * CJ + j]);  // d conv1[f][j]
-          din[k][j] = fmaf(dh, w[j], din[k][j]);                  // d input_j
+          if constexpr (DIN != 0) din[k][j] = fmaf(dh, w[j], din[k][j]);  // d input_j
         }
         acc[f * CJ + CIN] += dh;  // d conv1 bias
       }
     }
-    if (dinput) {
+    if constexpr (DIN != 0) {
+      constexpr bool ACCUM = DIN == 2;
       if (p + kPx <= npx) {
         float4* op = reinterpret_cast<float4*>(dinput + p * CIN);
         float4 ov[CIN];
@@ -358,12 +361,12 @@ template <int CIN, int NF>
 hipError_t launch_grad_t(const GuideGradArgs& a, int nb, hipStream_t s) {
   constexpr int NA = NF * (CIN + 1) + NF + 1;
   float* partial = static_cast<float*>(a.workspace);
-  if (a.accumulate_dinput)
-    guide_nn_grad<CIN, NF, true><<<nb, kThreads, 0, s>>>(a.input, a.guide, a.dguide, a.conv1, a.conv2,
-                                                          a.dinput, partial, a.npx);
+  if (!a.dinput)
+    guide_nn_grad<CIN, NF, 0><<<nb, kThreads, 0, s>>>(a.input, a.guide, a.dguide, a.conv1, a.conv2, nullptr, partial, a.npx);
+  else if (a.accumulate_dinput)
+    guide_nn_grad<CIN, NF, 2><<<nb, kThreads, 0, s>>>(a.input, a.guide, a.dguide, a.conv1, a.conv2, a.dinput, partial, a.npx);
   else
-    guide_nn_grad<CIN, NF, false><<<nb, kThreads, 0, s>>>(a.input, a.guide, a.dguide, a.conv1, a.conv2,
-                                                           a.dinput, partial, a.npx);
+    guide_nn_grad<CIN, NF, 1><<<nb, kThreads, 0, s>>>(a.input, a.guide, a.dguide, a.conv1, a.conv2, a.dinput, partial, a.npx);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   reduce_partials<<<NA, 256, 0, s>>>(partial, nb, NA,
