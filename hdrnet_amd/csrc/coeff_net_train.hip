@@ -6,7 +6,8 @@
 //
 // On stock ops the backward of this network is ~75 launches of a graph-captured training step (MIOpen backward-data
 // and backward-weights kernels with their companions, ReLU masks, pad slices, bias reductions), ~0.4 ms of launch
-// latency around a few tens of microseconds of arithmetic (profiles/r04/train_step.md).  Here it is ~26:
+// latency around a few tens of microseconds of arithmetic (profiles/r04/train_step.md).  Here it is 18 (a layer's
+// backward-weights and backward-data share a launch):
 //
 //   coeff_recompute   x1 / x2 (the fully connected layers' activated inputs, from their saved partial sums), the
 //                     global features g, the fusion relu(local + g); the incoming gradient permuted from the unrolled
@@ -62,14 +63,16 @@ struct DwParams {
 };
 
 template <int KS>
-__global__ __launch_bounds__(256) void coeff_conv_dw(const DwParams p) {
+constexpr int dw_lds_floats() { return 4 * KS * KS * 4 * 64 + 4 * 64; }
+
+template <int KS>
+__device__ __forceinline__ void conv_dw_body(const DwParams& p, float* lds, int chunk, int pair) {
   constexpr int KK = KS * KS;
-  __shared__ float red[4 * KK * 4 * 64];
-  __shared__ float bred[4 * 64];
+  float* red = lds;                       // [4 waves][KK][4][64]
+  float* bred = lds + 4 * KK * 4 * 64;    // [4 waves][64]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int chunk = blockIdx.x;
-  const int ocb = blockIdx.y / p.ic_blocks, icb = blockIdx.y - ocb * p.ic_blocks;
+  const int ocb = pair / p.ic_blocks, icb = pair - ocb * p.ic_blocks;
   const int oc0 = ocb * 16, ic0 = icb * 16;
   const int q = lane >> 4, m = lane & 15;  // q: pixel of the K-step (A and B); m: output channel (A) / input channel (B)
   const bool a_ok = oc0 + m < p.Cout, b_ok = ic0 + m < p.Cin;
@@ -172,6 +175,12 @@ __global__ __launch_bounds__(256) void coeff_conv_dw(const DwParams p) {
     }
     p.db_part[(size_t)chunk * p.Cout + oc0 + tid] = v;
   }
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void coeff_conv_dw(const DwParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  conv_dw_body<KS>(p, lds, blockIdx.x, blockIdx.y);
 }
 
 // Backward-weights of the FIRST splat layer (3x3, stride 2, Cin = 3, Cout <= 9): K = 27 per output channel is no
@@ -299,8 +308,7 @@ struct DxParams {
 // MFMA roles as in coeff_conv_mfma: rows = the tile's 16 pixels of dx, columns = 16 channels of dx (Cx), the k of
 // MFMA e of a 16-channel group of the gradient is channel 16 g + 4 kk + e.
 template <int KS>
-__global__ __launch_bounds__(256) void coeff_conv_dx(const DxParams p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void conv_dx_body(const DxParams& p, float* lds, int tile, int ocg, int b) {
   constexpr int KK = KS * KS;
   constexpr int kMaxSteps = KK;
   constexpr int TI = (kT - 1) + KS;  // stride 1 over the upsampled gradient
@@ -314,8 +322,6 @@ __global__ __launch_bounds__(256) void coeff_conv_dx(const DxParams p) {
     wstep[si] = p.w_off[wave][si];
   }
   const int nsw = (int)p.lds_off[wave][9];
-  const int b = blockIdx.z;
-  const int tile = blockIdx.x;
   const int tyi = udiv(tile, p.tx_mul, p.tiles_x), txi = tile - tyi * p.tiles_x;
   const int oy0 = tyi * kT, ox0 = txi * kT;
   const int iy0 = oy0 - p.pad_top, ix0 = ox0 - p.pad_left;  // in the upsampled gradient
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(256) void coeff_conv_dx(const DxParams p) {
   const int PS = cch + 4;
   float* red = lds + npix * PS;  // [4 waves][4][64]
   const int q = lane >> 4, j = lane & 15;
-  const int n0 = blockIdx.y * 16;
+  const int n0 = ocg * 16;
   const bool qvalid = 4 * q < cch;
   const bool bvalid = qvalid && n0 + j < Cx;
   const size_t img = (size_t)b * p.Hy * p.Wy * Cy;
@@ -431,6 +437,40 @@ __global__ __launch_bounds__(256) void coeff_conv_dx(const DxParams p) {
   const int oy = oy0 + (i >> 2), ox = ox0 + (i & 3);
   if (o >= Cx || oy >= p.Hx || ox >= p.Wx) return;
   p.dx[(((size_t)b * p.Hx + oy) * p.Wx + ox) * Cx + o] = v;
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void coeff_conv_dx(const DxParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  conv_dx_body<KS>(p, lds, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Backward-weights and backward-data of ONE layer in one launch (they read the same gradient and do not depend on
+// each other): the first `dw_blocks` workgroups are coeff_conv_dw's (chunk, channel-block pair), the rest
+// coeff_conv_dx's (tile, channel group, image).  A launch less per layer: ~6 us of ~14.
+struct BwdPair {
+  DwParams dw;
+  DxParams dx;
+  int dw_chunks, dw_blocks;   // dw grid: dw_chunks x pairs, flattened
+  int dx_tiles, dx_groups;    // dx grid: tiles x groups x B, flattened
+  unsigned chunk_mul, tile_mul, tg_mul;  // magic numbers of dw_chunks, dx_tiles, dx_tiles * dx_groups
+};
+
+template <int KS>
+__global__ __launch_bounds__(256) void coeff_conv_bwd(const BwdPair pr) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int id = blockIdx.x;
+  if (id < pr.dw_blocks) {  // uniform
+    const int pair = udiv(id, pr.chunk_mul, pr.dw_chunks);
+    conv_dw_body<KS>(pr.dw, lds, id - pair * pr.dw_chunks, pair);
+  } else {
+    const int r = id - pr.dw_blocks;
+    const int tg = pr.dx_tiles * pr.dx_groups;
+    const int b = udiv(r, pr.tg_mul, tg);
+    const int r2 = r - b * tg;
+    const int ocg = udiv(r2, pr.tile_mul, pr.dx_tiles);
+    conv_dx_body<KS>(pr.dx, lds, r2 - ocg * pr.dx_tiles, ocg, b);
+  }
 }
 
 // ---------------------------------------------------------------------------------------- fully connected layers
@@ -648,6 +688,33 @@ PartPlan part_plan_first(int B, int Hout) {  // 8 x 8 pixel tiles, one workgroup
   return pl;
 }
 
+DwParams make_dw(const Layer& L, int B, const float* dy, const float* dy2, bool mask, float* part, const PartPlan& pl,
+                 int icb) {
+  (void)B;
+  DwParams p{};
+  p.x = L.x; p.dy = dy; p.dy2 = dy2; p.ymask = mask ? L.y : nullptr;
+  const size_t nw = (size_t)L.Cout * L.ks * L.ks * L.Cin;
+  p.dw_part = part;
+  p.db_part = L.db ? part + (size_t)pl.nchunks * nw : nullptr;
+  p.Hin = L.Hin; p.Win = L.Hin; p.Cin = L.Cin; p.Hout = L.Hout; p.Wout = L.Hout; p.Cout = L.Cout;
+  p.stride = L.stride;
+  p.pad_top = p.pad_left = same_pad_before(L.Hin, L.Hout, L.ks, L.stride);
+  p.tiles_x = pl.tiles_x; p.tiles_per_image = pl.tpi; p.tiles_total = pl.total; p.tiles_per_chunk = pl.tpc;
+  p.tx_mul = magic32(pl.tiles_x); p.tpi_mul = magic32(pl.tpi);
+  p.ic_blocks = icb;
+  return p;
+}
+
+void add_reduce(ReduceTab* tab, const DwParams& p, const Layer& L, int nchunks) {
+  auto add = [&](const float* src, float* dst, int n) {
+    const int e = tab->count++;
+    tab->src[e] = src; tab->dst[e] = dst; tab->n[e] = n; tab->nsplit[e] = nchunks;
+    tab->first[e + 1] = tab->first[e] + (n + 15) / 16;
+  };
+  add(p.dw_part, L.dw, L.Cout * L.ks * L.ks * L.Cin);
+  if (L.db) add(p.db_part, L.db, L.Cout);
+}
+
 hipError_t launch_dw(const Layer& L, int B, const float* dy, const float* dy2, bool mask, float* part, ReduceTab* tab,
                      hipStream_t s) {
   const int ocb = (L.Cout + 15) / 16, icb = (L.Cin + 15) / 16;
@@ -671,32 +738,22 @@ hipError_t launch_dw(const Layer& L, int B, const float* dy, const float* dy2, b
     add1(f.db_part, L.db, L.Cout);
     return hipGetLastError();
   }
-  DwParams p{};
-  p.x = L.x; p.dy = dy; p.dy2 = dy2; p.ymask = mask ? L.y : nullptr;
-  const size_t nw = (size_t)L.Cout * L.ks * L.ks * L.Cin;
-  p.dw_part = part;
-  p.db_part = L.db ? part + (size_t)pl.nchunks * nw : nullptr;
-  p.Hin = L.Hin; p.Win = L.Hin; p.Cin = L.Cin; p.Hout = L.Hout; p.Wout = L.Hout; p.Cout = L.Cout;
-  p.stride = L.stride;
-  p.pad_top = p.pad_left = same_pad_before(L.Hin, L.Hout, L.ks, L.stride);
-  p.tiles_x = pl.tiles_x; p.tiles_per_image = pl.tpi; p.tiles_total = pl.total; p.tiles_per_chunk = pl.tpc;
-  p.tx_mul = magic32(pl.tiles_x); p.tpi_mul = magic32(pl.tpi);
-  p.ic_blocks = icb;
+  const DwParams p = make_dw(L, B, dy, dy2, mask, part, pl, icb);
   const dim3 grid((unsigned)pl.nchunks, (unsigned)(ocb * icb));
-  if (L.ks == 3) coeff_conv_dw<3><<<grid, 256, 0, s>>>(p);
-  else coeff_conv_dw<1><<<grid, 256, 0, s>>>(p);
-  auto add = [&](const float* src, float* dst, int n) {
-    const int e = tab->count++;
-    tab->src[e] = src; tab->dst[e] = dst; tab->n[e] = n; tab->nsplit[e] = pl.nchunks;
-    tab->first[e + 1] = tab->first[e] + (n + 15) / 16;
-  };
-  add(p.dw_part, L.dw, (int)nw);
-  if (L.db) add(p.db_part, L.db, L.Cout);
+  if (L.ks == 3) coeff_conv_dw<3><<<grid, 256, dw_lds_floats<3>() * sizeof(float), s>>>(p);
+  else coeff_conv_dw<1><<<grid, 256, dw_lds_floats<1>() * sizeof(float), s>>>(p);
+  add_reduce(tab, p, L, pl.nchunks);
   return hipGetLastError();
 }
 
-hipError_t launch_dx(const Layer& L, int B, const float* dy, const float* dy2, bool mask, float* dx, hipStream_t s) {
-  DxParams p{};
+struct DxSetup {
+  DxParams p;
+  size_t lds;
+};
+
+DxSetup make_dx(const Layer& L, const float* dy, const float* dy2, bool mask, float* dx) {
+  DxSetup su{};
+  DxParams& p = su.p;
   p.dy = dy; p.dy2 = dy2; p.ymask = mask ? L.y : nullptr; p.w = L.w; p.dx = dx;
   p.Hy = p.Wy = L.Hout; p.Cy = L.Cout; p.Hx = p.Wx = L.Hin; p.Cx = L.Cin;
   p.ups = L.stride;
@@ -725,10 +782,43 @@ hipError_t launch_dx(const Layer& L, int B, const float* dy, const float* dy2, b
     }
     p.lds_off[wv][9] = (unsigned)(s1 - s0);
   }
-  const size_t lds = ((size_t)ti * ti * ps + 4 * 4 * 64) * sizeof(float);
-  const dim3 grid((unsigned)p.tiles, (unsigned)p.oc_groups, (unsigned)B);
-  if (L.ks == 3) coeff_conv_dx<3><<<grid, 256, lds, s>>>(p);
-  else coeff_conv_dx<1><<<grid, 256, lds, s>>>(p);
+  su.lds = ((size_t)ti * ti * ps + 4 * 4 * 64) * sizeof(float);
+  return su;
+}
+
+hipError_t launch_dx(const Layer& L, int B, const float* dy, const float* dy2, bool mask, float* dx, hipStream_t s) {
+  const DxSetup su = make_dx(L, dy, dy2, mask, dx);
+  const dim3 grid((unsigned)su.p.tiles, (unsigned)su.p.oc_groups, (unsigned)B);
+  if (L.ks == 3) coeff_conv_dx<3><<<grid, 256, su.lds, s>>>(su.p);
+  else coeff_conv_dx<1><<<grid, 256, su.lds, s>>>(su.p);
+  return hipGetLastError();
+}
+
+// Backward-weights and backward-data of one layer in ONE launch (coeff_conv_bwd).
+hipError_t launch_pair(const Layer& L, int B, const float* dy, const float* dy2, bool mask, float* dx, float* part,
+                       ReduceTab* tab, hipStream_t s) {
+  const int ocb = (L.Cout + 15) / 16, icb = (L.Cin + 15) / 16;
+  const PartPlan pl = part_plan(B, L.Hout, ocb * icb);
+  BwdPair pr{};
+  pr.dw = make_dw(L, B, dy, dy2, mask, part, pl, icb);
+  const DxSetup su = make_dx(L, dy, dy2, mask, dx);
+  pr.dx = su.p;
+  pr.dw_chunks = pl.nchunks;
+  pr.dw_blocks = pl.nchunks * ocb * icb;
+  pr.dx_tiles = su.p.tiles;
+  pr.dx_groups = su.p.oc_groups;
+  pr.chunk_mul = magic32(pr.dw_chunks);
+  pr.tile_mul = magic32(pr.dx_tiles);
+  pr.tg_mul = magic32(pr.dx_tiles * pr.dx_groups);
+  const unsigned blocks = (unsigned)pr.dw_blocks + (unsigned)(pr.dx_tiles * pr.dx_groups * B);
+  if (L.ks == 3) {
+    const size_t lds = su.lds > dw_lds_floats<3>() * sizeof(float) ? su.lds : dw_lds_floats<3>() * sizeof(float);
+    coeff_conv_bwd<3><<<dim3(blocks), 256, lds, s>>>(pr);
+  } else {
+    const size_t lds = su.lds > dw_lds_floats<1>() * sizeof(float) ? su.lds : dw_lds_floats<1>() * sizeof(float);
+    coeff_conv_bwd<1><<<dim3(blocks), 256, lds, s>>>(pr);
+  }
+  add_reduce(tab, pr.dw, L, pl.nchunks);
   return hipGetLastError();
 }
 
@@ -841,10 +931,14 @@ hipError_t launch_coefficients_grad(const float* lowres, const hdrnet_coeff_net&
     parts += dw_part_floats(B, L);
     return r;
   };
+  auto pair = [&](const Layer& L, const float* dy, const float* dy2, bool mask, float* dx) -> hipError_t {
+    const hipError_t r = launch_pair(L, B, dy, dy2, mask, dx, parts, &tab, s);
+    parts += dw_part_floats(B, L);
+    return r;
+  };
   // ---- prediction layer (1x1 on the fusion; its own output has no ReLU)
   const Layer pr{buf(bs.fusion), nullptr, net.pred_w, gr.pred_w, gr.pred_b, d.sb, d.gl, d.sb, d.pred, 1, 1};
-  if ((e = dw(pr, buf(bs.dyp), nullptr, false)) != hipSuccess) return e;
-  if ((e = launch_dx(pr, B, buf(bs.dyp), nullptr, false, buf(bs.df), s)) != hipSuccess) return e;
+  if ((e = pair(pr, buf(bs.dyp), nullptr, false, buf(bs.df))) != hipSuccess) return e;
   // ---- fusion = relu(local2 + g): d local2 = df masked (applied by the consumers), dg = its sum over the cells
   {
     const int nslab = (P + 15) / 16;
@@ -863,19 +957,15 @@ hipError_t launch_coefficients_grad(const float* lowres, const hdrnet_coeff_net&
   }
   // ---- local path: local2 (no bias, no ReLU on its own output: the fusion's mask), local1
   const Layer l2{L1, buf(bs.fusion), net.local_w[1], gr.local_w[1], nullptr, d.sb, d.gl, d.sb, d.gl, 3, 1};
-  if ((e = dw(l2, buf(bs.df), nullptr, true)) != hipSuccess) return e;
-  if ((e = launch_dx(l2, B, buf(bs.df), nullptr, true, buf(bs.dl1), s)) != hipSuccess) return e;
+  if ((e = pair(l2, buf(bs.df), nullptr, true, buf(bs.dl1))) != hipSuccess) return e;
   const float* feat = S[d.n_ds - 1];
   const Layer l1{feat, L1, net.local_w[0], gr.local_w[0], gr.local_b[0], d.sb, d.feat, d.sb, d.gl, 3, 1};
-  if ((e = dw(l1, buf(bs.dl1), nullptr, true)) != hipSuccess) return e;
-  if ((e = launch_dx(l1, B, buf(bs.dl1), nullptr, true, buf(bs.ds4a), s)) != hipSuccess) return e;
+  if ((e = pair(l1, buf(bs.dl1), nullptr, true, buf(bs.ds4a))) != hipSuccess) return e;
   // ---- global path: conv2, conv1
   const Layer c2{G1, G2, net.global_conv_w[1], gr.global_conv_w[1], gr.global_conv_b[1], g1side, d.gl, d.gside, d.gl, 3, 2};
-  if ((e = dw(c2, buf(bs.dg2), nullptr, true)) != hipSuccess) return e;
-  if ((e = launch_dx(c2, B, buf(bs.dg2), nullptr, true, buf(bs.dg1), s)) != hipSuccess) return e;
+  if ((e = pair(c2, buf(bs.dg2), nullptr, true, buf(bs.dg1))) != hipSuccess) return e;
   const Layer c1{feat, G1, net.global_conv_w[0], gr.global_conv_w[0], gr.global_conv_b[0], d.sb, d.feat, g1side, d.gl, 3, 2};
-  if ((e = dw(c1, buf(bs.dg1), nullptr, true)) != hipSuccess) return e;
-  if ((e = launch_dx(c1, B, buf(bs.dg1), nullptr, true, buf(bs.ds4b), s)) != hipSuccess) return e;
+  if ((e = pair(c1, buf(bs.dg1), nullptr, true, buf(bs.ds4b))) != hipSuccess) return e;
   // ---- splat, last to first; the last layer's gradient is the sum of the two paths'
   const float* dy = buf(bs.ds4a);
   const float* dy2 = buf(bs.ds4b);
@@ -883,11 +973,12 @@ hipError_t launch_coefficients_grad(const float* lowres, const hdrnet_coeff_net&
     const int cout = (d.cm * d.gd) << i, cin = i > 0 ? (d.cm * d.gd) << (i - 1) : 3;
     const int hin = d.N >> i;
     const Layer L{i > 0 ? S[i - 1] : lowres, S[i], net.splat_w[i], gr.splat_w[i], gr.splat_b[i], hin, cin, hin / 2, cout, 3, 2};
-    if ((e = dw(L, dy, dy2, true)) != hipSuccess) return e;
     if (i > 0) {
-      if ((e = launch_dx(L, B, dy, dy2, true, buf(bs.ds[i - 1]), s)) != hipSuccess) return e;
+      if ((e = pair(L, dy, dy2, true, buf(bs.ds[i - 1]))) != hipSuccess) return e;
       dy = buf(bs.ds[i - 1]);
       dy2 = nullptr;
+    } else if ((e = dw(L, dy, dy2, true)) != hipSuccess) {
+      return e;
     }
   }
   // ---- the chunks' partial sums of every weight / bias gradient
