@@ -302,6 +302,10 @@ struct DxParams {
   int c4shift, nchunks;
   unsigned lds_off[4][12];  // per wave: LDS float offset of each (tap, 16-channel group) step | group << 24; [9] = count
   unsigned w_off[4][12];    // per wave: filter float offset of the step: (16 g * KK + flipped tap) * Cx
+  // the prediction layer only: the tile's column sums of dx where the fusion passed it,
+  // colsum_part[b][tile][c] = sum over the tile's pixels of dx[b][px][c] * (xmask[b][px][c] > 0)
+  const float* xmask;
+  float* colsum_part;
 };
 
 // dx[b, i, :] = sum_taps U[b, i - pad' + tap, :] . w[:, KK - 1 - tap, :],  U = the masked gradient, zero-upsampled.
@@ -435,8 +439,21 @@ __device__ __forceinline__ void conv_dx_body(const DxParams& p, float* lds, int 
   for (int w = 1; w < 4; ++w) v += red[(w * 4 + r) * 64 + lane];
   const int i = 4 * q + r, o = n0 + j;
   const int oy = oy0 + (i >> 2), ox = ox0 + (i & 3);
-  if (o >= Cx || oy >= p.Hx || ox >= p.Wx) return;
-  p.dx[(((size_t)b * p.Hx + oy) * p.Wx + ox) * Cx + o] = v;
+  const bool in = o < Cx && oy < p.Hx && ox < p.Wx;
+  const size_t off = (((size_t)b * p.Hx + min(oy, p.Hx - 1)) * p.Wx + min(ox, p.Wx - 1)) * Cx + min(o, Cx - 1);
+  if (in) p.dx[off] = v;
+  if (p.colsum_part) {  // uniform
+    const float mv = (in && p.xmask[off] > 0.0f) ? v : 0.0f;
+    __syncthreads();  // everyone has read its partial tiles
+    red[i * 16 + j] = mv;
+    __syncthreads();
+    if (tid < 16 && n0 + tid < Cx) {
+      float t = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += red[k * 16 + tid];
+      p.colsum_part[((size_t)b * p.tiles + tile) * Cx + n0 + tid] = t;
+    }
+  }
 }
 
 template <int KS>
@@ -604,25 +621,7 @@ __global__ __launch_bounds__(256) void coeff_recompute(const RecomputeParams p) 
   }
 }
 
-// dg_part[b][slab][c] = sum over the slab's 16 cells of df[b][px][c] * (fusion[b][px][c] > 0); dg = sum of the slabs
-// (coeff_slab_sum).  One load round per thread.
-__global__ __launch_bounds__(256) void coeff_masked_colsum(const float* __restrict__ df, const float* __restrict__ fusion,
-                                                          float* __restrict__ dg_part, int P, int C) {
-  const int b = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float v = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int px = slab * 16 + i;
-      if (px < P) {
-        const size_t off = ((size_t)b * P + px) * C + c;
-        v += fusion[off] > 0.0f ? df[off] : 0.0f;
-      }
-    }
-    dg_part[((size_t)b * nslab + slab) * C + c] = v;
-  }
-}
-
+// dg[b][c] = the sum of the prediction layer's per-tile column sums (coeff_conv_dx's colsum_part).
 __global__ __launch_bounds__(256) void coeff_slab_sum(const float* __restrict__ part, float* __restrict__ dg, int nslab, int C) {
   const int b = blockIdx.x;
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -751,7 +750,8 @@ struct DxSetup {
   size_t lds;
 };
 
-DxSetup make_dx(const Layer& L, const float* dy, const float* dy2, bool mask, float* dx) {
+DxSetup make_dx(const Layer& L, const float* dy, const float* dy2, bool mask, float* dx, const float* xmask = nullptr,
+               float* colsum_part = nullptr) {
   DxSetup su{};
   DxParams& p = su.p;
   p.dy = dy; p.dy2 = dy2; p.ymask = mask ? L.y : nullptr; p.w = L.w; p.dx = dx;
@@ -783,6 +783,8 @@ DxSetup make_dx(const Layer& L, const float* dy, const float* dy2, bool mask, fl
     p.lds_off[wv][9] = (unsigned)(s1 - s0);
   }
   su.lds = ((size_t)ti * ti * ps + 4 * 4 * 64) * sizeof(float);
+  p.xmask = xmask;
+  p.colsum_part = colsum_part;
   return su;
 }
 
@@ -796,12 +798,12 @@ hipError_t launch_dx(const Layer& L, int B, const float* dy, const float* dy2, b
 
 // Backward-weights and backward-data of one layer in ONE launch (coeff_conv_bwd).
 hipError_t launch_pair(const Layer& L, int B, const float* dy, const float* dy2, bool mask, float* dx, float* part,
-                       ReduceTab* tab, hipStream_t s) {
+                       ReduceTab* tab, hipStream_t s, const float* xmask = nullptr, float* colsum_part = nullptr) {
   const int ocb = (L.Cout + 15) / 16, icb = (L.Cin + 15) / 16;
   const PartPlan pl = part_plan(B, L.Hout, ocb * icb);
   BwdPair pr{};
   pr.dw = make_dw(L, B, dy, dy2, mask, part, pl, icb);
-  const DxSetup su = make_dx(L, dy, dy2, mask, dx);
+  const DxSetup su = make_dx(L, dy, dy2, mask, dx, xmask, colsum_part);
   pr.dx = su.p;
   pr.dw_chunks = pl.nchunks;
   pr.dw_blocks = pl.nchunks * ocb * icb;
@@ -838,7 +840,7 @@ BwdSpace bwd_space(const NetDims& d, const hdrnet_coeff_net& net, int B) {
   w.dyp = take(B * P * d.pred);
   w.df = take(B * P * d.gl);
   w.dg = take((size_t)B * d.gl);
-  w.dgp = take((size_t)B * ((P + 15) / 16) * d.gl);
+  w.dgp = take((size_t)B * ((d.sb + kT - 1) / kT) * ((d.sb + kT - 1) / kT) * d.gl);
   w.dx2 = take((size_t)B * 2 * d.gl);
   w.dx1 = take((size_t)B * 4 * d.gl);
   const int g1side = (d.sb + 1) / 2;
@@ -938,13 +940,13 @@ hipError_t launch_coefficients_grad(const float* lowres, const hdrnet_coeff_net&
   };
   // ---- prediction layer (1x1 on the fusion; its own output has no ReLU)
   const Layer pr{buf(bs.fusion), nullptr, net.pred_w, gr.pred_w, gr.pred_b, d.sb, d.gl, d.sb, d.pred, 1, 1};
-  if ((e = pair(pr, buf(bs.dyp), nullptr, false, buf(bs.df))) != hipSuccess) return e;
+  // (its backward-data half also leaves the per-tile column sums of df where the fusion passed it: dg's partial sums)
+  const int ntile = ((d.sb + kT - 1) / kT) * ((d.sb + kT - 1) / kT);
+  e = launch_pair(pr, B, buf(bs.dyp), nullptr, false, buf(bs.df), parts, &tab, s, buf(bs.fusion), buf(bs.dgp));
+  parts += dw_part_floats(B, pr);
+  if (e != hipSuccess) return e;
   // ---- fusion = relu(local2 + g): d local2 = df masked (applied by the consumers), dg = its sum over the cells
-  {
-    const int nslab = (P + 15) / 16;
-    coeff_masked_colsum<<<dim3((unsigned)B, (unsigned)nslab), 256, 0, s>>>(buf(bs.df), buf(bs.fusion), buf(bs.dgp), P, d.gl);
-    coeff_slab_sum<<<dim3((unsigned)B), 256, 0, s>>>(buf(bs.dgp), buf(bs.dg), nslab, d.gl);
-  }
+  coeff_slab_sum<<<dim3((unsigned)B), 256, 0, s>>>(buf(bs.dgp), buf(bs.dg), ntile, d.gl);
   // ---- fully connected layers
   {
     FcBwdParams f3{buf(bs.x2), buf(bs.dg), net.fc_w[2], gr.fc_w[2], gr.fc_b[2], buf(bs.dx2), B, 2 * d.gl, d.gl, 1};

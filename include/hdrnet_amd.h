@@ -383,7 +383,7 @@ size_t hdrnet_coefficients_workspace_bytes(const hdrnet_coeff_net* net, int B);
  * order ([Cout][kh][kw][Cin], the same layout as above) and fc_layout = 1 (Linear weights [out][in]) -- keeping its
  * workspace: `forward_workspace` here is that buffer, untouched since.  `dcoeffs` is [B][sb][sb][gd][n_out][n_in];
  * gradients are written (not accumulated) in the parameters' own layouts; local_b[1] is ignored (no such bias).
- * ~26 launches on `stream`, deterministic.  Supported: what the forward supports, n_levels = 1, fc_layout = 1,
+ * 15 launches on `stream`, deterministic.  Supported: what the forward supports, n_levels = 1, fc_layout = 1,
  * B <= 8, 8 * cm * gd <= 256; hdrnet_coefficients_grad_workspace_bytes returns 0 otherwise. */
 typedef struct hdrnet_coeff_net_grads {
   float* splat_w[8];
