@@ -156,7 +156,12 @@ class GradBucket:
                 src.append(p.grad)
             p.grad = v
         if dst:
-            torch._foreach_copy_(dst, src)
+            fused = getattr(torch, "_foreach_copy_", None)
+            if fused is not None:
+                fused(dst, src)  # one multi-tensor launch
+            else:
+                for d, g in zip(dst, src):
+                    d.copy_(g)
 
     def attached(self) -> bool:
         """True while every parameter's .grad still is its view of the flat buffer."""
