@@ -101,6 +101,11 @@ class HdrnetRuntimeError(RuntimeError):
     """HDRNET_RUNTIME_FAILURE (the reference: errors::Internal("... kernel failed."))."""
 
 
+# include/hdrnet_amd_train.h: training-loop helpers outside the operator boundary (same library).
+TRAIN_SIGNATURES = {
+    "hdrnet_adam_step_f32": (_I, [_FP, _FP, _FP, _FP, ctypes.c_longlong, _FP] + [ctypes.c_float] * 4 + [_VP]),
+}
+
 _lock = threading.Lock()
 _lib: Optional[ctypes.CDLL] = None
 _tools_lib: Optional[ctypes.CDLL] = None
@@ -149,6 +154,7 @@ def _open(tools: bool) -> ctypes.CDLL:
     except OSError as e:
         raise HdrnetLibraryError(f"cannot load {path}: {e}") from e
     table = dict(SIGNATURES)
+    table.update(TRAIN_SIGNATURES)
     if tools:
         table.update(TOOLS_SIGNATURES)
     for name, (res, args) in table.items():

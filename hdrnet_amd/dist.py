@@ -118,17 +118,25 @@ class GradBucket:
     re-bound.  ``runtime.TrainStep`` does (b).
     """
 
-    def __init__(self, params):
+    def __init__(self, params, align: int = 1):
+        """``align``: every parameter's segment starts at a multiple of ``align`` elements (``optim.FlatAdam`` lays the
+        parameters themselves out the same way and needs 16-byte aligned segments: 4)."""
         self.params = [p for p in params if p.requires_grad]
+        self.align = max(int(align), 1)
         if not self.params:
             raise ValueError("no trainable parameters")
         dev, dt = self.params[0].device, self.params[0].dtype
         if any(p.device != dev or p.dtype != dt for p in self.params):
             raise ValueError("GradBucket: parameters must share one device and dtype")
-        self.flat = torch.zeros(sum(p.numel() for p in self.params), device=dev, dtype=dt)
-        self.views = []
+        pad = lambda n: -(-n // self.align) * self.align  # noqa: E731
+        self.offsets = []
         off = 0
         for p in self.params:
+            self.offsets.append(off)
+            off += pad(p.numel())
+        self.flat = torch.zeros(off, device=dev, dtype=dt)
+        self.views = []
+        for p, off in zip(self.params, self.offsets):
             n = p.numel()
             seg = self.flat[off:off + n]
             # the view takes the PARAMETER's strides where it is a dense permutation (channels_last conv weights):
@@ -136,7 +144,6 @@ class GradBucket:
             dense = torch.empty_like(p).stride() == p.stride()  # preserve_format keeps a dense tensor's strides
             self.views.append(seg.as_strided(p.shape, p.stride()) if dense else seg.view_as(p))
             p.grad = self.views[-1]
-            off += n
 
     def release(self) -> None:
         """Unbind the views (``.grad = None``) so that the next backward assigns its gradients instead of adding them
@@ -165,11 +172,9 @@ class GradBucket:
 
     def attached(self) -> bool:
         """True while every parameter's .grad still is its view of the flat buffer."""
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
                 return False
-            off += p.numel()
         return True
 
     def zero_(self) -> None:

@@ -131,7 +131,8 @@ class TrainStep:
         self._hd = hd
         self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized() \
             and torch.distributed.get_world_size() > 1
-        self.bucket = hd.GradBucket(module.parameters())
+        # an optimizer that keeps its own flat gradient bucket (optim.FlatAdam) shares it with the step
+        self.bucket = getattr(optimizer, "bucket", None) or hd.GradBucket(module.parameters())
 
     def _forward_backward(self, inputs, targets) -> torch.Tensor:
         self.bucket.release()  # .grad = None: backward assigns its gradients (no memset, no `+=` launch per parameter)

@@ -1,0 +1,29 @@
+/* Training-loop helpers of libhdrnet_amd.so that are not part of the bilateral-grid operator boundary
+ * (include/hdrnet_amd.h): the optimizer update of the reference's training loop.
+ *
+ * hdrnet/bin/train.py:108-115 minimises the l2 loss with tf.train.AdamOptimizer; one update of the whole model
+ * (~482 k parameters) is 2 MB of state.  As a multi-tensor launch over 35 separate tensors it takes ~40 us of a
+ * 0.7-ms training step on MI355X (few, long-running workgroups); over ONE flat buffer it is a 2-us kernel.
+ *
+ * hdrnet_adam_step_f32: Adam (Kingma & Ba; the update of torch.optim.Adam without amsgrad / weight decay) on flat
+ * fp32 buffers of n elements, in place:
+ *   t = step[0] + 1;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2
+ *   param -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+ * `step` is a DEVICE float holding the number of updates done so far; the call increments it (a second, one-thread
+ * launch), so a captured hipGraph replays correctly.  Returns 0, or 1 for a bad argument (null / misaligned buffer,
+ * n <= 0); no host synchronisation. */
+#ifndef HDRNET_AMD_TRAIN_H_
+#define HDRNET_AMD_TRAIN_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int hdrnet_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
+                         float* step, float lr, float beta1, float beta2, float eps, void* stream);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* HDRNET_AMD_TRAIN_H_ */

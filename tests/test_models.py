@@ -949,3 +949,57 @@ def test_l2_loss_kernels_equal_the_reference_formula(shape):
     (want * 3.5).backward()
     assert abs(float(loss) - float(want)) <= 1e-6 * float(want)
     assert torch.allclose(p.grad.double(), p64.grad, rtol=1e-5, atol=1e-12)
+
+
+def _flat_adam_vs_torch(dev, steps=4):
+    import copy
+    from hdrnet_amd import optim
+    torch.manual_seed(8)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3), torch.nn.ReLU(), torch.nn.Flatten(), torch.nn.Linear(5 * 36, 7)).to(dev)
+    net = net.to(memory_format=torch.channels_last)
+    ref = copy.deepcopy(net)
+    opt = optim.FlatAdam(net.parameters(), lr=3e-3, betas=(0.9, 0.99), eps=1e-8)
+    ropt = torch.optim.Adam(ref.parameters(), lr=3e-3, betas=(0.9, 0.99), eps=1e-8)
+    for p in net.parameters():  # storage re-bound to the flat buffer, values and strides kept
+        assert p.data_ptr() >= opt.flat.data_ptr() and p.data_ptr() < opt.flat.data_ptr() + 4 * opt.flat.numel()
+        assert p.data_ptr() % 16 == 0
+    for (_, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert torch.equal(p, q) and p.stride() == q.stride()
+    for i in range(steps):
+        x = torch.rand(6, 3, 8, 8, device=dev)
+        opt.bucket.release()
+        net(x).square().mean().backward()
+        opt.bucket.gather()
+        opt.step()
+        ropt.zero_grad(set_to_none=True)
+        ref(x).square().mean().backward()
+        ropt.step()
+    for (name, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert torch.allclose(p, q, rtol=2e-5, atol=2e-7), (name, float((p - q).abs().max()))
+    assert float(opt.steps) == steps
+
+
+def test_flat_adam_equals_torch_adam_cpu():
+    _flat_adam_vs_torch("cpu")
+
+
+@pytest.mark.gpu
+def test_flat_adam_kernel_equals_torch_adam():
+    _flat_adam_vs_torch("cuda:0", steps=6)
+
+
+def test_train_header_symbols_are_exported_and_bound():
+    """include/hdrnet_amd_train.h <-> _lib.TRAIN_SIGNATURES <-> the library's exports."""
+    import ctypes
+    import re
+    from hdrnet_amd import _lib, build
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "hdrnet_amd_train.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(hdrnet_[a-z0-9_]+)\s*\(", src)))
+    assert names == sorted(_lib.TRAIN_SIGNATURES)
+    lib = ctypes.CDLL(build.build())
+    for n in names:
+        assert hasattr(lib, n)
+        m = re.search(r"\b" + n + r"\s*\(([^)]*)\)", src)
+        assert len(m.group(1).split(",")) == len(_lib.TRAIN_SIGNATURES[n][1])
+    lib.hdrnet_adam_step_f32.argtypes = _lib.TRAIN_SIGNATURES["hdrnet_adam_step_f32"][1]
+    assert lib.hdrnet_adam_step_f32(None, None, None, None, 16, None, 1e-3, 0.9, 0.999, 1e-8, None) == 1
