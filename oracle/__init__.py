@@ -14,6 +14,8 @@ the reference's NHWC layouts (``hdrnet/ops/bilateral_slice_apply_op.cc:201-227``
   time; the prebuilt library travels to the GPU box.
 
 ``jax_np`` restates ``jax/bilateral_slice.py`` in numpy (jax is not installed).
+``tf1_shim/tensorflow`` is an eager numpy stand-in for the TensorFlow 1.x calls of the reference's graph code
+(``hdrnet/models.py``, ``layers.py``), used by ``tests/golden/make_tf_shim_fixtures.py`` only.
 """
 from .cpu_oracle import (  # noqa: F401
     Oracle,

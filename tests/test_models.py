@@ -840,7 +840,8 @@ def test_tf_fixture_parity(cls):
     """Graph-level parity of the model modules against TensorFlow itself:
     consumes tests/golden/tf/<Model>.npz written by tools/export_tf_fixtures.py on a machine that has
     TensorFlow + the reference.  NO SUCH FIXTURE HAS BEEN PRODUCED YET (no TensorFlow in this image, no
-    network) -- until one is committed this test skips and the rows stay capped at 'partial'."""
+    network) -- until one is committed this test skips.  The fixtures that ARE committed come from the reference's
+    graph code executed on oracle/tf1_shim: tests/test_tf_shim_fixtures.py."""
     path = os.path.join(TF_FIXTURES, cls + ".npz")
     if not os.path.exists(path):
         pytest.skip("no TensorFlow fixture (run tools/export_tf_fixtures.py where TensorFlow and the reference exist)")
