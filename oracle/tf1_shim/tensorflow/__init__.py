@@ -246,6 +246,19 @@ def reduce_sum(input_tensor, axis=None, keep_dims=False, name=None, reduction_in
     return _t(np.sum(_f(input_tensor), axis=None if ax is None else tuple(np.atleast_1d(ax)), keepdims=keep_dims))
 
 
+def reduce_mean(input_tensor, axis=None, keep_dims=False, name=None, reduction_indices=None):
+    ax = axis if axis is not None else reduction_indices
+    return _t(np.mean(_f(input_tensor), axis=None if ax is None else tuple(np.atleast_1d(ax)), keepdims=keep_dims))
+
+
+def square(x, name=None):
+    return _t(np.square(_f(x)))
+
+
+def log(x, name=None):
+    return _t(np.log(_f(x)))
+
+
 def matmul(a, b, name=None):
     return _t(_f(a) @ _f(b))
 

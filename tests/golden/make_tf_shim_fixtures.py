@@ -49,8 +49,8 @@ def _sha(path):
 
 
 def load_reference(reference=REFERENCE):
-    """(tf shim, hdrnet.layers, hdrnet.models, {file: sha256}) with the reference's two files executed
-    unchanged on the shim."""
+    """(tf shim, hdrnet.layers, hdrnet.models, hdrnet.metrics, {file: sha256}) with the reference's files
+    executed unchanged on the shim."""
     if SHIM not in sys.path:
         sys.path.insert(0, SHIM)
     if ROOT not in sys.path:
@@ -79,7 +79,7 @@ def load_reference(reference=REFERENCE):
 
     hashes = {}
     mods = {}
-    for name in ("layers", "models"):
+    for name in ("layers", "models", "metrics"):
         path = os.path.join(reference, "hdrnet", name + ".py")
         hashes["hdrnet/%s.py" % name] = _sha(path)
         mod = types.ModuleType("hdrnet." + name)
@@ -90,7 +90,8 @@ def load_reference(reference=REFERENCE):
         with open(path) as f:
             exec(compile(f.read(), path, "exec"), mod.__dict__)
         mods[name] = mod
-    return tf, mods["layers"], mods["models"], hashes
+    graph = {k: v for k, v in hashes.items() if "metrics" not in k}       # what the model fixtures executed
+    return tf, mods["layers"], mods["models"], mods["metrics"], graph, {"hdrnet/metrics.py": hashes["hdrnet/metrics.py"]}
 
 
 def _bf16_round(a):
@@ -177,7 +178,7 @@ def main():
     ap.add_argument("--only", default=None, help="write this one fixture only (the regeneration test)")
     args = ap.parse_args()
     out_dir = args.out
-    tf, layers, models, hashes = load_reference()
+    tf, layers, models, metrics, hashes, metrics_hash = load_reference()
     os.makedirs(out_dir, exist_ok=True)
     for i, (name, cls, params, is_training, (b, h, w)) in enumerate(CASES):
         if args.only not in (None, name):
@@ -213,6 +214,14 @@ def main():
                                                dtype=np.float32),
                         reference_sha256=np.asarray(json.dumps(hashes, sort_keys=True)))
     print("layers_wrappers: sliced %s" % (np.asarray(sliced).shape,))
+
+    # hdrnet/metrics.py:21-33 -- the training loss and the evaluation metric of hdrnet/bin/train.py:137-143
+    target = (rng.randint(0, 256, (3, 17, 23, 3)) / 255.0).astype(np.float32)
+    prediction = (target + rng.randn(*target.shape) * 0.05).astype(np.float32)
+    np.savez_compressed(os.path.join(out_dir, "metrics.npz"), target=target, prediction=prediction,
+                        l2_loss=np.asarray(metrics.l2_loss(tf._t(target), tf._t(prediction)), dtype=np.float64),
+                        psnr=np.asarray(metrics.psnr(tf._t(target), tf._t(prediction)), dtype=np.float64),
+                        reference_sha256=np.asarray(json.dumps(metrics_hash, sort_keys=True)))
 
 
 if __name__ == "__main__":

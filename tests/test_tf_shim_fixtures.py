@@ -117,6 +117,29 @@ def test_layer_wrappers_fixture_is_self_consistent():
     np.testing.assert_allclose(fx["applied"], want, rtol=1e-5, atol=1e-5)
 
 
+def test_metrics_match_the_reference_module():
+    """hdrnet/metrics.py:21-33 executed on the shim: l2_loss(target, prediction) and psnr (mean over the batch).
+    The reference's ``target - prediction`` is a float32 subtraction (the operands are float32 tensors), the sums are
+    the shim's float64: 2.5e-9 from an all-float64 evaluation."""
+    from hdrnet_amd import metrics
+    fx = _load("metrics")
+    t, p = torch.from_numpy(fx["target"]).double(), torch.from_numpy(fx["prediction"]).double()
+    np.testing.assert_allclose(float(metrics.l2_loss(t, p)), float(fx["l2_loss"]), rtol=1e-7)
+    np.testing.assert_allclose(float(metrics.psnr(t, p)), float(fx["psnr"]), rtol=1e-7)
+    d = (torch.from_numpy(fx["target"]) - torch.from_numpy(fx["prediction"])).double()     # float32 subtraction
+    np.testing.assert_allclose(float(d.square().mean()), float(fx["l2_loss"]), rtol=1e-13)
+
+
+@pytest.mark.gpu
+def test_metrics_kernels_match_the_reference_module():
+    """The same through csrc/metrics.hip (float32 inputs, the loss kernels of the training step)."""
+    from hdrnet_amd import metrics
+    fx = _load("metrics")
+    t, p = torch.from_numpy(fx["target"]).cuda(), torch.from_numpy(fx["prediction"]).cuda()
+    np.testing.assert_allclose(float(metrics.l2_loss(t, p)), float(fx["l2_loss"]), rtol=2e-6)
+    np.testing.assert_allclose(float(metrics.psnr(t, p)), float(fx["psnr"]), rtol=2e-6)
+
+
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "hdrnet")), reason="needs /root/reference")
 def test_committed_fixtures_are_what_the_script_computes(tmp_path):
     """Provenance: the generator, run now against /root/reference, reproduces a committed fixture bit for bit,
@@ -131,9 +154,10 @@ def test_committed_fixtures_are_what_the_script_computes(tmp_path):
         assert sorted(z.files) == sorted(want)
         for k in z.files:
             np.testing.assert_array_equal(z[k], want[k], err_msg=k)
-    for rel, digest in json.loads(str(want["reference_sha256"])).items():
-        with open(os.path.join(REFERENCE, rel), "rb") as f:
-            assert hashlib.sha256(f.read()).hexdigest() == digest, rel
+    for fixture in MODEL_FIXTURES + ["layers_wrappers", "metrics"]:
+        for rel, digest in json.loads(str(_load(fixture)["reference_sha256"])).items():
+            with open(os.path.join(REFERENCE, rel), "rb") as f:
+                assert hashlib.sha256(f.read()).hexdigest() == digest, (fixture, rel)
 
 
 # ---- the shim's own restatements of TensorFlow's kernel conventions, against torch -----------------------------
