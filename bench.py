@@ -603,7 +603,8 @@ def main_train(args, rank, world, local_rank, stub=False):
         # Adam over ONE flat parameter buffer laid out like the flat gradient bucket: one 2-us kernel instead of the
         # ~40-us multi-tensor launch of torch.optim.Adam(fused=True) over 35 tensors (hdrnet_amd/optim.py)
         from hdrnet_amd import optim
-        opt = optim.FlatAdam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+        opt = optim.FlatAdam([p for p in model.parameters() if p.requires_grad], lr=1e-4,
+                             epsilon_hat=True)  # tf.train.AdamOptimizer's update (hdrnet/bin/train.py:113)
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)  # every rank its own images
         low = torch.rand((B, 256, 256, 3), device=dev, generator=gen)
         full = torch.rand((B, H, W, 3), device=dev, generator=gen)

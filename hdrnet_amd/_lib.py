@@ -104,6 +104,7 @@ class HdrnetRuntimeError(RuntimeError):
 # include/hdrnet_amd_train.h: training-loop helpers outside the operator boundary (same library).
 TRAIN_SIGNATURES = {
     "hdrnet_adam_step_f32": (_I, [_FP, _FP, _FP, _FP, ctypes.c_longlong, _FP] + [ctypes.c_float] * 4 + [_VP]),
+    "hdrnet_adam_step_tf_f32": (_I, [_FP, _FP, _FP, _FP, ctypes.c_longlong, _FP] + [ctypes.c_float] * 4 + [_VP]),
 }
 
 _lock = threading.Lock()

@@ -78,10 +78,13 @@ __global__ __launch_bounds__(256) void l2_loss_grad(const float* __restrict__ pr
 
 __global__ __launch_bounds__(256) void adam_flat(float* __restrict__ param, const float* __restrict__ grad,
                                                  float* __restrict__ m, float* __restrict__ v, long long n,
-                                                 const float* __restrict__ step, float lr, float b1, float b2, float eps) {
+                                                 const float* __restrict__ step, float lr, float b1, float b2, float eps_in,
+                                                 int eps_hat) {
   const float t = step[0] + 1.0f;
   const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
   const float step_size = lr / bc1, rs2 = 1.0f / sqrtf(bc2);
+  // TensorFlow's form, lr sqrt(bc2) / bc1 * m / (sqrt(v) + eps), is this one with eps / sqrt(bc2) ("epsilon hat")
+  const float eps = eps_hat ? eps_in * rs2 : eps_in;
   const long long n4 = n >> 2;
   v4f* p4 = reinterpret_cast<v4f*>(param);
   const v4f* g4 = reinterpret_cast<const v4f*>(grad);
@@ -130,15 +133,27 @@ hipError_t launch_l2_loss_grad(const float* pred, const float* target, const flo
 
 }  // namespace hdrnet_amd
 
-extern "C" int hdrnet_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
-                                    float* step, float lr, float beta1, float beta2, float eps, void* stream) {
+namespace {
+int adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float* step, float lr,
+              float beta1, float beta2, float eps, int eps_hat, void* stream) {
   using namespace hdrnet_amd;
   if (n <= 0 || !param || !grad || !exp_avg || !exp_avg_sq || !step) return 1;
   if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15u) return 1;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const long long want = ((n >> 2) + 255) / 256;
   const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
-  adam_flat<<<blocks, 256, 0, s>>>(param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps);
+  adam_flat<<<blocks, 256, 0, s>>>(param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, eps_hat);
   adam_count<<<1, 1, 0, s>>>(step);
   return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+}  // namespace
+
+extern "C" int hdrnet_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
+                                    float* step, float lr, float beta1, float beta2, float eps, void* stream) {
+  return adam_step(param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, 0, stream);
+}
+
+extern "C" int hdrnet_adam_step_tf_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
+                                       float* step, float lr, float beta1, float beta2, float eps, void* stream) {
+  return adam_step(param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, 1, stream);
 }

@@ -7,6 +7,8 @@ every parameter's storage to a view of one flat fp32 buffer laid out exactly lik
 (``dist.GradBucket``, 16-byte aligned segments), so that the update is one elementwise kernel over the buffer
 (``hdrnet_adam_step_f32``, include/hdrnet_amd_train.h) -- the same arithmetic, element by element, as
 ``torch.optim.Adam`` without amsgrad / weight decay.  The step count lives on the device: a captured hipGraph replays it.
+``epsilon_hat=True`` places epsilon where ``tf.train.AdamOptimizer`` does (``lr sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) +
+eps)``, tensorflow/python/training/adam.py) -- the reference's optimizer to the letter; torch's form is the default.
 
 Construct it AFTER the module is on its device and in its memory format (``module.to(...)`` afterwards would re-allocate the
 parameters and detach them from the flat buffer).
@@ -24,7 +26,8 @@ __all__ = ["FlatAdam"]
 
 class FlatAdam:
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999),
-                 eps: float = 1e-8):
+                 eps: float = 1e-8, epsilon_hat: bool = False):
+        self.epsilon_hat = bool(epsilon_hat)
         self.bucket = hd.GradBucket(params, align=4)  # runtime.TrainStep picks this bucket up instead of making its own
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         b = self.bucket
@@ -57,16 +60,18 @@ class FlatAdam:
             from .hdrnet_ops import _stream
             lib = _lib.load()
             with torch.cuda.device(self.flat.device):
-                rc = lib.hdrnet_adam_step_f32(self.flat.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(),
-                                              self.exp_avg_sq.data_ptr(), self.flat.numel(), self.steps.data_ptr(),
-                                              self.lr, b1, b2, self.eps, _stream(self.flat.device))
+                fn = lib.hdrnet_adam_step_tf_f32 if self.epsilon_hat else lib.hdrnet_adam_step_f32
+                rc = fn(self.flat.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(),
+                        self.exp_avg_sq.data_ptr(), self.flat.numel(), self.steps.data_ptr(),
+                        self.lr, b1, b2, self.eps, _stream(self.flat.device))
             if rc != 0:
-                raise RuntimeError(f"hdrnet_adam_step_f32 failed (rc={rc})")
+                raise RuntimeError(f"hdrnet_adam_step{'_tf' if self.epsilon_hat else ''}_f32 failed (rc={rc})")
             return
         # CPU (the gloo tests): the same formula with torch ops
         self.steps += 1
         t = float(self.steps)
         self.exp_avg.mul_(b1).add_(g, alpha=1 - b1)
         self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
-        denom = (self.exp_avg_sq.sqrt() / (1 - b2 ** t) ** 0.5).add_(self.eps)
+        rs2 = 1.0 / (1 - b2 ** t) ** 0.5
+        denom = (self.exp_avg_sq.sqrt() * rs2).add_(self.eps * rs2 if self.epsilon_hat else self.eps)
         self.flat.addcdiv_(self.exp_avg, denom, value=-self.lr / (1 - b1 ** t))

@@ -9,6 +9,10 @@
  * fp32 buffers of n elements, in place:
  *   t = step[0] + 1;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2
  *   param -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+ * hdrnet_adam_step_tf_f32: the same with TensorFlow's placement of epsilon -- tf.train.AdamOptimizer, the optimizer the
+ * reference constructs (hdrnet/bin/train.py:113), applies "epsilon hat" (tensorflow/python/training/adam.py):
+ *   param -= lr sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps)
+ * i.e. the formula above with eps / sqrt(1 - b2^t) in place of eps.  The two agree to rounding once sqrt(v) >> eps.
  * `step` is a DEVICE float holding the number of updates done so far; the call increments it (a second, one-thread
  * launch), so a captured hipGraph replays correctly.  Returns 0, or 1 for a bad argument (null / misaligned buffer,
  * n <= 0); no host synchronisation. */
@@ -21,6 +25,8 @@ extern "C" {
 
 int hdrnet_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
                          float* step, float lr, float beta1, float beta2, float eps, void* stream);
+int hdrnet_adam_step_tf_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
+                            float* step, float lr, float beta1, float beta2, float eps, void* stream);
 
 #ifdef __cplusplus
 } /* extern "C" */

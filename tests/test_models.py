@@ -984,6 +984,42 @@ def test_flat_adam_equals_torch_adam_cpu():
     _flat_adam_vs_torch("cpu")
 
 
+def _flat_adam_epsilon_hat_vs_tensorflow_formula(dev, steps=5):
+    """epsilon_hat=True against tf.train.AdamOptimizer's update (tensorflow/python/training/adam.py: lr_t = lr *
+    sqrt(1 - b2^t) / (1 - b1^t); m, v as usual; var -= lr_t * m / (sqrt(v) + eps)) restated in float64 -- the optimizer
+    hdrnet/bin/train.py:113 builds.  eps is large here so that the two placements of epsilon differ visibly."""
+    from hdrnet_amd import optim
+    torch.manual_seed(11)
+    lr, b1, b2, eps = 2e-3, 0.9, 0.99, 1e-3
+    w = torch.nn.Parameter(torch.randn(37, 5, device=dev))
+    w0 = w.detach().clone()
+    opt = optim.FlatAdam([w], lr=lr, betas=(b1, b2), eps=eps, epsilon_hat=True)
+    other = torch.nn.Parameter(w0.clone())
+    oopt = optim.FlatAdam([other], lr=lr, betas=(b1, b2), eps=eps)
+    var, m, v = w0.double().cpu(), torch.zeros(37, 5, dtype=torch.float64), torch.zeros(37, 5, dtype=torch.float64)
+    for t in range(1, steps + 1):
+        g = torch.randn(37, 5, device=dev) * 0.01
+        for o in (opt, oopt):
+            o.bucket.flat[:g.numel()].copy_(g.reshape(-1))
+            o.step()
+        g64 = g.double().cpu()
+        lr_t = lr * (1 - b2 ** t) ** 0.5 / (1 - b1 ** t)
+        m = b1 * m + (1 - b1) * g64
+        v = b2 * v + (1 - b2) * g64 * g64
+        var = var - lr_t * m / (v.sqrt() + eps)
+    assert torch.allclose(w.detach().double().cpu(), var, rtol=1e-5, atol=1e-7)
+    assert float((other.detach().double().cpu() - var).abs().max()) > 1e-4        # torch's placement is another update
+
+
+def test_flat_adam_epsilon_hat_is_tensorflows_adam_cpu():
+    _flat_adam_epsilon_hat_vs_tensorflow_formula("cpu")
+
+
+@pytest.mark.gpu
+def test_flat_adam_epsilon_hat_kernel_is_tensorflows_adam():
+    _flat_adam_epsilon_hat_vs_tensorflow_formula("cuda:0")
+
+
 @pytest.mark.gpu
 def test_flat_adam_kernel_equals_torch_adam():
     _flat_adam_vs_torch("cuda:0", steps=6)
@@ -1002,5 +1038,6 @@ def test_train_header_symbols_are_exported_and_bound():
         assert hasattr(lib, n)
         m = re.search(r"\b" + n + r"\s*\(([^)]*)\)", src)
         assert len(m.group(1).split(",")) == len(_lib.TRAIN_SIGNATURES[n][1])
-    lib.hdrnet_adam_step_f32.argtypes = _lib.TRAIN_SIGNATURES["hdrnet_adam_step_f32"][1]
-    assert lib.hdrnet_adam_step_f32(None, None, None, None, 16, None, 1e-3, 0.9, 0.999, 1e-8, None) == 1
+    for n in ("hdrnet_adam_step_f32", "hdrnet_adam_step_tf_f32"):
+        getattr(lib, n).argtypes = _lib.TRAIN_SIGNATURES[n][1]
+        assert getattr(lib, n)(None, None, None, None, 16, None, 1e-3, 0.9, 0.999, 1e-8, None) == 1
