@@ -196,11 +196,12 @@ struct DwFirstParams {
   float* db_part;      // [nchunks][Cout]
   int Hin, Win, Hout, Wout, Cout, pad_top, pad_left;
   int tiles_x, tiles_per_image, tiles_total, tiles_per_chunk;
-  unsigned tx_mul, tpi_mul;
+  unsigned tx_mul, tpi_mul, cout_mul;
 };
 
 __global__ __launch_bounds__(256) void coeff_conv_dw_first(const DwFirstParams p) {
   constexpr int T8 = 8, TI = 17;
+  constexpr int NX = (TI * TI * 3 + 255) / 256, NY = (T8 * T8 * 9 + 255) / 256;
   __shared__ float xs[TI * TI * 3];
   __shared__ float ys[T8 * T8 * 9];
   const int tid = threadIdx.x;
@@ -210,32 +211,54 @@ __global__ __launch_bounds__(256) void coeff_conv_dw_first(const DwFirstParams p
   const int xoff = tt < 27 ? ((tap / 3) * TI + (tap % 3)) * 3 + ic : 0;
   const int chunk = blockIdx.x;
   const int t_end = min((chunk + 1) * p.tiles_per_chunk, p.tiles_total);
-  float acc = 0.0f;
-  for (int t = chunk * p.tiles_per_chunk; t < t_end; ++t) {
+  // A tile's input patch and masked gradient travel through registers: the NEXT tile's loads are issued before this
+  // tile's products, and the ReLU mask and the gradient are two independent loads (a select, not a dependent load).
+  float xr[NX], yr[NY], mr[NY];
+  auto load = [&](int t) {
     const int b = udiv(t, p.tpi_mul, p.tiles_per_image);
     const int r = t - b * p.tiles_per_image;
     const int ty = udiv(r, p.tx_mul, p.tiles_x), tx = r - ty * p.tiles_x;
     const int oy0 = ty * T8, ox0 = tx * T8;
     const int iy0 = oy0 * 2 - p.pad_top, ix0 = ox0 * 2 - p.pad_left;
-    __syncthreads();  // the previous tile has been consumed
-    for (int i = tid; i < TI * TI * 3; i += 256) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int i = tid + 256 * j;
       const int pix = i / 3, c = i - pix * 3;
       const int py = pix / TI, px = pix - py * TI;
       const int gy = iy0 + py, gx = ix0 + px;
-      const bool ok = (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
-      xs[i] = ok ? p.x[(((size_t)b * p.Hin + gy) * p.Win + gx) * 3 + c] : 0.0f;
+      const bool ok = i < TI * TI * 3 && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
+      xr[j] = ok ? p.x[(((size_t)b * p.Hin + gy) * p.Win + gx) * 3 + c] : 0.0f;
     }
-    for (int i = tid; i < T8 * T8 * p.Cout; i += 256) {
-      const int pix = i / p.Cout, c = i - pix * p.Cout;
+#pragma unroll
+    for (int j = 0; j < NY; ++j) {
+      const int i = tid + 256 * j;
+      const int pix = udiv(i, p.cout_mul, p.Cout), c = i - pix * p.Cout;
       const int oy = oy0 + (pix >> 3), ox = ox0 + (pix & 7);
-      float v = 0.0f;
-      if (oy < p.Hout && ox < p.Wout) {
-        const size_t off = (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + c;
-        v = p.ymask[off] > 0.0f ? p.dy[off] : 0.0f;
-      }
-      ys[pix * 9 + c] = v;
+      const bool ok = pix < T8 * T8 && oy < p.Hout && ox < p.Wout;
+      const size_t off = ok ? (((size_t)b * p.Hout + oy) * p.Wout + ox) * p.Cout + c : 0;
+      const float m = p.ymask[off], d = p.dy[off];
+      mr[j] = ok ? m : 0.0f;
+      yr[j] = d;
+    }
+  };
+  float acc = 0.0f;
+  int t = chunk * p.tiles_per_chunk;
+  if (t < t_end) load(t);
+  for (; t < t_end; ++t) {
+    __syncthreads();  // the previous tile has been consumed
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int i = tid + 256 * j;
+      if (i < TI * TI * 3) xs[i] = xr[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NY; ++j) {
+      const int i = tid + 256 * j;
+      const int pix = udiv(i, p.cout_mul, p.Cout), c = i - pix * p.Cout;
+      if (pix < T8 * T8) ys[pix * 9 + c] = mr[j] > 0.0f ? yr[j] : 0.0f;
     }
     __syncthreads();
+    if (t + 1 < t_end) load(t + 1);
     if (on) {
       if (tt < 27) {
 #pragma unroll 8
@@ -259,31 +282,69 @@ struct ReduceTab {
   const float* src[kMaxParts];
   float* dst[kMaxParts];
   int n[kMaxParts], nsplit[kMaxParts], first[kMaxParts + 1];
+  int vec[kMaxParts];  // 4 elements per lane: the length is a multiple of 4 and the partial sums are 16-byte aligned
   int count;
 };
 
+// Block = 16 lanes of consecutive elements x 16 groups of the chunks; every load of the block is in flight at once (a loop
+// over 512 chunks, one load at a time, was 39 us of the step).  Entries whose length is a multiple of 4 -- every weight
+// tensor, most biases -- take 4 elements per lane as one 16-byte load (64 elements per block: a quarter of the ~11 000
+// workgroups the launch had, which were what its 12 us consisted of); `first` counts blocks accordingly.
 __global__ __launch_bounds__(256) void coeff_reduce_parts(const ReduceTab tab) {
-  __shared__ float red[16][17];
+  __shared__ float red[16][68];
   int e = 0;
   while (e + 1 < tab.count && (int)blockIdx.x >= tab.first[e + 1]) ++e;  // uniform
-  // block = 16 consecutive elements x 16 groups of the chunks: every load of the block in flight at once (a loop over
-  // 512 chunks, one load at a time, was 39 us of the step)
   const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
-  const int i = ((int)blockIdx.x - tab.first[e]) * 16 + el;
   const int n = tab.n[e], ns = tab.nsplit[e];
-  float v = 0.0f;
+  const int blk = (int)blockIdx.x - tab.first[e];
+  if (!tab.vec[e]) {  // scalar lanes
+    const int i = blk * 16 + el;
+    float v = 0.0f;
+    if (i < n) {
+      const float* s = tab.src[e] + i;
+      for (int k0 = 0; k0 < ns; k0 += 256) {
+        float t[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int k = k0 + g + 16 * j;
+          t[j] = k < ns ? s[(size_t)k * n] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v += t[j];
+      }
+    }
+    red[g][el] = v;
+    __syncthreads();
+    if (g == 0 && i < n) {
+      float t = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += red[k][el];
+      tab.dst[e][i] = t;
+    }
+    return;
+  }
+  const int i = (blk * 16 + el) * 4;
+  float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   if (i < n) {
     const float* s = tab.src[e] + i;
-#pragma unroll 8
-    for (int k = g; k < ns; k += 16) v += s[(size_t)k * n];
+    for (int k0 = 0; k0 < ns; k0 += 256) {
+      float4 t[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int k = k0 + g + 16 * j;
+        t[j] = k < ns ? *reinterpret_cast<const float4*>(s + (size_t)k * n) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w; }
+    }
   }
-  red[g][el] = v;
+  *reinterpret_cast<float4*>(&red[g][el * 4]) = v;
   __syncthreads();
-  if (g == 0 && i < n) {
+  if (g < 4 && i < n) {  // lane (el, g): element i + g
     float t = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][el];
-    tab.dst[e][i] = t;
+    for (int k = 0; k < 16; ++k) t += red[k][el * 4 + g];
+    tab.dst[e][i + g] = t;
   }
 }
 
@@ -298,6 +359,8 @@ struct DxParams {
   int Hy, Wy, Cy, Hx, Wx, Cx;
   int ups, pad_top, pad_left;  // the gradient upsampled by the forward stride; pad' = KS - 1 - forward pad
   int tiles_x, tiles, oc_groups;
+  int tpb, tile_blocks;  // a workgroup's run of consecutive tiles (one is a chain of round trips: the next tile's loads fly
+                         // under this tile's products); tile_blocks = ceil(tiles / tpb)
   unsigned ti_mul, tx_mul;
   int c4shift, nchunks;
   unsigned lds_off[4][12];  // per wave: LDS float offset of each (tap, 16-channel group) step | group << 24; [9] = count
@@ -312,7 +375,7 @@ struct DxParams {
 // MFMA roles as in coeff_conv_mfma: rows = the tile's 16 pixels of dx, columns = 16 channels of dx (Cx), the k of
 // MFMA e of a 16-channel group of the gradient is channel 16 g + 4 kk + e.
 template <int KS>
-__device__ __forceinline__ void conv_dx_body(const DxParams& p, float* lds, int tile, int ocg, int b) {
+__device__ __forceinline__ void conv_dx_body(const DxParams& p, float* lds, int tile_block, int ocg, int b) {
   constexpr int KK = KS * KS;
   constexpr int kMaxSteps = KK;
   constexpr int TI = (kT - 1) + KS;  // stride 1 over the upsampled gradient
@@ -326,9 +389,8 @@ __device__ __forceinline__ void conv_dx_body(const DxParams& p, float* lds, int 
     wstep[si] = p.w_off[wave][si];
   }
   const int nsw = (int)p.lds_off[wave][9];
-  const int tyi = udiv(tile, p.tx_mul, p.tiles_x), txi = tile - tyi * p.tiles_x;
-  const int oy0 = tyi * kT, ox0 = txi * kT;
-  const int iy0 = oy0 - p.pad_top, ix0 = ox0 - p.pad_left;  // in the upsampled gradient
+  const int tile0 = tile_block * p.tpb;
+  const int ntile = min(p.tpb, p.tiles - tile0);
   const int Hu = (p.Hy - 1) * p.ups + 1, Wu = (p.Wy - 1) * p.ups + 1;
   const int ushift = p.ups >> 1;  // ups in {1, 2}
   const int Cy = p.Cy, Cx = p.Cx;
@@ -346,7 +408,9 @@ __device__ __forceinline__ void conv_dx_body(const DxParams& p, float* lds, int 
   const int nU = ((npix << p.c4shift) + 255) >> 8;
   float4 st[kMaxU], st2[kMaxU], stm[kMaxU];
   unsigned okbits = 0;
-  auto fetch_tile = [&](int chunk) {
+  auto fetch_tile = [&](int tile, int chunk) {
+    const int tyi = udiv(tile, p.tx_mul, p.tiles_x), txi = tile - tyi * p.tiles_x;
+    const int iy0 = tyi * kT - p.pad_top, ix0 = txi * kT - p.pad_left;  // in the upsampled gradient
     okbits = 0;
 #pragma unroll
     for (int u = 0; u < kMaxU; ++u) {
@@ -399,19 +463,22 @@ __device__ __forceinline__ void conv_dx_body(const DxParams& p, float* lds, int 
     }
   };
   float4 bw[kMaxSteps];
-  fetch_tile(0);
+  fetch_tile(tile0, 0);
   fetch_w(0, bw);
   v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   const int ti = lane & 15;
   const float* tl = lds + ((ti >> 2) * TI + (ti & 3)) * PS + (qvalid ? 4 * q : 0);
-  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-    if (chunk > 0) __syncthreads();
+  int tile = tile0, chunk = 0;
+  for (int step = 0, nstep = ntile * p.nchunks; step < nstep; ++step) {  // (tile, chunk) pairs, tile-major
+    if (step > 0) __syncthreads();
     stash_tile();
     __syncthreads();
+    const bool last_chunk = chunk + 1 == p.nchunks;
+    const int ntl = last_chunk ? tile + 1 : tile, nch = last_chunk ? 0 : chunk + 1;
     float4 bwn[kMaxSteps];
-    if (chunk + 1 < p.nchunks) {
-      fetch_w(chunk + 1, bwn);
-      fetch_tile(chunk + 1);
+    if (step + 1 < nstep) {
+      if (p.nchunks > 1) fetch_w(nch, bwn);  // (one chunk: the same filter elements serve every tile)
+      fetch_tile(ntl, nch);
     }
 #pragma unroll
     for (int si = 0; si < kMaxSteps; ++si) {
@@ -424,35 +491,41 @@ __device__ __forceinline__ void conv_dx_body(const DxParams& p, float* lds, int 
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, bw[si].w, acc1, 0, 0, 0);
       }
     }
-    if (chunk + 1 < p.nchunks) {
+    if (p.nchunks > 1 && step + 1 < nstep) {
 #pragma unroll
       for (int si = 0; si < kMaxSteps; ++si) bw[si] = bwn[si];
     }
-  }
-  const v4f acc = acc0 + acc1;
+    if (last_chunk) {  // uniform: the tile is complete
+      const v4f acc = acc0 + acc1;
+      acc0 = acc1 = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
-  __syncthreads();
-  const int r = wave;
-  float v = red[r * 64 + lane];
+      for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
+      __syncthreads();
+      const int r = wave;
+      float v = red[r * 64 + lane];
 #pragma unroll
-  for (int w = 1; w < 4; ++w) v += red[(w * 4 + r) * 64 + lane];
-  const int i = 4 * q + r, o = n0 + j;
-  const int oy = oy0 + (i >> 2), ox = ox0 + (i & 3);
-  const bool in = o < Cx && oy < p.Hx && ox < p.Wx;
-  const size_t off = (((size_t)b * p.Hx + min(oy, p.Hx - 1)) * p.Wx + min(ox, p.Wx - 1)) * Cx + min(o, Cx - 1);
-  if (in) p.dx[off] = v;
-  if (p.colsum_part) {  // uniform
-    const float mv = (in && p.xmask[off] > 0.0f) ? v : 0.0f;
-    __syncthreads();  // everyone has read its partial tiles
-    red[i * 16 + j] = mv;
-    __syncthreads();
-    if (tid < 16 && n0 + tid < Cx) {
-      float t = 0.0f;
+      for (int w = 1; w < 4; ++w) v += red[(w * 4 + r) * 64 + lane];
+      const int tyi = udiv(tile, p.tx_mul, p.tiles_x), txi = tile - tyi * p.tiles_x;
+      const int i = 4 * q + r, o = n0 + j;
+      const int oy = tyi * kT + (i >> 2), ox = txi * kT + (i & 3);
+      const bool in = o < Cx && oy < p.Hx && ox < p.Wx;
+      const size_t off = (((size_t)b * p.Hx + min(oy, p.Hx - 1)) * p.Wx + min(ox, p.Wx - 1)) * Cx + min(o, Cx - 1);
+      if (in) p.dx[off] = v;
+      if (p.colsum_part) {  // uniform
+        const float mv = (in && p.xmask[off] > 0.0f) ? v : 0.0f;
+        __syncthreads();  // everyone has read its partial tiles
+        red[i * 16 + j] = mv;
+        __syncthreads();
+        if (tid < 16 && n0 + tid < Cx) {
+          float t = 0.0f;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) t += red[k * 16 + tid];
-      p.colsum_part[((size_t)b * p.tiles + tile) * Cx + n0 + tid] = t;
+          for (int k = 0; k < 16; ++k) t += red[k * 16 + tid];
+          p.colsum_part[((size_t)b * p.tiles + tile) * Cx + n0 + tid] = t;
+        }
+      }
     }
+    tile = ntl;
+    chunk = nch;
   }
 }
 
@@ -502,31 +575,51 @@ struct FcBwdParams {
   int B, K, O, mask_x;  // mask_x: dx passes where x > 0 (the input is a ReLU's output)
 };
 
-// Block = 16 inputs k x 16 parts of the outputs; every (o, k) of dW belongs to exactly one thread.
+// Block = 16 inputs k x 16 parts of the outputs; every (o, k) of dW belongs to exactly one thread.  The layers are tiny
+// (<= 1 MB of weights) and the kernel is a chain of memory round trips, so every load of a 256-output chunk is issued before
+// the first is used: the 16 weights of a thread as predicated loads of a fully unrolled loop (a run-time trip count leaves
+// small layers in the compiler's serial remainder loop: one round trip per output), dy staged through the LDS once per
+// workgroup instead of B broadcast loads per output, the bias gradient's loads at the top, spread over the workgroups.
 __global__ __launch_bounds__(256) void coeff_fc_bwd(const FcBwdParams p) {
   __shared__ float red[kMaxB][16][17];
+  __shared__ float dys[kMaxB][256];
   const int tid = threadIdx.x, kl = tid & 15, op = tid >> 4;
   const int k = blockIdx.x * 16 + kl;
   const bool k_ok = k < p.K;
-  float xk[kMaxB], dxp[kMaxB];
+  float xk[kMaxB], dxp[kMaxB], dbv[kMaxB];
+  const int ob = blockIdx.x * 256 + tid;  // this thread's bias gradient (one per thread of the first O / 256 workgroups)
 #pragma unroll
   for (int b = 0; b < kMaxB; ++b) {
     xk[b] = (b < p.B && k_ok) ? p.x[(size_t)b * p.K + k] : 0.0f;
+    dbv[b] = (b < p.B && ob < p.O) ? p.dy[(size_t)b * p.O + ob] : 0.0f;
     dxp[b] = 0.0f;
   }
-#pragma unroll 16
-  for (int o = op; o < p.O; o += 16) {
-    const float w = k_ok ? p.w[(size_t)o * p.K + k] : 0.0f;
-    float dwv = 0.0f;
+  for (int o0 = 0; o0 < p.O; o0 += 256) {
+    if (o0 > 0) __syncthreads();
 #pragma unroll
-    for (int b = 0; b < kMaxB; ++b) {
-      if (b < p.B) {
-        const float g = p.dy[(size_t)b * p.O + o];
-        dwv = __builtin_fmaf(g, xk[b], dwv);
-        dxp[b] = __builtin_fmaf(g, w, dxp[b]);
-      }
+    for (int b = 0; b < kMaxB; ++b)
+      if (b < p.B) dys[b][tid] = (o0 + tid < p.O) ? p.dy[(size_t)b * p.O + o0 + tid] : 0.0f;
+    float w[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int o = o0 + op + 16 * i;
+      w[i] = (k_ok && o < p.O) ? p.w[(size_t)o * p.K + k] : 0.0f;
     }
-    if (k_ok) p.dw[(size_t)o * p.K + k] = dwv;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int o = o0 + op + 16 * i;
+      float dwv = 0.0f;
+#pragma unroll
+      for (int b = 0; b < kMaxB; ++b) {
+        if (b < p.B) {
+          const float g = dys[b][op + 16 * i];
+          dwv = __builtin_fmaf(g, xk[b], dwv);
+          dxp[b] = __builtin_fmaf(g, w[i], dxp[b]);
+        }
+      }
+      if (k_ok && o < p.O) p.dw[(size_t)o * p.K + k] = dwv;
+    }
   }
 #pragma unroll
   for (int b = 0; b < kMaxB; ++b) red[b][op][kl] = dxp[b];
@@ -538,12 +631,16 @@ __global__ __launch_bounds__(256) void coeff_fc_bwd(const FcBwdParams p) {
     const float xv = p.x[(size_t)op * p.K + k];
     p.dx[(size_t)op * p.K + k] = (p.mask_x && !(xv > 0.0f)) ? 0.0f : v;
   }
-  if (blockIdx.x == 0) {
-    for (int o = tid; o < p.O; o += 256) {
-      float v = 0.0f;
-      for (int b = 0; b < p.B; ++b) v += p.dy[(size_t)b * p.O + o];
-      p.db[o] = v;
-    }
+  if (ob < p.O) {
+    float v = 0.0f;
+#pragma unroll
+    for (int b = 0; b < kMaxB; ++b) v += dbv[b];  // images beyond B hold zeros: the order of the sum is b = 0, 1, ...
+    p.db[ob] = v;
+  }
+  for (int o = ob + (int)gridDim.x * 256; o < p.O; o += (int)gridDim.x * 256) {  // (never taken: grid >= O / 256)
+    float v = 0.0f;
+    for (int b = 0; b < p.B; ++b) v += p.dy[(size_t)b * p.O + o];
+    p.db[o] = v;
   }
 }
 
@@ -704,12 +801,15 @@ DwParams make_dw(const Layer& L, int B, const float* dy, const float* dy2, bool 
   return p;
 }
 
+void add_reduce_entry(ReduceTab* tab, const float* src, float* dst, int n, int nchunks) {
+  const int e = tab->count++;
+  tab->src[e] = src; tab->dst[e] = dst; tab->n[e] = n; tab->nsplit[e] = nchunks;
+  tab->vec[e] = (n % 4 == 0 && ((uintptr_t)src & 15u) == 0) ? 1 : 0;
+  tab->first[e + 1] = tab->first[e] + (tab->vec[e] ? (n / 4 + 15) / 16 : (n + 15) / 16);
+}
+
 void add_reduce(ReduceTab* tab, const DwParams& p, const Layer& L, int nchunks) {
-  auto add = [&](const float* src, float* dst, int n) {
-    const int e = tab->count++;
-    tab->src[e] = src; tab->dst[e] = dst; tab->n[e] = n; tab->nsplit[e] = nchunks;
-    tab->first[e + 1] = tab->first[e] + (n + 15) / 16;
-  };
+  auto add = [&](const float* src, float* dst, int n) { add_reduce_entry(tab, src, dst, n, nchunks); };
   add(p.dw_part, L.dw, L.Cout * L.ks * L.ks * L.Cin);
   if (L.db) add(p.db_part, L.db, L.Cout);
 }
@@ -726,13 +826,9 @@ hipError_t launch_dw(const Layer& L, int B, const float* dy, const float* dy2, b
     f.Hin = f.Win = L.Hin; f.Hout = f.Wout = L.Hout; f.Cout = L.Cout;
     f.pad_top = f.pad_left = same_pad_before(L.Hin, L.Hout, 3, 2);
     f.tiles_x = pl.tiles_x; f.tiles_per_image = pl.tpi; f.tiles_total = pl.total; f.tiles_per_chunk = pl.tpc;
-    f.tx_mul = magic32(pl.tiles_x); f.tpi_mul = magic32(pl.tpi);
+    f.tx_mul = magic32(pl.tiles_x); f.tpi_mul = magic32(pl.tpi); f.cout_mul = magic32(L.Cout);
     coeff_conv_dw_first<<<dim3((unsigned)pl.nchunks), 256, 0, s>>>(f);
-    auto add1 = [&](const float* src, float* dst, int n) {
-      const int e = tab->count++;
-      tab->src[e] = src; tab->dst[e] = dst; tab->n[e] = n; tab->nsplit[e] = pl.nchunks;
-      tab->first[e + 1] = tab->first[e] + (n + 15) / 16;
-    };
+    auto add1 = [&](const float* src, float* dst, int n) { add_reduce_entry(tab, src, dst, n, pl.nchunks); };
     add1(f.dw_part, L.dw, (int)nw1);
     add1(f.db_part, L.db, L.Cout);
     return hipGetLastError();
@@ -762,6 +858,8 @@ DxSetup make_dx(const Layer& L, const float* dy, const float* dy2, bool mask, fl
   p.tiles_x = (L.Hin + kT - 1) / kT;
   p.tiles = p.tiles_x * p.tiles_x;
   p.oc_groups = (L.Cin + 15) / 16;
+  p.tpb = 1;
+  p.tile_blocks = p.tiles;
   const int ti = kT - 1 + L.ks;
   p.ti_mul = magic32(ti);
   p.tx_mul = magic32(p.tiles_x);
@@ -788,9 +886,18 @@ DxSetup make_dx(const Layer& L, const float* dy, const float* dy2, bool mask, fl
   return su;
 }
 
+// More than ~4 workgroups per CU of a few microseconds each is a launch bound by workgroup turnover (the second splat
+// layer's backward-data at 4 x 128 x 128: 4096 workgroups, 20 of the pair's 26 us): such layers take runs of tiles.
+void plan_dx_tiles(DxParams* p, int B) {
+  p->tpb = 1;
+  while (p->tpb < 8 && (long long)((p->tiles + p->tpb - 1) / p->tpb) * p->oc_groups * B > 1024) p->tpb *= 2;
+  p->tile_blocks = (p->tiles + p->tpb - 1) / p->tpb;
+}
+
 hipError_t launch_dx(const Layer& L, int B, const float* dy, const float* dy2, bool mask, float* dx, hipStream_t s) {
-  const DxSetup su = make_dx(L, dy, dy2, mask, dx);
-  const dim3 grid((unsigned)su.p.tiles, (unsigned)su.p.oc_groups, (unsigned)B);
+  DxSetup su = make_dx(L, dy, dy2, mask, dx);
+  plan_dx_tiles(&su.p, B);
+  const dim3 grid((unsigned)su.p.tile_blocks, (unsigned)su.p.oc_groups, (unsigned)B);
   if (L.ks == 3) coeff_conv_dx<3><<<grid, 256, su.lds, s>>>(su.p);
   else coeff_conv_dx<1><<<grid, 256, su.lds, s>>>(su.p);
   return hipGetLastError();
@@ -803,11 +910,12 @@ hipError_t launch_pair(const Layer& L, int B, const float* dy, const float* dy2,
   const PartPlan pl = part_plan(B, L.Hout, ocb * icb);
   BwdPair pr{};
   pr.dw = make_dw(L, B, dy, dy2, mask, part, pl, icb);
-  const DxSetup su = make_dx(L, dy, dy2, mask, dx, xmask, colsum_part);
+  DxSetup su = make_dx(L, dy, dy2, mask, dx, xmask, colsum_part);
+  plan_dx_tiles(&su.p, B);
   pr.dx = su.p;
   pr.dw_chunks = pl.nchunks;
   pr.dw_blocks = pl.nchunks * ocb * icb;
-  pr.dx_tiles = su.p.tiles;
+  pr.dx_tiles = su.p.tile_blocks;
   pr.dx_groups = su.p.oc_groups;
   pr.chunk_mul = magic32(pr.dw_chunks);
   pr.tile_mul = magic32(pr.dx_tiles);

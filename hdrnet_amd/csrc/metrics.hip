@@ -4,6 +4,9 @@
 //   backward  reads both again and writes d prediction = (2 / n) * grad_output * (prediction - target) (12 B per element)
 // torch's mse_loss is five launches here -- the squared differences written out (and read back by the mean), a
 // zeros_like of the gradient that the backward then overwrites -- 143 us at 4 x 1080p against ~85 us for these two.
+// When the prediction wants a gradient the forward also writes the UNIT gradient (2 / n) * (prediction - target) -- it has
+// both operands in registers -- and the backward only scales it by grad_output, which is 1 when the loss is the root of
+// the backward pass: that kernel reads one scalar and returns (8 + 4 B per element instead of 8 + 12; include/hdrnet_amd_train.h).
 //
 // Also here: the optimizer update of that loop over ONE flat parameter buffer (include/hdrnet_amd_train.h).
 #include <hip/hip_runtime.h>
@@ -19,21 +22,31 @@ namespace {
 constexpr int kLossBlocks = 2048;
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+template <bool GRAD>
 __global__ __launch_bounds__(256) void l2_loss_partial(const float* __restrict__ pred, const float* __restrict__ target,
-                                                       long long n, float* __restrict__ partial) {
+                                                       long long n, float* __restrict__ partial,
+                                                       float* __restrict__ dunit) {
   __shared__ float red[256];
   const long long n4 = n >> 2;
   const v4f* p4 = reinterpret_cast<const v4f*>(pred);
   const v4f* t4 = reinterpret_cast<const v4f*>(target);
+  v4f* d4 = reinterpret_cast<v4f*>(dunit);
+  const float k = (float)(2.0 / (double)n);
   float acc = 0.0f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const v4f a = __builtin_nontemporal_load(p4 + i), b = __builtin_nontemporal_load(t4 + i);
     const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, dw = a.w - b.w;
     acc += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    if constexpr (GRAD) {
+      v4f d;
+      d.x = k * dx, d.y = k * dy, d.z = k * dz, d.w = k * dw;
+      d4[i] = d;  // plain store: the slice-apply's gradient kernels read it next
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // the tail of a length that is not a multiple of 4
     const float d = pred[(n4 << 2) + threadIdx.x] - target[(n4 << 2) + threadIdx.x];
     acc += d * d;
+    if constexpr (GRAD) dunit[(n4 << 2) + threadIdx.x] = k * d;
   }
   red[threadIdx.x] = acc;
   __syncthreads();
@@ -74,6 +87,17 @@ __global__ __launch_bounds__(256) void l2_loss_grad(const float* __restrict__ pr
     const long long i = (n4 << 2) + threadIdx.x;
     dpred[i] = k * (pred[i] - target[i]);
   }
+}
+
+// d *= grad_output, skipped altogether when grad_output == 1 (the loss is the root of the backward pass)
+__global__ __launch_bounds__(256) void l2_loss_grad_scale(float* __restrict__ d, const float* __restrict__ grad_output,
+                                                          long long n) {
+  const float g = grad_output[0];
+  if (g == 1.0f) return;
+  const long long n4 = n >> 2;
+  v4f* d4 = reinterpret_cast<v4f*>(d);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) d4[i] = g * d4[i];
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) d[(n4 << 2) + threadIdx.x] *= g;
 }
 
 __global__ __launch_bounds__(256) void adam_flat(float* __restrict__ param, const float* __restrict__ grad,
@@ -120,7 +144,15 @@ size_t l2_loss_workspace_bytes(long long n) { return n > 0 ? (size_t)kLossBlocks
 hipError_t launch_l2_loss(const float* pred, const float* target, long long n, float* loss, void* workspace,
                           hipStream_t s) {
   float* partial = static_cast<float*>(workspace);
-  l2_loss_partial<<<kLossBlocks, 256, 0, s>>>(pred, target, n, partial);
+  l2_loss_partial<false><<<kLossBlocks, 256, 0, s>>>(pred, target, n, partial, nullptr);
+  l2_loss_final<<<1, 256, 0, s>>>(partial, kLossBlocks, n, loss);
+  return hipGetLastError();
+}
+
+hipError_t launch_l2_loss_with_grad(const float* pred, const float* target, long long n, float* loss, float* dunit,
+                                    void* workspace, hipStream_t s) {
+  float* partial = static_cast<float*>(workspace);
+  l2_loss_partial<true><<<kLossBlocks, 256, 0, s>>>(pred, target, n, partial, dunit);
   l2_loss_final<<<1, 256, 0, s>>>(partial, kLossBlocks, n, loss);
   return hipGetLastError();
 }
@@ -132,6 +164,24 @@ hipError_t launch_l2_loss_grad(const float* pred, const float* target, const flo
 }
 
 }  // namespace hdrnet_amd
+
+extern "C" int hdrnet_l2_loss_with_grad_f32(const float* prediction, const float* target, long long n, float* loss,
+                                            float* dprediction_unit, void* workspace, size_t workspace_bytes,
+                                            void* stream) {
+  using namespace hdrnet_amd;
+  if (n <= 0 || !prediction || !target || !loss || !dprediction_unit || !workspace) return 1;
+  if (workspace_bytes < l2_loss_workspace_bytes(n)) return 1;
+  if (((uintptr_t)prediction | (uintptr_t)target | (uintptr_t)dprediction_unit) & 15u) return 1;
+  return launch_l2_loss_with_grad(prediction, target, n, loss, dprediction_unit, workspace,
+                                  static_cast<hipStream_t>(stream)) == hipSuccess ? 0 : 2;
+}
+
+extern "C" int hdrnet_l2_loss_grad_scale_f32(float* dprediction, const float* grad_output, long long n, void* stream) {
+  using namespace hdrnet_amd;
+  if (n <= 0 || !dprediction || !grad_output || ((uintptr_t)dprediction & 15u)) return 1;
+  l2_loss_grad_scale<<<kLossBlocks, 256, 0, static_cast<hipStream_t>(stream)>>>(dprediction, grad_output, n);
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
 
 namespace {
 int adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float* step, float lr,

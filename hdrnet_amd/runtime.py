@@ -137,7 +137,10 @@ class TrainStep:
     def _forward_backward(self, inputs, targets) -> torch.Tensor:
         self.bucket.release()  # .grad = None: backward assigns its gradients (no memset, no `+=` launch per parameter)
         loss = self.loss_fn(self.module(*inputs), *targets)
-        loss.backward()
+        one = getattr(self, "_one", None)   # the root gradient, kept: `loss.backward()` fills a fresh ones_like per step
+        if one is None or one.shape != loss.shape or one.dtype != loss.dtype or one.device != loss.device:
+            one = self._one = torch.ones_like(loss)
+        loss.backward(one)
         self.bucket.gather()   # one multi-tensor copy into the flat buffer; every .grad is its view again
         return loss
 

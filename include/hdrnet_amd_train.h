@@ -19,9 +19,21 @@
 #ifndef HDRNET_AMD_TRAIN_H_
 #define HDRNET_AMD_TRAIN_H_
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* The l2 loss of hdrnet/metrics.py:21-24 WITH its unit gradient in one pass over the batch (the training step's form of
+ * hdrnet_l2_loss_f32 + hdrnet_l2_loss_grad_f32 of include/hdrnet_amd.h, which read prediction and target twice):
+ *   loss[0] = mean((target - prediction)^2);   dprediction_unit = (2 / n) * (prediction - target)
+ * `workspace`: hdrnet_l2_loss_workspace_bytes(n) bytes.  hdrnet_l2_loss_grad_scale_f32 then turns the unit gradient into
+ * the gradient, dprediction *= grad_output[0] (a DEVICE scalar), and does nothing but read that scalar when it is 1 --
+ * the loss as the root of the backward pass.  Tensors 16-byte aligned; 0 on success, 1 for a bad argument. */
+int hdrnet_l2_loss_with_grad_f32(const float* prediction, const float* target, long long n, float* loss,
+                                 float* dprediction_unit, void* workspace, size_t workspace_bytes, void* stream);
+int hdrnet_l2_loss_grad_scale_f32(float* dprediction, const float* grad_output, long long n, void* stream);
 
 int hdrnet_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
                          float* step, float lr, float beta1, float beta2, float eps, void* stream);

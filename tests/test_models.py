@@ -952,6 +952,35 @@ def test_l2_loss_kernels_equal_the_reference_formula(shape):
     assert torch.allclose(p.grad.double(), p64.grad, rtol=1e-5, atol=1e-12)
 
 
+@pytest.mark.gpu
+def test_l2_loss_fused_unit_gradient_paths():
+    """The forward's unit gradient: grad_output == 1 (the scale kernel returns at once), a second backward through a
+    retained graph (recomputed by hdrnet_l2_loss_grad_f32, not scaled twice), no gradient wanted (the plain forward),
+    and the C entry points' argument checks."""
+    from hdrnet_amd import _lib, metrics
+    torch.manual_seed(6)
+    shape = (2, 37, 53, 3)
+    t = torch.rand(shape, device="cuda:0")
+    p = torch.rand(shape, device="cuda:0", requires_grad=True)
+    want = (2.0 / p.numel()) * (p.detach().double() - t.double())
+    loss = metrics.l2_loss(t, p)
+    g1, = torch.autograd.grad(loss, p, retain_graph=True)                      # root: grad_output = 1
+    assert torch.allclose(g1.double(), want, rtol=1e-6, atol=1e-14)
+    g2, = torch.autograd.grad(loss, p, torch.tensor(-2.5, device="cuda:0"), retain_graph=True)
+    assert torch.allclose(g2.double(), -2.5 * want, rtol=1e-6, atol=1e-14)
+    assert torch.allclose(g1.double(), want, rtol=1e-6, atol=1e-14)            # the first result was not touched
+    loss = metrics.l2_loss(t, p)
+    g3, = torch.autograd.grad(loss, p, torch.tensor(0.75, device="cuda:0"))   # first backward with a scale
+    assert torch.allclose(g3.double(), 0.75 * want, rtol=1e-6, atol=1e-14)
+    with torch.no_grad():
+        plain = metrics.l2_loss(t, p)
+    assert plain.grad_fn is None and abs(float(plain) - float(loss)) <= 1e-7 * float(loss)
+    lib = _lib.load()
+    assert lib.hdrnet_l2_loss_with_grad_f32(None, None, 16, None, None, None, 0, None) == 1
+    assert lib.hdrnet_l2_loss_grad_scale_f32(None, None, 16, None) == 1
+    assert lib.hdrnet_l2_loss_grad_scale_f32(g3.data_ptr(), g3.data_ptr(), 0, None) == 1
+
+
 def _flat_adam_vs_torch(dev, steps=4):
     import copy
     from hdrnet_amd import optim
@@ -1041,3 +1070,5 @@ def test_train_header_symbols_are_exported_and_bound():
     for n in ("hdrnet_adam_step_f32", "hdrnet_adam_step_tf_f32"):
         getattr(lib, n).argtypes = _lib.TRAIN_SIGNATURES[n][1]
         assert getattr(lib, n)(None, None, None, None, 16, None, 1e-3, 0.9, 0.999, 1e-8, None) == 1
+    lib.hdrnet_l2_loss_with_grad_f32.argtypes = _lib.TRAIN_SIGNATURES["hdrnet_l2_loss_with_grad_f32"][1]
+    assert lib.hdrnet_l2_loss_with_grad_f32(None, None, 16, None, None, None, 0, None) == 1
