@@ -374,7 +374,9 @@ struct DxParams {
 // dx[b, i, :] = sum_taps U[b, i - pad' + tap, :] . w[:, KK - 1 - tap, :],  U = the masked gradient, zero-upsampled.
 // MFMA roles as in coeff_conv_mfma: rows = the tile's 16 pixels of dx, columns = 16 channels of dx (Cx), the k of
 // MFMA e of a 16-channel group of the gradient is channel 16 g + 4 kk + e.
-template <int KS>
+// MULTI: the gradient has more than one chunk of kChunkCh channels (the filter elements change from step to step: a second
+// set of 9 float4 in flight; without it the kernel fits a third wave per SIMD).
+template <int KS, bool MULTI>
 __device__ __forceinline__ void conv_dx_body(const DxParams& p, float* lds, int tile_block, int ocg, int b) {
   constexpr int KK = KS * KS;
   constexpr int kMaxSteps = KK;
@@ -475,9 +477,9 @@ __device__ __forceinline__ void conv_dx_body(const DxParams& p, float* lds, int 
     __syncthreads();
     const bool last_chunk = chunk + 1 == p.nchunks;
     const int ntl = last_chunk ? tile + 1 : tile, nch = last_chunk ? 0 : chunk + 1;
-    float4 bwn[kMaxSteps];
+    float4 bwn[MULTI ? kMaxSteps : 1];
     if (step + 1 < nstep) {
-      if (p.nchunks > 1) fetch_w(nch, bwn);  // (one chunk: the same filter elements serve every tile)
+      if constexpr (MULTI) fetch_w(nch, bwn);  // (one chunk: the same filter elements serve every tile)
       fetch_tile(ntl, nch);
     }
 #pragma unroll
@@ -491,9 +493,11 @@ __device__ __forceinline__ void conv_dx_body(const DxParams& p, float* lds, int 
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, bw[si].w, acc1, 0, 0, 0);
       }
     }
-    if (p.nchunks > 1 && step + 1 < nstep) {
+    if constexpr (MULTI) {
+      if (step + 1 < nstep) {
 #pragma unroll
-      for (int si = 0; si < kMaxSteps; ++si) bw[si] = bwn[si];
+        for (int si = 0; si < kMaxSteps; ++si) bw[si] = bwn[si];
+      }
     }
     if (last_chunk) {  // uniform: the tile is complete
       const v4f acc = acc0 + acc1;
@@ -529,10 +533,10 @@ __device__ __forceinline__ void conv_dx_body(const DxParams& p, float* lds, int 
   }
 }
 
-template <int KS>
+template <int KS, bool MULTI>
 __global__ __launch_bounds__(256) void coeff_conv_dx(const DxParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  conv_dx_body<KS>(p, lds, blockIdx.x, blockIdx.y, blockIdx.z);
+  conv_dx_body<KS, MULTI>(p, lds, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Backward-weights and backward-data of ONE layer in one launch (they read the same gradient and do not depend on
@@ -546,7 +550,7 @@ struct BwdPair {
   unsigned chunk_mul, tile_mul, tg_mul;  // magic numbers of dw_chunks, dx_tiles, dx_tiles * dx_groups
 };
 
-template <int KS>
+template <int KS, bool MULTI>
 __global__ __launch_bounds__(256) void coeff_conv_bwd(const BwdPair pr) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int id = blockIdx.x;
@@ -559,7 +563,7 @@ __global__ __launch_bounds__(256) void coeff_conv_bwd(const BwdPair pr) {
     const int b = udiv(r, pr.tg_mul, tg);
     const int r2 = r - b * tg;
     const int ocg = udiv(r2, pr.tile_mul, pr.dx_tiles);
-    conv_dx_body<KS>(pr.dx, lds, r2 - ocg * pr.dx_tiles, ocg, b);
+    conv_dx_body<KS, MULTI>(pr.dx, lds, r2 - ocg * pr.dx_tiles, ocg, b);
   }
 }
 
@@ -898,8 +902,11 @@ hipError_t launch_dx(const Layer& L, int B, const float* dy, const float* dy2, b
   DxSetup su = make_dx(L, dy, dy2, mask, dx);
   plan_dx_tiles(&su.p, B);
   const dim3 grid((unsigned)su.p.tile_blocks, (unsigned)su.p.oc_groups, (unsigned)B);
-  if (L.ks == 3) coeff_conv_dx<3><<<grid, 256, su.lds, s>>>(su.p);
-  else coeff_conv_dx<1><<<grid, 256, su.lds, s>>>(su.p);
+  const bool multi = su.p.nchunks > 1;
+  if (L.ks == 3 && multi) coeff_conv_dx<3, true><<<grid, 256, su.lds, s>>>(su.p);
+  else if (L.ks == 3) coeff_conv_dx<3, false><<<grid, 256, su.lds, s>>>(su.p);
+  else if (multi) coeff_conv_dx<1, true><<<grid, 256, su.lds, s>>>(su.p);
+  else coeff_conv_dx<1, false><<<grid, 256, su.lds, s>>>(su.p);
   return hipGetLastError();
 }
 
@@ -923,10 +930,12 @@ hipError_t launch_pair(const Layer& L, int B, const float* dy, const float* dy2,
   const unsigned blocks = (unsigned)pr.dw_blocks + (unsigned)(pr.dx_tiles * pr.dx_groups * B);
   if (L.ks == 3) {
     const size_t lds = su.lds > dw_lds_floats<3>() * sizeof(float) ? su.lds : dw_lds_floats<3>() * sizeof(float);
-    coeff_conv_bwd<3><<<dim3(blocks), 256, lds, s>>>(pr);
+    if (su.p.nchunks > 1) coeff_conv_bwd<3, true><<<dim3(blocks), 256, lds, s>>>(pr);
+    else coeff_conv_bwd<3, false><<<dim3(blocks), 256, lds, s>>>(pr);
   } else {
     const size_t lds = su.lds > dw_lds_floats<1>() * sizeof(float) ? su.lds : dw_lds_floats<1>() * sizeof(float);
-    coeff_conv_bwd<1><<<dim3(blocks), 256, lds, s>>>(pr);
+    if (su.p.nchunks > 1) coeff_conv_bwd<1, true><<<dim3(blocks), 256, lds, s>>>(pr);
+    else coeff_conv_bwd<1, false><<<dim3(blocks), 256, lds, s>>>(pr);
   }
   add_reduce(tab, pr.dw, L, pl.nchunks);
   return hipGetLastError();
