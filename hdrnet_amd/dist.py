@@ -144,12 +144,17 @@ class GradBucket:
             dense = torch.empty_like(p).stride() == p.stride()  # preserve_format keeps a dense tensor's strides
             self.views.append(seg.as_strided(p.shape, p.stride()) if dense else seg.view_as(p))
             p.grad = self.views[-1]
+            # a backward that computes this parameter's gradient with its own kernels may write it HERE when .grad is
+            # None (released): autograd then adopts the alias and gather() has nothing to copy (hdrnet_ops._grad_out)
+            p._hdrnet_grad_view = self.views[-1]
+            p._hdrnet_grad_claimed = True  # handed out at most once per release(): a second use of the parameter adds
 
     def release(self) -> None:
         """Unbind the views (``.grad = None``) so that the next backward assigns its gradients instead of adding them
         to a zeroed buffer; ``gather()`` brings them into the flat buffer."""
         for p in self.params:
             p.grad = None
+            p._hdrnet_grad_claimed = False
 
     def gather(self) -> None:
         """After a backward that ran on released gradients: copy them into the flat buffer (one multi-tensor launch),

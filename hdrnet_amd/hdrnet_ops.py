@@ -687,6 +687,20 @@ def coefficients_train_supported(hyper, n_out: int, n_in: int, params, n_splat: 
     return _lib.load().hdrnet_coefficients_grad_workspace_bytes(ctypes.byref(net), int(batch)) > 0
 
 
+def _grad_out(p: torch.Tensor) -> torch.Tensor:
+    """Where a kernel-computed gradient of parameter ``p`` goes: a fresh alias of the parameter's segment of a flat
+    gradient bucket (``dist.GradBucket`` registers it) while ``.grad`` is released -- autograd ASSIGNS a gradient it is
+    handed when ``.grad`` is None, adopting the alias, so the bucket's gather has nothing to copy for this parameter --
+    otherwise (no bucket, ``.grad`` bound: accumulation, or the segment already handed out since the release: the parameter
+    is used twice and autograd must ADD the second gradient) a new tensor in the parameter's layout."""
+    v = getattr(p, "_hdrnet_grad_view", None)
+    if (v is not None and p.grad is None and not getattr(p, "_hdrnet_grad_claimed", True) and v.device == p.device
+            and v.dtype == p.dtype and v.shape == p.shape and v.stride() == p.stride()):
+        p._hdrnet_grad_claimed = True
+        return v.detach()
+    return torch.empty_like(p)  # preserve_format: channels_last weights get channels_last grads
+
+
 class _CoefficientsTrain(torch.autograd.Function):
     """Forward = the inference launch sequence on the live parameters, its workspace kept; backward =
     ``hdrnet_coefficients_grad_f32`` (csrc/coeff_net_train.hip)."""
@@ -718,7 +732,7 @@ class _CoefficientsTrain(torch.autograd.Function):
         hyper, n_out, n_in, n_splat = ctx.meta
         B, dev = low.shape[0], low.device
         net = _live_net(hyper, n_out, n_in, params, n_splat)
-        grads = [torch.empty_like(p) for p in params]  # preserve_format: channels_last weights get channels_last grads
+        grads = [_grad_out(p) for p in params]
         gr = _lib.CoeffNetGrads()
         it = iter(grads)
         for i in range(n_splat):

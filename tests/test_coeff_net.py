@@ -349,3 +349,45 @@ def test_native_training_is_deterministic_and_falls_back_with_batch_norm():
     assert not mb.coefficients._use_native_training(low)
     low.requires_grad_(True)
     assert not m.coefficients._use_native_training(low)  # the input's own gradient: torch ops
+
+
+@pytest.mark.gpu
+def test_native_training_writes_into_a_released_gradient_bucket():
+    """With the gradients in a flat bucket (dist.GradBucket) and released (.grad = None), the backward kernels write every
+    coefficient-network gradient straight into its segment: autograd adopts the alias (.grad's memory IS the segment),
+    gather() has only the other parameters to copy, and the flat buffer equals the gradients of a run without a bucket.
+    A parameter used TWICE in one backward is handed its segment once; the second gradient is added by autograd."""
+    from hdrnet_amd import dist as hd
+    torch.manual_seed(4)
+    m = randomize(models.HDRNetPointwiseNNGuide(dict(batch_norm=False)), seed=2).to("cuda:0").train()
+    low = torch.rand(2, 256, 256, 3, device="cuda:0")
+    low2 = torch.rand(2, 256, 256, 3, device="cuda:0")
+    params = list(m.coefficients.parameters())
+
+    def plain(inputs):
+        for p in params:
+            p.grad = None
+        sum(m.coefficients(x).square().sum() for x in inputs).backward()
+        return [p.grad.clone() for p in params]
+
+    want1, want2 = plain([low]), plain([low, low2])
+    bucket = hd.GradBucket(params, align=4)
+    for inputs, want in (([low], want1), ([low, low2], want2)):
+        bucket.flat.fill_(float("nan"))
+        bucket.release()
+        sum(m.coefficients(x).square().sum() for x in inputs).backward()
+        adopted = sum(p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, bucket.views))
+        if len(inputs) == 1:
+            assert adopted == len(params), (adopted, len(params))  # nothing left for gather() to copy
+        bucket.gather()
+        assert bucket.attached()
+        for p, v, w in zip(params, bucket.views, want):
+            assert p.grad is v
+            scale = float(w.abs().max()) + 1e-30
+            assert float((v - w).abs().max()) <= 2e-6 * scale, float((v - w).abs().max()) / scale
+    # bound gradients (no release): accumulation must not alias
+    before = [v.clone() for v in bucket.views]
+    m.coefficients(low).square().sum().backward()
+    for v, b, w in zip(bucket.views, before, want1):
+        scale = float((b + w).abs().max()) + 1e-30
+        assert float((v - (b + w)).abs().max()) <= 4e-6 * scale
