@@ -520,6 +520,7 @@ class _GuideFoldBatch(torch.autograd.Function):
                 torch.autograd.graph.increment_version(t)
         ctx.save_for_backward(*args[:5])
         ctx.meta = (int(npx), float(eps), Cin, n, b2.shape)
+        ctx.leaves = (w1, beta, w2, b2)  # where their gradients may be written directly (_grad_out)
         return conv1, conv2
 
     @staticmethod
@@ -528,10 +529,11 @@ class _GuideFoldBatch(torch.autograd.Function):
         npx, eps, Cin, n, b2_shape = ctx.meta
         dev = w1.device
         dconv1, dconv2 = dconv1.contiguous(), dconv2.contiguous()
-        dw1 = torch.empty((Cin, n), dtype=torch.float32, device=dev)
-        dbeta = torch.empty((n,), dtype=torch.float32, device=dev)
-        dw2 = torch.empty((n,), dtype=torch.float32, device=dev)
-        db2 = torch.empty((1,), dtype=torch.float32, device=dev)
+        outs = []
+        for leaf, shape in zip(ctx.leaves, ((Cin, n), (n,), (n,), tuple(b2_shape))):
+            g = _grad_out(leaf) if tuple(leaf.shape) == shape and leaf.is_contiguous() else None
+            outs.append(g if g is not None and g.is_contiguous() else torch.empty(shape, dtype=torch.float32, device=dev))
+        dw1, dbeta, dw2, db2 = outs
         lib = _lib.load()
         with torch.cuda.device(dev):
             rc = lib.hdrnet_guide_fold_batch_grad_f32(
@@ -539,7 +541,7 @@ class _GuideFoldBatch(torch.autograd.Function):
                 dconv1.data_ptr(), dconv2.data_ptr(), dw1.data_ptr(), dbeta.data_ptr(), dw2.data_ptr(), db2.data_ptr(),
                 _stream(dev))
         _lib.check(rc, "GuideFoldBatchGrad")
-        return dw1, dbeta, dw2, db2.reshape(b2_shape), None, None, None, None, None, None, None, None, None
+        return dw1, dbeta, dw2, db2, None, None, None, None, None, None, None, None, None
 
 
 def guide_fold_batch(w1: torch.Tensor, beta: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, gamma: torch.Tensor,
