@@ -83,7 +83,8 @@ WORKLOADS = {
 # The two multi-GPU configurations of BASELINE.json AS STATED (configs[3], configs[4]); bench lines of their own
 # (main_train / main_hdrp_u16), never the headline.
 EXTRA_WORKLOADS = {
-    "train_1080p_b4": "training step fwd+bwd+Adam, HDRNetPointwiseNNGuide (batch norm), 4 x 1920x1080 per GPU, "
+    "train_1080p_b4": "training step fwd+bwd+Adam, HDRNetPointwiseNNGuide (coefficient network {bn}; the guide network's "
+                      "own batch norm in training mode either way), 4 x 1920x1080 per GPU, "
                       "gradient all-reduce = ONE flat fp32 bucket (RCCL over xGMI)",
     "hdrp_u16": "BilateralSliceApply fwd, HDR+ wire format uint16 / 32767 -> fp32, 4000x3000, grid 32x32x8x12, "
                 "1 image/GPU",
@@ -661,7 +662,9 @@ def main_train(args, rank, world, local_rank, stub=False):
         "allreduce": {"ms": round(ar_max * 1e3, 4), "share_of_step": round(ar_max * 1e3 / ms, 4),
                       "bucket_elements": int(step.bucket.flat.numel()), "collectives_per_step": 1 if world > 1 else 0,
                       "backend": backend if dist_on else None},
-        "config": {"workload": EXTRA_WORKLOADS["train_1080p_b4"], "images_per_gpu_per_step": B,
+        "config": {"workload": EXTRA_WORKLOADS["train_1080p_b4"].format(
+                       bn="with batch norm" if args.batch_norm else "without batch norm, as the reference's training scripts"),
+                   "images_per_gpu_per_step": B,
                    "global_batch": B * world, "parallelism": f"dp{world} (image shards)", "kernel": kernel,
                    "batch_norm": bool(args.batch_norm)},
     }

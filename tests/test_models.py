@@ -581,6 +581,50 @@ def test_graphed_train_step_split_form_matches_one_graph():
 
 
 @pytest.mark.gpu
+def test_graphed_train_step_double_buffered_feed_equals_the_serial_feed():
+    """GraphedTrainStep(feeds=2): batches staged by prefetch() on the copy stream into alternating buffer sets, each with
+    its own captured graph, give bit-for-bit the losses of the serial feed over the same sequence of batches; misuse
+    raises."""
+    from hdrnet_amd import metrics, optim
+    from hdrnet_amd.runtime import GraphedTrainStep
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(9)
+    batches = [(torch.rand(2, 256, 256, 3, device=dev, generator=gen), torch.rand(2, 136, 240, 3, device=dev, generator=gen),
+                torch.rand(2, 136, 240, 3, device=dev, generator=gen)) for _ in range(3)]
+    losses = []
+    for feeds in (1, 2):
+        torch.manual_seed(12)
+        m = models.HDRNetPointwiseNNGuide(dict(batch_norm=False)).to(dev).train()
+        opt = optim.FlatAdam([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+        low, full, tgt = batches[0]
+        g = GraphedTrainStep(m, lambda out, t: metrics.l2_loss(t, out), opt, [low, full], [tgt], warmup=2, feeds=feeds)
+        got = []
+        if feeds == 1:
+            with pytest.raises(RuntimeError, match="feeds=2"):
+                g.prefetch([low, full], [tgt])
+            for k in range(5):
+                low, full, tgt = batches[k % 3]
+                got.append(float(g([low, full], [tgt]).detach()))
+        else:
+            with pytest.raises(RuntimeError, match="no staged batch"):
+                g.step()
+            g.prefetch([low, full], [tgt])
+            for k in range(5):
+                if k < 4:
+                    low, full, tgt = batches[(k + 1) % 3]
+                    g.prefetch([low, full], [tgt])
+                if k == 0:
+                    with pytest.raises(RuntimeError, match="every buffer set"):
+                        g.prefetch([low, full], [tgt])
+                    with pytest.raises(RuntimeError, match="pending"):
+                        g([low, full], [tgt])
+                got.append(float(g.step().detach()))
+        assert g.bucket.attached()
+        losses.append(got)
+    assert losses[0] == losses[1], losses
+
+
+@pytest.mark.gpu
 def test_pyramid_model_fused_matches_composed():
     """HDRNetGaussianPyrNN inference: the fused path (resize kernel, per-level guide net + slice-apply
     + up-add in one launch) == the composition of the un-fused ops (hdrnet/models.py:213-289)."""
