@@ -659,27 +659,47 @@ struct RecomputeParams {
   float* x1; float* x2; float* g; float* fusion;  // [B][K2], [B][K3], [B][O3], [B][P][O3]
   float* dyp;                   // [B][P][gd * n_out * n_in] in the prediction layer's channel order
   int K2, K3, O3, P, gd, n_out, n_in;
+  unsigned C_mul, gd_mul, nout_mul;  // magic numbers of gd * n_out * n_in, gd, n_out
 };
 
-// One workgroup per image (grid.x) and slab of cells (grid.y); every slab re-derives the (tiny) global features.
+// One workgroup per image (grid.x) and slab of cells (grid.y < slabs); every slab re-derives the (tiny) global features.
+// The workgroups y == slabs do nothing but x1 (64 partial sums per element: the longest chain of loads, and nothing in this
+// launch needs its result).  A slab is a chain of memory round trips -- x2, g, then the two streaming loops -- so every
+// loop issues its loads in batches (predicated, fully unrolled) and the index arithmetic uses host-made magic numbers.
+constexpr int kRecomputeSlabs = 32;
+
 __global__ __launch_bounds__(256) void coeff_recompute(const RecomputeParams p) {
   __shared__ float x2s[512];
   __shared__ float gs[256];
   __shared__ float red[256];
   const int tid = threadIdx.x, b = blockIdx.x;
-  const bool first = blockIdx.y == 0;
-  for (int k = tid; k < p.K2 && first; k += 256) {
-    float v = p.b1[k];
-    const float* s = p.f1part + (size_t)b * p.s1 * p.K2 + k;
-#pragma unroll 16
-    for (int i = 0; i < p.s1; ++i) v += s[(size_t)i * p.K2];
-    p.x1[(size_t)b * p.K2 + k] = fmaxf(v, 0.0f);
+  const int slabs = (int)gridDim.y - 1;
+  if ((int)blockIdx.y == slabs) {  // uniform
+    for (int k = tid; k < p.K2; k += 256) {
+      float v = p.b1[k];
+      const float* s = p.f1part + (size_t)b * p.s1 * p.K2 + k;
+      for (int i0 = 0; i0 < p.s1; i0 += 16) {
+        float t[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t[j] = i0 + j < p.s1 ? s[(size_t)(i0 + j) * p.K2] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v += t[j];
+      }
+      p.x1[(size_t)b * p.K2 + k] = fmaxf(v, 0.0f);
+    }
+    return;
   }
+  const bool first = blockIdx.y == 0;
   for (int k = tid; k < p.K3; k += 256) {
     float v = p.b2[k];
     const float* s = p.f2part + (size_t)b * p.s2 * p.K3 + k;
-#pragma unroll 16
-    for (int i = 0; i < p.s2; ++i) v += s[(size_t)i * p.K3];
+    for (int i0 = 0; i0 < p.s2; i0 += 16) {
+      float t[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) t[j] = i0 + j < p.s2 ? s[(size_t)(i0 + j) * p.K3] : 0.0f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v += t[j];
+    }
     v = fmaxf(v, 0.0f);
     x2s[k] = v;
     if (first) p.x2[(size_t)b * p.K3 + k] = v;
@@ -693,8 +713,14 @@ __global__ __launch_bounds__(256) void coeff_recompute(const RecomputeParams p) 
     float v = 0.0f;
     if (c < p.O3) {
       const float* wr = p.w3 + (size_t)c * p.K3 + kp * nk;
-#pragma unroll 8
-      for (int k = 0; k < nk; ++k) v = __builtin_fmaf(x2s[kp * nk + k], wr[k], v);
+      for (int k0 = 0; k0 < nk; k0 += 16) {
+        float t[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t[j] = k0 + j < nk ? wr[k0 + j] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (k0 + j < nk) v = __builtin_fmaf(x2s[kp * nk + k0 + j], t[j], v);
+      }
     }
     red[tid] = v;
     __syncthreads();
@@ -706,19 +732,45 @@ __global__ __launch_bounds__(256) void coeff_recompute(const RecomputeParams p) 
     }
     __syncthreads();
   }
-  const int slabs = gridDim.y, per = (p.P + slabs - 1) / slabs;
+  const int per = (p.P + slabs - 1) / slabs;
   const int px0 = blockIdx.y * per, px1 = min(px0 + per, p.P);
-  for (int i = px0 * p.O3 + tid; i < px1 * p.O3; i += 256) {
-    const int c = i % p.O3;
-    const size_t off = (size_t)b * p.P * p.O3 + i;
-    p.fusion[off] = fmaxf(p.local2[off] + gs[c], 0.0f);
+  {
+    const size_t base = ((size_t)b * p.P + px0) * p.O3;
+    const int n = max(px1 - px0, 0) * p.O3;
+    for (int i0 = 0; i0 < n; i0 += 4 * 256) {
+      float t[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = i0 + j * 256 + tid;
+        t[j] = i < n ? p.local2[base + i] : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = i0 + j * 256 + tid;
+        if (i < n) p.fusion[base + i] = fmaxf(t[j] + gs[i & (p.O3 - 1)], 0.0f);  // px0 * O3 is a multiple of O3
+      }
+    }
   }
   const int C = p.gd * p.n_out * p.n_in;
-  for (int i = px0 * C + tid; i < px1 * C; i += 256) {
-    const int px = i / C, o = i - px * C;  // o = (j * n_out + ii) * gd + z
-    const int ji = o / p.gd, z = o - ji * p.gd;
-    const int jj = ji / p.n_out, ii = ji - jj * p.n_out;
-    p.dyp[(size_t)b * p.P * C + i] = p.dcoeffs[(((size_t)b * p.P + px) * p.gd + z) * p.n_out * p.n_in + ii * p.n_in + jj];
+  {
+    const size_t base = ((size_t)b * p.P + px0) * C;
+    const int n = max(px1 - px0, 0) * C;  // < 2^16 (the magic divisions): <= 32 cells x 288 channels per slab
+    for (int i0 = 0; i0 < n; i0 += 4 * 256) {
+      float t[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = i0 + j * 256 + tid;
+        const int px = udiv(i, p.C_mul, C), o = i - px * C;  // o = (jj * n_out + ii) * gd + z
+        const int ji = udiv(o, p.gd_mul, p.gd), z = o - ji * p.gd;
+        const int jj = udiv(ji, p.nout_mul, p.n_out), ii = ji - jj * p.n_out;
+        t[j] = i < n ? p.dcoeffs[(((size_t)b * p.P + px0 + px) * p.gd + z) * p.n_out * p.n_in + ii * p.n_in + jj] : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = i0 + j * 256 + tid;
+        if (i < n) p.dyp[base + i] = t[j];
+      }
+    }
   }
 }
 
@@ -1037,8 +1089,11 @@ hipError_t launch_coefficients_grad(const float* lowres, const hdrnet_coeff_net&
   {
     RecomputeParams p{fbuf(fw.fc1), fw.s1, fbuf(fw.fc2), fw.s2, net.fc_b[0], net.fc_b[1], net.fc_w[2], net.fc_b[2], L2,
                       dcoeffs, buf(bs.x1), buf(bs.x2), buf(bs.g), buf(bs.fusion), buf(bs.dyp),
-                      4 * d.gl, 2 * d.gl, d.gl, P, d.gd, net.n_out, net.n_in};
-    coeff_recompute<<<dim3((unsigned)B, 8), 256, 0, s>>>(p);
+                      4 * d.gl, 2 * d.gl, d.gl, P, d.gd, net.n_out, net.n_in,
+                      magic32(d.gd * net.n_out * net.n_in), magic32(d.gd), magic32(net.n_out)};
+    int slabs = kRecomputeSlabs;
+    while (slabs > 1 && ((P + slabs - 1) / slabs) * (d.gd * net.n_out * net.n_in) >= 65536) slabs *= 2;  // (never: see the kernel)
+    coeff_recompute<<<dim3((unsigned)B, (unsigned)slabs + 1), 256, 0, s>>>(p);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   ReduceTab tab{};
@@ -1063,6 +1118,8 @@ hipError_t launch_coefficients_grad(const float* lowres, const hdrnet_coeff_net&
   parts += dw_part_floats(B, pr);
   if (e != hipSuccess) return e;
   // ---- fusion = relu(local2 + g): d local2 = df masked (applied by the consumers), dg = its sum over the cells
+  // (summed inside fc3's backward instead -- 16 partial sums per element while staging dy -- the launch was 17 us slower:
+  // the extra loads sit on every workgroup's critical path; a launch of its own costs 4.9)
   coeff_slab_sum<<<dim3((unsigned)B), 256, 0, s>>>(buf(bs.dgp), buf(bs.dg), ntile, d.gl);
   // ---- fully connected layers
   {

@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from hdrnet_amd import dist as hd  # noqa: E402
-from hdrnet_amd import metrics, models  # noqa: E402
+from hdrnet_amd import metrics, models, optim  # noqa: E402
 
 
 def timeit(fn, steps):
@@ -161,13 +161,24 @@ def main():
     for bn, native in ((True, True), (False, False), (False, True)):
         mg = models.HDRNetPointwiseNNGuide(dict(batch_norm=bn)).to(dev).train()
         mg.coefficients.native_training = native
-        optg = torch.optim.Adam([p for p in mg.parameters() if p.requires_grad], lr=1e-4, capturable=True, fused=True)
+        optg = optim.FlatAdam([p for p in mg.parameters() if p.requires_grad], lr=1e-4, epsilon_hat=True)
         gstep = GraphedTrainStep(mg, lambda out, tgt: metrics.l2_loss(tgt, out), optg, [low, full], [target])
         t_graph[(bn, native)] = timeit(lambda: gstep([low, full], [target]), max(5, args.steps // 2))
     t = t_graph[(False, True)]
     print(f"config #4  the whole step as one hipGraph, no batch norm (the reference's scripts), coefficient network's "
           f"forward + backward on the HIP kernels: {t * 1e3:.3f} ms/step = {B * 1080 * 1920 / 1e6 / t:.0f} MP/s per GPU;  "
           f"on stock ops: {t_graph[(False, False)] * 1e3:.3f};  with batch norm (stock ops): {t_graph[(True, True)] * 1e3:.3f}")
+
+    # the reference's DEFAULT model class (hdrnet/bin/train.py:225: models.__all__[0] = HDRNetCurves) and the pyramid model,
+    # the same graph-captured step without batch norm
+    for cls in (models.HDRNetCurves, models.HDRNetGaussianPyrNN):
+        mg = cls(dict(batch_norm=False)).to(dev).train()
+        optg = optim.FlatAdam([p for p in mg.parameters() if p.requires_grad], lr=1e-4, epsilon_hat=True)
+        gstep = GraphedTrainStep(mg, lambda out, tgt: metrics.l2_loss(tgt, out), optg, [low, full], [target])
+        t = timeit(lambda: gstep([low, full], [target]), max(5, args.steps // 2))
+        print(f"{cls.__name__:<22s} the whole training step as one hipGraph, no batch norm, {B} x 1080p: {t * 1e3:.3f} ms/step = "
+              f"{B * 1080 * 1920 / 1e6 / t:.0f} MP/s per GPU  (coefficient network native: "
+              f"{bool(mg.coefficients._use_native_training(low))})")
 
 
 if __name__ == "__main__":
