@@ -5,7 +5,7 @@ rocprofv3 kernel trace of that command:
     cd /tmp && rocprofv3 --kernel-trace --stats -d out -o tr --output-format csv -- python bench.py --workload train_1080p_b4 --steps 50 --warmup 10
     python tools/train_step_profile.py out/.../tr_kernel_trace.csv [--list]
 
-One step = the kernels between two consecutive launches of the slice-apply forward.  Prints the launch count, the span,
+One step = the kernels between two consecutive launches of the slice-apply forward (or of --anchor NAME).  Prints the launch count, the span,
 the launches grouped by kernel; --list prints them in order.  (Under the profiler a launch costs ~4.5 us even when it
 does nothing: the un-profiled step is ~25 % shorter than the span shown.)
 """
@@ -23,7 +23,10 @@ def short(n):
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if "apply_fwd_seg" in r["Kernel_Name"]]
+    anchor = "apply_fwd_seg"  # a kernel launched once per step; --anchor NAME for graphs where that is another one
+    if "--anchor" in sys.argv:
+        anchor = sys.argv[sys.argv.index("--anchor") + 1]
+    idx = [i for i, r in enumerate(rows) if anchor in r["Kernel_Name"]]
     a, b = idx[-3], idx[-2]
     step = rows[a:b]
     dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3  # noqa: E731
