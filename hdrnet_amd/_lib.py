@@ -105,6 +105,8 @@ class HdrnetRuntimeError(RuntimeError):
 TRAIN_SIGNATURES = {
     "hdrnet_l2_loss_with_grad_f32": (_I, [_FP, _FP, ctypes.c_longlong, _FP, _FP, _VP, ctypes.c_size_t, _VP]),
     "hdrnet_l2_loss_grad_scale_f32": (_I, [_FP, _FP, ctypes.c_longlong, _VP]),
+    "hdrnet_resize_add_f32": (_I, [_FP, _FP, _FP] + [_I] * 6 + [_VP]),
+    "hdrnet_resize_bilinear_grad_f32": (_I, [_FP, _FP] + [_I] * 6 + [_VP]),
     "hdrnet_adam_step_f32": (_I, [_FP, _FP, _FP, _FP, ctypes.c_longlong, _FP] + [ctypes.c_float] * 4 + [_VP]),
     "hdrnet_adam_step_tf_f32": (_I, [_FP, _FP, _FP, _FP, ctypes.c_longlong, _FP] + [ctypes.c_float] * 4 + [_VP]),
 }

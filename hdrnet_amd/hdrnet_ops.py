@@ -786,6 +786,51 @@ def resize_bilinear(input: torch.Tensor, height: int, width: int) -> torch.Tenso
     return out
 
 
+class _UpsampleAdd(torch.autograd.Function):
+    """``resize(coarse -> fine's size, bilinear, align_corners) + fine`` in one pass; backward: d fine = the incoming gradient
+    itself, d coarse = the resize's transpose as a fixed-order gather (csrc/resize_bilinear.hip)."""
+
+    @staticmethod
+    def forward(ctx, coarse, fine):
+        c, f = coarse.detach().contiguous(), fine.detach().contiguous()
+        B, IH, IW, C = c.shape
+        OH, OW = f.shape[1], f.shape[2]
+        out = torch.empty_like(f)
+        with torch.cuda.device(f.device):
+            rc = _lib.load().hdrnet_resize_add_f32(c.data_ptr(), f.data_ptr(), out.data_ptr(), B, IH, IW, OH, OW, C,
+                                                   _stream(f.device))
+        if rc != 0:
+            raise RuntimeError(f"hdrnet_resize_add_f32 failed (rc={rc})")
+        ctx.dims = (B, IH, IW, OH, OW, C)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad):
+        B, IH, IW, OH, OW, C = ctx.dims
+        g = grad.contiguous()
+        dcoarse = None
+        if ctx.needs_input_grad[0]:
+            dcoarse = torch.empty((B, IH, IW, C), dtype=torch.float32, device=g.device)
+            with torch.cuda.device(g.device):
+                rc = _lib.load().hdrnet_resize_bilinear_grad_f32(g.data_ptr(), dcoarse.data_ptr(), B, IH, IW, OH, OW, C,
+                                                                 _stream(g.device))
+            if rc != 0:
+                raise RuntimeError(f"hdrnet_resize_bilinear_grad_f32 failed (rc={rc})")
+        return dcoarse, (g if ctx.needs_input_grad[1] else None)
+
+
+def upsample_add(coarse: torch.Tensor, fine: torch.Tensor) -> torch.Tensor:
+    """``tf.image.resize_images(coarse, fine's size, BILINEAR, align_corners=True) + fine`` -- the up-add of
+    HDRNetGaussianPyrNN's output pyramid (hdrnet/models.py:283-287) -- NHWC fp32 on the GPU, differentiable in both."""
+    for name, t in (("coarse", coarse), ("fine", fine)):
+        _require_f32(name, t)
+        _require_gpu(name, t)
+    if coarse.dim() != 4 or fine.dim() != 4 or coarse.shape[0] != fine.shape[0] or coarse.shape[3] != fine.shape[3]:
+        raise ValueError(f"upsample_add: [B, h, w, C] and [B, H, W, C] expected, got {tuple(coarse.shape)}, {tuple(fine.shape)}")
+    return _UpsampleAdd.apply(coarse, fine)
+
+
 def bilateral_slice_apply_upadd(grid: torch.Tensor, input: torch.Tensor, coarse: torch.Tensor,  # noqa: A002
                                 guide: Optional[torch.Tensor] = None,
                                 guide_conv1: Optional[torch.Tensor] = None,

@@ -529,7 +529,7 @@ class HDRNetGaussianPyrNN(HDRNetPointwiseNNGuide):
 
     def _forward_fused_differentiable(self, lowres_input: torch.Tensor, fullres_input: torch.Tensor) -> torch.Tensor:
         """Training / autograd path: per level the differentiable fused op (guide network + slice-
-        apply, batch-norm statistics from the level's input moments); the up-adds stay torch ops."""
+        apply, batch-norm statistics from the level's input moments) and the differentiable up-add kernel."""
         from . import hdrnet_ops
         coeffs = self.coefficients(lowres_input)
         gs = coeffs.shape
@@ -548,7 +548,7 @@ class HDRNetGaussianPyrNN(HDRNetPointwiseNNGuide):
             else:
                 conv1, conv2 = gnet.folded(detach=False)
             out = hdrnet_ops.bilateral_slice_apply_nnguide(c, lvl, conv1, conv2, has_offset=True)
-            current = out if current is None else self._resize(current, out.shape[1], out.shape[2]) + out
+            current = out if current is None else hdrnet_ops.upsample_add(current, out)  # resize + add, one pass each way
         return current
 
     def _forward_fused(self, lowres_input: torch.Tensor, fullres_input: torch.Tensor) -> torch.Tensor:

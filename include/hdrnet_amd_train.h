@@ -35,6 +35,17 @@ int hdrnet_l2_loss_with_grad_f32(const float* prediction, const float* target, l
                                  float* dprediction_unit, void* workspace, size_t workspace_bytes, void* stream);
 int hdrnet_l2_loss_grad_scale_f32(float* dprediction, const float* grad_output, long long n, void* stream);
 
+/* The pyramid model's up-add and its VJP (hdrnet/models.py:283-287: `current = tf.image.resize_images(current, sz, BILINEAR,
+ * align_corners=True) + out_lvl`), NHWC fp32, the resize of hdrnet_resize_bilinear_f32 (include/hdrnet_amd.h):
+ *   hdrnet_resize_add_f32            output[B, OH, OW, C] = resize(coarse[B, IH, IW, C]) + fine[B, OH, OW, C], one pass
+ *   hdrnet_resize_bilinear_grad_f32  dinput[B, IH, IW, C] = the transpose of the resize applied to doutput[B, OH, OW, C], as a
+ *                                    gather in a fixed order (no atomics: bit-reproducible)
+ * (the gradient of the up-add with respect to `fine` is doutput itself).  0 on success, 1 for a bad argument. */
+int hdrnet_resize_add_f32(const float* coarse, const float* fine, float* output, int batch, int in_height, int in_width,
+                          int out_height, int out_width, int channels, void* stream);
+int hdrnet_resize_bilinear_grad_f32(const float* doutput, float* dinput, int batch, int in_height, int in_width,
+                                    int out_height, int out_width, int channels, void* stream);
+
 int hdrnet_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
                          float* step, float lr, float beta1, float beta2, float eps, void* stream);
 int hdrnet_adam_step_tf_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,

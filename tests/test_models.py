@@ -581,6 +581,37 @@ def test_graphed_train_step_split_form_matches_one_graph():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 17, 23, 34, 46, 3), (1, 5, 7, 11, 13, 3), (2, 8, 8, 16, 16, 1), (1, 1, 4, 3, 9, 3),
+                                   (1, 12, 10, 6, 5, 3), (1, 6, 6, 6, 6, 5)])
+def test_upsample_add_and_its_vjp_vs_torch_float64(shape):
+    """hdrnet_ops.upsample_add = resize(coarse, align_corners) + fine (hdrnet/models.py:283-287) and its two gradients
+    against torch's interpolate in float64: up-sampling by two and by odd ratios, one source row, DOWN-sampling, equal
+    sizes, a channel count without a specialisation; the gather-form transpose is bit-reproducible."""
+    from hdrnet_amd import hdrnet_ops
+    B, ih, iw, oh, ow, C = shape
+    torch.manual_seed(sum(shape))
+    coarse = torch.randn(B, ih, iw, C, device="cuda:0", requires_grad=True)
+    fine = torch.randn(B, oh, ow, C, device="cuda:0", requires_grad=True)
+    w = torch.randn(B, oh, ow, C, device="cuda:0")
+    out = hdrnet_ops.upsample_add(coarse, fine)
+    (out * w).sum().backward()
+    c64 = coarse.detach().double().requires_grad_(True)
+    f64 = fine.detach().double().requires_grad_(True)
+    ref = F.interpolate(c64.permute(0, 3, 1, 2), size=(oh, ow), mode="bilinear", align_corners=True).permute(0, 2, 3, 1) + f64
+    (ref * w.double()).sum().backward()
+    assert torch.allclose(out.double(), ref, rtol=0, atol=1e-5)
+    assert torch.equal(fine.grad, w)
+    scale = float(c64.grad.abs().max()) + 1e-30
+    assert float((coarse.grad.double() - c64.grad).abs().max()) <= 2e-6 * scale + 1e-6
+    g1 = coarse.grad.clone()
+    coarse.grad = None
+    (hdrnet_ops.upsample_add(coarse, fine.detach()) * w).sum().backward()
+    assert torch.equal(coarse.grad, g1)
+    with pytest.raises(ValueError):
+        hdrnet_ops.upsample_add(coarse, fine[..., :1] if C > 1 else fine.repeat(1, 1, 1, 2))
+
+
+@pytest.mark.gpu
 def test_graphed_train_step_double_buffered_feed_equals_the_serial_feed():
     """GraphedTrainStep(feeds=2): batches staged by prefetch() on the copy stream into alternating buffer sets, each with
     its own captured graph, give bit-for-bit the losses of the serial feed over the same sequence of batches; misuse
