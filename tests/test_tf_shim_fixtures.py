@@ -52,7 +52,11 @@ def test_reference_graph_coefficients_guide_pyramid(name):
     with torch.no_grad():
         coeffs = m.coefficients(lo)
         assert tuple(coeffs.shape) == fx["bilateral_coefficients"].shape       # [B, GH, GW, GD, n_out, n_in]
-        np.testing.assert_allclose(coeffs.numpy(), fx["bilateral_coefficients"], rtol=1e-5, atol=2e-5)
+        # float32 torch against the shim's float64: 1.1e-5 at |c| <= 14.6 in inference mode; with the batch's own statistics
+        # (training mode) a low-variance channel amplifies the convolutions' rounding, and that rounding depends on torch's
+        # CPU thread count / convolution backend: 1.6e-5 to 4.1e-5 observed
+        tol = dict(rtol=1e-4, atol=1e-4) if bool(fx["is_training"]) else dict(rtol=2e-5, atol=5e-5)
+        np.testing.assert_allclose(coeffs.numpy(), fx["bilateral_coefficients"], **tol)
         if str(fx["model"]) == "HDRNetGaussianPyrNN":
             lvls = [hi]
             for _ in range(2):
