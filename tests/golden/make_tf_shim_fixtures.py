@@ -168,6 +168,15 @@ CASES = [
     ("HDRNetCurves__training_lb4", "HDRNetCurves",
      dict(net_input_size=128, spatial_bin=16, luma_bins=4, channel_multiplier=1, guide_complexity=16,
           batch_norm=True, batch_size=3), True, (3, 32, 48)),
+    # the guide network's own batch norm in TRAINING mode (hdrnet/models.py:205: batch_norm=True whatever the flag says):
+    # statistics over every full-resolution pixel of the batch -- what hdrnet_guide_fold_batch_f32 folds from the moments
+    ("HDRNetPointwiseNNGuide__training_nobn_lb4_gc8", "HDRNetPointwiseNNGuide",
+     dict(net_input_size=128, spatial_bin=16, luma_bins=4, channel_multiplier=1, guide_complexity=8,
+          batch_norm=False, batch_size=2), True, (2, 48, 64)),
+    # the pyramid in training mode: three guide networks with batch statistics, the up-adds (hdrnet_ops.upsample_add)
+    ("HDRNetGaussianPyrNN__training_nobn_lb4", "HDRNetGaussianPyrNN",
+     dict(net_input_size=128, spatial_bin=16, luma_bins=4, channel_multiplier=1, guide_complexity=16,
+          batch_norm=False, batch_size=1), True, (1, 64, 96)),
 ]
 
 

@@ -25,7 +25,8 @@ from hdrnet_amd import models, tf_import
 
 FIXTURES = os.path.join(ROOT, "tests", "golden", "tf_shim")
 MODEL_FIXTURES = ["HDRNetCurves", "HDRNetPointwiseNNGuide", "HDRNetGaussianPyrNN",
-                  "HDRNetPointwiseNNGuide__nobn_sb8_lb4_cm2_gc8", "HDRNetCurves__training_lb4"]
+                  "HDRNetPointwiseNNGuide__nobn_sb8_lb4_cm2_gc8", "HDRNetCurves__training_lb4",
+                  "HDRNetPointwiseNNGuide__training_nobn_lb4_gc8", "HDRNetGaussianPyrNN__training_nobn_lb4"]
 REFERENCE = "/root/reference"
 
 
@@ -57,15 +58,16 @@ def test_reference_graph_coefficients_guide_pyramid(name):
         # CPU thread count / convolution backend: 1.6e-5 to 4.1e-5 observed
         tol = dict(rtol=1e-4, atol=1e-4) if bool(fx["is_training"]) else dict(rtol=2e-5, atol=5e-5)
         np.testing.assert_allclose(coeffs.numpy(), fx["bilateral_coefficients"], **tol)
+        gtol = 2e-5 if bool(fx["is_training"]) else 5e-6   # (training: float32 batch statistics, 7.5e-6 on a 16 x 24 level)
         if str(fx["model"]) == "HDRNetGaussianPyrNN":
             lvls = [hi]
             for _ in range(2):
                 lvls.append(m._resize(lvls[-1], lvls[-1].shape[1] // 2, lvls[-1].shape[2] // 2))
             for l, lvl in enumerate(lvls):
                 np.testing.assert_allclose(lvl.numpy(), fx["multiscale_%d" % l], rtol=0, atol=1e-5)
-                np.testing.assert_allclose(m.guide[l](lvl).numpy(), fx["guide_%d" % l], rtol=0, atol=5e-6)
+                np.testing.assert_allclose(m.guide[l](lvl).numpy(), fx["guide_%d" % l], rtol=0, atol=gtol)
         else:
-            np.testing.assert_allclose(m.guide(hi).numpy(), fx["guide"], rtol=0, atol=2e-6)
+            np.testing.assert_allclose(m.guide(hi).numpy(), fx["guide"], rtol=0, atol=gtol)
 
 
 @pytest.mark.parametrize("name", MODEL_FIXTURES)
