@@ -152,6 +152,101 @@ def run_model(tf, models, cls, params, lowres, fullres, is_training, seed):
     return fx
 
 
+def slice_apply_f64(grid, guide, inp):
+    """BilateralSliceApply forward (hdrnet/ops/bilateral_slice_apply.cc:24-82, has_offset) with every product and sum in
+    float64 and the guide as a float64 variable -- the op under the finite-difference gradients below, where the float32
+    kernel's rounding (1e-7) would drown a 1e-4 step.  grid [B, GH, GW, GD, 12], guide [B, H, W], inp [B, H, W, 3]."""
+    grid, guide, inp = (np.asarray(a, dtype=np.float64) for a in (grid, guide, inp))
+    B, GH, GW, GD, _ = grid.shape
+    _, H, W = guide.shape
+    G = grid.reshape(B, GH, GW, GD, 3, 4)
+    gx = (np.arange(W) + 0.5) * GW / W
+    gy = (np.arange(H) + 0.5) * GH / H
+    gz = guide * GD
+    fx, fy, fz = np.floor(gx - 0.5).astype(int), np.floor(gy - 0.5).astype(int), np.floor(gz - 0.5).astype(int)
+    coeff = np.zeros((B, H, W, 3, 4))
+    bidx = np.arange(B)[:, None, None]
+    for dy in (0, 1):
+        yy = fy + dy
+        wy = np.maximum(1 - np.abs(yy + 0.5 - gy), 0)[None, :, None]
+        yc = np.clip(yy, 0, GH - 1)[None, :, None]
+        for dx in (0, 1):
+            xx = fx + dx
+            wx = np.maximum(1 - np.abs(xx + 0.5 - gx), 0)[None, None, :]
+            xc = np.clip(xx, 0, GW - 1)[None, None, :]
+            for dz in (0, 1):
+                zz = fz + dz
+                wz = np.maximum(1 - np.sqrt((zz + 0.5 - gz) ** 2 + 1e-8), 0)       # the smoothed tent, numerics.h:104-114
+                zc = np.clip(zz, 0, GD - 1)
+                coeff += (wy * wx * wz)[..., None, None] * G[bidx, yc, xc, zc]
+    return np.einsum("bhwij,bhwj->bhwi", coeff[..., :3], inp) + coeff[..., 3]
+
+
+def gradient_fixture(tf, models, hashes, out_dir):
+    """Graph-level GRADIENTS of the reference's graph code: central differences of l2_loss(target, inference(...)) in
+    float64 with respect to three entries of every variable (h = 2e-6), the slice-apply evaluated in float64."""
+    import oracle
+    cls = "HDRNetPointwiseNNGuide"
+    params = dict(net_input_size=128, spatial_bin=16, luma_bins=4, channel_multiplier=1, guide_complexity=8,
+                  batch_norm=False, batch_size=1)
+    seed = 4321
+    rng = np.random.RandomState(seed)
+    lowres = (rng.randint(0, 256, (1, 128, 128, 3)) / 255.0).astype(np.float32)
+    fullres = (rng.randint(0, 256, (1, 32, 48, 3)) / 255.0).astype(np.float32)
+    target = (rng.randint(0, 256, (1, 32, 48, 3)) / 255.0).astype(np.float32)
+    ops = sys.modules["hdrnet.hdrnet_ops"]
+    f32_op = ops.bilateral_slice_apply
+    fx = run_model(tf, models, cls, params, lowres, fullres, False, seed)      # float32 op: the variables + a check below
+    mdl = getattr(models, cls)
+
+    def loss():
+        tf._STATE.collections.clear()
+        with tf.variable_scope("inference"):
+            out = mdl.inference(tf._t(lowres), tf._t(fullres), params, is_training=False)
+        return float(np.mean(np.square(np.asarray(out, dtype=np.float64) - target.astype(np.float64))))
+
+    try:
+        ops.bilateral_slice_apply = lambda grid, guide, input, has_offset=True, name=None: tf._t(   # noqa: A002, E731
+            slice_apply_f64(grid, guide, input))
+        tf._STATE.collections.clear()
+        with tf.variable_scope("inference"):
+            out64 = np.asarray(mdl.inference(tf._t(lowres), tf._t(fullres), params, is_training=False))
+        assert np.abs(out64 - fx["output"]).max() < 2e-6 * max(1.0, np.abs(out64).max()), "float64 op != the reference op"
+        names, index, grads = [], [], []
+        pick = np.random.RandomState(seed + 2)
+        h = 2e-6   # small: the op has kinks where a z tap enters or leaves (|dz| = 1); a step that straddles them biases the quotient
+        for name, v in tf._STATE.variables.items():
+            cand = []
+            for flat in sorted(set(pick.randint(0, v.size, 6).tolist())):
+                v0 = v.reshape(-1)[flat]
+                # variables are float32 storage: step to representable values and divide by the step actually taken
+                hi_v, lo_v = np.float32(v0 + h), np.float32(v0 - h)
+                v.reshape(-1)[flat] = hi_v
+                lp = loss()
+                v.reshape(-1)[flat] = lo_v
+                lm = loss()
+                v.reshape(-1)[flat] = v0
+                cand.append((flat, (lp - lm) / (float(hi_v) - float(lo_v))))
+            # the three largest of six random entries (dead ReLU units give exact zeros: one of those is kept if present)
+            cand.sort(key=lambda t: -abs(t[1]))
+            for flat, g in cand[:3]:
+                names.append(name + ":0")
+                index.append(flat)
+                grads.append(g)
+        l0 = loss()
+    finally:
+        ops.bilateral_slice_apply = f32_op
+    keep = {k: a for k, a in fx.items() if k.startswith("var/")}
+    np.savez_compressed(os.path.join(out_dir, "gradients_fd.npz"), lowres_input=lowres, fullres_input=fullres,
+                        target=target, loss=np.asarray(l0),
+                        fd_names=np.asarray(names), fd_index=np.asarray(index, dtype=np.int64),
+                        fd_grad=np.asarray(grads, dtype=np.float64), fd_step=np.asarray(h), model=np.asarray(cls),
+                        params_json=np.asarray(json.dumps(params, sort_keys=True)), is_training=np.asarray(False),
+                        reference_sha256=np.asarray(json.dumps(hashes, sort_keys=True)), **keep)
+    g = np.asarray(grads)
+    print("gradients_fd: loss %.6f, %d entries, |grad| from %.2e to %.2e" % (l0, len(g), np.abs(g).min(), np.abs(g).max()))
+
+
 DEFAULT = dict(net_input_size=256, spatial_bin=16, luma_bins=8, channel_multiplier=1, guide_complexity=16,
                batch_norm=True, batch_size=1)     # hdrnet/bin/train.py:227-236
 
@@ -208,29 +303,32 @@ def main():
         print("%-50s %3d variables  coefficients %s  output %s  %.0f KiB" % (
             name, nvar, fx["bilateral_coefficients"].shape, fx["output"].shape, os.path.getsize(path) / 1024))
 
-    if args.only not in (None, "layers_wrappers"):
-        return
     # the 6-D wrappers of hdrnet/layers.py:99-148, :153-199 on their own: slice + apply == slice_apply
     rng = np.random.RandomState(99)
     grid = rng.randn(2, 5, 6, 4, 3, 4).astype(np.float32)
     guide = rng.rand(2, 21, 34).astype(np.float32)
     inp = rng.rand(2, 21, 34, 3).astype(np.float32)
-    sliced = layers.bilateral_slice(tf._t(grid), tf._t(guide))
-    np.savez_compressed(os.path.join(out_dir, "layers_wrappers.npz"), grid=grid, guide=guide, input=inp,
-                        sliced=np.asarray(sliced, dtype=np.float32),
-                        applied=np.asarray(layers.apply(sliced, tf._t(inp)), dtype=np.float32),
-                        slice_apply=np.asarray(layers.bilateral_slice_apply(tf._t(grid), tf._t(guide), tf._t(inp)),
-                                               dtype=np.float32),
-                        reference_sha256=np.asarray(json.dumps(hashes, sort_keys=True)))
-    print("layers_wrappers: sliced %s" % (np.asarray(sliced).shape,))
+    if args.only in (None, "layers_wrappers"):
+        sliced = layers.bilateral_slice(tf._t(grid), tf._t(guide))
+        np.savez_compressed(os.path.join(out_dir, "layers_wrappers.npz"), grid=grid, guide=guide, input=inp,
+                            sliced=np.asarray(sliced, dtype=np.float32),
+                            applied=np.asarray(layers.apply(sliced, tf._t(inp)), dtype=np.float32),
+                            slice_apply=np.asarray(layers.bilateral_slice_apply(tf._t(grid), tf._t(guide), tf._t(inp)),
+                                                   dtype=np.float32),
+                            reference_sha256=np.asarray(json.dumps(hashes, sort_keys=True)))
+        print("layers_wrappers: sliced %s" % (np.asarray(sliced).shape,))
+
+    if args.only in (None, "gradients_fd"):
+        gradient_fixture(tf, models, hashes, out_dir)
 
     # hdrnet/metrics.py:21-33 -- the training loss and the evaluation metric of hdrnet/bin/train.py:137-143
-    target = (rng.randint(0, 256, (3, 17, 23, 3)) / 255.0).astype(np.float32)
+    target = (rng.randint(0, 256, (3, 17, 23, 3)) / 255.0).astype(np.float32)    # (continues the stream of the block above)
     prediction = (target + rng.randn(*target.shape) * 0.05).astype(np.float32)
-    np.savez_compressed(os.path.join(out_dir, "metrics.npz"), target=target, prediction=prediction,
-                        l2_loss=np.asarray(metrics.l2_loss(tf._t(target), tf._t(prediction)), dtype=np.float64),
-                        psnr=np.asarray(metrics.psnr(tf._t(target), tf._t(prediction)), dtype=np.float64),
-                        reference_sha256=np.asarray(json.dumps(metrics_hash, sort_keys=True)))
+    if args.only in (None, "metrics"):
+        np.savez_compressed(os.path.join(out_dir, "metrics.npz"), target=target, prediction=prediction,
+                            l2_loss=np.asarray(metrics.l2_loss(tf._t(target), tf._t(prediction)), dtype=np.float64),
+                            psnr=np.asarray(metrics.psnr(tf._t(target), tf._t(prediction)), dtype=np.float64),
+                            reference_sha256=np.asarray(json.dumps(metrics_hash, sort_keys=True)))
 
 
 if __name__ == "__main__":

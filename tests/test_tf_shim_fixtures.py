@@ -102,6 +102,40 @@ def test_reference_graph_output_through_the_hip_path(name, fuse):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fuse", [False, True])
+def test_reference_graph_gradients_through_the_hip_path(fuse):
+    """GRADIENTS at graph level: d l2_loss(target, inference(...)) / d (entries of every variable) as central differences of
+    the reference's graph code in float64 (tests/golden/make_tf_shim_fixtures.py: gradient_fixture, the slice-apply in
+    float64, step 2e-6: the reference's own analytic gradient -- its C++ op under torch autograd on the CPU -- is within
+    2e-5 of these quotients; a step of 1e-4 straddles the z taps' kinks and is 2.4e-3 off) against autograd through this package's model on the GPU -- the coefficient network's backward kernels, the
+    slice-apply VJPs, the guide network's VJP, the loss kernels, fp32."""
+    from hdrnet_amd import metrics
+    fx = _load("gradients_fd")
+    m = _model(fx).cuda()            # inference-mode graph (moving statistics), gradients wanted
+    m.fuse_guide = fuse
+    lo, hi = torch.from_numpy(fx["lowres_input"]).cuda(), torch.from_numpy(fx["fullres_input"]).cuda()
+    target = torch.from_numpy(fx["target"]).cuda()
+    loss = metrics.l2_loss(target, m(lo, hi))
+    np.testing.assert_allclose(float(loss), float(fx["loss"]), rtol=2e-5)
+    loss.backward()
+    tensors = {tf_import.PREFIX + name + ":0": (t, kind) for name, t, kind in tf_import._all_tensors(m)}
+    checked, worst = 0, 0.0
+    scale = float(np.abs(fx["fd_grad"]).max())
+    for name, flat, want in zip(fx["fd_names"], fx["fd_index"], fx["fd_grad"]):
+        t, kind = tensors[str(name)]
+        if t.grad is None:           # the batch norm's moving statistics: buffers here, variables in TensorFlow
+            assert "moving_" in str(name), name
+            continue
+        got = float(tf_import._to_tf(t.grad.detach().cpu().numpy().astype(np.float64), kind).reshape(-1)[int(flat)])
+        err = abs(got - float(want))
+        worst = max(worst, err / (abs(float(want)) + 1e-3 * scale))
+        assert err <= 5e-4 * abs(float(want)) + 1e-5 * scale, (str(name), int(flat), got, float(want))
+        checked += 1
+    assert checked >= 60, checked
+    print("graph-level gradients: %d entries, worst relative error %.2e" % (checked, worst))
+
+
+@pytest.mark.gpu
 def test_layer_wrappers_match_the_reference_wrappers():
     """hdrnet/layers.py:99-148 on a 6-D grid: the unstack / concat / split / stack channel orders of
     bilateral_slice and the reshape of bilateral_slice_apply."""
@@ -160,7 +194,7 @@ def test_committed_fixtures_are_what_the_script_computes(tmp_path):
         assert sorted(z.files) == sorted(want)
         for k in z.files:
             np.testing.assert_array_equal(z[k], want[k], err_msg=k)
-    for fixture in MODEL_FIXTURES + ["layers_wrappers", "metrics"]:
+    for fixture in MODEL_FIXTURES + ["layers_wrappers", "metrics", "gradients_fd"]:
         for rel, digest in json.loads(str(_load(fixture)["reference_sha256"])).items():
             with open(os.path.join(REFERENCE, rel), "rb") as f:
                 assert hashlib.sha256(f.read()).hexdigest() == digest, (fixture, rel)
