@@ -182,27 +182,26 @@ def slice_apply_f64(grid, guide, inp):
     return np.einsum("bhwij,bhwj->bhwi", coeff[..., :3], inp) + coeff[..., 3]
 
 
-def gradient_fixture(tf, models, hashes, out_dir):
+def gradient_fixture(tf, models, hashes, out_dir, fname="gradients_fd", is_training=False, batch=1, seed=4321):
     """Graph-level GRADIENTS of the reference's graph code: central differences of l2_loss(target, inference(...)) in
     float64 with respect to three entries of every variable (h = 2e-6), the slice-apply evaluated in float64."""
     import oracle
     cls = "HDRNetPointwiseNNGuide"
     params = dict(net_input_size=128, spatial_bin=16, luma_bins=4, channel_multiplier=1, guide_complexity=8,
-                  batch_norm=False, batch_size=1)
-    seed = 4321
+                  batch_norm=False, batch_size=batch)
     rng = np.random.RandomState(seed)
-    lowres = (rng.randint(0, 256, (1, 128, 128, 3)) / 255.0).astype(np.float32)
-    fullres = (rng.randint(0, 256, (1, 32, 48, 3)) / 255.0).astype(np.float32)
-    target = (rng.randint(0, 256, (1, 32, 48, 3)) / 255.0).astype(np.float32)
+    lowres = (rng.randint(0, 256, (batch, 128, 128, 3)) / 255.0).astype(np.float32)
+    fullres = (rng.randint(0, 256, (batch, 32, 48, 3)) / 255.0).astype(np.float32)
+    target = (rng.randint(0, 256, (batch, 32, 48, 3)) / 255.0).astype(np.float32)
     ops = sys.modules["hdrnet.hdrnet_ops"]
     f32_op = ops.bilateral_slice_apply
-    fx = run_model(tf, models, cls, params, lowres, fullres, False, seed)      # float32 op: the variables + a check below
+    fx = run_model(tf, models, cls, params, lowres, fullres, is_training, seed)  # float32 op: the variables + a check below
     mdl = getattr(models, cls)
 
     def loss():
         tf._STATE.collections.clear()
         with tf.variable_scope("inference"):
-            out = mdl.inference(tf._t(lowres), tf._t(fullres), params, is_training=False)
+            out = mdl.inference(tf._t(lowres), tf._t(fullres), params, is_training=is_training)
         return float(np.mean(np.square(np.asarray(out, dtype=np.float64) - target.astype(np.float64))))
 
     try:
@@ -210,7 +209,7 @@ def gradient_fixture(tf, models, hashes, out_dir):
             slice_apply_f64(grid, guide, input))
         tf._STATE.collections.clear()
         with tf.variable_scope("inference"):
-            out64 = np.asarray(mdl.inference(tf._t(lowres), tf._t(fullres), params, is_training=False))
+            out64 = np.asarray(mdl.inference(tf._t(lowres), tf._t(fullres), params, is_training=is_training))
         assert np.abs(out64 - fx["output"]).max() < 2e-6 * max(1.0, np.abs(out64).max()), "float64 op != the reference op"
         names, index, grads = [], [], []
         pick = np.random.RandomState(seed + 2)
@@ -237,14 +236,14 @@ def gradient_fixture(tf, models, hashes, out_dir):
     finally:
         ops.bilateral_slice_apply = f32_op
     keep = {k: a for k, a in fx.items() if k.startswith("var/")}
-    np.savez_compressed(os.path.join(out_dir, "gradients_fd.npz"), lowres_input=lowres, fullres_input=fullres,
+    np.savez_compressed(os.path.join(out_dir, fname + ".npz"), lowres_input=lowres, fullres_input=fullres,
                         target=target, loss=np.asarray(l0),
                         fd_names=np.asarray(names), fd_index=np.asarray(index, dtype=np.int64),
                         fd_grad=np.asarray(grads, dtype=np.float64), fd_step=np.asarray(h), model=np.asarray(cls),
-                        params_json=np.asarray(json.dumps(params, sort_keys=True)), is_training=np.asarray(False),
+                        params_json=np.asarray(json.dumps(params, sort_keys=True)), is_training=np.asarray(is_training),
                         reference_sha256=np.asarray(json.dumps(hashes, sort_keys=True)), **keep)
     g = np.asarray(grads)
-    print("gradients_fd: loss %.6f, %d entries, |grad| from %.2e to %.2e" % (l0, len(g), np.abs(g).min(), np.abs(g).max()))
+    print(fname + ": loss %.6f, %d entries, |grad| from %.2e to %.2e" % (l0, len(g), np.abs(g).min(), np.abs(g).max()))
 
 
 DEFAULT = dict(net_input_size=256, spatial_bin=16, luma_bins=8, channel_multiplier=1, guide_complexity=16,
@@ -320,6 +319,8 @@ def main():
 
     if args.only in (None, "gradients_fd"):
         gradient_fixture(tf, models, hashes, out_dir)
+    if args.only in (None, "gradients_fd_training"):   # the guide network's batch norm on the batch's own statistics
+        gradient_fixture(tf, models, hashes, out_dir, "gradients_fd_training", True, 2, 4391)
 
     # hdrnet/metrics.py:21-33 -- the training loss and the evaluation metric of hdrnet/bin/train.py:137-143
     target = (rng.randint(0, 256, (3, 17, 23, 3)) / 255.0).astype(np.float32)    # (continues the stream of the block above)

@@ -102,16 +102,18 @@ def test_reference_graph_output_through_the_hip_path(name, fuse):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fixture", ["gradients_fd", "gradients_fd_training"])
 @pytest.mark.parametrize("fuse", [False, True])
-def test_reference_graph_gradients_through_the_hip_path(fuse):
+def test_reference_graph_gradients_through_the_hip_path(fuse, fixture):
     """GRADIENTS at graph level: d l2_loss(target, inference(...)) / d (entries of every variable) as central differences of
     the reference's graph code in float64 (tests/golden/make_tf_shim_fixtures.py: gradient_fixture, the slice-apply in
     float64, step 2e-6: the reference's own analytic gradient -- its C++ op under torch autograd on the CPU -- is within
     2e-5 of these quotients; a step of 1e-4 straddles the z taps' kinks and is 2.4e-3 off) against autograd through this package's model on the GPU -- the coefficient network's backward kernels, the
     slice-apply VJPs, the guide network's VJP, the loss kernels, fp32."""
     from hdrnet_amd import metrics
-    fx = _load("gradients_fd")
-    m = _model(fx).cuda()            # inference-mode graph (moving statistics), gradients wanted
+    fx = _load(fixture)
+    m = _model(fx).cuda()            # inference-mode graph (moving statistics) / training mode (the guide's batch statistics:
+                                     # input moments + hdrnet_guide_fold_batch_f32 and its VJP when fused), gradients wanted
     m.fuse_guide = fuse
     lo, hi = torch.from_numpy(fx["lowres_input"]).cuda(), torch.from_numpy(fx["fullres_input"]).cuda()
     target = torch.from_numpy(fx["target"]).cuda()
@@ -194,7 +196,7 @@ def test_committed_fixtures_are_what_the_script_computes(tmp_path):
         assert sorted(z.files) == sorted(want)
         for k in z.files:
             np.testing.assert_array_equal(z[k], want[k], err_msg=k)
-    for fixture in MODEL_FIXTURES + ["layers_wrappers", "metrics", "gradients_fd"]:
+    for fixture in MODEL_FIXTURES + ["layers_wrappers", "metrics", "gradients_fd", "gradients_fd_training"]:
         for rel, digest in json.loads(str(_load(fixture)["reference_sha256"])).items():
             with open(os.path.join(REFERENCE, rel), "rb") as f:
                 assert hashlib.sha256(f.read()).hexdigest() == digest, (fixture, rel)
