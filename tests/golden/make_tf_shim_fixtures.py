@@ -182,11 +182,10 @@ def slice_apply_f64(grid, guide, inp):
     return np.einsum("bhwij,bhwj->bhwi", coeff[..., :3], inp) + coeff[..., 3]
 
 
-def gradient_fixture(tf, models, hashes, out_dir, fname="gradients_fd", is_training=False, batch=1, seed=4321):
+def gradient_fixture(tf, models, hashes, out_dir, fname="gradients_fd", is_training=False, batch=1, seed=4321,
+                     cls="HDRNetPointwiseNNGuide"):
     """Graph-level GRADIENTS of the reference's graph code: central differences of l2_loss(target, inference(...)) in
     float64 with respect to three entries of every variable (h = 2e-6), the slice-apply evaluated in float64."""
-    import oracle
-    cls = "HDRNetPointwiseNNGuide"
     params = dict(net_input_size=128, spatial_bin=16, luma_bins=4, channel_multiplier=1, guide_complexity=8,
                   batch_norm=False, batch_size=batch)
     rng = np.random.RandomState(seed)
@@ -321,6 +320,10 @@ def main():
         gradient_fixture(tf, models, hashes, out_dir)
     if args.only in (None, "gradients_fd_training"):   # the guide network's batch norm on the batch's own statistics
         gradient_fixture(tf, models, hashes, out_dir, "gradients_fd_training", True, 2, 4391)
+    if args.only in (None, "gradients_fd_curves"):     # the reference's default class: the curves guide's VJP
+        gradient_fixture(tf, models, hashes, out_dir, "gradients_fd_curves", False, 1, 4461, "HDRNetCurves")
+    if args.only in (None, "gradients_fd_pyramid"):    # three levels, their up-adds, three guide networks on batch statistics
+        gradient_fixture(tf, models, hashes, out_dir, "gradients_fd_pyramid", True, 1, 4531, "HDRNetGaussianPyrNN")
 
     # hdrnet/metrics.py:21-33 -- the training loss and the evaluation metric of hdrnet/bin/train.py:137-143
     target = (rng.randint(0, 256, (3, 17, 23, 3)) / 255.0).astype(np.float32)    # (continues the stream of the block above)
