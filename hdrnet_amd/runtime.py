@@ -205,7 +205,8 @@ class GraphedTrainStep(TrainStep):
         if not self.bucket.attached():
             raise RuntimeError("a parameter's .grad was re-bound during capture: the flat bucket is detached")
         self._copy_stream = torch.cuda.Stream(device=dev) if feeds > 1 else None
-        self._ready = [torch.cuda.Event() for _ in range(feeds)]
+        with torch.cuda.device(dev):  # events belong to the device current at their creation
+            self._ready = [torch.cuda.Event() for _ in range(feeds)]
         self._staged: list = []   # slots filled by prefetch(), oldest first
         self._next_slot = 0
 
