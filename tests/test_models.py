@@ -1147,3 +1147,9 @@ def test_train_header_symbols_are_exported_and_bound():
         assert getattr(lib, n)(None, None, None, None, 16, None, 1e-3, 0.9, 0.999, 1e-8, None) == 1
     lib.hdrnet_l2_loss_with_grad_f32.argtypes = _lib.TRAIN_SIGNATURES["hdrnet_l2_loss_with_grad_f32"][1]
     assert lib.hdrnet_l2_loss_with_grad_f32(None, None, 16, None, None, None, 0, None) == 1
+    lib.hdrnet_l2_loss_grad_scale_f32.argtypes = _lib.TRAIN_SIGNATURES["hdrnet_l2_loss_grad_scale_f32"][1]
+    assert lib.hdrnet_l2_loss_grad_scale_f32(None, None, 16, None) == 1
+    lib.hdrnet_resize_add_f32.argtypes = _lib.TRAIN_SIGNATURES["hdrnet_resize_add_f32"][1]
+    assert lib.hdrnet_resize_add_f32(None, None, None, 1, 4, 4, 8, 8, 3, None) == 1      # null tensors
+    lib.hdrnet_resize_bilinear_grad_f32.argtypes = _lib.TRAIN_SIGNATURES["hdrnet_resize_bilinear_grad_f32"][1]
+    assert lib.hdrnet_resize_bilinear_grad_f32(None, None, 1, 4, 4, 8, 8, 3, None) == 1
