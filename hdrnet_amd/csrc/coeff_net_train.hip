@@ -551,9 +551,7 @@ struct BwdPair {
 };
 
 template <int KS, bool MULTI>
-__global__ __launch_bounds__(256) void coeff_conv_bwd(const BwdPair pr) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int id = blockIdx.x;
+__device__ __forceinline__ void bwd_pair_block(const BwdPair& pr, float* lds, int id) {
   if (id < pr.dw_blocks) {  // uniform
     const int pair = udiv(id, pr.chunk_mul, pr.dw_chunks);
     conv_dw_body<KS>(pr.dw, lds, id - pair * pr.dw_chunks, pair);
@@ -565,6 +563,27 @@ __global__ __launch_bounds__(256) void coeff_conv_bwd(const BwdPair pr) {
     const int ocg = udiv(r2, pr.tile_mul, pr.dx_tiles);
     conv_dx_body<KS, MULTI>(pr.dx, lds, r2 - ocg * pr.dx_tiles, ocg, b);
   }
+}
+
+template <int KS, bool MULTI>
+__global__ __launch_bounds__(256) void coeff_conv_bwd(const BwdPair pr) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  bwd_pair_block<KS, MULTI>(pr, lds, blockIdx.x);
+}
+
+// TWO layers' pairs in one launch: the local and the global path of the network do not depend on each other (local2 with
+// global conv2, then local1 with global conv1) -- the forward batches them the same way (coeff_net.hip: ConvBatch).
+struct BwdTwo {
+  BwdPair p[2];
+  int first_blocks;
+};
+
+template <int KS, bool MULTI>
+__global__ __launch_bounds__(256) void coeff_conv_bwd2(const BwdTwo two) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const bool second = (int)blockIdx.x >= two.first_blocks;  // uniform
+  if (second) bwd_pair_block<KS, MULTI>(two.p[1], lds, (int)blockIdx.x - two.first_blocks);
+  else bwd_pair_block<KS, MULTI>(two.p[0], lds, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------- fully connected layers
@@ -963,11 +982,20 @@ hipError_t launch_dx(const Layer& L, int B, const float* dy, const float* dy2, b
 }
 
 // Backward-weights and backward-data of one layer in ONE launch (coeff_conv_bwd).
-hipError_t launch_pair(const Layer& L, int B, const float* dy, const float* dy2, bool mask, float* dx, float* part,
-                       ReduceTab* tab, hipStream_t s, const float* xmask = nullptr, float* colsum_part = nullptr) {
+struct PairSetup {
+  BwdPair pr;
+  size_t lds;
+  unsigned blocks;
+  int ks;
+  bool multi;
+};
+
+PairSetup make_pair(const Layer& L, int B, const float* dy, const float* dy2, bool mask, float* dx, float* part,
+                    ReduceTab* tab, const float* xmask = nullptr, float* colsum_part = nullptr) {
   const int ocb = (L.Cout + 15) / 16, icb = (L.Cin + 15) / 16;
   const PartPlan pl = part_plan(B, L.Hout, ocb * icb);
-  BwdPair pr{};
+  PairSetup ps{};
+  BwdPair& pr = ps.pr;
   pr.dw = make_dw(L, B, dy, dy2, mask, part, pl, icb);
   DxSetup su = make_dx(L, dy, dy2, mask, dx, xmask, colsum_part);
   plan_dx_tiles(&su.p, B);
@@ -979,17 +1007,44 @@ hipError_t launch_pair(const Layer& L, int B, const float* dy, const float* dy2,
   pr.chunk_mul = magic32(pr.dw_chunks);
   pr.tile_mul = magic32(pr.dx_tiles);
   pr.tg_mul = magic32(pr.dx_tiles * pr.dx_groups);
-  const unsigned blocks = (unsigned)pr.dw_blocks + (unsigned)(pr.dx_tiles * pr.dx_groups * B);
-  if (L.ks == 3) {
-    const size_t lds = su.lds > dw_lds_floats<3>() * sizeof(float) ? su.lds : dw_lds_floats<3>() * sizeof(float);
-    if (su.p.nchunks > 1) coeff_conv_bwd<3, true><<<dim3(blocks), 256, lds, s>>>(pr);
-    else coeff_conv_bwd<3, false><<<dim3(blocks), 256, lds, s>>>(pr);
-  } else {
-    const size_t lds = su.lds > dw_lds_floats<1>() * sizeof(float) ? su.lds : dw_lds_floats<1>() * sizeof(float);
-    if (su.p.nchunks > 1) coeff_conv_bwd<1, true><<<dim3(blocks), 256, lds, s>>>(pr);
-    else coeff_conv_bwd<1, false><<<dim3(blocks), 256, lds, s>>>(pr);
-  }
+  ps.blocks = (unsigned)pr.dw_blocks + (unsigned)(pr.dx_tiles * pr.dx_groups * B);
+  ps.ks = L.ks;
+  ps.multi = su.p.nchunks > 1;
+  const size_t dwl = (L.ks == 3 ? dw_lds_floats<3>() : dw_lds_floats<1>()) * sizeof(float);
+  ps.lds = su.lds > dwl ? su.lds : dwl;
   add_reduce(tab, pr.dw, L, pl.nchunks);
+  return ps;
+}
+
+hipError_t launch_setup(const PairSetup& ps, hipStream_t s) {
+  if (ps.ks == 3) {
+    if (ps.multi) coeff_conv_bwd<3, true><<<dim3(ps.blocks), 256, ps.lds, s>>>(ps.pr);
+    else coeff_conv_bwd<3, false><<<dim3(ps.blocks), 256, ps.lds, s>>>(ps.pr);
+  } else {
+    if (ps.multi) coeff_conv_bwd<1, true><<<dim3(ps.blocks), 256, ps.lds, s>>>(ps.pr);
+    else coeff_conv_bwd<1, false><<<dim3(ps.blocks), 256, ps.lds, s>>>(ps.pr);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_pair(const Layer& L, int B, const float* dy, const float* dy2, bool mask, float* dx, float* part,
+                       ReduceTab* tab, hipStream_t s, const float* xmask = nullptr, float* colsum_part = nullptr) {
+  return launch_setup(make_pair(L, B, dy, dy2, mask, dx, part, tab, xmask, colsum_part), s);
+}
+
+// Two independent 3 x 3 layers' pairs in one launch (coeff_conv_bwd2); one after the other if their shapes differ in kind.
+hipError_t launch_two(const PairSetup& a, const PairSetup& b, hipStream_t s) {
+  if (a.ks != 3 || b.ks != 3 || a.multi != b.multi) {
+    const hipError_t e = launch_setup(a, s);
+    return e != hipSuccess ? e : launch_setup(b, s);
+  }
+  BwdTwo two{};
+  two.p[0] = a.pr;
+  two.p[1] = b.pr;
+  two.first_blocks = (int)a.blocks;
+  const size_t lds = a.lds > b.lds ? a.lds : b.lds;
+  if (a.multi) coeff_conv_bwd2<3, true><<<dim3(a.blocks + b.blocks), 256, lds, s>>>(two);
+  else coeff_conv_bwd2<3, false><<<dim3(a.blocks + b.blocks), 256, lds, s>>>(two);
   return hipGetLastError();
 }
 
@@ -1131,17 +1186,27 @@ hipError_t launch_coefficients_grad(const float* lowres, const hdrnet_coeff_net&
     coeff_fc_bwd<<<dim3((unsigned)((K1 + 15) / 16)), 256, 0, s>>>(f1);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
-  // ---- local path: local2 (no bias, no ReLU on its own output: the fusion's mask), local1
-  const Layer l2{L1, buf(bs.fusion), net.local_w[1], gr.local_w[1], nullptr, d.sb, d.gl, d.sb, d.gl, 3, 1};
-  if ((e = pair(l2, buf(bs.df), nullptr, true, buf(bs.dl1))) != hipSuccess) return e;
+  // ---- the local path (local2: no bias, no ReLU on its own output -- the fusion's mask --, local1) and the global path's
+  // convolutions (conv2, conv1) do not depend on each other: local2 + conv2 in one launch, then local1 + conv1
   const float* feat = S[d.n_ds - 1];
-  const Layer l1{feat, L1, net.local_w[0], gr.local_w[0], gr.local_b[0], d.sb, d.feat, d.sb, d.gl, 3, 1};
-  if ((e = pair(l1, buf(bs.dl1), nullptr, true, buf(bs.ds4a))) != hipSuccess) return e;
-  // ---- global path: conv2, conv1
-  const Layer c2{G1, G2, net.global_conv_w[1], gr.global_conv_w[1], gr.global_conv_b[1], g1side, d.gl, d.gside, d.gl, 3, 2};
-  if ((e = pair(c2, buf(bs.dg2), nullptr, true, buf(bs.dg1))) != hipSuccess) return e;
-  const Layer c1{feat, G1, net.global_conv_w[0], gr.global_conv_w[0], gr.global_conv_b[0], d.sb, d.feat, g1side, d.gl, 3, 2};
-  if ((e = pair(c1, buf(bs.dg1), nullptr, true, buf(bs.ds4b))) != hipSuccess) return e;
+  {
+    const Layer l2{L1, buf(bs.fusion), net.local_w[1], gr.local_w[1], nullptr, d.sb, d.gl, d.sb, d.gl, 3, 1};
+    const Layer c2{G1, G2, net.global_conv_w[1], gr.global_conv_w[1], gr.global_conv_b[1], g1side, d.gl, d.gside, d.gl, 3, 2};
+    const PairSetup a = make_pair(l2, B, buf(bs.df), nullptr, true, buf(bs.dl1), parts, &tab);
+    parts += dw_part_floats(B, l2);
+    const PairSetup b = make_pair(c2, B, buf(bs.dg2), nullptr, true, buf(bs.dg1), parts, &tab);
+    parts += dw_part_floats(B, c2);
+    if ((e = launch_two(a, b, s)) != hipSuccess) return e;
+  }
+  {
+    const Layer l1{feat, L1, net.local_w[0], gr.local_w[0], gr.local_b[0], d.sb, d.feat, d.sb, d.gl, 3, 1};
+    const Layer c1{feat, G1, net.global_conv_w[0], gr.global_conv_w[0], gr.global_conv_b[0], d.sb, d.feat, g1side, d.gl, 3, 2};
+    const PairSetup a = make_pair(l1, B, buf(bs.dl1), nullptr, true, buf(bs.ds4a), parts, &tab);
+    parts += dw_part_floats(B, l1);
+    const PairSetup b = make_pair(c1, B, buf(bs.dg1), nullptr, true, buf(bs.ds4b), parts, &tab);
+    parts += dw_part_floats(B, c1);
+    if ((e = launch_two(a, b, s)) != hipSuccess) return e;
+  }
   // ---- splat, last to first; the last layer's gradient is the sum of the two paths'
   const float* dy = buf(bs.ds4a);
   const float* dy2 = buf(bs.ds4b);
