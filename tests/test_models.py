@@ -946,6 +946,21 @@ def test_tf_fixture_parity(cls):
         np.testing.assert_allclose(got, fx["output"], **tol)
 
 
+def test_split_levels_equals_the_three_slices():
+    """models._SplitLevels: the pyramid's per-level grids (hdrnet/models.py:280) in one copy / one stack == slicing +
+    reshape under autograd, values and gradients, including a level whose output is not used."""
+    torch.manual_seed(0)
+    c = torch.randn(2, 4, 5, 3, 9, 4, dtype=torch.float64, requires_grad=True)
+    ws = [torch.randn(2, 4, 5, 3, 12, dtype=torch.float64) for _ in range(3)]
+    for used in ((0, 1, 2), (0,), (2, 1)):
+        outs = models._SplitLevels.apply(c, 3)
+        ref = [c[:, :, :, :, l * 3:(l + 1) * 3, :].reshape(2, 4, 5, 3, 12) for l in range(3)]
+        assert all(o.is_contiguous() and torch.equal(o, r) for o, r in zip(outs, ref))
+        g1, = torch.autograd.grad(sum((outs[l] * ws[l]).sum() for l in used), c)
+        g2, = torch.autograd.grad(sum((ref[l] * ws[l]).sum() for l in used), c)
+        assert torch.equal(g1, g2)
+
+
 def test_metrics_match_the_reference_formulas():
     """hdrnet/metrics.py:8-20: l2_loss = mean(square(target - prediction)), psnr = mean over the batch of
     -10 / ln 10 * log(mean(square))."""
