@@ -222,25 +222,30 @@ def timed(step_fn, steps, dist_on, dev):
     torch.cuda.synchronize(dev)
     trace = os.environ.get("HDRNET_BENCH_TRACE") == "1" and steps <= 64  # diagnostics: per-launch events
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps)] if trace else None
+    ev0.record()  # (before the wall clock starts: recording an event is not one of the K steps)
     t0 = time.perf_counter()
-    ev0.record()
     if trace:
         for k in range(steps):
             step_fn(1, k)
             evs[k].record()
     else:
         step_fn(steps, 0)
-    ev1.record()
     th = time.perf_counter()
+    ev1.record()
     # The closing synchronize is entered with the work already done: a blocking wait wakes up 30-60 us late,
     # which is 5 % of a 20-launch region (profiles/r03/bench_steps20.txt: 41.5 us wall vs 38.9 us events per
     # launch); polling the closing event first costs one core for the length of the region.
     while not ev1.query():
         pass
+    tq = time.perf_counter()
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
     if dist_on:
         hd.barrier()
+    if os.environ.get("HDRNET_BENCH_TRACE") == "2":  # diagnostics: where the host's share of a short region goes
+        print("host trace: launch loop %.1f us, until the closing event fired %.1f us, closing synchronize %.1f us; "
+              "events %.1f us" % ((th - t0) * 1e6, (tq - t0) * 1e6, (t1 - tq) * 1e6, ev0.elapsed_time(ev1) * 1e3),
+              file=sys.stderr)
     if trace:
         marks = [ev0] + evs
         print("trace: host loop %.0f us; per-launch us: %s" % (
@@ -408,6 +413,9 @@ def main():
                          "The default is without, as every training script of the reference runs it (scripts/*/*.sh: "
                          "--nobatch_norm; hdrnet/bin/train.py:244 batch_norm=False)")
     ap.add_argument("--no-batch-norm", action="store_true", help=argparse.SUPPRESS)  # the default since round 4; accepted
+    ap.add_argument("--force-collective", action="store_true",
+                    help="train_1080p_b4 at N = 1: create a one-rank RCCL communicator and issue the flat-bucket all-reduce "
+                         "in every step all the same (the multi-rank structure with the real collective kernel on one GPU)")
     ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)  # tests: gloo + a stub timed body
     args = ap.parse_args()
 
@@ -472,8 +480,14 @@ def main():
     # of its own; rows: the N ranks together did K frames.
     mp_per_step = B * H * W / 1e6
     value = (1 if band else world) * args.steps * mp_per_step / wall_max
+    # ONE clock for the line: `value`, `ms_per_step` and `roofline.achieved` / `.frac` all come from the wall clock of the
+    # K timed launches (the events of the same region -- 5-8 % shorter at K = 20, where the host's launch
+    # and wake-up latencies are a visible share of 0.8 ms -- used to be `frac` beside a wall-clock `value`).  The event
+    # quotient stays in the line under its own name.
     avg_kernel_s = gpu_max / args.steps  # events bracket K back-to-back launches of ONE kernel
-    achieved = abytes / avg_kernel_s / 1e9
+    wall_per_launch_s = wall_max / args.steps
+    achieved = abytes / wall_per_launch_s / 1e9
+    achieved_events = abytes / avg_kernel_s / 1e9
     traffic, traffic_note = measured_traffic(args.workload, kernel) if not band else (None, "row-split launch")
 
     result = {
@@ -496,9 +510,14 @@ def main():
                      "traffic": (traffic or {}).get("bytes_per_launch"),
                      "traffic_source": (traffic or {}).get("source") or traffic_note,
                      "source_digest": source_digest(),
-                     "algorithmic_bytes_per_launch": abytes, "avg_kernel_us": round(avg_kernel_s * 1e6, 3),
-                     "event_ms_per_step": round(gpu_max / args.steps * 1e3, 5),
-                     "timing": "HIP events on the launch stream around the K timed launches / K"},
+                     "algorithmic_bytes_per_launch": abytes,
+                     "wall_us_per_launch": round(wall_per_launch_s * 1e6, 3),
+                     "timing": "achieved = algorithmic bytes per launch / (wall clock of the K timed launches / K): the "
+                               "clock of `value`; frac_events = the same bytes over HIP events on the launch stream "
+                               "around the same K launches / K; frac_sustained = over the mean of 100-launch event "
+                               "windows during a further 0.5 s (N = 1)",
+                     "frac_events": round(achieved_events / HBM_PEAK_GBPS, 4),
+                     "event_us_per_launch": round(avg_kernel_s * 1e6, 3)},
     }
 
     if world == 1:
@@ -545,8 +564,8 @@ def main():
 
 
 
-def _init_ranks(world, local_rank, cpu=False):
-    """One process per GPU (main()'s rules): returns (device, dist_on, backend)."""
+def _init_ranks(world, local_rank, cpu=False, single=False):
+    """One process per GPU (main()'s rules): returns (device, dist_on, backend).  single: a one-rank group at N = 1."""
     from hdrnet_amd import dist as hd
     if cpu:
         dev, backend = torch.device("cpu"), "gloo"
@@ -556,9 +575,9 @@ def _init_ranks(world, local_rank, cpu=False):
         dev = torch.device("cuda", local_rank % torch.cuda.device_count())
         torch.cuda.set_device(dev)
         backend = os.environ.get("HDRNET_BENCH_BACKEND", "nccl")
-    if world > 1:
-        hd.init(backend=backend, device=dev)
-    return dev, world > 1, backend
+    if world > 1 or single:
+        hd.init(backend=backend, device=dev, single=single)
+    return dev, world > 1 or single, backend
 
 
 def _finish(result, rank, dist_on):
@@ -583,7 +602,8 @@ def main_train(args, rank, world, local_rank, stub=False):
     kernels have no CPU path by design."""
     from hdrnet_amd import dist as hd
     from hdrnet_amd import metrics
-    dev, dist_on, backend = _init_ranks(world, local_rank, cpu=stub)
+    force = bool(getattr(args, "force_collective", False)) and world == 1
+    dev, dist_on, backend = _init_ranks(world, local_rank, cpu=stub, single=force)
     B, H, W = 4, 1080, 1920
     torch.manual_seed(0)  # identical initial weights on every rank
     if stub:
@@ -612,6 +632,7 @@ def main_train(args, rank, world, local_rank, stub=False):
         target = torch.rand((B, H, W, 3), device=dev, generator=gen)
         step = GraphedTrainStep(model, lambda out, tgt: metrics.l2_loss(tgt, out), opt, [low, full], [target],
                                 flat_bucket=True)  # the multi-rank structure at every N, N = 1 included
+        step.force_collective = force
         run = lambda: step([low, full], [target])  # noqa: E731
         sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
         kernel = "hipGraph(fwd + loss + bwd) + flat-bucket all-reduce + flat Adam"
@@ -632,7 +653,7 @@ def main_train(args, rank, world, local_rank, stub=False):
     sync()
     t1 = time.perf_counter()
     for _ in range(n_ar):
-        step.bucket.allreduce()
+        step.bucket.allreduce(force=force)
     sync()
     ar = (time.perf_counter() - t1) / n_ar
     # the same step fed from the graph's own input buffers (a loader that writes the batch where the graph reads it):
@@ -660,7 +681,8 @@ def main_train(args, rank, world, local_rank, stub=False):
         "per_gpu_MPps": round(args.steps * mp / wall_max, 1),
         "ms_per_step_static_feed": None if static_ms is None else round(static_ms, 4),
         "allreduce": {"ms": round(ar_max * 1e3, 4), "share_of_step": round(ar_max * 1e3 / ms, 4),
-                      "bucket_elements": int(step.bucket.flat.numel()), "collectives_per_step": 1 if world > 1 else 0,
+                      "bucket_elements": int(step.bucket.flat.numel()), "collectives_per_step": 1 if (world > 1 or force) else 0,
+                      "forced_at_world_1": force,
                       "backend": backend if dist_on else None},
         "config": {"workload": EXTRA_WORKLOADS["train_1080p_b4"].format(
                        bn="with batch norm" if args.batch_norm else "without batch norm, as the reference's training scripts"),
@@ -713,6 +735,7 @@ def main_hdrp_u16(args, rank, world, local_rank):
     wall_max, gpu_max = hd.max_over_ranks([wall, gpu_s], device=dev if backend == "nccl" else torch.device("cpu"))
     mp = B * H * W / 1e6
     avg = gpu_max / args.steps
+    wall_l = wall_max / args.steps  # the clock of `value` (main(): one clock for the line)
     result = {
         "metric": "megapixels/sec BilateralSliceApply fwd, HDR+ uint16 wire format @4000x3000 (BASELINE config #5)",
         "value": round(world * args.steps * mp / wall_max, 1), "unit": "MP/s", "n_gpus": world, "steps": args.steps,
@@ -721,10 +744,13 @@ def main_hdrp_u16(args, rank, world, local_rank):
         "preroll_launches": n_pre, "preroll_ms": round(pre_s * 1e3, 1), "per_gpu_MPps": round(args.steps * mp / wall_max, 1),
         "config": {"workload": EXTRA_WORKLOADS["hdrp_u16"], "images_per_gpu_per_step": B, "global_batch": B * world,
                    "rotating_buffer_sets": nsets, "parallelism": f"image-shard x{world}", "kernel": kernel},
-        "roofline": {"bound": "hbm", "achieved": round(abytes / avg / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(abytes / avg / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
-                     "algorithmic_bytes_per_launch": abytes, "avg_kernel_us": round(avg * 1e6, 3),
-                     "timing": "HIP events on the launch stream around the K timed launches / K"},
+        "roofline": {"bound": "hbm", "achieved": round(abytes / wall_l / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(abytes / wall_l / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": abytes, "wall_us_per_launch": round(wall_l * 1e6, 3),
+                     "frac_events": round(abytes / avg / 1e9 / HBM_PEAK_GBPS, 4),
+                     "event_us_per_launch": round(avg * 1e6, 3),
+                     "timing": "achieved / frac: wall clock of the K timed launches / K (the clock of `value`); "
+                               "frac_events: HIP events on the launch stream around the same launches"},
     }
     _finish(result, rank, dist_on)
 

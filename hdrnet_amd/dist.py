@@ -23,12 +23,20 @@ def env_rank_world() -> Tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def init(backend: Optional[str] = None, device: Optional[torch.device] = None) -> Tuple[int, int]:
-    """Join the process group described by the environment (no-op for world size 1)."""
+def init(backend: Optional[str] = None, device: Optional[torch.device] = None, single: bool = False) -> Tuple[int, int]:
+    """Join the process group described by the environment (no-op for world size 1).
+
+    ``single=True`` creates the group at world size 1 as well -- a one-rank RCCL communicator on one GPU, so that the
+    collective code path (communicator set-up, the flat-bucket all-reduce kernel) runs on a single-GPU box exactly
+    as it will on the node (tests/test_gpu_rccl.py, ``bench.py --workload train_1080p_b4 --force-collective``)."""
     rank, world, _ = env_rank_world()
-    if world == 1:
+    if world == 1 and not single:
         return 0, 1
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world == 1:
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if not dist.is_initialized():
@@ -37,6 +45,13 @@ def init(backend: Optional[str] = None, device: Optional[torch.device] = None) -
             kw["device_id"] = device
         dist.init_process_group(backend=backend, **kw)
     return dist.get_rank(), dist.get_world_size()
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
@@ -185,14 +200,17 @@ class GradBucket:
     def zero_(self) -> None:
         self.flat.zero_()
 
-    def allreduce(self, world: Optional[int] = None) -> int:
+    def allreduce(self, world: Optional[int] = None, force: bool = False) -> int:
         """Average over the ranks, in place, ONE collective (RCCL over xGMI on the GPU node; gloo in the CPU
-        tests).  No-op without a process group.  Returns the element count."""
+        tests).  No-op without a process group, and at world size 1 unless ``force`` (then the one-rank collective
+        is issued all the same: the communicator and its kernel run, the values do not change).  Returns the
+        element count."""
         if dist.is_available() and dist.is_initialized():
             w = float(world or dist.get_world_size())
-            if w > 1:
+            if w > 1 or force:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-                self.flat.mul_(1.0 / w)
+                if w > 1:
+                    self.flat.mul_(1.0 / w)
         return int(self.flat.numel())
 
 

@@ -29,7 +29,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import layers
+from . import _state, layers
 
 __all__ = ["HDRNetCurves", "HDRNetPointwiseNNGuide", "HDRNetGaussianPyrNN", "default_params", "tf_same_pad"]
 
@@ -53,8 +53,10 @@ def tf_same_pad(x: torch.Tensor, kernel: int, stride: int) -> torch.Tensor:
 
 
 def _param_key(tensors) -> tuple:
-    """Identity + in-place version of every tensor: changes when a parameter is stepped, loaded or replaced."""
-    return tuple((t.data_ptr(), t._version) for t in tensors)
+    """Identity + in-place version of every tensor, + the package's parameter-state generation (``_state``): changes
+    when a parameter is stepped, loaded or replaced -- also by the writers that bypass the version counters
+    (``optim.FlatAdam``'s raw-pointer update, a replayed training hipGraph)."""
+    return (_state.generation(),) + tuple((t.data_ptr(), t._version) for t in tensors)
 
 
 def _cacheable() -> bool:

@@ -19,6 +19,7 @@ from typing import Iterable, Tuple
 
 import torch
 
+from . import _state
 from . import dist as hd
 
 __all__ = ["FlatAdam"]
@@ -42,6 +43,23 @@ class FlatAdam:
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.steps = torch.zeros((1,), dtype=torch.float32, device=self.flat.device)
 
+    def state_dict(self) -> dict:
+        """The Adam slots and the step count (the reference's checkpoints carry them: tf.train.Saver over the optimizer's
+        variables, hdrnet/bin/train.py:140-150) + the hyper-parameters; the parameters themselves are the module's."""
+        return {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "steps": self.steps.clone(),
+                "lr": self.lr, "betas": self.betas, "eps": self.eps, "epsilon_hat": self.epsilon_hat,
+                "numel": int(self.flat.numel())}
+
+    def load_state_dict(self, state: dict) -> None:
+        if int(state["numel"]) != int(self.flat.numel()):
+            raise ValueError(f"optimizer state of {state['numel']} elements does not fit {self.flat.numel()}")
+        with torch.no_grad():
+            self.exp_avg.copy_(state["exp_avg"])
+            self.exp_avg_sq.copy_(state["exp_avg_sq"])
+            self.steps.copy_(state["steps"])
+        self.lr, self.betas, self.eps = float(state["lr"]), tuple(float(b) for b in state["betas"]), float(state["eps"])
+        self.epsilon_hat = bool(state["epsilon_hat"])
+
     @property
     def param_groups(self):  # enough of torch.optim's surface for code that reads the learning rate
         return [{"params": self.bucket.params, "lr": self.lr, "betas": self.betas, "eps": self.eps}]
@@ -55,6 +73,11 @@ class FlatAdam:
         gradients -- ``runtime.TrainStep`` does)."""
         g = self.bucket.flat
         b1, b2 = self.betas
+        b = self.bucket
+        if any(p.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size() for p, off in zip(b.params, b.offsets)):
+            raise RuntimeError("FlatAdam: a parameter no longer lives in the flat buffer (module.to(...) or a re-allocated "
+                               "parameter after construction): the update would not reach it")
+        _state.bump()  # the update below does not touch the parameters' version counters: invalidate derived caches
         if self.flat.is_cuda:
             from . import _lib
             from .hdrnet_ops import _stream

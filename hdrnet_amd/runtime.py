@@ -15,6 +15,8 @@ from typing import Sequence
 
 import torch
 
+from . import _state
+
 
 class GraphedInference:
     """Capture ``module(*example_inputs)`` once; ``__call__`` copies new inputs into the static
@@ -25,16 +27,25 @@ class GraphedInference:
     The PARAMETERS are those of capture time: the models keep the derived arrays the kernels read (batch norm folded
     into the guide and the coefficient network, ``models._Coefficients.exported``) in a cache that the warm-up fills,
     so the graph holds pointers to them rather than the ~40 launches that derive them.  After changing the module's
-    parameters (an optimizer step, ``load_state_dict``) call ``recapture()``.
+    parameters (an optimizer step, ``load_state_dict``) call ``recapture()``: a replay with parameters other than the
+    captured ones RAISES (``check_parameters``; the check reads every parameter's and buffer's identity and version
+    counter plus the package's parameter-state generation, ~10 us of host time per call) instead of serving the stale
+    weights.
     """
 
-    def __init__(self, module: torch.nn.Module, example_inputs: Sequence[torch.Tensor], warmup: int = 3):
+    def __init__(self, module: torch.nn.Module, example_inputs: Sequence[torch.Tensor], warmup: int = 3,
+                 check_parameters: bool = True):
         if not all(t.is_cuda for t in example_inputs):
             raise RuntimeError("GraphedInference needs device tensors (MI355X)")
         self.module = module.eval()
         self.static_inputs = [t.clone() for t in example_inputs]
         self.warmup = warmup
+        self.check_parameters = bool(check_parameters)
         self.recapture()
+
+    def _parameter_state(self) -> tuple:
+        m = self.module
+        return (_state.generation(),) + tuple((t.data_ptr(), t._version) for t in list(m.parameters()) + list(m.buffers()))
 
     def recapture(self) -> None:
         """(Re-)capture the graph with the module's current parameters; the static input buffers are kept."""
@@ -47,10 +58,15 @@ class GraphedInference:
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.static_output = self.module(*self.static_inputs)
+        self._captured_state = self._parameter_state()
 
     def __call__(self, *inputs: torch.Tensor) -> torch.Tensor:
         if len(inputs) != len(self.static_inputs):
             raise ValueError(f"expected {len(self.static_inputs)} inputs, got {len(inputs)}")
+        if self.check_parameters and self._parameter_state() != self._captured_state:
+            raise RuntimeError("GraphedInference: the module's parameters or buffers changed since the graph was captured "
+                               "(optimizer step, load_state_dict, .to()); the graph holds the OLD folded weights -- call "
+                               "recapture()")
         for dst, src in zip(self.static_inputs, inputs):
             if dst.shape != src.shape or dst.dtype != src.dtype:
                 raise ValueError(f"captured for {tuple(dst.shape)} {dst.dtype}, got {tuple(src.shape)} {src.dtype}")
@@ -131,6 +147,8 @@ class TrainStep:
         self._hd = hd
         self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized() \
             and torch.distributed.get_world_size() > 1
+        # True: issue the flat-bucket all-reduce even at world size 1 (a one-rank communicator; dist.init(single=True))
+        self.force_collective = False
         # an optimizer that keeps its own flat gradient bucket (optim.FlatAdam) shares it with the step
         self.bucket = getattr(optimizer, "bucket", None) or hd.GradBucket(module.parameters())
 
@@ -145,8 +163,8 @@ class TrainStep:
         return loss
 
     def _after_backward(self) -> None:
-        if self.distributed:
-            self.bucket.allreduce()
+        if self.distributed or self.force_collective:
+            self.bucket.allreduce(force=self.force_collective)
         self.optimizer.step()
 
     def __call__(self, inputs: Sequence[torch.Tensor], targets: Sequence[torch.Tensor]) -> torch.Tensor:
@@ -244,6 +262,7 @@ class GraphedTrainStep(TrainStep):
         slot = self._staged.pop(0)
         torch.cuda.current_stream(self._copy_stream.device).wait_event(self._ready[slot])
         self.graphs[slot].replay()  # gradients land in the flat bucket
+        _state.bump()  # the replay wrote parameters / batch-norm statistics behind the version counters' back
         if self.split:
             self._after_backward()
         return self._losses[slot]
@@ -256,6 +275,7 @@ class GraphedTrainStep(TrainStep):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         self.graph.replay()  # gradients land in the flat bucket
+        _state.bump()  # the replay wrote parameters / batch-norm statistics behind the version counters' back
         if self.split:
             self._after_backward()
         return self.static_loss

@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-from bench import CACHE_BYTES, WORKLOADS  # noqa: E402
+from bench import CACHE_BYTES, WORKLOADS, make_sets  # noqa: E402
 from hdrnet_amd import _lib  # noqa: E402
 
 
@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--cases", default="all,gg,g")
     ap.add_argument("--variants", default="0,3,4,5")
+    ap.add_argument("--smooth", action="store_true", help="a smooth luminance-like guide (bench.make_sets) instead of U[0,1)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load_tools()
@@ -51,12 +52,13 @@ def main():
     nsets = max(3, -(-int(CACHE_BYTES * 1.5) // (4 * npx * 11)))
     gen = torch.Generator(device=dev).manual_seed(1)
     S = [dict(grid=torch.rand((B, GH, GW, GD, C), device=dev, generator=gen),
-              guide=torch.rand((B, H, W), device=dev, generator=gen),
+              guide=(make_sets(dev, 1, B, H, W, GH, GW, GD, seed=3 + i, smooth_guide=True)[0][1] if args.smooth
+                     else torch.rand((B, H, W), device=dev, generator=gen)),
               inp=torch.rand((B, H, W, Cin), device=dev, generator=gen),
               dout=torch.randn((B, H, W, Cout), device=dev, generator=gen),
               dgrid=torch.empty((B, GH, GW, GD, C), device=dev),
               dguide=torch.empty((B, H, W), device=dev),
-              dinput=torch.empty((B, H, W, Cin), device=dev)) for _ in range(nsets)]
+              dinput=torch.empty((B, H, W, Cin), device=dev)) for i in range(nsets)]
     sl = [torch.randn((B, H, W, C), device=dev, generator=gen) for _ in range(2)]
     stream = torch.cuda.current_stream(dev).cuda_stream
     wsb = lib.hdrnet_bilateral_slice_apply_grad_workspace_bytes(B, H, W, GH, GW, GD, Cin, Cout, 1)
@@ -105,7 +107,7 @@ def main():
         for k, f in fns.items():
             time_launches(f, 20)  # settle (see tools/ab_bench.py)
             res[k].append(time_launches(f, args.steps))
-    print(desc)
+    print(desc + ("; SMOOTH guide" if args.smooth else ""))
     for (c, v), t in res.items():
         print(f"case {c:4s} variant {v:3d} {names[(c, v)]:34s} median {statistics.median(t):8.2f} us  min {min(t):8.2f}"
               f"   all: {[round(x, 1) for x in t]}")
