@@ -211,6 +211,29 @@ def run_steps(lib, sets, dims, stream, n, start=0, band=None):
             raise RuntimeError(f"{fn.__name__} rc={rc}: {lib.hdrnet_last_error().decode()}")
 
 
+_JSON_FD = None
+
+
+def protect_stdout():
+    """The driver reads ONE JSON line from stdout.  Libraries write there too -- RCCL prints a version banner from C
+    stdio when its first communicator comes up, after Python's own buffers have been flushed -- so the process's fd 1
+    is pointed at stderr for everything else and the line goes to the original stdout."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(result):
+    line = (json.dumps(result) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
 def timed(step_fn, steps, dist_on, dev):
     """Barrier + sync, K launches (also bracketed by HIP events on the launch stream), sync + barrier.
     Returns (wall seconds, event seconds)."""
@@ -421,6 +444,7 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
+    protect_stdout()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -556,7 +580,7 @@ def main():
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(H, W, GH, GW, GD)
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)
     if dist_on:
         import torch.distributed as dist
         hd.barrier()
@@ -583,7 +607,7 @@ def _init_ranks(world, local_rank, cpu=False, single=False):
 def _finish(result, rank, dist_on):
     from hdrnet_amd import dist as hd
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)
     if dist_on:
         import torch.distributed as dist
         hd.barrier()
@@ -769,10 +793,10 @@ def stub_main(args, rank, world):
         hd.barrier()
     (wall_max,) = hd.max_over_ranks([wall], device=torch.device("cpu"))
     if rank == 0:
-        print(json.dumps({"metric": "stub", "workload": args.workload, "value": round(world * args.steps / wall_max, 1), "unit": "steps/s",
+        emit({"metric": "stub", "workload": args.workload, "value": round(world * args.steps / wall_max, 1), "unit": "steps/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(wall_max / max(args.steps, 1) * 1e3, 5),
-                          "higher_is_better": True, "scaling": "weak"}), flush=True)
+                          "higher_is_better": True, "scaling": "weak"})
     if world > 1:
         import torch.distributed as dist
         hd.barrier()

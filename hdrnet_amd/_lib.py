@@ -16,6 +16,7 @@ HDRNET_INVALID_ARGUMENT = 1
 HDRNET_RUNTIME_FAILURE = 2
 
 KERNEL_AUTO = 0
+GUIDE_SIGMOID_FAST = 0x10000  # HDRNET_GUIDE_SIGMOID_FAST (flags of the guide-network ..._ex entry points)
 KERNEL_GENERIC = 1
 KERNEL_FAST = 2
 
@@ -37,8 +38,10 @@ SIGNATURES = {
     "hdrnet_bilateral_slice_apply_rows_f32": (_I, [_FP] * 4 + [_I] * 11 + [_VP]),
     "hdrnet_bilateral_slice_apply_rows_f32_ex": (_I, [_FP] * 4 + [_I] * 11 + [_U, _VP]),
     "hdrnet_bilateral_slice_apply_nnguide_f32": (_I, [_FP] * 6 + [_I] * 10 + [_VP]),
+    "hdrnet_bilateral_slice_apply_nnguide_f32_ex": (_I, [_FP] * 6 + [_I] * 10 + [_U, _VP]),
     "hdrnet_bilateral_slice_apply_io_curves": (_I, [_FP] * 3 + [_I] * 10 + [ctypes.c_float, _I] + [_FP] * 4 + [_I, _FP, _VP]),
     "hdrnet_bilateral_slice_apply_upadd_f32": (_I, [_FP] * 4 + [_I, _I, _FP] + [_I] * 9 + [_FP, _FP, _I, _VP]),
+    "hdrnet_bilateral_slice_apply_upadd_f32_ex": (_I, [_FP] * 4 + [_I, _I, _FP] + [_I] * 9 + [_FP, _FP, _I, _U, _VP]),
     "hdrnet_resize_bilinear_f32": (_I, [_FP, _FP] + [_I] * 6 + [_VP]),
     "hdrnet_pointwise_guide_grad_workspace_bytes": (_SZ, [ctypes.c_longlong, _I, _I]),
     "hdrnet_pointwise_guide_grad_f32": (_I, [_FP] * 6 + [_I] + [_FP] * 2 + [ctypes.c_longlong, _I, _I, _VP, _SZ, _VP]),
@@ -56,6 +59,7 @@ SIGNATURES = {
     "hdrnet_coefficients_grad_workspace_bytes": (_SZ, [_VP, _I]),
     "hdrnet_coefficients_grad_f32": (_I, [_FP, _VP, _VP, _FP, _VP, _I, _VP, _SZ, _VP]),
     "hdrnet_bilateral_slice_apply_io": (_I, [_FP] * 4 + [_I] * 10 + [ctypes.c_float, _I] + [_FP] * 2 + [_I, _FP, _VP]),
+    "hdrnet_bilateral_slice_apply_io_ex": (_I, [_FP] * 4 + [_I] * 10 + [ctypes.c_float, _I] + [_FP] * 2 + [_I, _FP, _U, _VP]),
     "hdrnet_bilateral_slice_apply_grad_workspace_bytes": (_SZ, [_I] * 9),
     "hdrnet_bilateral_slice_apply_grad_f32": (_I, [_FP] * 7 + [_I] * 9 + [_VP, _SZ, _VP]),
     "hdrnet_bilateral_slice_apply_grad_f32_ex": (_I, [_FP] * 7 + [_I] * 9 + [_VP, _SZ, _U, _VP]),

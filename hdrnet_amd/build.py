@@ -60,6 +60,40 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
+_FLAG_OK: dict = {}
+
+
+def _flag_supported(cc: str, flags: List[str]) -> bool:
+    """Does this hipcc accept `flags`?  (-mllvm options are hidden LLVM knobs: an older or newer ROCm LLVM that does not
+    know one rejects the whole compile.  Probed once per process on an empty translation unit.)"""
+    key = tuple(flags)
+    if key not in _FLAG_OK:
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            src = os.path.join(d, "probe.hip")
+            with open(src, "w") as fh:
+                fh.write("__global__ void probe() {}\n")
+            res = subprocess.run([cc, f"--offload-arch={ARCH}", "-c", src, "-o", os.path.join(d, "probe.o"), *flags],
+                                 capture_output=True, text=True)
+            _FLAG_OK[key] = res.returncode == 0
+    return _FLAG_OK[key]
+
+
+# flags a compile can do without (tuning only): dropped when the compiler does not know them
+OPTIONAL_FLAG_GROUPS = [["-mllvm", "-amdgpu-mfma-vgpr-form"]]
+
+
+def _usable_flags(cc: str, extra: List[str]) -> List[str]:
+    out = list(extra)
+    for group in OPTIONAL_FLAG_GROUPS:
+        n = len(group)
+        for i in range(len(out) - n + 1):
+            if out[i:i + n] == group and not _flag_supported(cc, group):
+                del out[i:i + n]
+                break
+    return out
+
+
 def _deps() -> List[str]:
     out = [os.path.join(INCLUDE, "hdrnet_amd.h"), os.path.abspath(__file__)]
     for f in os.listdir(CSRC):
@@ -136,7 +170,8 @@ def build(force: bool = False, verbose: bool = False, tools: bool = False) -> st
             procs = []
             for src, extra in SOURCES + (TOOLS_ONLY_SOURCES if tools else []):
                 obj = os.path.join(objdir, src.replace(".hip", ".o") + tag)
-                cmd = [cc, *COMMON, *define, *extra, "-I", CSRC, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
+                cmd = [cc, *COMMON, *define, *_usable_flags(cc, extra), "-I", CSRC, "-I", INCLUDE, "-c",
+                       os.path.join(CSRC, src), "-o", obj]
                 if verbose:
                     print(" ".join(cmd), flush=True)
                 procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -47,6 +47,7 @@ struct GuideNet {
   const float* slopes;  //                            curves: [n][CIN]
   float* guide_out;    // optional
   int n;               // NN: features                curves: knots per channel
+  bool fast_sigmoid;   // NN: GuideNN::fast_sigmoid (rows_common.hip.h)
 };
 
 typedef __attribute__((address_space(4))) const float cfloat;  // wave-uniform parameters: s_load
@@ -383,7 +384,7 @@ __device__ __forceinline__ void guide_nn_quad_mfma_u8(const unsigned* __restrict
       for (int i = 0; i < 4; ++i) acc[q] = fmaf(m[i], __builtin_fabsf(h[i]), acc[q]);
     }
   }
-  if (gn.guide_out) {  // training forward: tf.nn.sigmoid with an IEEE divide (rows_common.hip.h: guide_nn_quad)
+  if (!gn.fast_sigmoid) {  // the reference's sigmoid (rows_common.hip.h: GuideNN::fast_sigmoid)
 #pragma unroll
     for (int q = 0; q < kPxPerThread; ++q) g[q] = 1.0f / (1.0f + expf(-acc[q]));
   } else {
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
             done = true;
           }
         }
-        if (!done) guide_nn_quad<CIN>(GuideNN{p.gn.conv1, p.gn.conv2, p.gn.guide_out, p.gn.n}, inf, gs);  // (writes nothing itself)
+        if (!done) guide_nn_quad<CIN>(GuideNN{p.gn.conv1, p.gn.conv2, p.gn.guide_out, p.gn.n, p.gn.fast_sigmoid}, inf, gs);  // (writes nothing itself)
       }
       else if constexpr (GUIDE == kGuideCurves)
         guide_curves_quad<CIN>(ctab, p.gn, inf, gs);
@@ -646,7 +647,7 @@ hipError_t launch_io(const ApplyIoArgs& a, const Plan&, hipStream_t s) {
   p.white = io_white_level(a.white_level);
   p.grid_image = a.GH * a.GW * a.GD * C;
   p.tab = make_seg_tab(a.W, g.pl.seg, g.pl.nseg, p.scale_x);
-  p.gn = GuideNet{a.guide_conv1, a.guide_conv2, a.guide_shifts, a.guide_slopes, a.guide_out, a.n_feats};
+  p.gn = GuideNet{a.guide_conv1, a.guide_conv2, a.guide_shifts, a.guide_slopes, a.guide_out, a.n_feats, a.fast_sigmoid};
 #ifdef HDRNET_TOOLS_BUILD
   p.nn_mfma = tools_knob(5);
 #else

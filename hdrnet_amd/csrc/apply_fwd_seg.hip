@@ -620,7 +620,7 @@ bool apply_fwd_seg_nnguide_supported(const ApplyArgs& a, const float* guide_out)
 
 hipError_t launch_apply_fwd_seg_nnguide(const ApplyArgs& a, const float* conv1, const float* conv2, int n_feats,
                                         float* guide_out, hipStream_t s, const char** name) {
-  const GuideNN gn{conv1, conv2, guide_out, n_feats};
+  const GuideNN gn{conv1, conv2, guide_out, n_feats, a.fast_sigmoid};
   *name = "apply_fwd_seg/vec4+nnguide";
 #define HDRNET_CASE(CI, CO, OFF)                          \
   if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF) \
@@ -647,7 +647,7 @@ hipError_t launch_apply_fwd_seg_upadd(const ApplyArgs& a, const float* coarse, i
   if (conv1) {
     *name = "apply_fwd_seg/vec4+nnguide+upadd";
     return launch_seg_t<3, 3, true, kProductDma, kStoresBufNt, false, true, true, kGuideNNPix>(
-        a, s, nullptr, GuideNN{conv1, conv2, nullptr, n_feats}, up);
+        a, s, nullptr, GuideNN{conv1, conv2, nullptr, n_feats, a.fast_sigmoid}, up);
   }
   *name = "apply_fwd_seg/vec4+upadd";
   return launch_seg_t<3, 3, true, kProductDma, kStoresBufNt, false, false, true, kProductPix>(

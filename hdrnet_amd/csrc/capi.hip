@@ -78,6 +78,13 @@ int check_common(int B, int H, int W, int GH, int GW, int GD) {
 
 // flags: bits 0..7 kernel family (HDRNET_KERNEL_*), bits 8..15 variant inside the family
 // (0 = the library's default; used by benchmarks for A/B runs), rest must be zero.
+// flags of the guide-network entry points (..._nnguide_f32_ex, ..._upadd_f32_ex, ..._io_ex): only the sigmoid choice
+int check_guide_flags(unsigned flags) {
+  if ((flags & ~HDRNET_GUIDE_SIGMOID_FAST) != 0)
+    return fail(HDRNET_INVALID_ARGUMENT, "unknown flags 0x%x (guide-network entry points take HDRNET_GUIDE_SIGMOID_FAST)", flags);
+  return HDRNET_OK;
+}
+
 int check_flags(unsigned flags) {
   if ((flags & 0xffu) > HDRNET_KERNEL_FAST || (flags >> 16) != 0)
     return fail(HDRNET_INVALID_ARGUMENT, "unknown flags 0x%x", flags);
@@ -196,8 +203,18 @@ int hdrnet_bilateral_slice_apply_nnguide_f32(const float* grid, const float* inp
                                              float* out, float* guide_out, int B, int H, int W,
                                              int GH, int GW, int GD, int Cin, int Cout,
                                              int has_offset, int n_feats, void* stream) {
+  return hdrnet_bilateral_slice_apply_nnguide_f32_ex(grid, input, guide_conv1, guide_conv2, out, guide_out, B, H, W,
+                                                     GH, GW, GD, Cin, Cout, has_offset, n_feats, 0u, stream);
+}
+
+int hdrnet_bilateral_slice_apply_nnguide_f32_ex(const float* grid, const float* input,
+                                                const float* guide_conv1, const float* guide_conv2,
+                                                float* out, float* guide_out, int B, int H, int W,
+                                                int GH, int GW, int GD, int Cin, int Cout,
+                                                int has_offset, int n_feats, unsigned flags, void* stream) {
   using namespace hdrnet_amd;
   if (int rc = check_common(B, H, W, GH, GW, GD)) return rc;
+  if (int rc = check_guide_flags(flags)) return rc;
   if (Cin <= 0 || Cout <= 0 || n_feats <= 0 || n_feats > 4096)
     return fail(HDRNET_INVALID_ARGUMENT, "bad channel / feature counts (Cin=%d, Cout=%d, n=%d)", Cin,
                 Cout, n_feats);
@@ -210,6 +227,7 @@ int hdrnet_bilateral_slice_apply_nnguide_f32(const float* grid, const float* inp
     return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
   ApplyArgs a{grid, nullptr, input, out, B, H, W, GH, GW, GD, Cin, Cout,
               Cin + (has_offset ? 1 : 0), has_offset != 0, 0};
+  a.fast_sigmoid = (flags & HDRNET_GUIDE_SIGMOID_FAST) != 0;
   if (!apply_fwd_nnguide_supported(a, guide_out))
     return fail(HDRNET_INVALID_ARGUMENT,
                 "fused guide + slice-apply needs (Cin, Cout) in {(3,3), (1,1)}, W %% 4 == 0 and 16-B "
@@ -227,8 +245,19 @@ int hdrnet_bilateral_slice_apply_upadd_f32(const float* grid, const float* guide
                                            int H, int W, int GH, int GW, int GD, int Cin, int Cout,
                                            int has_offset, const float* guide_conv1,
                                            const float* guide_conv2, int n_feats, void* stream) {
+  return hdrnet_bilateral_slice_apply_upadd_f32_ex(grid, guide, input, coarse, Hc, Wc, out, B, H, W, GH, GW, GD, Cin,
+                                                   Cout, has_offset, guide_conv1, guide_conv2, n_feats, 0u, stream);
+}
+
+int hdrnet_bilateral_slice_apply_upadd_f32_ex(const float* grid, const float* guide, const float* input,
+                                              const float* coarse, int Hc, int Wc, float* out, int B,
+                                              int H, int W, int GH, int GW, int GD, int Cin, int Cout,
+                                              int has_offset, const float* guide_conv1,
+                                              const float* guide_conv2, int n_feats, unsigned flags,
+                                              void* stream) {
   using namespace hdrnet_amd;
   if (int rc = check_common(B, H, W, GH, GW, GD)) return rc;
+  if (int rc = check_guide_flags(flags)) return rc;
   if (Cin <= 0 || Cout <= 0) return fail(HDRNET_INVALID_ARGUMENT, "bad channel counts");
   if (Hc <= 0 || Wc <= 0) return fail(HDRNET_INVALID_ARGUMENT, "bad coarse extents (%d x %d)", Hc, Wc);
   if ((guide != nullptr) == (guide_conv1 != nullptr))
@@ -243,6 +272,7 @@ int hdrnet_bilateral_slice_apply_upadd_f32(const float* grid, const float* guide
   if (!grid || !input || !out || !coarse) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
   ApplyArgs a{grid, guide, input, out, B, H, W, GH, GW, GD, Cin, Cout,
               Cin + (has_offset ? 1 : 0), has_offset != 0, 0};
+  a.fast_sigmoid = (flags & HDRNET_GUIDE_SIGMOID_FAST) != 0;
   if (!apply_fwd_upadd_supported(a, coarse, guide_conv1 != nullptr))
     return fail(HDRNET_INVALID_ARGUMENT,
                 "slice-apply + up-add needs Cin = Cout = 3 with offset, W %% 4 == 0 and 16-B aligned "
@@ -537,8 +567,20 @@ int hdrnet_bilateral_slice_apply_io(const float* grid, const float* guide, const
                                     float input_white_level, int output_dtype,
                                     const float* guide_conv1, const float* guide_conv2, int n_feats,
                                     float* guide_out, void* stream) {
+  return hdrnet_bilateral_slice_apply_io_ex(grid, guide, input, out, B, H, W, GH, GW, GD, Cin, Cout, has_offset,
+                                            input_dtype, input_white_level, output_dtype, guide_conv1, guide_conv2,
+                                            n_feats, guide_out, 0u, stream);
+}
+
+int hdrnet_bilateral_slice_apply_io_ex(const float* grid, const float* guide, const void* input,
+                                       void* out, int B, int H, int W, int GH, int GW, int GD, int Cin,
+                                       int Cout, int has_offset, int input_dtype,
+                                       float input_white_level, int output_dtype,
+                                       const float* guide_conv1, const float* guide_conv2, int n_feats,
+                                       float* guide_out, unsigned flags, void* stream) {
   using namespace hdrnet_amd;
   if (int rc = check_common(B, H, W, GH, GW, GD)) return rc;
+  if (int rc = check_guide_flags(flags)) return rc;
   if (Cin <= 0 || Cout <= 0) return fail(HDRNET_INVALID_ARGUMENT, "bad channel counts");
   if (input_dtype < 0 || input_dtype > 2 || output_dtype < 0 || output_dtype > 1)
     return fail(HDRNET_INVALID_ARGUMENT, "unknown dtype code (input %d, output %d)", input_dtype,
@@ -556,6 +598,7 @@ int hdrnet_bilateral_slice_apply_io(const float* grid, const float* guide, const
   ApplyIoArgs a{grid, guide, input, out, B, H, W, GH, GW, GD, Cin, Cout, has_offset != 0,
                 input_dtype, output_dtype, input_white_level, guide_conv1, guide_conv2, n_feats,
                 guide_out};
+  a.fast_sigmoid = (flags & HDRNET_GUIDE_SIGMOID_FAST) != 0;
   if (!apply_fwd_io_supported(a))
     return fail(HDRNET_INVALID_ARGUMENT,
                 "the wire-format forward supports Cin = Cout = 3 with offset, W %% 4 == 0, aligned "

@@ -74,7 +74,6 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
-#include <random>
 
 #include "launch.hip.h"
 #include "numerics.hip.h"
@@ -117,11 +116,6 @@ struct GGParams {
   long long ntasks;
   float scale_x, scale_y;  // GW / W, GH / H  (forward's expressions)
   long long* trace;        // tools variant 9 (ABL 6): per-chunk phase stamps of wave 0, [task][kTraceChunks][5]
-  // FOLD2 (stage 2 folded into stage 1's last arrivers, below): the result, one arrival word per grid column
-  // (b, gy, gx) at the head of the workspace, and this launch's tag for those words
-  float* dgrid;
-  unsigned long long* arrivals;
-  unsigned long long epoch;  // < 2^40
 };
 
 // LDS traffic of ONE wave needs no fence: the LDS executes a wave's instructions in order, so
@@ -148,62 +142,6 @@ __device__ __forceinline__ int interval_start(int g, int W, float scale_x) {
 
 __device__ __forceinline__ int gy_base_of(int y_first, float scale_y, int GH) {
   return clamp_index(floor_to_int(mul_rn(y_first + 0.5f, scale_y) - 0.5f), 0, GH - 1);
-}
-
-// ---- the column sum of stage 2 (shared by grid_grad_stage2 and stage 1's folded form) ------------------------
-// dgrid[b, gy, gx, z, c] = the partial tiles of the row groups that touch grid row gy, for the two x-intervals that
-// cover column gx (+ the clamp-to-edge halves of the border intervals), added in FIXED order: row groups
-// yg = yg_lo + part, + kS2Parts, ... per part, then part 0 + 1 + 2 + 3.  Whoever evaluates it gets the same bits.
-constexpr int kS2Parts = 4;
-
-struct S2Window {
-  int yg_lo, yg_hi;  // conservative window of row groups that can touch gy; exact membership is `rel`
-};
-
-__device__ __forceinline__ S2Window s2_window(int gy, int rg, int nyg, float scale_y) {
-  return S2Window{max(0, (int)floorf((gy - 2.0f) / scale_y) / rg - 1),
-                  min(nyg, (int)ceilf((gy + 2.5f) / scale_y) / rg + 2)};
-}
-
-// COHERENT: the tiles were written by other workgroups of the SAME launch (stage 1's folded form): read them with
-// agent-scope loads (global_load ... sc1), which do not hit a stale line of this XCD's L2 or this CU's L1.
-template <bool COHERENT = false>
-__device__ __forceinline__ float s2_part_sum(const float* partial, long long b, int gy, int gx, int z, int c,
-                                             int part, int GH, int GW, int rg, int nyg, float scale_y) {
-  auto ld = [](const float* q) {
-    if constexpr (COHERENT) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else return *q;
-  };
-  const int nint = GW + 1;
-  const S2Window w = s2_window(gy, rg, nyg, scale_y);
-  float s = 0.0f;
-  for (int yg = w.yg_lo + part; yg < w.yg_hi; yg += kS2Parts) {
-    const int rel = gy - gy_base_of(yg * rg, scale_y, GH);
-    if (rel < 0 || rel > 2) continue;
-    const size_t t0 = ((size_t)b * nyg + yg) * nint;
-    float v0 = ld(partial + (t0 + gx + 1) * kTileFloats + (rel * 16 + z) * 16 + c);
-    float v1 = ld(partial + (t0 + gx) * kTileFloats + (rel * 16 + 8 + z) * 16 + c);
-    // clamp-to-edge: interval g = -1's corner 0 and interval g = GW - 1's corner 1 land on the edge columns
-    float v2 = 0.0f, v3 = 0.0f;
-    if (gx == 0) v2 = ld(partial + t0 * kTileFloats + (rel * 16 + z) * 16 + c);
-    if (gx == GW - 1) v3 = ld(partial + (t0 + GW) * kTileFloats + (rel * 16 + 8 + z) * 16 + c);
-    s += v0;
-    s += v1;
-    if (gx == 0) s += v2;
-    if (gx == GW - 1) s += v3;
-  }
-  return s;
-}
-
-// Row groups whose tiles stage 2 reads for grid row gy (every task of such a group writes all three of its tiles).
-__device__ __forceinline__ int s2_groups_touching(int gy, int GH, int rg, int nyg, float scale_y) {
-  const S2Window w = s2_window(gy, rg, nyg, scale_y);
-  int n = 0;
-  for (int yg = w.yg_lo; yg < w.yg_hi; ++yg) {
-    const int rel = gy - gy_base_of(yg * rg, scale_y, GH);
-    n += (rel >= 0 && rel <= 2) ? 1 : 0;
-  }
-  return n;
 }
 
 // ---- stage 1 ---------------------------------------------------------------------------------
@@ -266,17 +204,7 @@ constexpr int kTStride = 68;  // floats per operand row: 64 pixels + 4 (16-B ali
 // like apply_fwd_seg.hip: 2 x (GD + 2) x C floats per wave, re-blended by the wave at the start of
 // each row from grid rows it prefetched with the row's first pixel batch.  The z tent and its
 // derivative share one v_sqrt_f32 per tap with the dgrid weights.
-//
-// OPT (round 5 experiments, profiles/r05/bwd_steps.md):
-//   kOptFold2  stage 2 folded into stage 1: a workgroup that has written its partial tile ARRIVES at the (<= 6) grid
-//              columns the tile feeds; the workgroup whose arrival completes a column adds that column's tiles -- the
-//              column sum of grid_grad_stage2, same order, same bits -- and writes dgrid.  One launch instead of two.
-//   kOptGeo1   the four waves of a workgroup on ONE row: wave w owns the chunk columns w, w + 4, ... of every row
-//              (VERDICT r04's geometry) instead of every fourth row.
-constexpr int kOptFold2 = 1, kOptGeo1 = 2;
-constexpr int kProductOpt = 0;  // what the library's own launches use
-
-template <int CIN, int COUT, bool OFFSET, bool APPLY, bool SPLIT, bool WG = false, bool WI = false, int ABL = 0, int OPT = 0>
+template <int CIN, int COUT, bool OFFSET, bool APPLY, bool SPLIT, bool WG = false, bool WI = false, int ABL = 0>
 __global__ __launch_bounds__(kWaves * 64)
 __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET ? 1 : 0) : 1) <= 12) ? 4 : 1))) void grid_grad_stage1(GGParams p) {
   constexpr int CJ = APPLY ? CIN + (OFFSET ? 1 : 0) : 1;
@@ -291,8 +219,7 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
   // then fits 4 waves / SIMD instead of 3: 113 -> 120 us, the shorter prefetch costs more than the wave
   // buys).  A wide BilateralSlice (dout = 48-64 B/px) is the exception: its batch is 26-34 registers, one
   // chunk ahead brings the pass from 3 to 4 waves / SIMD and 115 -> 110 us at 4K.
-  constexpr bool FOLD2 = (OPT & kOptFold2) != 0, GEO1 = (OPT & kOptGeo1) != 0;
-  constexpr int kBatch = (GEO1 || (!APPLY && COUT >= 12)) ? 1 : 2;
+  constexpr int kBatch = (!APPLY && COUT >= 12) ? 1 : 2;
   constexpr int kLoadAux = FUSED ? rows::kAuxNt : 0;  // fused pass is an HBM stream: nontemporal pixel loads
   constexpr int kImg = FUSED ? 2 * 10 * C : 0;  // [x corner][plane 0 .. GD + 1 (GD <= 8)][c]
   constexpr int kSlab = (16 + C) * kTStride + kImg;  // floats per wave: A^T [16][68], V^T [C][68], image
@@ -328,12 +255,7 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
     return (x < x_hi) ? gc0 - gxf : 2.0f;
   };
   const int span = x_hi - x_lo;
-  // batches per row of this wave (GEO1: its chunk columns wave, wave + kWaves, ... of the row)
-  const int nch_row = (span + 63) / 64;
-  const int nbr = GEO1 ? (nch_row > wave ? (nch_row - wave + kWaves - 1) / kWaves : 0)
-                       : (span + 64 * kBatch - 1) / (64 * kBatch);
-  constexpr int kRowStep = GEO1 ? 1 : kWaves;
-  const int row0 = GEO1 ? y_first : y_first + wave;
+  const int nbr = (span + 64 * kBatch - 1) / (64 * kBatch);  // batches per row
   // fused: this lane's element of the row's coefficient image (2 columns x GD planes x C / 4 float4)
   constexpr int C4 = C / 4 > 0 ? C / 4 : 1;
   const int nst = 2 * p.GD * C4;
@@ -370,14 +292,12 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
   struct Batch {
     float g[kBatch], in[kBatch][CIN_Q], d[kBatch][COUT];
   };
-  const int nrows = (y_end - row0 + kRowStep - 1) / kRowStep;
-  const int nbt = (ABL != 3 && span > 0 && nrows > 0 && nbr > 0) ? nrows * nbr : 0;  // ABL 3: prologue + epilogue only
-  // first pixel of batch bi of a row
-  auto batch_x = [&](int bi) { return x_lo + (GEO1 ? (wave + kWaves * bi) * 64 : bi * 64 * kBatch); };
+  const int nrows = (y_end - (y_first + wave) + kWaves - 1) / kWaves;
+  const int nbt = (ABL != 3 && span > 0 && nrows > 0) ? nrows * nbr : 0;  // ABL 3: prologue + epilogue only
   // (row, batch in row) of the next batch to load / to contract: advanced incrementally -- `t / nbr` is an
   // integer division by a run-time value, ~20 instructions each on this target
-  int ld_y = row0, ld_bi = 0;
-  int pr_y = row0, pr_bi = 0;
+  int ld_y = y_first + wave, ld_bi = 0;
+  int pr_y = y_first + wave, pr_bi = 0;
   // `live` = false past the wave's last batch: the loads are still ISSUED (through zero-record descriptors).
   // s_waitcnt vmcnt(N) takes a compile-time N = the fewest VMEM operations any path can have issued after the
   // one being waited for; with the refill under `if (t + 1 < nbt)` that minimum was "none", so every chunk
@@ -387,13 +307,13 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
     const int y = ld_y, bi = ld_bi;
     if (++ld_bi == nbr) {
       ld_bi = 0;
-      ld_y += kRowStep;
+      ld_y += kWaves;
     }
     const size_t prow = ((size_t)b * p.H + y) * p.W;  // wave-uniform
     const __amdgpu_buffer_rsrc_t grs = row_rsrc(p.guide + prow, live);
     const __amdgpu_buffer_rsrc_t irs = row_rsrc((APPLY && CIN > 0) ? p.input + prow * CIN : p.guide, live);
     const __amdgpu_buffer_rsrc_t drs = row_rsrc(p.dout + prow * COUT, live);
-    const int xb = batch_x(bi);
+    const int xb = x_lo + bi * 64 * kBatch;
 #pragma unroll
     for (int cb = 0; cb < kBatch; ++cb) {
       // unconditional (clamped) loads: no exec-masked branch around VMEM keeps the compiler's
@@ -413,7 +333,7 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
   // loop unrolled over it).  Two ahead in the fused pass measured the same as one (118.5 vs 120 us all
   // three, 101 vs 101 us dgrid + dguide at 4K; profiles/r02/exp21): what tools variant 4 removes is the
   // exposed first load of every wave, not a too-short steady-state distance.
-  constexpr int kAhead = GEO1 ? 2 : 1;  // GEO1: batches are single chunks
+  constexpr int kAhead = 1;
   Batch ring[kAhead + 1];
   load_batch(ring[0], nbt > 0);  // issued first: the rest of the prologue runs under its latency
   if constexpr (kAhead > 1 && ABL != 1 && ABL != 4) load_batch(ring[1], nbt > 1);
@@ -428,7 +348,7 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
     sb = reinterpret_cast<const f32x4*>(grid_b + (size_t)gy1c * p.GW * p.GD * C)[st_src];
   };
   if constexpr (FUSED) {
-    if (nbt > 0) load_grid_rows(floor_to_int(mul_rn(row0 + 0.5f, p.scale_y) - 0.5f));
+    if (nbt > 0) load_grid_rows(floor_to_int(mul_rn(y_first + wave + 0.5f, p.scale_y) - 0.5f));
   }
   {  // zero the A slab once; afterwards every chunk restores the entries it wrote
     f32x4* az = reinterpret_cast<f32x4*>(at);
@@ -441,7 +361,7 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
   constexpr int kXW = 4;
   float dxc[kXW];
 #pragma unroll
-  for (int cb = 0; cb < kXW; ++cb) dxc[cb] = x_offset(x_lo + 64 * (GEO1 ? wave + kWaves * cb : cb) + lane);
+  for (int cb = 0; cb < kXW; ++cb) dxc[cb] = x_offset(x_lo + 64 * cb + lane);
   f32x4 dacc = {0.f, 0.f, 0.f, 0.f}, dacc2 = {0.f, 0.f, 0.f, 0.f};
   // y terms of the row being contracted (bilateral_slice_apply.cc:42,47,55-56), formed once per row
   int row_gy0 = 0;
@@ -454,9 +374,9 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
     const int y = pr_y, bi = pr_bi;
     if (++pr_bi == nbr) {
       pr_bi = 0;
-      pr_y += kRowStep;
+      pr_y += kWaves;
     }
-    const int xb = batch_x(bi);
+    const int xb = x_lo + bi * 64 * kBatch;
     if (bi == 0) {
       const float gyf = mul_rn(y + 0.5f, p.scale_y);
       row_gy0 = floor_to_int(gyf - 0.5f);
@@ -493,7 +413,7 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
       if (x0 < x_hi) {  // wave-uniform
         [[maybe_unused]] long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
         if constexpr (ABL == 6) ts0 = clock64();
-        const int ci = GEO1 ? bi : bi * kBatch + cb;  // index into the cached x offsets, wave-uniform
+        const int ci = bi * kBatch + cb;  // chunk in row, wave-uniform
         float dx;
         if (ci == 0) dx = dxc[0];
         else if (ci == 1) dx = dxc[1];
@@ -794,72 +714,7 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
     float sum = lds[e];
 #pragma unroll
     for (int w = 1; w < kWaves; ++w) sum += lds[w * kSlab + e];
-    if constexpr (FOLD2) {
-      // agent-scope store (global_store ... sc1): written through this XCD's L2, so that no cache write-back is needed
-      // before another XCD's workgroup reads the tile (an agent-scope release FENCE writes back the whole L2 -- with one
-      // per workgroup the first form of this experiment ran 610 us instead of 107, profiles/r05/bwd_steps.md)
-      __hip_atomic_store(dst + e, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      dst[e] = sum;
-    }
-  }
-  if constexpr (FOLD2) {
-    // ARRIVE at the grid columns this tile feeds: rows gy_base + r (r = 0 .. 2, the tile's three planes -- stage 2 reads
-    // all three of every row group whose base is within two rows below gy, whether its pixels reached them or not) x
-    // columns g (the corner-0 half; clamped: none for g = -1 ... the edge column takes it as corner 1's neighbour) and
-    // g + 1 (corner 1): column gx is fed by the workgroups blockIdx.x = gx and gx + 1 of every such row group, so it
-    // expects 2 x s2_groups_touching(gy) arrivals.  An arrival word is {epoch : 40, count : 24}; a word that carries
-    // another launch's epoch (or the allocator's leftovers) counts as zero, and the completing arrival leaves
-    // {epoch, 0}: a hipGraph replay (same kernel arguments, same epoch) finds its own words at zero.
-    // Order: every thread's write-through tile stores complete (the barrier's s_waitcnt vmcnt(0)) -> barrier -> the
-    // arrivals (relaxed agent-scope read-modify-writes at the L2 / memory side, one lane per column, in parallel) ->
-    // agent-scope LOADS of the other workgroups' tiles by the workgroup that completes a column.  No fence anywhere:
-    // an agent-scope release / acquire fence writes back / invalidates the whole L2.
-    __syncthreads();
-    unsigned* fold_mask = reinterpret_cast<unsigned*>(lds);  // the slabs are free now
-    if (wave == 0) {
-      bool last = false;
-      const int r = lane >> 1, gy = gy_base + r, gx = g + (lane & 1);
-      if (lane < 6 && gy < p.GH && gx >= 0 && gx < p.GW) {
-        const unsigned need = 2u * (unsigned)s2_groups_touching(gy, p.GH, p.rg, p.nyg, p.scale_y);
-        unsigned long long* word = p.arrivals + ((size_t)b * p.GH + gy) * p.GW + gx;
-        unsigned long long old = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), next;
-        unsigned cnt;
-        do {
-          cnt = ((old >> 24) == p.epoch ? (unsigned)(old & 0xffffffu) : 0u) + 1u;
-          next = (p.epoch << 24) | (cnt == need ? 0u : cnt);
-        } while (!__hip_atomic_compare_exchange_strong(word, &old, next, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT));
-        last = cnt == need;
-      }
-      const unsigned long long m = __ballot(last);
-      if (lane == 0) *fold_mask = (unsigned)m;
-    }
-    __syncthreads();
-    const unsigned todo = *fold_mask;  // workgroup-uniform
-    if (todo != 0u) {
-      __syncthreads();  // (everyone has read fold_mask before the sums reuse the LDS)
-      float* red = lds;  // [kS2Parts][8 * 16 + 1]
-      const int c = threadIdx.x & 15, z = (threadIdx.x >> 4) & 7, ph = threadIdx.x >> 7;  // 256 threads: parts ph, ph + 2
-      for (int q = 0; q < 6; ++q) {
-        if (!((todo >> q) & 1u)) continue;  // workgroup-uniform
-        const int gy = gy_base + (q >> 1), gx = g + (q & 1);
-#pragma unroll
-        for (int pp = 0; pp < kS2Parts; pp += 2) {
-          const int part = ph + pp;
-          red[part * (8 * 16 + 1) + z * 16 + c] =
-              z < p.GD ? s2_part_sum<true>(p.partial, b, gy, gx, z, c, part, p.GH, p.GW, p.rg, p.nyg, p.scale_y) : 0.0f;
-        }
-        __syncthreads();
-        if (ph == 0 && z < p.GD && c < C) {
-          float t = red[z * 16 + c];
-#pragma unroll
-          for (int qq = 1; qq < kS2Parts; ++qq) t += red[qq * (8 * 16 + 1) + z * 16 + c];
-          p.dgrid[((((size_t)b * p.GH + gy) * p.GW + gx) * p.GD + z) * C + c] = t;
-        }
-        __syncthreads();
-      }
-    }
+    dst[e] = sum;
   }
 }
 
@@ -869,6 +724,7 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
 // then the 4 partial sums are added in fixed order.  A wave reads 256-B runs (4 planes x 16 channels of one tile);
 // the result is deterministic.  (Round 2: one 256-thread workgroup per (column, plane), 16 parts: 5.6 us of device
 // time per call at 4K, profiles/r03/bwd_kernel_stats.csv.)
+constexpr int kS2Parts = 4;
 __global__ __launch_bounds__(512) void grid_grad_stage2(const float* __restrict__ partial,
                                                         float* __restrict__ dgrid, int GH, int GW,
                                                         int GD, int C, int rg, int nyg,
@@ -877,7 +733,29 @@ __global__ __launch_bounds__(512) void grid_grad_stage2(const float* __restrict_
   const int c = threadIdx.x & 15, z = (threadIdx.x >> 4) & 7, part = threadIdx.x >> 7;
   const int gx = blockIdx.x, gy = blockIdx.y;
   const long long b = blockIdx.z;
-  red[part][z * 16 + c] = z < GD ? s2_part_sum(partial, b, gy, gx, z, c, part, GH, GW, rg, nyg, scale_y) : 0.0f;
+  const int nint = GW + 1;
+  // Conservative window of row groups that can touch gy; exact membership is `rel`.
+  const int yg_lo = max(0, (int)floorf((gy - 2.0f) / scale_y) / rg - 1);
+  const int yg_hi = min(nyg, (int)ceilf((gy + 2.5f) / scale_y) / rg + 2);
+  float s = 0.0f;
+  if (z < GD) {
+    for (int yg = yg_lo + part; yg < yg_hi; yg += kS2Parts) {
+      const int rel = gy - gy_base_of(yg * rg, scale_y, GH);
+      if (rel < 0 || rel > 2) continue;
+      const size_t t0 = ((size_t)b * nyg + yg) * nint;
+      float v0 = partial[(t0 + gx + 1) * kTileFloats + (rel * 16 + z) * 16 + c];
+      float v1 = partial[(t0 + gx) * kTileFloats + (rel * 16 + 8 + z) * 16 + c];
+      // clamp-to-edge: interval g = -1's corner 0 and interval g = GW - 1's corner 1 land on the edge columns
+      float v2 = 0.0f, v3 = 0.0f;
+      if (gx == 0) v2 = partial[t0 * kTileFloats + (rel * 16 + z) * 16 + c];
+      if (gx == GW - 1) v3 = partial[(t0 + GW) * kTileFloats + (rel * 16 + 8 + z) * 16 + c];
+      s += v0;
+      s += v1;
+      if (gx == 0) s += v2;
+      if (gx == GW - 1) s += v3;
+    }
+  }
+  red[part][z * 16 + c] = s;
   __syncthreads();
   if (part == 0 && z < GD && c < C) {
     float t = red[0][z * 16 + c];
@@ -890,7 +768,6 @@ __global__ __launch_bounds__(512) void grid_grad_stage2(const float* __restrict_
 struct GGPlan {
   int rg, nyg;
   long long ntasks;
-  size_t arrivals_bytes;  // head of the workspace: one 8-byte arrival word per grid column (folded stage 2)
   size_t ws_bytes;
 };
 
@@ -937,8 +814,7 @@ bool gg_plan(int B, int H, int W, int GH, int GW, int GD, int C, long long slots
   pl->nyg = (H + rg - 1) / rg;
   pl->ntasks = cols * pl->nyg;
   if (pl->ntasks > 0x7fffffffLL || (long long)B * GH * GW * GD > 0x7fffffffLL || pl->nyg > 65535 || B > 65535 || GH > 65535) return false;
-  pl->arrivals_bytes = (((size_t)B * GH * GW * sizeof(unsigned long long)) + 255) & ~(size_t)255;
-  pl->ws_bytes = pl->arrivals_bytes + (size_t)pl->ntasks * kTileFloats * sizeof(float);
+  pl->ws_bytes = (size_t)pl->ntasks * kTileFloats * sizeof(float);
   return true;
 }
 
@@ -1007,17 +883,6 @@ long long resident_slots(Stage1Fn kfn, std::atomic<int>* cache) {
   return (long long)occ * rows::num_cus();  // CU count of the CURRENT device (cached per ordinal)
 }
 
-// Tag of one launch's arrival words (folded stage 2): 40 bits, never repeated within a process, started at a
-// per-process random point so that another process's (or an earlier run's) leftovers in recycled device memory do
-// not carry it either.
-unsigned long long next_epoch() {
-  static std::atomic<unsigned long long> ctr{[] {
-    std::random_device rd;
-    return ((unsigned long long)rd() << 20) ^ (unsigned long long)rd();
-  }()};
-  return ctr.fetch_add(1, std::memory_order_relaxed) & ((1ull << 40) - 1);
-}
-
 struct GGPtrs {
   const float *guide, *input, *dout, *grid;
   float *dgrid, *dguide, *dinput;
@@ -1025,32 +890,12 @@ struct GGPtrs {
 
 template <int CIN, int COUT, bool OFFSET, bool APPLY>
 hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int GD, void* ws, size_t ws_bytes,
-                     hipStream_t s, bool split, int ablate = 0, [[maybe_unused]] int opt = 0) {
+                     hipStream_t s, bool split, int ablate = 0) {
   constexpr int C = APPLY ? COUT * (CIN + (OFFSET ? 1 : 0)) : COUT;
   const bool wg = q.dguide != nullptr, wi = q.dinput != nullptr;
   Stage1Fn kfn = nullptr;
   std::atomic<int>* occ = nullptr;
   static std::atomic<int> occ_cache[8];  // per (split, dguide, dinput) of this shape
-  bool fold2 = (kProductOpt & kOptFold2) != 0;
-#ifdef HDRNET_TOOLS_BUILD
-  // round-5 experiments (tools variants 10, 12, 13: OPT = 1, 2, 3), the shapes the benchmarks run
-  if constexpr (C == 12 && ((APPLY && CIN == 3 && COUT == 3 && OFFSET) || (!APPLY && COUT == 12))) {
-    if (opt >= 1 && opt <= 3 && !split && ablate == 0) {
-      static std::atomic<int> occ_cache_opt[4][4];
-      constexpr bool CAN_WI = APPLY && CIN > 0;
-      if (wi && !CAN_WI) return hipErrorInvalidValue;
-#define GG_OPT(O)                                                                                           \
-  (wg && wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, true, CAN_WI, 0, O>               \
-            : wg ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, true, false, 0, O>           \
-                 : wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, false, CAN_WI, 0, O>    \
-                      : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, false, false, 0, O>)
-      kfn = opt == 1 ? GG_OPT(1) : opt == 2 ? GG_OPT(2) : GG_OPT(3);
-#undef GG_OPT
-      fold2 = (opt & kOptFold2) != 0;
-      occ = &occ_cache_opt[opt][(wg ? 2 : 0) + (wi ? 1 : 0)];
-    }
-  }
-#endif
 #ifdef HDRNET_TOOLS_BUILD
   if constexpr (APPLY && CIN == 3 && COUT == 3 && OFFSET) {  // ablations (tools variants 4 .. 8): timing only
     if (ablate >= 1 && ablate <= 6) {
@@ -1060,7 +905,6 @@ hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int G
             : wg ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, true, false, A> \
                  : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, false, false, A>)
       kfn = ablate == 1 ? GG_ABL(1) : ablate == 2 ? GG_ABL(2) : ablate == 3 ? GG_ABL(3) : ablate == 4 ? GG_ABL(4) : ablate == 5 ? GG_ABL(5) : GG_ABL(6);
-      fold2 = false;
 #undef GG_ABL
     }
   }
@@ -1071,10 +915,10 @@ hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int G
       constexpr bool CAN_WI = APPLY && CIN > 0;
       if (wi && !CAN_WI) return hipErrorInvalidValue;
 #define GG_PICK(SPL)                                                                                  \
-  (wg && wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, true, CAN_WI, 0, kProductOpt>            \
-            : wg ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, true, false, 0, kProductOpt>        \
-                 : wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, false, CAN_WI, 0, kProductOpt> \
-                      : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, false, false, 0, kProductOpt>)
+  (wg && wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, true, CAN_WI>                 \
+            : wg ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, true, false>             \
+                 : wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, false, CAN_WI>      \
+                      : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, false, false>)
 #ifdef HDRNET_TOOLS_BUILD  // the bf16-split contraction is an experiment: not in the product library
       kfn = split ? GG_PICK(true) : GG_PICK(false);
 #else
@@ -1085,27 +929,25 @@ hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int G
     } else {
       if (wg || wi) return hipErrorInvalidValue;  // fused VJPs read the coefficient image as float4
 #ifdef HDRNET_TOOLS_BUILD
-      kfn = split ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, true, false, false, 0, kProductOpt>
-                  : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, false, false, 0, kProductOpt>;
+      kfn = split ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, true>
+                  : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false>;
 #else
       if (split) return hipErrorNotSupported;
-      kfn = (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, false, false, 0, kProductOpt>;
+      kfn = (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false>;
 #endif
     }
   }
   GGPlan pl;
   if (!gg_plan(B, H, W, GH, GW, GD, C, resident_slots(kfn, occ), &pl) || pl.ws_bytes > ws_bytes)
     return hipErrorInvalidValue;
-  float* partial = reinterpret_cast<float*>(static_cast<char*>(ws) + pl.arrivals_bytes);
-  GGParams p{q.guide, q.input, q.dout, q.grid, q.dguide, q.dinput, partial, H, W, GH, GW, GD,
-             pl.rg, pl.nyg, pl.ntasks, (float)GW / W, (float)GH / H, g_gg_trace,
-             q.dgrid, static_cast<unsigned long long*>(ws), fold2 ? next_epoch() : 0ull};
+  GGParams p{q.guide, q.input, q.dout, q.grid, q.dguide, q.dinput, static_cast<float*>(ws), H, W, GH, GW, GD,
+             pl.rg, pl.nyg, pl.ntasks, (float)GW / W, (float)GH / H, g_gg_trace};
   const dim3 nblocks((unsigned)(GW + 1), (unsigned)pl.nyg, (unsigned)B);
   kfn<<<nblocks, kWaves * 64, 0, s>>>(p);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess || fold2) return e;
+  if (e != hipSuccess) return e;
   grid_grad_stage2<<<dim3((unsigned)GW, (unsigned)GH, (unsigned)B), 512, 0, s>>>(
-      partial, q.dgrid, GH, GW, GD, C, pl.rg, pl.nyg, (float)GH / H);
+      static_cast<const float*>(ws), q.dgrid, GH, GW, GD, C, pl.rg, pl.nyg, (float)GH / H);
   return hipGetLastError();
 }
 
@@ -1148,8 +990,7 @@ static hipError_t apply_gg(const ApplyGradArgs& a, bool fused, hipStream_t s) {
   if constexpr (CO * (CI + (OFF ? 1 : 0)) <= 16) {                                                \
     if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF)                                       \
       return gg_launch<CI, CO, OFF, true>(q, a.B, a.H, a.W, a.GH, a.GW, a.GD, a.workspace, a.workspace_bytes, s, \
-                                          split, (a.variant >= 4 && a.variant <= 9) ? a.variant - 3 : 0,  \
-                                          a.variant == 10 ? 1 : a.variant == 12 ? 2 : a.variant == 13 ? 3 : 0); \
+                                          split, (a.variant >= 4 && a.variant <= 9) ? a.variant - 3 : 0); \
   }
   HDRNET_APPLY_FAST_SHAPES(HDRNET_CASE)
 #undef HDRNET_CASE
@@ -1193,8 +1034,7 @@ static hipError_t slice_gg(const SliceGradArgs& a, bool fused, hipStream_t s) {
   const bool split = a.variant == 2;
 #define HDRNET_CASE(CC)                                                                            \
   if (a.C == CC)                                                                                   \
-  return gg_launch<0, CC, false, false>(q, a.B, a.H, a.W, a.GH, a.GW, a.GD, a.workspace, a.workspace_bytes, s, split, 0, \
-                                        a.variant == 10 ? 1 : a.variant == 12 ? 2 : a.variant == 13 ? 3 : 0)
+  return gg_launch<0, CC, false, false>(q, a.B, a.H, a.W, a.GH, a.GW, a.GD, a.workspace, a.workspace_bytes, s, split)
   HDRNET_CASE(1);
   HDRNET_CASE(2);
   HDRNET_CASE(4);

@@ -24,6 +24,8 @@ struct ApplyArgs {
   // H_total = 0: a whole frame (H_total = H, y0 = 0).
   int y0 = 0, H_total = 0;
   int frame_rows() const { return H_total > 0 ? H_total : H; }
+  // fused guide network: v_exp_f32 + v_rcp_f32 sigmoid (HDRNET_GUIDE_SIGMOID_FAST) instead of expf + IEEE divide
+  bool fast_sigmoid = false;
 };
 
 // Forward with wire-format conversion and / or the fused guide network (apply_fwd_io.hip).
@@ -42,6 +44,7 @@ struct ApplyIoArgs {
   float* guide_out;  // optional
   const float* guide_shifts = nullptr;  // non-null selects the curves guide: [n][Cin]
   const float* guide_slopes = nullptr;  //                                    [n][Cin]
+  bool fast_sigmoid = false;            // guide network: as ApplyArgs::fast_sigmoid
 };
 
 struct ApplyGradArgs {

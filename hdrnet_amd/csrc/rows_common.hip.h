@@ -344,6 +344,13 @@ struct GuideNN {
   const float* conv2;  // [n + 1]: mixing weights then bias
   float* guide_out;    // optional [B][H][W] copy of the guide (null: not written)
   int n;
+  // The sigmoid: false = tf.nn.sigmoid's form, expf + an IEEE divide (the reference's bits to ~1 ulp; what a
+  // backward pass wants: the guide's VJP is steep near bin centres, and a 1-ulp guide moves dinput by 3e-4 of its
+  // scale there); true = v_exp_f32 + v_rcp_f32 (<= 2 ulp of the guide, 1e-6 of the output's scale; 10 instead of
+  // ~24 instructions per pixel, worth 9-11 % of these VALU-bound kernels).  Chosen by the CALLER
+  // (HDRNET_GUIDE_SIGMOID_FAST in the flags of the ..._ex entry points) -- until round 5 it followed
+  // `guide_out == NULL`, an implicit numerics switch.
+  bool fast_sigmoid = false;
 };
 
 // Evaluated for a lane's 4 consecutive pixels at once (inf = [pixel][CIN] floats): one pass over the
@@ -382,12 +389,10 @@ __device__ __forceinline__ void guide_nn_quad(const GuideNN& gn, const float* in
     }
   }
   const float acc[kPxPerThread] = {acc2[0].x, acc2[0].y, acc2[1].x, acc2[1].y};
-  if (gn.guide_out) {  // wave-uniform.  The guide is handed back for a backward pass: tf.nn.sigmoid with an IEEE divide --
-    // the guide's VJP is steep near bin centres, and a 1-ulp guide moves dinput by 3e-4 of its scale there
+  if (!gn.fast_sigmoid) {  // wave-uniform: the reference's sigmoid (GuideNN::fast_sigmoid)
 #pragma unroll
     for (int q = 0; q < kPxPerThread; ++q) g[q] = 1.0f / (1.0f + expf(-acc[q]));
-  } else {  // inference: v_exp_f32 + v_rcp_f32 (<= 2 ulp of the guide, 1e-6 of the output's scale): 10 instead of ~24
-    // instructions per pixel, worth 9-11 % of these VALU-bound kernels
+  } else {
 #pragma unroll
     for (int q = 0; q < kPxPerThread; ++q)
       g[q] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * acc[q]));

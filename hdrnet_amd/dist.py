@@ -173,7 +173,14 @@ class GradBucket:
 
     def gather(self) -> None:
         """After a backward that ran on released gradients: copy them into the flat buffer (one multi-tensor launch),
-        zero the segments of parameters that received none, re-bind every ``.grad`` to its view."""
+        zero the segments of parameters that received none, re-bind every ``.grad`` to its view.
+
+        A parameter that received NO gradient in this backward (an unused branch) thus ends up with a zero gradient,
+        not ``None``: an Adam-type optimizer then still decays its moments and moves it by what is left of its momentum,
+        where ``torch.optim`` would skip a ``None`` gradient.  Every parameter of the three model graphs receives a
+        gradient in every step; ``self.no_grad_last`` lists the parameters that did not, for a caller that freezes
+        branches and wants to mask them."""
+        self.no_grad_last = [p for p in self.params if p.grad is None]
         dst, src = [], []
         for p, v in zip(self.params, self.views):
             if p.grad is None:

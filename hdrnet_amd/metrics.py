@@ -73,7 +73,11 @@ def l2_loss(target: torch.Tensor, prediction: torch.Tensor) -> torch.Tensor:
     """``tf.reduce_mean(tf.square(target - prediction))`` (hdrnet/metrics.py:8-11).  On the GPU in fp32 with no
     gradient wanted for the target: the two-pass HIP kernels; otherwise ``F.mse_loss``."""
     if (prediction.is_cuda and target.is_cuda and prediction.dtype == torch.float32 and target.dtype == torch.float32
-            and prediction.shape == target.shape and not target.requires_grad and prediction.numel() > 0):
+            and prediction.shape == target.shape and not target.requires_grad and prediction.numel() > 0
+            # the kernels read float4s: a contiguous but offset view (x.flatten()[1:]) takes the stock op instead of
+            # failing in the C-ABI's alignment check
+            and prediction.is_contiguous() and target.is_contiguous()
+            and prediction.data_ptr() % 16 == 0 and target.data_ptr() % 16 == 0):
         return _L2Loss.apply(prediction, target)
     return F.mse_loss(prediction, target)
 

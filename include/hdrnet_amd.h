@@ -128,20 +128,31 @@ int hdrnet_bilateral_slice_apply_rows_f32_ex(const float* grid, const float* gui
 /* Fused point-wise guide network + BilateralSliceApply forward (inference).
  * guide[b,y,x] = sigmoid(conv2[n] + sum_k conv2[k] * relu(conv1[k][Cin] + sum_j conv1[k][j] * input[b,y,x,j]))
  * is computed in registers and sliced immediately; it is written to `guide_out` [B][H][W] only if
- * that pointer is non-NULL.  With `guide_out` the sigmoid is expf + an IEEE divide (the copy feeds a
- * backward pass, which is sensitive to the guide's last bit); without it, v_exp_f32 + v_rcp_f32
- * (<= 2 ulp of the guide) -- the two calls' outputs agree to ~1e-6 of their scale, not bit for bit.  This is HDRNetPointwiseNNGuide._guide (hdrnet/models.py:203-210) with
+ * that pointer is non-NULL.  The sigmoid is tf.nn.sigmoid's form, expf + an IEEE divide, unless the caller
+ * asks for the fast one with HDRNET_GUIDE_SIGMOID_FAST in the `flags` of the ..._ex twin: v_exp_f32 +
+ * v_rcp_f32, <= 2 ulp of the guide and ~1e-6 of the output's scale away, 9-11 % faster (these kernels are
+ * instruction-bound).  A forward whose guide feeds a backward pass should keep the default: the guide's
+ * VJP is steep near bin centres.  (Until round 5 the choice followed `guide_out == NULL`.)
+ * This is HDRNetPointwiseNNGuide._guide (hdrnet/models.py:203-210) with
  * batch-norm folded, in the parameter layout hdrnet/bin/freeze_graph.py:170-184 exports
  * (guide_conv1.bin = [n][Cin+1], guide_conv2.bin = [n+1]) -- the fusion the reference's GL
  * renderer performs (benchmark/assets/gpyrnn.frag:42-63, benchmark/src/renderer.cc:119-171).
  * Supported: (Cin, Cout) in {(3,3), (1,1)}, W % 4 == 0, 16-B aligned buffers; otherwise
  * HDRNET_INVALID_ARGUMENT (run the guide network and the plain entry point instead). */
+#define HDRNET_GUIDE_SIGMOID_FAST 0x10000u
 int hdrnet_bilateral_slice_apply_nnguide_f32(const float* grid, const float* input,
                                              const float* guide_conv1,
                                              const float* guide_conv2, float* out,
                                              float* guide_out, int B, int H, int W,
                                              int GH, int GW, int GD, int Cin, int Cout,
                                              int has_offset, int n_feats, void* stream);
+int hdrnet_bilateral_slice_apply_nnguide_f32_ex(const float* grid, const float* input,
+                                                const float* guide_conv1,
+                                                const float* guide_conv2, float* out,
+                                                float* guide_out, int B, int H, int W,
+                                                int GH, int GW, int GD, int Cin, int Cout,
+                                                int has_offset, int n_feats, unsigned flags,
+                                                void* stream);
 
 /* The standard model's one-pass inference: HDRNetCurves._guide (hdrnet/models.py:145-190) evaluated
  * in registers, then BilateralSliceApply, with the wire-format conversions of
@@ -180,6 +191,14 @@ int hdrnet_bilateral_slice_apply_upadd_f32(const float* grid, const float* guide
                                            int GW, int GD, int Cin, int Cout, int has_offset,
                                            const float* guide_conv1, const float* guide_conv2,
                                            int n_feats, void* stream);
+/* ... with `flags`: HDRNET_GUIDE_SIGMOID_FAST (see hdrnet_bilateral_slice_apply_nnguide_f32) or 0. */
+int hdrnet_bilateral_slice_apply_upadd_f32_ex(const float* grid, const float* guide,
+                                              const float* input, const float* coarse, int Hc,
+                                              int Wc, float* out, int B, int H, int W, int GH,
+                                              int GW, int GD, int Cin, int Cout, int has_offset,
+                                              const float* guide_conv1,
+                                              const float* guide_conv2, int n_feats,
+                                              unsigned flags, void* stream);
 int hdrnet_resize_bilinear_f32(const float* in, float* out, int B, int Hin, int Win, int Hout,
                                int Wout, int C, void* stream);
 
@@ -242,6 +261,14 @@ int hdrnet_bilateral_slice_apply_io(const float* grid, const float* guide, const
                                     float input_white_level, int output_dtype,
                                     const float* guide_conv1, const float* guide_conv2,
                                     int n_feats, float* guide_out, void* stream);
+/* ... with `flags`: HDRNET_GUIDE_SIGMOID_FAST (guide network only; see ..._nnguide_f32) or 0. */
+int hdrnet_bilateral_slice_apply_io_ex(const float* grid, const float* guide, const void* input,
+                                       void* out, int B, int H, int W, int GH, int GW, int GD,
+                                       int Cin, int Cout, int has_offset, int input_dtype,
+                                       float input_white_level, int output_dtype,
+                                       const float* guide_conv1, const float* guide_conv2,
+                                       int n_feats, float* guide_out, unsigned flags,
+                                       void* stream);
 
 /* Scratch (bytes) the grad entry point wants for its deterministic two-stage
  * grid-gradient reduction (partial tiles; no atomics anywhere); 0 is a legal answer

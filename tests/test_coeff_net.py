@@ -257,10 +257,14 @@ def test_native_coefficients_under_hipgraph_and_determinism():
         want = m(low2, full)
         assert torch.equal(out, want)
         assert not torch.equal(out, eager)
-        # the graph holds the parameters of capture time; recapture() picks up a change
+        # the graph holds the parameters of capture time: a replay after a change RAISES (it used to
+        # serve the old folded weights silently), check_parameters=False keeps the old behaviour, recapture() picks it up
+        unchecked = GraphedInference(m, [low, full], check_parameters=False)
         m.coefficients.pred.conv.bias.add_(0.25)
         m.guide.b2.add_(0.5)
-        stale = g(low2, full).clone()
+        with pytest.raises(RuntimeError, match="recapture"):
+            g(low2, full)
+        stale = unchecked(low2, full).clone()
         assert torch.equal(stale, want)
         g.recapture()
         fresh = g(low2, full).clone()

@@ -1168,3 +1168,97 @@ def test_train_header_symbols_are_exported_and_bound():
     assert lib.hdrnet_resize_add_f32(None, None, None, 1, 4, 4, 8, 8, 3, None) == 1      # null tensors
     lib.hdrnet_resize_bilinear_grad_f32.argtypes = _lib.TRAIN_SIGNATURES["hdrnet_resize_bilinear_grad_f32"][1]
     assert lib.hdrnet_resize_bilinear_grad_f32(None, None, 1, 4, 4, 8, 8, 3, None) == 1
+
+
+# ---- parameter-state generation: caches of derived arrays vs the writers that bypass version counters ----
+def test_derived_array_caches_follow_flat_adam_cpu():
+    """optim.FlatAdam updates the flat parameter buffer behind the parameters' version counters (a raw pointer on the
+    GPU, the flat tensor on the CPU): the caches of derived arrays (guide network folded with batch norm, the curves
+    guide's exported layout) are keyed on those counters PLUS hdrnet_amd._state.generation(), which FlatAdam.step()
+    bumps -- eval -> train -> eval must see the new weights."""
+    from hdrnet_amd import optim
+    torch.manual_seed(3)
+    for guide, get in ((models._PointwiseNNGuide(16), lambda g: g.folded()),
+                       (models._CurvesGuide(), lambda g: g.exported())):
+        guide.eval()
+        before = [t.clone() for t in get(guide)]
+        assert all(a is b for a, b in zip(get(guide), get(guide)))  # cached
+        opt = optim.FlatAdam([p for p in guide.parameters() if p.requires_grad], lr=0.05)
+        versions = [p._version for p in opt.bucket.params]
+        opt.bucket.flat.fill_(1.0)
+        opt.step()
+        assert [p._version for p in opt.bucket.params] == versions  # the update really is invisible to the counters
+        after = get(guide)
+        assert any(not torch.equal(a, b) for a, b in zip(before, after)), "the cache served the old parameters"
+        fresh = guide.folded(detach=False) if isinstance(guide, models._PointwiseNNGuide) else guide.exported_differentiable()
+        for a, b in zip(after, fresh):
+            torch.testing.assert_close(a, b.detach(), rtol=0, atol=0)
+
+
+def test_flat_adam_state_dict_round_trip_and_detached_parameter_cpu():
+    from hdrnet_amd import optim
+    torch.manual_seed(5)
+    lin = torch.nn.Linear(7, 5)
+    opt = optim.FlatAdam(lin.parameters(), lr=0.01)
+    for _ in range(3):
+        opt.bucket.flat.copy_(torch.randn_like(opt.bucket.flat))
+        opt.step()
+    state = opt.state_dict()
+    params = opt.flat.clone()
+    g = torch.randn_like(opt.bucket.flat)
+    opt.bucket.flat.copy_(g)
+    opt.step()
+    want = opt.flat.clone()
+    lin2 = torch.nn.Linear(7, 5)
+    opt2 = optim.FlatAdam(lin2.parameters(), lr=0.5)
+    opt2.flat.copy_(params)
+    opt2.load_state_dict(state)
+    opt2.bucket.flat.copy_(g)
+    opt2.step()
+    torch.testing.assert_close(opt2.flat, want, rtol=0, atol=0)
+    with pytest.raises(ValueError):
+        optim.FlatAdam(torch.nn.Linear(3, 3).parameters()).load_state_dict(state)
+    lin2.weight.data = lin2.weight.data.clone()  # what module.to(...) does: the parameter leaves the flat buffer
+    with pytest.raises(RuntimeError, match="flat buffer"):
+        opt2.step()
+
+
+@pytest.mark.gpu
+def test_eval_train_eval_sees_the_trained_weights_and_stale_graph_raises():
+    """ADVICE r04 (high) + VERDICT r04 item 6: an eval forward fills the derived-array caches (native coefficient
+    network weights, folded guide); FlatAdam steps and GraphedTrainStep replays then change parameters and batch-norm
+    statistics without touching a version counter.  The next eval forward must use the NEW state (compared with the
+    torch-op composition, native = False), and a GraphedInference captured before the training must refuse to replay."""
+    from hdrnet_amd import metrics, optim
+    from hdrnet_amd.runtime import GraphedInference, GraphedTrainStep
+    dev = torch.device("cuda:0")
+    torch.manual_seed(8)
+    m = models.HDRNetPointwiseNNGuide(dict(batch_norm=True)).to(dev)
+    low = torch.rand(2, 256, 256, 3, device=dev)
+    full = torch.rand(2, 96, 128, 3, device=dev)
+    target = torch.rand(2, 96, 128, 3, device=dev)
+    m.eval()
+    with torch.no_grad():
+        out0 = m(low, full).clone()
+    gi = GraphedInference(m, [low, full])
+    torch.testing.assert_close(gi(low, full), out0, rtol=1e-6, atol=1e-6)
+    m.train()
+    opt = optim.FlatAdam([p for p in m.parameters() if p.requires_grad], lr=1e-2, epsilon_hat=True)
+    step = GraphedTrainStep(m, lambda out, tgt: metrics.l2_loss(tgt, out), opt, [low, full], [target])
+    for _ in range(4):
+        step([low, full], [target])
+    m.eval()
+    with torch.no_grad():
+        out1 = m(low, full).clone()
+        m.coefficients.native = False
+        m.fuse_guide = False
+        try:
+            ref = m(low, full).clone()
+        finally:
+            del m.coefficients.native, m.fuse_guide  # back to the class defaults
+    assert (out1 - out0).abs().max() > 1e-3, "training did not move the output: the test would prove nothing"
+    torch.testing.assert_close(out1, ref, rtol=1e-4, atol=1e-4)
+    with pytest.raises(RuntimeError, match="recapture"):
+        gi(low, full)
+    gi.recapture()
+    torch.testing.assert_close(gi(low, full), out1, rtol=1e-6, atol=1e-6)

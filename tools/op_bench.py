@@ -97,21 +97,23 @@ def main():
     conv1 = (torch.randn((16, Cin + 1), device=dev, generator=gen) * 0.8).contiguous()
     conv2 = (torch.randn((17,), device=dev, generator=gen) * 0.5).contiguous()
 
-    def apply_fwd_nnguide(k):
+    FAST = _lib.GUIDE_SIGMOID_FAST  # the inference lines: the models' explicit choice (HDRNET_GUIDE_SIGMOID_FAST)
+
+    def apply_fwd_nnguide(k, flags=FAST):
         s = S[k % nsets]
-        chk(lib.hdrnet_bilateral_slice_apply_nnguide_f32(
+        chk(lib.hdrnet_bilateral_slice_apply_nnguide_f32_ex(
             s["grid"].data_ptr(), s["inp"].data_ptr(), conv1.data_ptr(), conv2.data_ptr(), s["out"].data_ptr(),
-            None, B, H, W, GH, GW, GD, Cin, Cout, 1, 16, stream))
+            None, B, H, W, GH, GW, GD, Cin, Cout, 1, 16, flags, stream))
 
     u8 = [dict(inp=torch.randint(0, 256, (B, H, W, 3), device=dev, dtype=torch.uint8),
                out=torch.empty((B, H, W, 3), device=dev, dtype=torch.uint8)) for _ in range(nsets)]
 
     def apply_io_u8(k, nn=True):
         s, t = S[k % nsets], u8[k % nsets]
-        chk(lib.hdrnet_bilateral_slice_apply_io(
+        chk(lib.hdrnet_bilateral_slice_apply_io_ex(
             s["grid"].data_ptr(), None if nn else s["guide"].data_ptr(), t["inp"].data_ptr(), t["out"].data_ptr(),
             B, H, W, GH, GW, GD, 3, 3, 1, 1, 255.0, 1, conv1.data_ptr() if nn else None,
-            conv2.data_ptr() if nn else None, 16 if nn else 0, None, stream))
+            conv2.data_ptr() if nn else None, 16 if nn else 0, None, FAST if nn else 0, stream))
 
     ccm = torch.cat([torch.eye(3, device=dev), torch.zeros((3, 1), device=dev)], 1) + 0.1 * torch.randn((3, 4), device=dev, generator=gen)
     shifts = torch.linspace(0, 1, 17, device=dev)[:-1, None].repeat(1, 3).contiguous()
@@ -130,10 +132,11 @@ def main():
 
     def apply_upadd(k, nn=True):
         s = S[k % nsets]
-        chk(lib.hdrnet_bilateral_slice_apply_upadd_f32(
+        chk(lib.hdrnet_bilateral_slice_apply_upadd_f32_ex(
             s["grid"].data_ptr(), None if nn else s["guide"].data_ptr(), s["inp"].data_ptr(),
             coarse[k % nsets].data_ptr(), H // 2, W // 2, s["out"].data_ptr(), B, H, W, GH, GW, GD, 3, 3, 1,
-            conv1.data_ptr() if nn else None, conv2.data_ptr() if nn else None, 16 if nn else 0, stream))
+            conv1.data_ptr() if nn else None, conv2.data_ptr() if nn else None, 16 if nn else 0, FAST if nn else 0,
+            stream))
 
     def resize_half(k):
         chk(lib.hdrnet_resize_bilinear_f32(S[k % nsets]["inp"].data_ptr(), half[k % nsets].data_ptr(),

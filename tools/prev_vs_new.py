@@ -108,6 +108,12 @@ def main():
         if case == "nn":  # guide network fused into the forward
             def fn(k):
                 s = S[k % nsets]
+                # (a build with the ..._ex twin chooses its sigmoid by flag; older builds: fast when guide_out is NULL)
+                if hasattr(lib, "hdrnet_bilateral_slice_apply_nnguide_f32_ex"):
+                    chk(lib.hdrnet_bilateral_slice_apply_nnguide_f32_ex(
+                        s["grid"].data_ptr(), s["inp"].data_ptr(), conv1.data_ptr(), conv2.data_ptr(), s["out"].data_ptr(),
+                        None, B, H, W, GH, GW, GD, Cin, Cout, 1, 16, _lib.GUIDE_SIGMOID_FAST, stream))
+                    return
                 chk(lib.hdrnet_bilateral_slice_apply_nnguide_f32(
                     s["grid"].data_ptr(), s["inp"].data_ptr(), conv1.data_ptr(), conv2.data_ptr(), s["out"].data_ptr(),
                     None, B, H, W, GH, GW, GD, Cin, Cout, 1, 16, stream))
@@ -117,6 +123,12 @@ def main():
 
             def fn(k):
                 s, t = S[k % nsets], u8[k % nsets]
+                if hasattr(lib, "hdrnet_bilateral_slice_apply_io_ex"):
+                    chk(lib.hdrnet_bilateral_slice_apply_io_ex(
+                        s["grid"].data_ptr(), None if nn else s["guide"].data_ptr(), t["inp"].data_ptr(), t["out"].data_ptr(),
+                        B, H, W, GH, GW, GD, 3, 3, 1, 1, 255.0, 1, conv1.data_ptr() if nn else None,
+                        conv2.data_ptr() if nn else None, 16 if nn else 0, None, _lib.GUIDE_SIGMOID_FAST if nn else 0, stream))
+                    return
                 chk(lib.hdrnet_bilateral_slice_apply_io(
                     s["grid"].data_ptr(), None if nn else s["guide"].data_ptr(), t["inp"].data_ptr(), t["out"].data_ptr(),
                     B, H, W, GH, GW, GD, 3, 3, 1, 1, 255.0, 1, conv1.data_ptr() if nn else None,
