@@ -123,6 +123,7 @@ _tools_lib: Optional[ctypes.CDLL] = None
 TOOLS_SIGNATURES = {
     "hdrnet_tools_set_trace": (None, [_VP]),
     "hdrnet_tools_set_knob": (None, [ctypes.c_int, ctypes.c_int]),
+    "hdrnet_tools_pyramid_onepass_f32": (_I, [_VP] * 4 + [_I, _FP] + [_I] * 7 + [_U, _VP]),
 }
 
 

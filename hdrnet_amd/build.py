@@ -50,6 +50,7 @@ SOURCES = [
 ]
 TOOLS_ONLY_SOURCES = [
     ("apply_fwd_variants.hip", ["-fno-slp-vectorize"]),
+    ("pyramid_onepass.hip", ["-fno-slp-vectorize"]),
 ]
 
 

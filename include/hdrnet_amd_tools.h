@@ -55,6 +55,16 @@ void hdrnet_tools_set_trace(void* device_buf);
  *      instructions (apply_fwd_io.hip; rejected on time, kept for the record) */
 void hdrnet_tools_set_knob(int idx, int value);
 
+/* EXPERIMENT (round 5, csrc/pyramid_onepass.hip): the multi-scale output of HDRNetGaussianPyrNN
+ * (hdrnet/models.py:277-289) in ONE pass over the full-resolution frame -- a workgroup owns 4 rows of a `seg`-pixel
+ * row segment and re-evaluates the coarse pixels they tap.  grids / inputs / conv1 / conv2 [0] = full resolution,
+ * [1] = half, [2] = quarter (inputs as hdrnet_resize_bilinear_f32 makes them; H % 4 == 0, W % 16 == 0).  Timed against
+ * the product's per-level chain by tools/pyramid_onepass_bench.py (profiles/r05/pyramid_onepass.md). */
+int hdrnet_tools_pyramid_onepass_f32(const float* const grids[3], const float* const inputs[3],
+                                     const float* const conv1[3], const float* const conv2[3], int n_feats,
+                                     float* out, int B, int H, int W, int GH, int GW, int GD, int seg,
+                                     unsigned flags, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
