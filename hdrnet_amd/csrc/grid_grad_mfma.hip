@@ -221,7 +221,8 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
   // chunk ahead brings the pass from 3 to 4 waves / SIMD and 115 -> 110 us at 4K.
   constexpr int kBatch = (!APPLY && COUT >= 12) ? 1 : 2;
   constexpr int kLoadAux = FUSED ? rows::kAuxNt : 0;  // fused pass is an HBM stream: nontemporal pixel loads
-  constexpr int kImg = FUSED ? 2 * 10 * C : 0;  // [x corner][plane 0 .. GD + 1 (GD <= 8)][c]
+  // [A, D = x difference, dzA = z difference of A, dzD][plane 0 .. GD + 1 (GD <= 8)][c]  (round 5: + the two z differences)
+  constexpr int kImg = FUSED ? 4 * 10 * C : 0;
   constexpr int kSlab = (16 + C) * kTStride + kImg;  // floats per wave: A^T [16][68], V^T [C][68], image
   static_assert(kSlab >= kTileFloats, "the final reduction reuses the slabs");
   __shared__ __attribute__((aligned(16))) float lds[kWaves * kSlab];
@@ -358,7 +359,7 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
   }
   // x offsets depend on (chunk-in-row, lane) only: cached for the first kXW chunks of a row (every
   // interval up to 256 px: 4K's 240, 1080p's 120), recomputed per chunk only beyond that
-  constexpr int kXW = 4;
+  constexpr int kXW = (WG && WI) ? 1 : 4;  // (all three gradients: registers; recomputed beyond)
   float dxc[kXW];
 #pragma unroll
   for (int cb = 0; cb < kXW; ++cb) dxc[cb] = x_offset(x_lo + 64 * cb + lane);
@@ -397,10 +398,26 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
           for (int e = 0; e < 4; ++e) o[e] = __shfl(v[e], partner);
           if (st_col == 1) v = v - o;
         }
+        // (round 5) ... and beside every plane its z DIFFERENCE to the plane above (the lane C4 above holds plane z + 1 of
+        // the same column; the topmost plane's neighbour is its own clamped copy: 0): dguide contracts this difference
+        // directly instead of subtracting two contracted taps (below).  Formed from the blended values: its rounding,
+        // ~1 ulp of a coefficient, is far below what the contraction of two full taps carried.
+        f32x4 dv;
+        {
+          const int up = min(lane + C4, 63);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dv[e] = __shfl(v[e], up) - v[e];
+          if (st_z == p.GD - 1) dv = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         if (lane < nst) {
           f32x4* d4 = reinterpret_cast<f32x4*>(img);
+          const int dzo = 2 * (p.GD + 2) * C4;  // the difference planes follow the two columns
           d4[st_dst] = v;
-          if (st_z == 0) d4[st_dst - C4] = v;
+          d4[st_dst + dzo] = dv;
+          if (st_z == 0) {
+            d4[st_dst - C4] = v;
+            d4[st_dst - C4 + dzo] = f32x4{0.f, 0.f, 0.f, 0.f};  // plane -1 is the clamped copy of plane 0
+          }
           if (st_z == p.GD - 1) d4[st_dst + C4] = v;
         }
         wave_lds_order();
@@ -416,10 +433,10 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
         const int ci = bi * kBatch + cb;  // chunk in row, wave-uniform
         float dx;
         if (ci == 0) dx = dxc[0];
-        else if (ci == 1) dx = dxc[1];
-        else if (ci == 2) dx = dxc[2];
-        else if (ci == 3) dx = dxc[3];
-        else dx = x_offset(x0 + lane);  // only intervals wider than 256 px
+        else if (kXW > 1 && ci == 1) dx = dxc[kXW > 1 ? 1 : 0];
+        else if (kXW > 2 && ci == 2) dx = dxc[kXW > 2 ? 2 : 0];
+        else if (kXW > 3 && ci == 3) dx = dxc[kXW > 3 ? 3 : 0];
+        else dx = x_offset(x0 + lane);  // only intervals wider than 64 kXW px
         // max(1 - |dx|, 0) == clamp(1 - |dx|) to [0, 1] (the difference never exceeds 1): one instruction
         const float w0 = __builtin_amdgcn_fmed3f(1.0f - fabsf(dx), 0.0f, 1.0f);
         const float w1 = __builtin_amdgcn_fmed3f(1.0f - fabsf(dx + 1.0f), 0.0f, 1.0f);
@@ -468,8 +485,26 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
           //  correctly rounded s > 1 except for q within 2 ulp above 1, which no guide produces -- dz is an exact
           //  difference in [-1, 1] or, for wild guides, +-2 and beyond -- while q * rsq(q) may round to 1 + ulp
           //  for q just BELOW 1, i.e. a guide within 1e-7 of a cell boundary: ~16 pixels of a random 4K frame)
-          const float dw0 = (qza > 1.0f) ? 0.0f : gd_f * (dza * (WG ? rza : __builtin_amdgcn_rcpf(sza)));
           const float dw1 = (qzb > 1.0f) ? 0.0f : gd_f * (dzb * (WG ? rzb : __builtin_amdgcn_rcpf(szb)));
+          // (round 5) dguide = dw0 <G0, U> + dw1 <G1, U> with dw0 ~ -GD, dw1 ~ +GD and dot products up to ~10: terms of
+          // ~80 cancel, and both the 1.5-ulp error of dw and the rounding of the two dot products survive the
+          // cancellation (the reference's own float32 evaluation carries the same noise, 1.5e-5 on the suite's data;
+          // this kernel's was 1.2-1.9 x that).  Evaluated instead as  dw1 <G1 - G0, U> + (dw0 + dw1) <G0, U>:
+          //   * G1 - G0 comes from the image's z-difference planes (differences of the raw grid values): the
+          //     cancellation happens per coefficient, before the contraction;
+          //   * dw0 + dw1 = GD (dza / sza + dzb / szb) without subtracting two numbers near GD: with s^2 = dz^2 + eps,
+          //     dz / s = sign(dz) (1 - e), e = eps / (s (s + |dz|)), so the sum is GD (e_a - e_b)  (dza <= 0 < dzb).
+          [[maybe_unused]] float dwsum = 0.0f;
+          if constexpr (WG) {
+            const float ea = __builtin_amdgcn_rcpf(sza * (sza + fabsf(dza)));
+            const float eb = __builtin_amdgcn_rcpf(szb * (szb + fabsf(dzb)));
+            dwsum = (gd_f * kSmoothEps) * (ea - eb);
+            if (__builtin_expect(__ballot(qza > 1.0f || qzb > 1.0f) != 0ull, 0)) {  // wave-uniform; wild guides only:
+              // a tap past its cell has derivative 0 (numerics.h:116-126), the sum is the direct one
+              const float dw0 = (qza > 1.0f) ? 0.0f : gd_f * (dza * rza);
+              if (qza > 1.0f || qzb > 1.0f) dwsum = dw0 + dw1;
+            }
+          }
           // Direct form (no 2 x C blended-coefficient accumulators: 4 scalars instead of 24 registers
           // live, which is what keeps this kernel at 4 waves per SIMD).  With U[c] = dout_i * [in; 1]_j
           // -- the SAME per-pixel products the dgrid contraction uses -- and G_v the coefficient
@@ -487,15 +522,20 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
             //   dguide   += dw_t <G_t, U>                 (bilateral_slice_apply.cc:140-206)
             //   dinput_j += wz_t sum_i dout_i G_t[i, j]   (:208-259)
             // 2 x (C + C + 3 CIN) FMAs per pixel instead of the four-corner form's 4 x (C + 3 CIN).
-            const float wzt[2] = {__builtin_amdgcn_fmed3f(1.0f - sza, 0.0f, 1.0f),   // max(1 - s, 0): s > 0
-                                  __builtin_amdgcn_fmed3f(1.0f - szb, 0.0f, 1.0f)};
-            const float dwt[2] = {dw0, dw1};
+            const float wz0 = __builtin_amdgcn_fmed3f(1.0f - sza, 0.0f, 1.0f);  // max(1 - s, 0): s > 0
+            const float wz1 = __builtin_amdgcn_fmed3f(1.0f - szb, 0.0f, 1.0f);
+            // "tap" 0 = the lower plane's vector G0, "tap" 1 = the z difference G1 - G0:
+            //   dguide = (dw0 + dw1) <G0, U> + dw1 <G1 - G0, U>;  dinput = (wz0 + wz1) T(G0) + wz1 T(G1 - G0)
+            const float wzt[2] = {wz0 + wz1, wz1};
+            const float dwt[2] = {dwsum, dw1};
             const f32x4 wx1 = {wb, wb, wb, wb};
             // One float4 of a tap at a time (row i of [COUT][CJ = 4] for APPLY, channels 4 q .. 4 q + 3 for a
             // slice), the next one's two reads issued under this one's math: a whole tap in registers (A and the
-            // difference: 2 C floats) costs the fourth wave per SIMD.  Tap 1's vectors follow tap 0's in the image.
+            // difference: 2 C floats) costs the fourth wave per SIMD.  The z-difference planes ("tap" 1) lie two
+            // columns behind the planes themselves.
             constexpr int NQ = C / 4, NS = 2 * NQ;
             const char* ibase = reinterpret_cast<const char*>(img) + a0;
+            const int dzb_off = 2 * colb - NQ * 16;  // vector st >= NQ: (st - NQ) * 16 + 2 * colb
             f32x4 nA = *reinterpret_cast<const f32x4*>(ibase), nD = *reinterpret_cast<const f32x4*>(ibase + colb);
             f32x2 acc = {0.0f, 0.0f}, t01 = {0.0f, 0.0f}, t23 = {0.0f, 0.0f};
 #pragma unroll
@@ -503,8 +543,9 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
               const int t = st / NQ, q = st % NQ;
               const f32x4 G = __builtin_elementwise_fma(wx1, nD, nA);
               if (st + 1 < NS) {
-                nA = *reinterpret_cast<const f32x4*>(ibase + (st + 1) * 16);
-                nD = *reinterpret_cast<const f32x4*>(ibase + colb + (st + 1) * 16);
+                const int o = (st + 1) * 16 + ((st + 1) >= NQ ? dzb_off : 0);
+                nA = *reinterpret_cast<const f32x4*>(ibase + o);
+                nD = *reinterpret_cast<const f32x4*>(ibase + colb + o);
               }
               if (q == 0) acc = t01 = t23 = f32x2{0.0f, 0.0f};
               if constexpr (WG) {

@@ -103,7 +103,7 @@ def test_hdrp_uint16_wire_format_vs_oracle(dev, ops, mt_port):
 def test_backward_vs_oracle_at_config_size(dev, ops, mt_port, name):
     """All three VJPs of a full frame against the oracle's gather-form gradients.  Tolerances
     (tests/conftest.py): rtol 1e-4; dgrid atol = 1e-5 x max|want| (cells are sums of ~30 000 terms of
-    random sign), dinput FLAT atol 1e-5, dguide FLAT atol 4e-5 (the reference's own f32 noise is 1.1e-5)."""
+    random sign), dinput FLAT atol 1e-5, dguide FLAT atol 2e-5 (the reference's own f32 noise is 1.1e-5)."""
     H, W, GH, GW, GD = CONFIGS[name]
     rng = np.random.default_rng(H + 3 * W)
     grid, guide, inp = frame(rng, H, W, GH, GW, GD)
@@ -241,11 +241,12 @@ def test_jax_twin_equals_op_at_reference_size(dev, ops):
 
 @pytest.mark.parametrize("name", ["1080p (config #2)", "4K (config #3 hot path)"])
 def test_dguide_noise_hip_vs_float64_against_the_reference_s_own(dev, ops, mt_port, name):
-    """tests/conftest.py holds dguide to a flat 4e-5 because the reference's OWN float32 arithmetic is
+    """tests/conftest.py holds dguide to a flat 2e-5 (4e-5 until round 5) because the reference's OWN float32 arithmetic is
     ~1e-5 away from the float64 value of its formulas -- but is the HIP path merely ordered differently, or noisier?
     Measured here instead of argued: max|HIP - f64| and max|oracle - f64| of dguide (and dinput) on a full frame of the
     suite's data, for both HIP paths that produce dguide (the fused all-gradients pass and the per-pixel VJP kernel).
-    Required: HIP's distance to the exact value <= 2 x the reference's own."""
+    Required: HIP's distance to the exact value <= 1.5 x the reference's own (round 4: 2 x, met at 1.91; round 5's
+    fused pass contracts the grid's z difference and sums the two tap derivatives without cancellation: 0.5-0.7 x)."""
     from oracle.f64_vjps import f64_vjps
     H, W, GH, GW, GD = CONFIGS[name]
     rng = np.random.default_rng(H + 3 * W)
@@ -264,8 +265,8 @@ def test_dguide_noise_hip_vs_float64_against_the_reference_s_own(dev, ops, mt_po
         hip_g, hip_i = np.abs(N(gu) - dg64).max(), np.abs(N(gi) - di64).max()
         print(f"{name} [{label}]: dguide |HIP - f64| = {hip_g:.3e}, |reference f32 - f64| = {ref_g:.3e}, ratio {hip_g / ref_g:.2f}; "
               f"dinput {hip_i:.3e} vs {ref_i:.3e}, ratio {hip_i / ref_i:.2f}; max|dguide| = {np.abs(dg64).max():.3g}")
-        assert hip_g <= 2.0 * ref_g, (label, hip_g, ref_g)
-        assert hip_i <= 2.0 * ref_i + 1e-7, (label, hip_i, ref_i)
+        assert hip_g <= 1.5 * ref_g, (label, hip_g, ref_g)
+        assert hip_i <= 1.5 * ref_i + 1e-7, (label, hip_i, ref_i)
 
 
 @pytest.mark.parametrize("name", list(CONFIGS))

@@ -381,7 +381,7 @@ def test_port_row_bands_concatenate_to_the_pinned_whole_frame(port, cuts):
 
 
 def test_reference_float32_noise_floor_of_the_per_pixel_vjps():
-    """Why tests/conftest.py holds dguide to a flat 4e-5 and dinput to the flat 1e-5 of SURVEY.md section
+    """Why tests/conftest.py holds dguide to a flat 2e-5 (twice the reference's own noise) and dinput to the flat 1e-5 of SURVEY.md section
     8c: the reference's own float32 evaluation (the oracle) against the float64 value of the same formulas
     (tools/dguide_noise_floor.py) on the suite's data.  dinput's noise is far below 1e-5; dguide's is
     already a good fraction of it on a quarter-megapixel frame (1.1e-5 at 0.5 MP) -- but below the bar the
