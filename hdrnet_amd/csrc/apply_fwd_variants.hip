@@ -602,16 +602,21 @@ hipError_t launch_variant_t(const ApplyArgs& a, const Plan& pl, hipStream_t s, c
 
 }  // namespace
 
+// Experiment knobs of the tools build (hdrnet_tools_set_knob; include/hdrnet_amd_tools.h).
+static int g_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+void tools_set_knob(int idx, int value) {
+  if (idx >= 0 && idx < 8) g_knob[idx] = value;
+}
+int tools_knob(int idx) { return idx >= 0 && idx < 8 ? g_knob[idx] : 0; }
+
 // hipErrorNotSupported: no such variant for this shape -- the caller launches the product kernel.
 hipError_t launch_apply_fwd_variant(const ApplyArgs& a, hipStream_t s, const char** name) {
   const bool aligned = (((uintptr_t)a.guide | (uintptr_t)a.input | (uintptr_t)a.out |
                          (uintptr_t)a.grid) & 15u) == 0;
   const Plan pl = make_row_plan(a.W, a.GW, aligned);
   if (!pl.vec4) return hipErrorNotSupported;
-  if (a.variant >= 20 && a.variant < 60) return launch_apply_fwd_seg_knob(a, a.variant - 20, s, name);
-  if (a.variant >= 60 && a.variant < 68) return launch_apply_fwd_seg_pix(a, a.variant - 60, s, name);
-  if (a.variant == 70 || a.variant == 71) return launch_apply_fwd_seg_dyn(a, a.variant == 71, s, name);
-  if (a.variant == 72) return launch_apply_fwd_seg_product_trace(a, s, name);
+  // (variants 20 .. 72 -- the product kernel's load / store / pixel-phase flavours, the ticketed tail, the timeline
+  //  trace -- were removed in round 5: profiles/r02 .. r04 hold their measurements, the history their code)
   if (a.variant == kVariantDirectStores) return launch_apply_fwd_rows_direct_stores(a, s, name, 0);
   if (a.variant == kVariantNtLoads) return launch_apply_fwd_rows_direct_stores(a, s, name, 1);
   if (a.Cin == 3 && a.Cout == 3 && a.has_offset) {

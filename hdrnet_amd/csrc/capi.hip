@@ -113,10 +113,9 @@ void hdrnet_enable_kernel_names(int on) { g_kernel_names.store(on ? 1 : 0, std::
 
 #ifdef HDRNET_TOOLS_BUILD
 // tools build only (include/hdrnet_amd_tools.h)
-void hdrnet_tools_set_knob(int idx, int value) { hdrnet_amd::apply_fwd_seg_set_knob(idx, value); }
+void hdrnet_tools_set_knob(int idx, int value) { hdrnet_amd::tools_set_knob(idx, value); }
 
 void hdrnet_tools_set_trace(void* device_buf) {
-  hdrnet_amd::apply_fwd_seg_set_trace(static_cast<long long*>(device_buf));
   hdrnet_amd::grid_grad_set_trace(static_cast<long long*>(device_buf));
   hdrnet_amd::coeff_net_set_trace(static_cast<long long*>(device_buf));
 }

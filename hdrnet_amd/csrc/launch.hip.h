@@ -154,14 +154,8 @@ bool apply_fwd_seg_upadd_supported(const ApplyArgs& a, const float* coarse, bool
 hipError_t launch_apply_fwd_seg_upadd(const ApplyArgs& a, const float* coarse, int Hc, int Wc, const float* conv1,
                                       const float* conv2, int n_feats, hipStream_t s, const char** name);
 #ifdef HDRNET_TOOLS_BUILD
-// knob: loads + 4 * stores (+ 20: timeline trace); include/hdrnet_amd_tools.h
-hipError_t launch_apply_fwd_seg_knob(const ApplyArgs& a, int knob, hipStream_t s, const char** name);
-hipError_t launch_apply_fwd_seg_pix(const ApplyArgs& a, int knob, hipStream_t s, const char** name);
-void apply_fwd_seg_set_trace(long long* device_buf);
-void apply_fwd_seg_set_knob(int idx, int value);
-int tools_knob(int idx);  // experiment knobs of the tools build (include/hdrnet_amd_tools.h)
-hipError_t launch_apply_fwd_seg_dyn(const ApplyArgs& a, bool trace, hipStream_t s, const char** name);
-hipError_t launch_apply_fwd_seg_product_trace(const ApplyArgs& a, hipStream_t s, const char** name);
+void tools_set_knob(int idx, int value);  // apply_fwd_variants.hip: experiment knobs (include/hdrnet_amd_tools.h)
+int tools_knob(int idx);
 void grid_grad_set_trace(long long* device_buf);
 void coeff_net_set_trace(long long* device_buf);
 #endif

@@ -10,12 +10,9 @@
  *       2        one wavefront per tile            3..6   persistent software-pipelined stream
  *       7        per-lane strided stores           8      round-1 kernel + nontemporal loads
  *       9..11    2 / 3 / 4 quads per thread        19     the round-1 product kernel (apply_fwd_rows)
- *       20..39   the product kernel's (apply_fwd_seg) load / store flavours: v - 20 = loads + 4 * stores,
- *                loads  {0 per-lane, 1 nontemporal lane-contiguous, 2 LDS-DMA, 3 LDS-DMA nontemporal}
- *                stores {0 global, 1 buffer, 2 buffer nt, 3 buffer sc1 (write-through), 4 buffer sc0 sc1}
- *                (31 = the product configuration)
- *       40..59   the same with a per-workgroup timeline trace (hdrnet_tools_set_trace)
- *       60..67   pixel-phase / DMA-form variants of the product kernel; 70 / 71 ticketed tail (knobs 1, 2), 72 product + trace
+ *       (20..72, through round 4: the product kernel's own load / store / pixel-phase flavours, the ticketed tail, the
+ *                per-workgroup timeline trace.  Removed in round 5 -- apply_fwd_seg.hip holds the product's
+ *                configurations only; measurements in profiles/r02 .. r04, code in the history.)
  *       101, 103..106  memory skeletons; 107 an empty kernel with the product's launch geometry,
  *                108 skeleton 106 on flat 1024-pixel tasks
  *   - kernel variants of the GRADIENT entry points (HDRNET_VARIANT(n) in the flags of
@@ -27,8 +24,8 @@
  *             given to hdrnet_tools_set_trace; tools/exp/r02_exp29.py)
  *       11    (dgrid == NULL) the round-1 per-pixel VJP kernel (apply_vjp_rows) instead of apply_vjp_seg
  *       HDRNET_GG_RG (environment): rows per workgroup task
- *   - hdrnet_tools_set_trace: device buffer that the trace variants fill with
- *     [workgroup][3] = {start, end in wall_clock64() ticks (100 MHz), XCC id}.
+ *   - hdrnet_tools_set_trace: device buffer for the phase trace of gradient variant 9 and the coefficient network's
+ *     per-workgroup timeline (tools/coeff_trace.py).
  *
  * Nothing in the product path links or loads this library.
  */
@@ -41,16 +38,10 @@
 extern "C" {
 #endif
 
-/* device_buf: at least 3 * (number of workgroups of the traced launch) int64; NULL disables. */
+/* device_buf: sized by the tracing tool (tools/coeff_trace.py, tools/exp/r02_exp29.py); NULL disables. */
 void hdrnet_tools_set_trace(void* device_buf);
 
-/* Experiment knobs read by some variants at launch (apply_fwd_seg.hip):
- *   0  extra dynamic LDS bytes per workgroup (fewer workgroups resident per CU), all apply_fwd_seg variants; -1 = WITHOUT
- *      the product's resident-wave cap (round 3's residency: 9 three-wave workgroups per CU at 4K)
- *   1  variants 70 / 71: D, the number of tasks at the end of the launch that are handed out by ticket
- *   2  variants 70 / 71: surplus ticketed workgroups (E = D + surplus, rounded up to a multiple of 256)
- *   7  apply_fwd_seg: the workgroups of the launch's first round sleep (index % 8) * value * 64 cycles before their pixel
- *      phase (de-synchronises the first round)
+/* Experiment knobs read at launch (knobs 0-2 and 7 drove the product kernel's removed flavours):
  *   5  hdrnet_bilateral_slice_apply_io, uint8 input + guide network: 1 = the hidden layer as bf16-split 4x4x4 matrix
  *      instructions (apply_fwd_io.hip; rejected on time, kept for the record) */
 void hdrnet_tools_set_knob(int idx, int value);

@@ -168,17 +168,13 @@ def test_apply_forward_random(dev, ops, port, shape):
 
 
 # The benchmark-only forward kernels DESIGN.md quotes timings for (tools build of the library:
-# apply_fwd_variants.hip, the apply_fwd_seg knobs) must compute the same op as the shipped one, or
+# apply_fwd_variants.hip; the product kernel's own load / store flavours, variants 20-72, were removed in round 5) must
+# compute the same op as the shipped one, or
 # those timings compare nothing.  They are reached through the TOOLS library's C-ABI only.
 @pytest.mark.parametrize("variant,expect", [(2, "apply_fwd_wave"), (3, "apply_fwd_stream"),
                                             (5, "apply_fwd_stream"), (7, "direct-stores"),
                                             (8, "nt-loads"), (9, "multiquad2"), (11, "multiquad4"),
-                                            (19, "apply_fwd_rows/vec4"),
-                                            (20, "seg/lane"), (21, "seg/ntcontig"),
-                                            (22, "seg/dma"), (23, "seg/dma-nt"),
-                                            (25, "seg/ntcontig+bufst"), (29, "seg/ntcontig+bufst-nt"),
-                                            (33, "seg/ntcontig+bufst-sc1"), (35, "seg/dma-nt+bufst-sc1"),
-                                            (39, "seg/dma-nt+bufst-sc0sc1")])
+                                            (19, "apply_fwd_rows/vec4")])
 @pytest.mark.parametrize("shape", [(2, 48, 2048, 16, 16, 8, 3, 3, True, -0.2, 1.2),
                                    (1, 37, 3076, 16, 16, 8, 3, 3, True, 0.0, 1.0),
                                    (1, 21, 1920, 16, 16, 8, 3, 3, True, -0.1, 1.1)])

@@ -5,9 +5,9 @@
                              [--trace 36,39] [--settle 80] [--out gpurun_out/ab.json]
 
 A variant may carry experiment knobs (include/hdrnet_amd_tools.h: hdrnet_tools_set_knob), written
-`variant@knob=value@knob=value`, e.g. `66@0=8192` (the product flavour with 8 KiB of extra LDS per workgroup) or
-`70@1=2000@2=1200` (ticketed tail of 2000 tasks, 1200 surplus workgroups); the knobs are set before every launch
-batch of that entry and cleared after it.  --trace takes the same syntax (71 = traced twin of 70, 72 of the product).
+`variant@knob=value@knob=value`; the knobs are set before every launch batch of that entry and cleared after it.
+(The product kernel's own flavours -- variants 20-72: loads / stores / pixel phase / ticketed tail / timeline trace,
+knobs 0-2 and 7 -- were removed in round 5; their records are profiles/r02 .. r04.)
 
 Uses the TOOLS build of the library (libhdrnet_amd_tools.so, include/hdrnet_amd_tools.h): variant 0
 is the product kernel, the others are documented in that header.  Every round times each variant

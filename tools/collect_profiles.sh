@@ -68,9 +68,9 @@ python tools/op_bench.py --tools --workload 1080p --json $O/ops_1080p.json > $O/
 python tools/op_bench.py --workload 1080p_b4 --json $O/ops_1080p_b4.json > $O/ops_1080p_b4.txt 2>&1
 python tools/op_bench.py --workload hdrp --json $O/ops_hdrp.json > $O/ops_hdrp.txt 2>&1
 python tools/op_bench.py --workload refbench --json $O/ops_refbench.json > $O/ops_refbench.txt 2>&1
-python tools/ab_bench.py --variants 0,65,66,70@1=2048@2=1024,106,108 --rounds 9 --steps 200 --trace 72,71@1=2048@2=1024 > $O/ab_variants_4k.txt 2>&1
-python tools/ab_bench.py --workload 1080p --variants 0,28,31,106,108 --rounds 7 --steps 400 --trace 72 > $O/ab_variants_1080p.txt 2>&1
-python tools/ab_bench.py --workload hdrp --variants 0,31,66,70@1=2048@2=1024,106,108 --rounds 5 --steps 100 > $O/ab_variants_hdrp.txt 2>&1
+python tools/ab_bench.py --variants 0,19,106,108 --rounds 9 --steps 200 > $O/ab_variants_4k.txt 2>&1
+python tools/ab_bench.py --workload 1080p --variants 0,19,106,108 --rounds 7 --steps 400 > $O/ab_variants_1080p.txt 2>&1
+python tools/ab_bench.py --workload hdrp --variants 0,19,106,108 --rounds 5 --steps 100 > $O/ab_variants_hdrp.txt 2>&1
 if [ -f $PREV ]; then
   python tools/prev_vs_new.py --prev $PREV --workload 4k --cases fwd,nn,u8,u8nn,curves,u8curves,all,gg,g,v,slice_fwd > $O/prev_vs_new_4k.txt 2>&1
   python tools/prev_vs_new.py --prev $PREV --workload 1080p --steps 150 --cases fwd,u8,u8nn,curves,u8curves,all > $O/prev_vs_new_1080p.txt 2>&1
