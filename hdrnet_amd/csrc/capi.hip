@@ -103,7 +103,7 @@ int variant(unsigned flags) { return (int)((flags >> 8) & 0xffu); }
 
 extern "C" {
 
-int hdrnet_version(void) { return 220; /* 0.2.2: + the coefficient network (inference, gradients), guide fold, l2 loss */ }
+int hdrnet_version(void) { return 230; /* 0.2.3: + the ..._ex guide-network entry points (HDRNET_GUIDE_SIGMOID_FAST) */ }
 
 const char* hdrnet_last_error(void) { return g_error; }
 

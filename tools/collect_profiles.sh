@@ -17,7 +17,7 @@ O=$R/gpurun_out/profiles
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 MODE=${1:-timing}
-PREV=$R/tools/exp/prev/libhdrnet_amd_r03.so
+PREV=$R/tools/exp/prev/libhdrnet_amd_r04.so
 if [ "$MODE" = pmc ]; then
 # 1. HBM traffic of the forward kernel: separate --pmc passes (never combined with trace domains), each
 #    with a calibration twin on the memory skeleton (known byte count, same access widths)
@@ -34,7 +34,14 @@ python $R/tools/make_traffic.py --fetch $O/pmc_fetch --write $O/pmc_write --cali
 CMD="python $R/tools/bwd_ab.py --rounds 1 --steps 5 --cases g,gg,all --variants 0"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA -d $O/b1 -o p --output-format csv -- $CMD > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $O/b2 -o p --output-format csv -- $CMD > /dev/null 2>&1
-python $R/tools/pmc_summary.py $O/b1 $O/b2 --match grid_grad_stage1 > $O/bwd_pmc.txt 2>&1
+# ... its HBM traffic (the backward's roofline fraction rested on algorithmic bytes alone): FETCH_SIZE / WRITE_SIZE
+# of stage 1 and stage 2, separate passes; and the LDS counters again with a smooth guide (the A-operand scatter's bank
+# conflicts are a property of a random guide: bank = 4 z + lane, z random)
+rocprofv3 --pmc FETCH_SIZE -d $O/b3 -o p --output-format csv -- $CMD > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/b4 -o p --output-format csv -- $CMD > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $O/b5 -o p --output-format csv -- $CMD --smooth > /dev/null 2>&1
+python $R/tools/pmc_summary.py $O/b1 $O/b2 $O/b3 $O/b4 --match grid_grad_stage > $O/bwd_pmc.txt 2>&1
+python $R/tools/pmc_summary.py $O/b5 --match grid_grad_stage1 > $O/bwd_pmc_smooth_guide.txt 2>&1
 # the fused-guide / wire-format forwards: every apply_fwd_io instantiation and the guide-network
 # instantiation of apply_fwd_seg that tools/op_bench.py launches at 4K
 CMD="python $R/tools/op_bench.py --workload 4k --steps 5"
@@ -42,7 +49,7 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CO
 rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD -d $O/g2 -o p --output-format csv -- $CMD > /dev/null 2>&1
 python $R/tools/pmc_summary.py $O/g1 $O/g2 --match apply_fwd_io_rows > $O/guide_wire_pmc.txt 2>&1
 python $R/tools/pmc_summary.py $O/g1 $O/g2 --match "false, true, false, 1" >> $O/guide_wire_pmc.txt 2>&1
-rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_sq2 $O/cal_fetch $O/cal_write $O/b1 $O/b2 $O/g1 $O/g2
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_sq2 $O/cal_fetch $O/cal_write $O/b1 $O/b2 $O/b3 $O/b4 $O/b5 $O/g1 $O/g2
 tail -40 $O/fwd_pmc.txt; tail -25 $O/traffic.log
 exit 0
 fi
@@ -61,6 +68,8 @@ python $R/bench.py --workload hdrp_u16 > $O/bench_hdrp_u16.json 2>> $O/bench.err
 python $R/bench.py --workload train_1080p_b4 --steps 100 --warmup 20 > $O/bench_train_1080p_b4.json 2>> $O/bench.err
 python $R/bench.py --workload train_1080p_b4 --batch-norm --steps 100 --warmup 20 > $O/bench_train_1080p_b4_batch_norm.json 2>> $O/bench.err
 for i in 1 2 3; do python $R/bench.py --no-cpu-baseline; done > $O/bench_repeat.txt 2>> $O/bench.err
+# the smooth-guide pair SURVEY.md section 8d asks for beside U[0,1) (+ the cache-resident rate), same protocol
+python $R/bench.py --extra --no-cpu-baseline --no-pipelined > $O/bench_extra_smooth_guide.json 2>> $O/bench.err
 # 3. every entry point, all sizes; A/B of the forward variants; this build vs the previous round's; end to end
 cd $R
 python tools/op_bench.py --tools --workload 4k --json $O/ops_4k.json > $O/ops_4k.txt 2>&1
@@ -77,6 +86,8 @@ if [ -f $PREV ]; then
 fi
 python tools/bwd_ab.py --rounds 5 --steps 50 --cases all,gg,g,sl,v --variants 0,2,3,4,5,6,7,8 > $O/bwd_ab_4k.txt 2>&1
 python tools/bwd_ab.py --workload 1080p --rounds 5 --steps 100 --cases all,gg,g,sl,v --variants 0,3 > $O/bwd_ab_1080p.txt 2>&1
+python tools/bwd_ab.py --smooth --rounds 5 --steps 50 --cases all,gg,g --variants 0 > $O/bwd_ab_4k_smooth_guide.txt 2>&1
+python tools/pyramid_onepass_bench.py --workload 4k --segs 512,768,1024 > $O/pyramid_onepass_4k.txt 2>&1
 python tools/e2e_bench.py > $O/e2e.txt 2>&1
 # the coefficient network's launches, per-workgroup timeline (tools build)
 python tools/coeff_trace.py > $O/coeff_trace.txt 2>&1
