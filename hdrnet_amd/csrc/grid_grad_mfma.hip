@@ -458,9 +458,10 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
         // v_rsq_f32 per tap -- s = q * rsq(q), 1.5 ulp instead of v_sqrt_f32's 1 -- instead of a v_sqrt_f32 and a
         // v_rcp_f32 (each a quarter-rate instruction); rsq(1.0f) is exact, so is s there.
         const float qza = fmaf(dza, dza, kSmoothEps), qzb = fmaf(dzb, dzb, kSmoothEps);
-        [[maybe_unused]] const float rza = WG ? __builtin_amdgcn_rsqf(qza) : 0.0f;
+        // (round 5: only the upper tap's reciprocal is still needed -- the lower tap's derivative enters dguide through
+        //  the cancellation-free sum below)
         [[maybe_unused]] const float rzb = WG ? __builtin_amdgcn_rsqf(qzb) : 0.0f;
-        const float sza = WG ? qza * rza : __builtin_amdgcn_sqrtf(qza);
+        const float sza = __builtin_amdgcn_sqrtf(qza);
         const float szb = WG ? qzb * rzb : __builtin_amdgcn_sqrtf(qzb);
         // U[i] = dout_i * [in; 1]: the rows of V the dgrid contraction stages AND the vectors the fused dguide
         // contracts with, as column pairs (CJ = 4 shapes; two packed multiplies per output channel)
@@ -496,12 +497,12 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
           //     dz / s = sign(dz) (1 - e), e = eps / (s (s + |dz|)), so the sum is GD (e_a - e_b)  (dza <= 0 < dzb).
           [[maybe_unused]] float dwsum = 0.0f;
           if constexpr (WG) {
-            const float ea = __builtin_amdgcn_rcpf(sza * (sza + fabsf(dza)));
-            const float eb = __builtin_amdgcn_rcpf(szb * (szb + fabsf(dzb)));
-            dwsum = (gd_f * kSmoothEps) * (ea - eb);
+            // e_a - e_b = eps (D_b - D_a) / (D_a D_b), D = s (s + |dz|): one reciprocal for both taps
+            const float Da = sza * (sza + fabsf(dza)), Db = szb * (szb + fabsf(dzb));
+            dwsum = (gd_f * kSmoothEps) * ((Db - Da) * __builtin_amdgcn_rcpf(Da * Db));
             if (__builtin_expect(__ballot(qza > 1.0f || qzb > 1.0f) != 0ull, 0)) {  // wave-uniform; wild guides only:
               // a tap past its cell has derivative 0 (numerics.h:116-126), the sum is the direct one
-              const float dw0 = (qza > 1.0f) ? 0.0f : gd_f * (dza * rza);
+              const float dw0 = (qza > 1.0f) ? 0.0f : gd_f * (dza * __builtin_amdgcn_rcpf(sza));
               if (qza > 1.0f || qzb > 1.0f) dwsum = dw0 + dw1;
             }
           }
