@@ -89,15 +89,23 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// SPLIT operands: an f32 value x travels as ONE dword {hi, lo} of two bf16 with
-// hi = bf16(x) (round to nearest even), lo = bf16(x - hi):  x = hi + lo to 2^-17 relative.
-__device__ __forceinline__ float split_pack(float x) {
-  const f32x2 xx = {x, x};
-  const unsigned tb = __builtin_bit_cast(unsigned, __builtin_convertvector(xx, bf16x2));
-  const float hi = __uint_as_float(tb << 16);
-  const f32x2 xr = {x, x - hi};
-  return __uint_as_float(__builtin_bit_cast(unsigned, __builtin_convertvector(xr, bf16x2)));
+// SPLIT operands (tools variant 2): an f32 value x travels as ONE dword {hi, lo} of two bf16.  Two values at once
+// (round 5; round 2's form took 4 instructions per value): hi = the upper 16 bits (truncation, so the remainder x - hi
+// is exact), lo = the remainder ROUNDED to bf16 (v_cvt_pk_bf16_f32, both values in one instruction): x = hi + lo to
+// 2^-17 relative, unbiased (a truncated lo -- 3 instructions per value, another 2-5 % faster -- biases every product by
+// ~-1e-5).  Per pair: 2 v_and, 1 v_pk_add (negated), 1 cvt, 2 v_perm.
+typedef float f32x2_sp __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_sp __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_sp split_pack2(f32x2_sp x) {
+  const unsigned u0 = __float_as_uint(x.x), u1 = __float_as_uint(x.y);
+  const f32x2_sp hi = {__uint_as_float(u0 & 0xffff0000u), __uint_as_float(u1 & 0xffff0000u)};
+  const f32x2_sp lo = x - hi;
+  const unsigned lp = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2_sp));  // {bf16(lo0), bf16(lo1)}
+  return f32x2_sp{__uint_as_float(__builtin_amdgcn_perm(lp, u0, 0x05040302u)),   // {u0[31:16], lp[15:0]}
+                  __uint_as_float(__builtin_amdgcn_perm(lp, u1, 0x07060302u))};  // {u1[31:16], lp[31:16]}
 }
+
+__device__ __forceinline__ float split_pack(float x) { return split_pack2(f32x2_sp{x, x}).x; }
 
 constexpr int kWaves = 4;      // waves per workgroup; they share ONE task and split its rows
 constexpr int kTileFloats = 3 * 16 * 16;  // partial tile: [rel 3][k 16][c 16]
@@ -188,13 +196,14 @@ __device__ __forceinline__ void buf_load(__amdgpu_buffer_rsrc_t rs, unsigned byt
 
 constexpr int kTStride = 68;  // floats per operand row: 64 pixels + 4 (16-B aligned, 4-bank skew)
 
-// SPLIT = true: the contraction runs on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16, 16x the
-// f32-input rate) with every f32 operand split into two bf16 terms.  A K-slot pair is one pixel's
-// {hi, lo}; with A2 = [a_hi, a_lo] and the V dword [v_hi, v_lo] re-arranged as B1 = [v_hi, v_hi],
-// B2 = [v_lo, 0], two MFMAs give a_hi v_hi + a_lo v_hi + a_hi v_lo -- every product term except
-// a_lo v_lo (<= 2^-16 relative), accumulated in f32.  Per 64-pixel chunk: 8 MFMA x ~17 cycles
-// instead of 16 x 32, for 4 extra VALU per operand value (16 values per pixel).  The LDS traffic
-// is unchanged: a record is still one dword per (row, pixel).
+// SPLIT = true (tools variant 2): the contraction runs on the bf16 matrix pipe (v_mfma_f32_16x16x32_bf16, 16x the
+// f32-input rate) with every f32 operand split into two bf16 terms (split_pack2 above).  A K-slot pair is one pixel's
+// {hi, lo}: [a_hi, a_lo] x [v_hi, v_lo] gives hi hi + lo lo, the same A against the dword ROTATED by 16 bits gives the
+// two cross terms -- all four products, f32 accumulate.  Per 64-pixel chunk 8 MFMAs of ~17 cycles instead of 16 of 32,
+// for 3.5 VALU per staged value + one rotate per B dword (72 per chunk; round 2's form: 96, and no gain).  Measured in
+// round 5 (profiles/r05/bwd_steps.md): dgrid -8 %, dgrid + dguide -4 %, all three -2 % at 4K -- and 6e-6 of dgrid's
+// scale away from the exact-f32 contraction, as much as the summation-order noise the parity bar (1e-5 x scale) is set
+// against.  Not the product for that reason; the product's contraction is bit-equal to an fmaf chain.
 //
 // WG / WI (FUSED BACKWARD): the same pass also produces the per-pixel VJPs -- dguide (WG) and dinput
 // (WI), bilateral_slice_apply.cc:140-259 -- from the pixel data it has loaded anyway (guide, input,
@@ -610,18 +619,24 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
         float* aP = at + __umul24((unsigned)zP, (unsigned)kTStride) + lane;
         float* aQ = at + __umul24((unsigned)zQ, (unsigned)kTStride) + lane;
         auto enc = [](float v) { return SPLIT ? split_pack(v) : v; };
-        aQ[0] = enc(w0 * wQ);
-        aQ[8 * kTStride] = enc(w1 * wQ);
-        aP[0] = enc(w0 * wP);
-        aP[8 * kTStride] = enc(w1 * wP);
+        auto enc2 = [](f32x2 v) { return SPLIT ? f32x2(split_pack2(v)) : v; };
+        {
+          const f32x2 wx = {w0, w1};
+          const f32x2 q2 = enc2(wx * f32x2{wQ, wQ}), p2 = enc2(wx * f32x2{wP, wP});
+          aQ[0] = q2.x;
+          aQ[8 * kTStride] = q2.y;
+          aP[0] = p2.x;
+          aP[8 * kTStride] = p2.y;
+        }
         // V^T[c][px]: dout x [in; 1] (slice: dout)
         if constexpr (UPAIRS) {
 #pragma unroll
           for (int i = 0; i < COUT; ++i) {
-            vt[(i * CJ + 0) * kTStride + lane] = enc(U01[i].x);
-            vt[(i * CJ + 1) * kTStride + lane] = enc(U01[i].y);
-            vt[(i * CJ + 2) * kTStride + lane] = enc(U23[i].x);
-            vt[(i * CJ + 3) * kTStride + lane] = enc(U23[i].y);
+            const f32x2 e01 = enc2(U01[i]), e23 = enc2(U23[i]);
+            vt[(i * CJ + 0) * kTStride + lane] = e01.x;
+            vt[(i * CJ + 1) * kTStride + lane] = e01.y;
+            vt[(i * CJ + 2) * kTStride + lane] = e23.x;
+            vt[(i * CJ + 3) * kTStride + lane] = e23.y;
           }
         } else if constexpr (APPLY) {
 #pragma unroll
@@ -661,15 +676,14 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
               const f32x4 a4 = {av[2 * q][0], av[2 * q][1], av[2 * q + 1][0], av[2 * q + 1][1]};
               const f32x4 b4 = {bv[2 * q][0], bv[2 * q][1], bv[2 * q + 1][0], bv[2 * q + 1][1]};
               const u32x4_t vb = __builtin_bit_cast(u32x4_t, b4);
-              u32x4_t b1, b2;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                b1[e] = __builtin_amdgcn_perm(vb[e], vb[e], 0x01000100u);  // [v_hi, v_hi]
-                b2[e] = vb[e] >> 16;                                        // [v_lo, 0]
-              }
               const bf16x8 a8 = __builtin_bit_cast(bf16x8, a4);
-              dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, b1), dacc, 0, 0, 0);
-              dacc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, b2), dacc2, 0, 0, 0);
+              // [a_hi, a_lo] x [v_hi, v_lo] = hi hi + lo lo, then x the ROTATED dword [v_lo, v_hi] = the two cross terms:
+              // all four products, one v_alignbit per B dword (round 2: three products, a perm and a shift per dword)
+              u32x4_t br;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) br[e] = __builtin_amdgcn_alignbit(vb[e], vb[e], 16);
+              dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, vb), dacc, 0, 0, 0);
+              dacc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, br), dacc2, 0, 0, 0);
             }
           } else {
 #pragma unroll
