@@ -34,29 +34,14 @@
 //     where segments are whole 128-B lines and 10 % worse than `nt` where they are not, so the
 //     flavour is chosen per launch (launch_apply_fwd_seg below; rows_common.hip.h; profiles/r02/).
 //   * 3-D launch grid (segment, row, batch): no integer division in the kernel.
-//   * ROUND 3 -- a shorter pixel phase (it, not the memory system, is what slows down in the power management's
-//     slow state -- at an unchanged REPORTED clock: profiles/r03/power/summary.txt; the kernel runs at the
-//     1400-W package cap, 1.74-1.9 GHz): the LEAN per-pixel code of seg_common.hip.h
-//     (v_fract x weight, float byte addresses, clamp-modifier tents), the pixel runs fetched as
-//     `buffer_load_dwordx4 ... lds` (one per-lane offset register for all four 1-KiB pieces, the run's end
-//     enforced by the descriptor instead of four clamps + 64-bit address adds), the segment's grid-column
-//     window from a host-side table in the kernel arguments, 32-bit row arithmetic.  40.4 -> 39.4 us interleaved
-//     on two boxes, the no-compute skeleton at 39.0 (profiles/r03/ab_variants_4k_*.txt).  The BLEND the product
-//     ships is the SCALAR one (kPixLeanScalar: 48 v_fma_f32 per pixel, 419 VALU + 113 SALU instructions per wave;
-//     the packed form, 24 v_pk_fma_f32, is 323 + 114): same time on steady boxes, bit-identical results, less time in
-//     the power manager's braked state on the boxes that fall into it (launch_apply_fwd_seg below).  The guide-network
-//     / wire-format kernels, which are VALU-bound, keep the packed blend.
-//   * ROUND 4 -- the launch shape (profiles/r04/fwd_launch_shape.md).  ONE thing changed: the resident waves per CU are
-//     CAPPED (resident_cap_lds below: 7 three-wave workgroups per CU instead of the 9 the LDS footprint allows) -- the
-//     same 38-39.5 us per 4K launch on steady boxes, and the end of the power manager's 42-46-us state on the boxes that
-//     had it (profiles/r04/power_state/).  Everything else was measured and left as it is: fewer resident
-//     workgroups shorten a workgroup's life (9 -> 6 per CU: 5.1 -> 4.0 us) and leave the launch where it was (39.4 vs
-//     39.7 us): it is throughput-, not latency-bound; flat 1024-px tasks that ignore rows (1080p: 2025 workgroups for
-//     2048 slots) do not beat row segments in a no-compute skeleton (11.5 vs 11.3 us); a ticketed tail (rounds 3-4, flat grid:
-//     the last ~2000 tasks drawn from counters so that the XCDs finish together) narrows the XCDs' finish from 3.2 to
-//     1.5 us but nets 0.3 us (0.8 %) at 4K and 1.1 us (1.8 %) at 4000x3000 -- not the product (removed in round 5).
-//     Per launch ~2.5-3 us lie outside the workgroups' span (38.8 us per launch, 35.9 us from the first workgroup's
-//     start to the last one's end): the gap between dependent kernels of one stream.
+//   * ROUND 3 -- the LEAN per-pixel code of seg_common.hip.h (v_fract x weight, float byte addresses, clamp-modifier
+//     tents), the pixel runs as `buffer_load_dwordx4 ... lds`, the segment's grid-column window from a host-side table.
+//     The plain forward ships the SCALAR blend (kPixLeanScalar: 419 VALU + 113 SALU per wave; bit-identical to the packed
+//     form's 323 + 114, same time on steady boxes, less time in the power manager's braked state); the instruction-bound
+//     guide-network / wire-format kernels keep the packed blend.
+//   * ROUND 4 -- the resident waves per CU are CAPPED (resident_cap_lds below).  Everything else about the launch shape
+//     was measured and left as it is (docs/EXPERIMENTS.md section 4.1, profiles/r04/fwd_launch_shape.md): per launch
+//     ~2.5-3 us lie outside the workgroups' span -- the gap between dependent kernels of one stream.
 //
 // Numerics: the coordinate and weight expressions of the reference in the reference's order
 // (products (x+.5)*scale_x, guide*GD explicitly rounded, see numerics.hip.h: mul_rn); wy is folded

@@ -699,7 +699,13 @@ def _grad_out(p: torch.Tensor) -> torch.Tensor:
     gradient bucket (``dist.GradBucket`` registers it) while ``.grad`` is released -- autograd ASSIGNS a gradient it is
     handed when ``.grad`` is None, adopting the alias, so the bucket's gather has nothing to copy for this parameter --
     otherwise (no bucket, ``.grad`` bound: accumulation, or the segment already handed out since the release: the parameter
-    is used twice and autograd must ADD the second gradient) a new tensor in the parameter's layout."""
+    is used twice and autograd must ADD the second gradient) a new tensor in the parameter's layout.
+
+    That autograd adopts (rather than copies) a gradient it is handed for a leaf whose ``.grad`` is None is PyTorch's current
+    behaviour, not a documented contract.  Nothing here depends on it for correctness: should a version copy instead,
+    ``.grad`` is a tensor of its own holding the same values, and ``GradBucket.gather()`` -- which compares data pointers,
+    not flags -- copies it into the segment as it does for every gradient autograd computed itself; the only loss is the
+    copy this alias saves (``tests/test_coeff_net.py`` asserts the adopted case so that a change is noticed)."""
     v = getattr(p, "_hdrnet_grad_view", None)
     if (v is not None and p.grad is None and not getattr(p, "_hdrnet_grad_claimed", True) and v.device == p.device
             and v.dtype == p.dtype and v.shape == p.shape and v.stride() == p.stride()):

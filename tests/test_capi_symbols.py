@@ -113,6 +113,27 @@ def test_new_entry_points_validate_without_gpu(libpath):
     rc = lib.hdrnet_bilateral_slice_apply_upadd_f32(None, None, None, None, 0, 2, None, 1, 4, 4, 2, 2, 2, 3, 3, 1,
                                                     None, None, 0, None)
     assert rc == 1 and b"coarse extents" in lib.hdrnet_last_error()
+    # the ..._ex twins of the guide-network entry points (round 5): the sigmoid is chosen by HDRNET_GUIDE_SIGMOID_FAST in
+    # `flags` -- any other bit is refused before anything else is looked at
+    U = ctypes.c_uint
+    lib.hdrnet_bilateral_slice_apply_upadd_f32_ex.argtypes = [P] * 4 + [I, I, P] + [I] * 9 + [P, P, I, U, P]
+    rc = lib.hdrnet_bilateral_slice_apply_upadd_f32_ex(None, None, None, None, 2, 2, None, 1, 4, 4, 2, 2, 2, 3, 3, 1,
+                                                       None, None, 0, 0x20000, None)
+    assert rc == 1 and b"HDRNET_GUIDE_SIGMOID_FAST" in lib.hdrnet_last_error()
+    rc = lib.hdrnet_bilateral_slice_apply_upadd_f32_ex(None, None, None, None, 2, 2, None, 1, 4, 4, 2, 2, 2, 3, 3, 1,
+                                                       None, None, 0, 0x10000, None)
+    assert rc == 1 and b"either a guide map or the guide network" in lib.hdrnet_last_error()  # flag accepted
+    lib.hdrnet_bilateral_slice_apply_nnguide_f32_ex.argtypes = [P] * 6 + [I] * 10 + [U, P]
+    rc = lib.hdrnet_bilateral_slice_apply_nnguide_f32_ex(None, None, None, None, None, None, 1, 4, 4, 2, 2, 2, 3, 3, 1, 16,
+                                                         0x1, None)
+    assert rc == 1 and b"unknown flags" in lib.hdrnet_last_error()
+    rc = lib.hdrnet_bilateral_slice_apply_nnguide_f32_ex(None, None, None, None, None, None, 1, 4, 4, 2, 2, 2, 3, 3, 1, 16,
+                                                         0x10000, None)
+    assert rc == 1 and b"null buffer" in lib.hdrnet_last_error()
+    lib.hdrnet_bilateral_slice_apply_io_ex.argtypes = [P] * 4 + [I] * 10 + [ctypes.c_float, I] + [P] * 2 + [I, P, U, P]
+    rc = lib.hdrnet_bilateral_slice_apply_io_ex(None, None, None, None, 1, 4, 4, 2, 2, 2, 3, 3, 1, 0, 1.0, 0, None, None, 0,
+                                                None, 0x30000, None)
+    assert rc == 1 and b"unknown flags" in lib.hdrnet_last_error()
 
 
 def test_curves_entry_points_validate_without_gpu(libpath):
