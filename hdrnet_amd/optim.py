@@ -10,6 +10,10 @@ every parameter's storage to a view of one flat fp32 buffer laid out exactly lik
 ``epsilon_hat=True`` places epsilon where ``tf.train.AdamOptimizer`` does (``lr sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) +
 eps)``, tensorflow/python/training/adam.py) -- the reference's optimizer to the letter; torch's form is the default.
 
+The device-side step count is a float32 (the kernel's ABI, include/hdrnet_amd_train.h): it stops incrementing at 2^24 =
+16.7 M steps.  By then both bias corrections ``1 - beta^t`` have been exactly 1.0 in float32 for millions of steps (beta2 =
+0.999: t > ~17 000), so the update is unaffected; only ``state_dict()["steps"]`` saturates.
+
 Construct it AFTER the module is on its device and in its memory format (``module.to(...)`` afterwards would re-allocate the
 parameters and detach them from the flat buffer).
 """
