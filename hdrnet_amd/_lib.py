@@ -17,6 +17,7 @@ HDRNET_RUNTIME_FAILURE = 2
 
 KERNEL_AUTO = 0
 GUIDE_SIGMOID_FAST = 0x10000  # HDRNET_GUIDE_SIGMOID_FAST (flags of the guide-network ..._ex entry points)
+GUIDE_RELU_PRESCALED = 0x20000  # HDRNET_GUIDE_RELU_PRESCALED: conv1 / conv2 are hdrnet_guide_nn_prescale_f32's arrays
 KERNEL_GENERIC = 1
 KERNEL_FAST = 2
 
@@ -52,6 +53,7 @@ SIGNATURES = {
     "hdrnet_l2_loss_workspace_bytes": (_SZ, [ctypes.c_longlong]),
     "hdrnet_l2_loss_f32": (_I, [_FP, _FP, ctypes.c_longlong, _FP, _VP, _SZ, _VP]),
     "hdrnet_l2_loss_grad_f32": (_I, [_FP, _FP, _FP, ctypes.c_longlong, _FP, _VP]),
+    "hdrnet_guide_nn_prescale_f32": (_I, [_FP, _FP, _I, _I, ctypes.c_float, _FP, _FP, _VP]),
     "hdrnet_guide_fold_batch_f32": (_I, [_FP, _FP, ctypes.c_longlong] + [_FP] * 5 + [ctypes.c_double, ctypes.c_double, _I, _I] + [_FP] * 5 + [_VP]),
     "hdrnet_guide_fold_batch_grad_f32": (_I, [_FP, _FP, ctypes.c_longlong] + [_FP] * 3 + [ctypes.c_double, _I, _I] + [_FP] * 6 + [_VP]),
     "hdrnet_coefficients_workspace_bytes": (_SZ, [_VP, _I]),

@@ -48,6 +48,7 @@ struct GuideNet {
   float* guide_out;    // optional
   int n;               // NN: features                curves: knots per channel
   bool fast_sigmoid;   // NN: GuideNN::fast_sigmoid (rows_common.hip.h)
+  bool prescaled;      // NN: GuideNN::prescaled
 };
 
 typedef __attribute__((address_space(4))) const float cfloat;  // wave-uniform parameters: s_load
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
             done = true;
           }
         }
-        if (!done) guide_nn_quad<CIN>(GuideNN{p.gn.conv1, p.gn.conv2, p.gn.guide_out, p.gn.n, p.gn.fast_sigmoid}, inf, gs);  // (writes nothing itself)
+        if (!done) guide_nn_quad<CIN>(GuideNN{p.gn.conv1, p.gn.conv2, p.gn.guide_out, p.gn.n, p.gn.fast_sigmoid, p.gn.prescaled}, inf, gs);  // (writes nothing itself)
       }
       else if constexpr (GUIDE == kGuideCurves)
         guide_curves_quad<CIN>(ctab, p.gn, inf, gs);
@@ -647,7 +648,7 @@ hipError_t launch_io(const ApplyIoArgs& a, const Plan&, hipStream_t s) {
   p.white = io_white_level(a.white_level);
   p.grid_image = a.GH * a.GW * a.GD * C;
   p.tab = make_seg_tab(a.W, g.pl.seg, g.pl.nseg, p.scale_x);
-  p.gn = GuideNet{a.guide_conv1, a.guide_conv2, a.guide_shifts, a.guide_slopes, a.guide_out, a.n_feats, a.fast_sigmoid};
+  p.gn = GuideNet{a.guide_conv1, a.guide_conv2, a.guide_shifts, a.guide_slopes, a.guide_out, a.n_feats, a.fast_sigmoid, a.guide_prescaled};
 #ifdef HDRNET_TOOLS_BUILD
   p.nn_mfma = tools_knob(5);
 #else

@@ -318,7 +318,7 @@ hipError_t launch_apply_fwd_nnguide(const ApplyArgs& a, const float* conv1, cons
     const hipError_t e = launch_apply_fwd_seg_nnguide(a, conv1, conv2, n_feats, guide_out, s, name);
     if (e != hipErrorNotSupported) return e;  // (a network too wide for its LDS copy falls through)
   }
-  const GuideNN gn{conv1, conv2, guide_out, n_feats, a.fast_sigmoid};
+  const GuideNN gn{conv1, conv2, guide_out, n_feats, a.fast_sigmoid, a.guide_prescaled};
   ApplyArgs t = a;
   t.guide = a.input;
   *name = "apply_fwd_rows/vec4+nnguide";
@@ -348,7 +348,7 @@ hipError_t launch_apply_fwd_upadd(const ApplyArgs& a, const float* coarse, int H
     if (e != hipErrorNotSupported) return e;
   }
   if (conv1) {
-    const GuideNN gn{conv1, conv2, nullptr, n_feats, a.fast_sigmoid};
+    const GuideNN gn{conv1, conv2, nullptr, n_feats, a.fast_sigmoid, a.guide_prescaled};
     ApplyArgs t = a;
     t.guide = a.input;  // alignment stand-in: no guide buffer is read
     *name = "apply_fwd_rows/vec4+nnguide+upadd";

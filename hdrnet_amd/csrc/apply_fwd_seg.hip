@@ -412,8 +412,10 @@ bool apply_fwd_seg_nnguide_supported(const ApplyArgs& a, const float* guide_out)
 
 hipError_t launch_apply_fwd_seg_nnguide(const ApplyArgs& a, const float* conv1, const float* conv2, int n_feats,
                                         float* guide_out, hipStream_t s, const char** name) {
-  const GuideNN gn{conv1, conv2, guide_out, n_feats, a.fast_sigmoid};
+  const GuideNN gn{conv1, conv2, guide_out, n_feats, a.fast_sigmoid, a.guide_prescaled};
   *name = "apply_fwd_seg/vec4+nnguide";
+  // (stores: nontemporal.  The write-through form the plain 4K forward uses was timed here in round 5, interleaved:
+  //  41.92 vs 41.74-41.99 us -- no difference on an instruction-bound kernel; profiles/r05/f2_prescale.md)
 #define HDRNET_CASE(CI, CO, OFF)                          \
   if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF) \
     return launch_seg_t<CI, CO, OFF, kProductDma, kStoresBufNt, true, false, kGuideNNPix>(a, s, gn)
@@ -439,7 +441,7 @@ hipError_t launch_apply_fwd_seg_upadd(const ApplyArgs& a, const float* coarse, i
   if (conv1) {
     *name = "apply_fwd_seg/vec4+nnguide+upadd";
     return launch_seg_t<3, 3, true, kProductDma, kStoresBufNt, true, true, kGuideNNPix>(
-        a, s, GuideNN{conv1, conv2, nullptr, n_feats, a.fast_sigmoid}, up);
+        a, s, GuideNN{conv1, conv2, nullptr, n_feats, a.fast_sigmoid, a.guide_prescaled}, up);
   }
   *name = "apply_fwd_seg/vec4+upadd";
   return launch_seg_t<3, 3, true, kProductDma, kStoresBufNt, false, true, kProductPix>(

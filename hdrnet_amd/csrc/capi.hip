@@ -78,10 +78,24 @@ int check_common(int B, int H, int W, int GH, int GW, int GD) {
 
 // flags: bits 0..7 kernel family (HDRNET_KERNEL_*), bits 8..15 variant inside the family
 // (0 = the library's default; used by benchmarks for A/B runs), rest must be zero.
-// flags of the guide-network entry points (..._nnguide_f32_ex, ..._upadd_f32_ex, ..._io_ex): only the sigmoid choice
+// flags of the guide-network entry points (..._nnguide_f32_ex, ..._upadd_f32_ex, ..._io_ex): the sigmoid choice and
+// whether conv1 / conv2 are the prescaled arrays of hdrnet_guide_nn_prescale_f32
 int check_guide_flags(unsigned flags) {
-  if ((flags & ~HDRNET_GUIDE_SIGMOID_FAST) != 0)
-    return fail(HDRNET_INVALID_ARGUMENT, "unknown flags 0x%x (guide-network entry points take HDRNET_GUIDE_SIGMOID_FAST)", flags);
+  if ((flags & ~(HDRNET_GUIDE_SIGMOID_FAST | HDRNET_GUIDE_RELU_PRESCALED)) != 0)
+    return fail(HDRNET_INVALID_ARGUMENT,
+                "unknown flags 0x%x (guide-network entry points take HDRNET_GUIDE_SIGMOID_FAST, HDRNET_GUIDE_RELU_PRESCALED)",
+                flags);
+  return HDRNET_OK;
+}
+
+// HDRNET_GUIDE_RELU_PRESCALED: a guide NETWORK of three input channels whose arrays are 16-B aligned ([n][4] rows, s_load_dwordx4)
+int check_guide_prescaled(unsigned flags, int Cin, const float* conv1, const float* conv2) {
+  if (!(flags & HDRNET_GUIDE_RELU_PRESCALED)) return HDRNET_OK;
+  if (!conv1 || !conv2 || Cin != 3)
+    return fail(HDRNET_INVALID_ARGUMENT, "HDRNET_GUIDE_RELU_PRESCALED needs a guide network with Cin = 3 (Cin=%d)", Cin);
+  if (((uintptr_t)conv1 | (uintptr_t)conv2) & 15u)
+    return fail(HDRNET_INVALID_ARGUMENT, "HDRNET_GUIDE_RELU_PRESCALED needs 16-B aligned guide_conv1 / guide_conv2 "
+                                         "(the arrays hdrnet_guide_nn_prescale_f32 wrote)");
   return HDRNET_OK;
 }
 
@@ -103,7 +117,7 @@ int variant(unsigned flags) { return (int)((flags >> 8) & 0xffu); }
 
 extern "C" {
 
-int hdrnet_version(void) { return 230; /* 0.2.3: + the ..._ex guide-network entry points (HDRNET_GUIDE_SIGMOID_FAST) */ }
+int hdrnet_version(void) { return 240; /* 0.2.4: + hdrnet_guide_nn_prescale_f32, HDRNET_GUIDE_RELU_PRESCALED */ }
 
 const char* hdrnet_last_error(void) { return g_error; }
 
@@ -224,9 +238,11 @@ int hdrnet_bilateral_slice_apply_nnguide_f32_ex(const float* grid, const float* 
   }
   if (!grid || !input || !out || !guide_conv1 || !guide_conv2)
     return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  if (int rc = check_guide_prescaled(flags, Cin, guide_conv1, guide_conv2)) return rc;
   ApplyArgs a{grid, nullptr, input, out, B, H, W, GH, GW, GD, Cin, Cout,
               Cin + (has_offset ? 1 : 0), has_offset != 0, 0};
   a.fast_sigmoid = (flags & HDRNET_GUIDE_SIGMOID_FAST) != 0;
+  a.guide_prescaled = (flags & HDRNET_GUIDE_RELU_PRESCALED) != 0;
   if (!apply_fwd_nnguide_supported(a, guide_out))
     return fail(HDRNET_INVALID_ARGUMENT,
                 "fused guide + slice-apply needs (Cin, Cout) in {(3,3), (1,1)}, W %% 4 == 0 and 16-B "
@@ -269,9 +285,11 @@ int hdrnet_bilateral_slice_apply_upadd_f32_ex(const float* grid, const float* gu
     return HDRNET_OK;
   }
   if (!grid || !input || !out || !coarse) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  if (int rc = check_guide_prescaled(flags, Cin, guide_conv1, guide_conv2)) return rc;
   ApplyArgs a{grid, guide, input, out, B, H, W, GH, GW, GD, Cin, Cout,
               Cin + (has_offset ? 1 : 0), has_offset != 0, 0};
   a.fast_sigmoid = (flags & HDRNET_GUIDE_SIGMOID_FAST) != 0;
+  a.guide_prescaled = (flags & HDRNET_GUIDE_RELU_PRESCALED) != 0;
   if (!apply_fwd_upadd_supported(a, coarse, guide_conv1 != nullptr))
     return fail(HDRNET_INVALID_ARGUMENT,
                 "slice-apply + up-add needs Cin = Cout = 3 with offset, W %% 4 == 0 and 16-B aligned "
@@ -409,6 +427,23 @@ int hdrnet_input_moments_f32(const float* input, long long npx, int Cin, float* 
   const int rc = check_launch(launch_input_moments(input, npx, Cin, sums, moments, workspace, s, &name),
                               "InputMoments");
   if (rc == HDRNET_OK) set_kernel(name);
+  return rc;
+}
+
+int hdrnet_guide_nn_prescale_f32(const float* guide_conv1, const float* guide_conv2, int n_feats, int Cin, float x_max,
+                                 float* conv1_out, float* conv2_out, void* stream) {
+  using namespace hdrnet_amd;
+  if (Cin != 3 || n_feats <= 0 || n_feats > 4096)
+    return fail(HDRNET_INVALID_ARGUMENT, "guide prescale needs Cin = 3 and 0 < n_feats <= 4096 (Cin=%d, n=%d)", Cin, n_feats);
+  if (!(x_max > 0.0f) || !(x_max < 1e30f))
+    return fail(HDRNET_INVALID_ARGUMENT, "guide prescale needs a finite positive x_max");
+  if (!guide_conv1 || !guide_conv2 || !conv1_out || !conv2_out) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  if (((uintptr_t)conv1_out | (uintptr_t)conv2_out) & 15u)
+    return fail(HDRNET_INVALID_ARGUMENT, "guide prescale needs 16-B aligned output arrays");
+  const int rc = check_launch(launch_guide_nn_prescale(guide_conv1, guide_conv2, n_feats, x_max, conv1_out, conv2_out,
+                                                       static_cast<hipStream_t>(stream)),
+                              "GuideNNPrescale");
+  if (rc == HDRNET_OK) set_kernel("guide_nn_prescale");
   return rc;
 }
 
@@ -597,7 +632,9 @@ int hdrnet_bilateral_slice_apply_io_ex(const float* grid, const float* guide, co
   ApplyIoArgs a{grid, guide, input, out, B, H, W, GH, GW, GD, Cin, Cout, has_offset != 0,
                 input_dtype, output_dtype, input_white_level, guide_conv1, guide_conv2, n_feats,
                 guide_out};
+  if (int rc = check_guide_prescaled(flags, guide ? 0 : Cin, guide ? nullptr : guide_conv1, guide ? nullptr : guide_conv2)) return rc;
   a.fast_sigmoid = (flags & HDRNET_GUIDE_SIGMOID_FAST) != 0;
+  a.guide_prescaled = (flags & HDRNET_GUIDE_RELU_PRESCALED) != 0;
   if (!apply_fwd_io_supported(a))
     return fail(HDRNET_INVALID_ARGUMENT,
                 "the wire-format forward supports Cin = Cout = 3 with offset, W %% 4 == 0, aligned "

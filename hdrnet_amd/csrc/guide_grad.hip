@@ -502,6 +502,32 @@ __global__ void guide_fold_batch_grad(const FoldArgs a, const float* __restrict_
   dw2[k] = dconv2[k];
 }
 
+// The PRESCALED form of a folded guide network (rows_common.hip.h: GuideNN::prescaled; Cin = 3): feature k's first-layer
+// row, reordered to {w0, b, w1, w2} and multiplied by 2^-e_k, its mixing weight multiplied by 2^e_k, with
+//   2^e_k >= 2 (|b_k| + x_max sum_j |w_kj|)          (a factor 2 above the bound: the bound itself is rounded)
+// -- exact scalings, so the network's value is unchanged while relu(h) becomes clamp(h 2^-e, 0, 1) for every input with
+// |x_j| <= x_max.  e_k is held to [-96, 96]: weights beyond 2^79 are outside what the fused kernels promise.
+__global__ void guide_nn_prescale(const float* __restrict__ conv1, const float* __restrict__ conv2, int n, float x_max,
+                                  float* __restrict__ conv1_out, float* __restrict__ conv2_out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0) conv2_out[n] = conv2[n];
+  if (k >= n) return;
+  const float w0 = conv1[4 * k + 0], w1 = conv1[4 * k + 1], w2 = conv1[4 * k + 2], b = conv1[4 * k + 3];
+  const float bound = fabsf(b) + x_max * (fabsf(w0) + fabsf(w1) + fabsf(w2));
+  int e = 0;
+  if (bound > 0.0f && bound < __builtin_inff()) (void)frexpf(bound, &e);  // bound = f 2^e, f in [0.5, 1)
+  e = min(max(e + 1, -96), 96);
+  const float down = ldexpf(1.0f, -e);
+  reinterpret_cast<float4*>(conv1_out)[k] = make_float4(w0 * down, b * down, w1 * down, w2 * down);
+  conv2_out[k] = ldexpf(conv2[k], e);
+}
+
+hipError_t launch_guide_nn_prescale(const float* conv1, const float* conv2, int n_feats, float x_max, float* conv1_out,
+                                    float* conv2_out, hipStream_t s) {
+  guide_nn_prescale<<<(n_feats + 63) / 64, 64, 0, s>>>(conv1, conv2, n_feats, x_max, conv1_out, conv2_out);
+  return hipGetLastError();
+}
+
 hipError_t launch_guide_fold_batch(const float* sums, const float* moments, long long npx, const float* w1,
                                    const float* gamma, const float* beta, const float* w2, const float* b2, double eps,
                                    double momentum, int Cin, int n, float* conv1, float* conv2, float* running_mean,

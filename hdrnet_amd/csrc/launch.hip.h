@@ -26,6 +26,8 @@ struct ApplyArgs {
   int frame_rows() const { return H_total > 0 ? H_total : H; }
   // fused guide network: v_exp_f32 + v_rcp_f32 sigmoid (HDRNET_GUIDE_SIGMOID_FAST) instead of expf + IEEE divide
   bool fast_sigmoid = false;
+  // fused guide network: conv1 / conv2 are the PRESCALED arrays of hdrnet_guide_nn_prescale_f32 (HDRNET_GUIDE_RELU_PRESCALED)
+  bool guide_prescaled = false;
 };
 
 // Forward with wire-format conversion and / or the fused guide network (apply_fwd_io.hip).
@@ -45,6 +47,7 @@ struct ApplyIoArgs {
   const float* guide_shifts = nullptr;  // non-null selects the curves guide: [n][Cin]
   const float* guide_slopes = nullptr;  //                                    [n][Cin]
   bool fast_sigmoid = false;            // guide network: as ApplyArgs::fast_sigmoid
+  bool guide_prescaled = false;         // guide network: as ApplyArgs::guide_prescaled
 };
 
 struct ApplyGradArgs {
@@ -221,6 +224,8 @@ hipError_t launch_input_moments(const float* input, long long npx, int Cin, floa
                                 void* workspace, hipStream_t s, const char** name);
 
 // guide_grad.hip -- training-mode fold of the guide network's batch norm (statistics from the input's moments) and its VJP.
+hipError_t launch_guide_nn_prescale(const float* conv1, const float* conv2, int n_feats, float x_max, float* conv1_out,
+                                    float* conv2_out, hipStream_t s);
 hipError_t launch_guide_fold_batch(const float* sums, const float* moments, long long npx, const float* w1,
                                    const float* gamma, const float* beta, const float* w2, const float* b2, double eps,
                                    double momentum, int Cin, int n, float* conv1, float* conv2, float* running_mean,

@@ -351,7 +351,36 @@ struct GuideNN {
   // (HDRNET_GUIDE_SIGMOID_FAST in the flags of the ..._ex entry points) -- until round 5 it followed
   // `guide_out == NULL`, an implicit numerics switch.
   bool fast_sigmoid = false;
+  // PRESCALED parameters (HDRNET_GUIDE_RELU_PRESCALED; CIN = 3; written by hdrnet_guide_nn_prescale_f32, guide_grad.hip):
+  //   conv1 = [n][4] {w0, b, w1, w2} * 2^-e_k,  conv2 = [n + 1] {m_k * 2^e_k ..., bias},  2^e_k >= 2 (|b| + x_max sum_j |w_j|)
+  // so that the hidden activation of feature k, scaled by the power of two, cannot exceed 1 for any input with
+  // |x_j| <= x_max, and relu(h) 2^-e == clamp(h 2^-e, 0, 1) -- the CLAMP output modifier of the feature's last
+  // v_pk_fma_f32 instead of two v_max_f32 per pixel pair.  Powers of two commute with every rounding of the chain
+  // (outside the denormal range: |h| < 2^(e - 126)), so the guide is the un-scaled evaluation's bit for bit; with the
+  // feature's {w0, b} in ONE aligned SGPR pair the chain's first FMA takes weight and bias from the same scalar operand
+  // (one constant-bus read), which also removes the v_mov of the bias: 4 packed instructions per feature and pixel pair
+  // instead of 4 packed + 2 v_max + 1 v_mov (208 -> 128 VALU per wave of 256 pixels).  Inputs beyond x_max saturate the
+  // activation at 2^e_k instead of overflowing the bound: the caller's contract (include/hdrnet_amd.h).
+  bool prescaled = false;
 };
+
+// One feature of a PRESCALED guide network (GuideNN::prescaled) on both pixel pairs of a lane: hv = w0 x0 + b (weight =
+// the SGPR pair's low half, bias = its high half: one constant-bus operand), + w1 x1, + w2 x2 clamped to [0, 1];
+// acc += m hv with m the low (HI = false) or high half of its SGPR pair.
+template <bool HI>
+__device__ __forceinline__ void nn_feature_prescaled(f32x2 wa, f32x2 wb, f32x2 mm, const f32x2 (&in2)[2][3], f32x2 (&acc2)[2]) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    f32x2 hv;
+    asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,0,1] op_sel_hi:[0,1,1]" : "=v"(hv) : "s"(wa), "v"(in2[h][0]));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(hv) : "s"(wb), "v"(in2[h][1]));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1] clamp" : "+v"(hv) : "s"(wb), "v"(in2[h][2]));
+    if constexpr (HI)
+      asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc2[h]) : "s"(mm), "v"(hv));
+    else
+      asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc2[h]) : "s"(mm), "v"(hv));
+  }
+}
 
 // Evaluated for a lane's 4 consecutive pixels at once (inf = [pixel][CIN] floats): one pass over the
 // features, the weights read ONCE per feature through the constant address space (wave-uniform s_load; a plain global
@@ -373,19 +402,43 @@ __device__ __forceinline__ void guide_nn_quad(const GuideNN& gn, const float* in
     for (int j = 0; j < CIN; ++j) in2[h][j] = f32x2{inf[(2 * h) * CIN + j], inf[(2 * h + 1) * CIN + j]};
   }
   f32x2 acc2[2] = {f32x2{bias, bias}, f32x2{bias, bias}};
+  bool done = false;
+  if constexpr (CIN == 3) {
+    if (gn.prescaled) {  // wave-uniform (GuideNN::prescaled)
+      done = true;
+      typedef __attribute__((address_space(4))) const f32x4 cfloat4;
+      cfloat4* q1 = (cfloat4*)gn.conv1;
+      int k = 0;
+      for (; k + 4 <= gn.n; k += 4) {
+        const f32x4 m4 = *(cfloat4*)(c2 + k);  // (conv2 is 16-B aligned: checked by the entry points)
+        const f32x4 wq[4] = {q1[k], q1[k + 1], q1[k + 2], q1[k + 3]};
+        nn_feature_prescaled<false>(f32x2{wq[0].x, wq[0].y}, f32x2{wq[0].z, wq[0].w}, f32x2{m4.x, m4.y}, in2, acc2);
+        nn_feature_prescaled<true>(f32x2{wq[1].x, wq[1].y}, f32x2{wq[1].z, wq[1].w}, f32x2{m4.x, m4.y}, in2, acc2);
+        nn_feature_prescaled<false>(f32x2{wq[2].x, wq[2].y}, f32x2{wq[2].z, wq[2].w}, f32x2{m4.z, m4.w}, in2, acc2);
+        nn_feature_prescaled<true>(f32x2{wq[3].x, wq[3].y}, f32x2{wq[3].z, wq[3].w}, f32x2{m4.z, m4.w}, in2, acc2);
+      }
+      for (; k < gn.n; ++k) {
+        const f32x4 w = q1[k];
+        const float m = c2[k];
+        nn_feature_prescaled<false>(f32x2{w.x, w.y}, f32x2{w.z, w.w}, f32x2{m, m}, in2, acc2);
+      }
+    }
+  }
+  if (!done) {
 #pragma unroll 4
-  for (int k = 0; k < gn.n; ++k) {
-    float w[CIN + 1];
+    for (int k = 0; k < gn.n; ++k) {
+      float w[CIN + 1];
 #pragma unroll
-    for (int j = 0; j <= CIN; ++j) w[j] = c1[k * (CIN + 1) + j];
-    const float m = c2[k];
+      for (int j = 0; j <= CIN; ++j) w[j] = c1[k * (CIN + 1) + j];
+      const float m = c2[k];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      f32x2 hv = {w[CIN], w[CIN]};
+      for (int h = 0; h < 2; ++h) {
+        f32x2 hv = {w[CIN], w[CIN]};
 #pragma unroll
-      for (int j = 0; j < CIN; ++j) hv = __builtin_elementwise_fma(f32x2{w[j], w[j]}, in2[h][j], hv);
-      const f32x2 r = {fmaxf(hv.x, 0.0f), fmaxf(hv.y, 0.0f)};
-      acc2[h] = __builtin_elementwise_fma(f32x2{m, m}, r, acc2[h]);
+        for (int j = 0; j < CIN; ++j) hv = __builtin_elementwise_fma(f32x2{w[j], w[j]}, in2[h][j], hv);
+        const f32x2 r = {fmaxf(hv.x, 0.0f), fmaxf(hv.y, 0.0f)};
+        acc2[h] = __builtin_elementwise_fma(f32x2{m, m}, r, acc2[h]);
+      }
     }
   }
   const float acc[kPxPerThread] = {acc2[0].x, acc2[0].y, acc2[1].x, acc2[1].y};

@@ -36,7 +36,7 @@ from . import _lib
 
 __all__ = ["bilateral_slice", "bilateral_slice_apply", "bilateral_slice_apply_rows", "bilateral_slice_apply_nnguide",
            "bilateral_slice_apply_io", "bilateral_slice_apply_curves", "bilateral_slice_apply_upadd", "resize_bilinear", "input_moments",
-           "CoefficientWeights", "coefficients", "coefficients_train", "coefficients_train_supported", "guide_fold_batch",
+           "CoefficientWeights", "coefficients", "coefficients_train", "coefficients_train_supported", "guide_fold_batch", "guide_nn_prescale",
            "kernel_override", "last_kernel"]
 
 _tls = threading.local()
@@ -301,6 +301,35 @@ def bilateral_slice_apply_rows(grid: torch.Tensor, guide_rows: torch.Tensor, inp
     return out
 
 
+def _guide_flags(fast_sigmoid: bool, prescaled: bool) -> int:
+    return (_lib.GUIDE_SIGMOID_FAST if fast_sigmoid else 0) | (_lib.GUIDE_RELU_PRESCALED if prescaled else 0)
+
+
+def guide_nn_prescale(guide_conv1: torch.Tensor, guide_conv2: torch.Tensor, x_max: float = 65536.0):
+    """The PRESCALED form of a folded guide network (``hdrnet_guide_nn_prescale_f32``; Cin = 3): per feature k the
+    first-layer row reordered to ``{w0, b, w1, w2} * 2**-e_k`` and the mixing weight ``* 2**e_k`` with
+    ``2**e_k >= 2 (|b_k| + x_max sum_j |w_kj|)``.  Passed back to the guide-network forwards with ``prescaled=True``
+    (``HDRNET_GUIDE_RELU_PRESCALED``) the guide is the plain evaluation's bit for bit for every input with
+    ``|x| <= x_max`` -- the kernels then take ``relu`` from the clamp modifier of the feature's last multiply-add
+    (128 instead of 208 vector instructions per 256 pixels).  Returns ``(conv1 [n, 4], conv2 [n + 1])``; prepare once
+    per parameter set.  Inference only: the guide network's VJP reads the exported layout."""
+    _require_f32("guide_conv1", guide_conv1)
+    _require_f32("guide_conv2", guide_conv2)
+    _require_gpu("guide_conv1", guide_conv1)
+    _require_gpu("guide_conv2", guide_conv2)
+    if guide_conv1.dim() != 2 or guide_conv1.shape[1] != 4 or tuple(guide_conv2.shape) != (guide_conv1.shape[0] + 1,):
+        raise ValueError(f"guide_nn_prescale: guide_conv1 [n, 4] (Cin = 3) and guide_conv2 [n + 1] expected, got "
+                         f"{tuple(guide_conv1.shape)}, {tuple(guide_conv2.shape)}")
+    c1, c2 = guide_conv1.detach().contiguous(), guide_conv2.detach().contiguous()
+    o1, o2 = torch.empty_like(c1), torch.empty_like(c2)
+    dev = c1.device
+    with torch.cuda.device(dev):
+        rc = _lib.load().hdrnet_guide_nn_prescale_f32(c1.data_ptr(), c2.data_ptr(), c1.shape[0], 3, float(x_max),
+                                                      o1.data_ptr(), o2.data_ptr(), _stream(dev))
+    _lib.check(rc, "GuideNNPrescale")
+    return o1, o2
+
+
 def _check_nnguide(grid, input, guide_conv1, guide_conv2, has_offset):  # noqa: A002
     _require_f32("guide_conv1", guide_conv1)
     _require_f32("guide_conv2", guide_conv2)
@@ -319,7 +348,8 @@ def _check_nnguide(grid, input, guide_conv1, guide_conv2, has_offset):  # noqa: 
     return dims + (n,)
 
 
-def _nnguide_forward(grid, inp, c1, c2, has_offset: bool, want_guide: bool, fast_sigmoid: bool = False):
+def _nnguide_forward(grid, inp, c1, c2, has_offset: bool, want_guide: bool, fast_sigmoid: bool = False,
+                     prescaled: bool = False):
     B, H, W, GH, GW, GD, Cin, Cout, n = _check_nnguide(grid, inp, c1, c2, has_offset)
     grid, inp, c1, c2 = grid.contiguous(), inp.contiguous(), c1.contiguous(), c2.contiguous()
     dev = inp.device
@@ -330,7 +360,7 @@ def _nnguide_forward(grid, inp, c1, c2, has_offset: bool, want_guide: bool, fast
         rc = lib.hdrnet_bilateral_slice_apply_nnguide_f32_ex(
             grid.data_ptr(), inp.data_ptr(), c1.data_ptr(), c2.data_ptr(), out.data_ptr(), _ptr(gout),
             B, H, W, GH, GW, GD, Cin, Cout, int(bool(has_offset)), n,
-            _lib.GUIDE_SIGMOID_FAST if fast_sigmoid else 0, _stream(dev))
+            _guide_flags(fast_sigmoid, prescaled), _stream(dev))
     _lib.check(rc, "BilateralSliceApplyNNGuide")
     return out, gout
 
@@ -386,13 +416,17 @@ class _BilateralSliceApplyNNGuide(torch.autograd.Function):
 
 def bilateral_slice_apply_nnguide(grid: torch.Tensor, input: torch.Tensor,  # noqa: A002
                                   guide_conv1: torch.Tensor, guide_conv2: torch.Tensor,
-                                  has_offset: bool = True, return_guide: bool = False, fast_sigmoid: bool = False):
+                                  has_offset: bool = True, return_guide: bool = False, fast_sigmoid: bool = False,
+                                  prescaled: bool = False):
     """Fusion of ``HDRNetPointwiseNNGuide._guide`` (hdrnet/models.py:203-210, batch norm folded)
     with ``bilateral_slice_apply``: the guide is computed in registers and sliced immediately.
 
     ``fast_sigmoid`` (forward without autograd only): the hardware exp / reciprocal sigmoid instead of
     ``tf.nn.sigmoid``'s form -- <= 2 ulp of the guide, ~1e-6 of the output's scale, ~10 % faster; an explicit choice
     (``HDRNET_GUIDE_SIGMOID_FAST``).  A differentiable call always uses the exact form: the backward reads the guide.
+
+    ``prescaled`` (forward without autograd only): ``guide_conv1`` / ``guide_conv2`` are ``guide_nn_prescale``'s arrays
+    (``HDRNET_GUIDE_RELU_PRESCALED``) -- the same guide bit for bit for inputs within the prescale's ``x_max``.
 
     ``guide_conv1`` is ``[n, Cin + 1]`` (weights then bias of feature k) and ``guide_conv2``
     ``[n + 1]`` (mixing weights then bias) -- the layout ``hdrnet/bin/freeze_graph.py:170-184``
@@ -405,8 +439,11 @@ def bilateral_slice_apply_nnguide(grid: torch.Tensor, input: torch.Tensor,  # no
     specialisation."""
     if return_guide:
         return _nnguide_forward(grid.detach(), input.detach(), guide_conv1.detach(), guide_conv2.detach(),
-                                has_offset, want_guide=True, fast_sigmoid=fast_sigmoid)
+                                has_offset, want_guide=True, fast_sigmoid=fast_sigmoid, prescaled=prescaled)
     if torch.is_grad_enabled() and any(t.requires_grad for t in (grid, input, guide_conv1, guide_conv2)):
+        if prescaled:
+            raise ValueError("bilateral_slice_apply_nnguide: prescaled guide parameters are inference-only "
+                             "(the guide network's VJP reads the exported layout)")
         dims = _check_nnguide(grid, input, guide_conv1, guide_conv2, has_offset)
         # the guide-network VJP has specialisations for a few widths only: say so NOW, not from
         # inside backward() on the autograd thread
@@ -418,7 +455,7 @@ def bilateral_slice_apply_nnguide(grid: torch.Tensor, input: torch.Tensor,  # no
                     "call bilateral_slice_apply, or run without autograd")
         return _BilateralSliceApplyNNGuide.apply(grid, input, guide_conv1, guide_conv2, has_offset)
     return _nnguide_forward(grid.detach(), input.detach(), guide_conv1.detach(), guide_conv2.detach(),
-                            has_offset, want_guide=False, fast_sigmoid=fast_sigmoid)[0]
+                            has_offset, want_guide=False, fast_sigmoid=fast_sigmoid, prescaled=prescaled)[0]
 
 
 class _BilateralSliceApplyCurves(torch.autograd.Function):
@@ -846,12 +883,13 @@ def bilateral_slice_apply_upadd(grid: torch.Tensor, input: torch.Tensor, coarse:
                                 guide: Optional[torch.Tensor] = None,
                                 guide_conv1: Optional[torch.Tensor] = None,
                                 guide_conv2: Optional[torch.Tensor] = None,
-                                has_offset: bool = True, fast_sigmoid: bool = False) -> torch.Tensor:
+                                has_offset: bool = True, fast_sigmoid: bool = False,
+                                prescaled: bool = False) -> torch.Tensor:
     """One level of ``HDRNetGaussianPyrNN._output`` (hdrnet/models.py:277-289) in one pass:
     ``bilateral_slice_apply(grid, guide, input) + resize_bilinear(coarse -> H x W, align_corners)``.
     Give either a ``guide`` map or the folded guide network (``guide_conv1``, ``guide_conv2``), which
-    is then evaluated in registers (``fast_sigmoid``: as ``bilateral_slice_apply_nnguide``).  Inference only (no
-    autograd)."""
+    is then evaluated in registers (``fast_sigmoid``, ``prescaled``: as ``bilateral_slice_apply_nnguide``).  Inference
+    only (no autograd)."""
     if (guide is None) == (guide_conv1 is None):
         raise ValueError("give either guide or (guide_conv1, guide_conv2)")
     if input.dim() != 4:
@@ -876,7 +914,7 @@ def bilateral_slice_apply_upadd(grid: torch.Tensor, input: torch.Tensor, coarse:
         rc = lib.hdrnet_bilateral_slice_apply_upadd_f32_ex(
             grid.data_ptr(), _ptr(gd), inp.data_ptr(), coarse.data_ptr(), coarse.shape[1], coarse.shape[2],
             out.data_ptr(), B, H, W, GH, GW, GD, Cin, Cout, int(bool(has_offset)), _ptr(c1), _ptr(c2), n,
-            _lib.GUIDE_SIGMOID_FAST if fast_sigmoid else 0, _stream(dev))
+            _guide_flags(fast_sigmoid, prescaled and guide is None), _stream(dev))
     _lib.check(rc, "BilateralSliceApplyUpAdd")
     return out
 
@@ -947,7 +985,7 @@ def bilateral_slice_apply_io(grid: torch.Tensor, input: torch.Tensor,  # noqa: A
                              out_dtype: torch.dtype = torch.float32,
                              has_offset: bool = True,
                              guide_curves: Optional[Tuple[torch.Tensor, ...]] = None,
-                             return_guide: bool = False, fast_sigmoid: bool = False):
+                             return_guide: bool = False, fast_sigmoid: bool = False, prescaled: bool = False):
     """Inference forward with the product's wire formats fused in: ``input`` may be uint8 / uint16
     (``value / input_white_level``: 255, 65535, or 32767 for HDR+ -- hdrnet/data_pipeline.py:202-232,
     :267-274) and the output may be uint8 ``= (uint8)(255 * clip(out, 0, 1))`` (hdrnet/bin/run.py:95).
@@ -958,7 +996,8 @@ def bilateral_slice_apply_io(grid: torch.Tensor, input: torch.Tensor,  # noqa: A
     standard GL shader does (benchmark/assets/std.frag:36-45).  ``return_guide`` (guide network or curves) also
     returns the guide map the kernel computed.  ``fast_sigmoid`` (guide network): the hardware exp / reciprocal
     sigmoid, <= 2 ulp of the guide away from the default (tf.nn.sigmoid's form) and ~10 % faster -- an explicit
-    choice of the caller (HDRNET_GUIDE_SIGMOID_FAST), never implied by another argument.  No autograd."""
+    choice of the caller (HDRNET_GUIDE_SIGMOID_FAST), never implied by another argument.  ``prescaled`` (guide network):
+    ``guide_conv1`` / ``guide_conv2`` are ``guide_nn_prescale``'s arrays (HDRNET_GUIDE_RELU_PRESCALED).  No autograd."""
     if input.dim() != 4:
         raise ValueError(f"Input image should be 4D (batch_size, height, width, input_channels), got {tuple(input.shape)}")
     if input.dtype not in _DTYPE_CODE:
@@ -1002,6 +1041,6 @@ def bilateral_slice_apply_io(grid: torch.Tensor, input: torch.Tensor,  # noqa: A
             grid.data_ptr(), _ptr(guide), inp.data_ptr(), out.data_ptr(), B, H, W, GH, GW, GD, Cin, Cout,
             int(bool(has_offset)), _DTYPE_CODE[input.dtype], float(input_white_level), _DTYPE_CODE[out_dtype],
             _ptr(guide_conv1) if guide is None else None, _ptr(guide_conv2) if guide is None else None,
-            n, _ptr(gout), _lib.GUIDE_SIGMOID_FAST if fast_sigmoid else 0, _stream(dev))
+            n, _ptr(gout), _guide_flags(fast_sigmoid, prescaled and guide is None), _stream(dev))
     _lib.check(rc, "BilateralSliceApplyIO")
     return (out, gout) if return_guide else out

@@ -374,6 +374,28 @@ class _PointwiseNNGuide(nn.Module):
             self._folded_cache = (key, out)
         return out
 
+    # the range of |input| the prescaled form promises its bit-equality for (hdrnet_ops.guide_nn_prescale); the model's
+    # inputs are in [0, 1], its wire formats' raw samples at most 65535
+    prescale_x_max = 65536.0
+
+    def inference_params(self, prescale: bool):
+        """``(conv1, conv2, prescaled)`` for an inference forward: the folded arrays, in their PRESCALED form
+        (``HDRNET_GUIDE_RELU_PRESCALED``: the same guide bit for bit, 80 fewer vector instructions per 256 pixels) when
+        ``prescale`` and the network has three input channels on a GPU -- prepared once per parameter state."""
+        conv1, conv2 = self.folded()
+        if not (prescale and conv1.is_cuda and conv1.shape[1] == 4):
+            return conv1, conv2, False
+        key = _param_key(list(self.parameters()) + list(self.buffers()))
+        cached = getattr(self, "_prescaled_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        from . import hdrnet_ops
+        p1, p2 = hdrnet_ops.guide_nn_prescale(conv1, conv2, self.prescale_x_max)
+        out = (p1, p2, True)
+        if _cacheable():
+            self._prescaled_cache = (key, out)
+        return out
+
     def folded_batch(self, sums: torch.Tensor, moments: torch.Tensor, npx: int):
         """Training-mode fold: batch norm normalises the conv output h = x . w1 with ITS mean and
         biased variance over the batch (hdrnet/layers.py:40-58, is_training=True).  h is linear
@@ -428,6 +450,9 @@ class HDRNetCurves(nn.Module):
     # ~10 % faster, HDRNET_GUIDE_SIGMOID_FAST) -- the MODEL's explicit choice, passed to every such call; False = the
     # exact tf.nn.sigmoid form everywhere.  Training forwards always use the exact form.
     fast_sigmoid = True
+    # ... and the guide network's PRESCALED parameters (HDRNET_GUIDE_RELU_PRESCALED): bit-identical guide for |input| <=
+    # _PointwiseNNGuide.prescale_x_max, relu from the clamp modifier.  Inference only, like fast_sigmoid.
+    prescale_guide = True
 
     def forward(self, lowres_input: torch.Tensor, fullres_input: torch.Tensor) -> torch.Tensor:
         coeffs = self.coefficients(lowres_input)
@@ -481,12 +506,18 @@ class HDRNetPointwiseNNGuide(HDRNetCurves):
             sums, moments = hdrnet_ops.input_moments(fullres_input)
             npx = fullres_input.numel() // fullres_input.shape[3]
             conv1, conv2 = self.guide.folded_batch(sums, moments, npx)
+        prescaled = False
+        if self.training:
+            pass
+        elif differentiable:
+            conv1, conv2 = self.guide.folded(detach=False)
         else:
-            conv1, conv2 = self.guide.folded(detach=not differentiable)
+            conv1, conv2, prescaled = self.guide.inference_params(self.prescale_guide)
         # inference (nothing differentiable): the model opts into the hardware sigmoid -- explicitly, HDRNET_GUIDE_SIGMOID_FAST
         return hdrnet_ops.bilateral_slice_apply_nnguide(
             coeffs.reshape(gs[0], gs[1], gs[2], gs[3], gs[4] * gs[5]), fullres_input, conv1, conv2,
-            has_offset=True, fast_sigmoid=self.fast_sigmoid and not self.training and not differentiable)
+            has_offset=True, fast_sigmoid=self.fast_sigmoid and not self.training and not differentiable,
+            prescaled=prescaled)
 
 
 class _SplitLevels(torch.autograd.Function):
@@ -597,12 +628,12 @@ class HDRNetGaussianPyrNN(HDRNetPointwiseNNGuide):
         current = None
         for il, (lvl, gnet) in enumerate(reversed(list(zip(lvls, self.guide)))):  # models.py:278
             c = grids[il]
-            conv1, conv2 = gnet.folded()
+            conv1, conv2, prescaled = gnet.inference_params(self.prescale_guide)
             if current is None:
                 current = hdrnet_ops.bilateral_slice_apply_nnguide(c, lvl, conv1, conv2, has_offset=True,
-                                                                   fast_sigmoid=self.fast_sigmoid)
+                                                                   fast_sigmoid=self.fast_sigmoid, prescaled=prescaled)
             else:
                 current = hdrnet_ops.bilateral_slice_apply_upadd(c, lvl, current, guide_conv1=conv1,
                                                                  guide_conv2=conv2, has_offset=True,
-                                                                 fast_sigmoid=self.fast_sigmoid)
+                                                                 fast_sigmoid=self.fast_sigmoid, prescaled=prescaled)
         return current

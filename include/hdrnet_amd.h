@@ -154,6 +154,19 @@ int hdrnet_bilateral_slice_apply_nnguide_f32_ex(const float* grid, const float* 
                                                 int has_offset, int n_feats, unsigned flags,
                                                 void* stream);
 
+/* HDRNET_GUIDE_RELU_PRESCALED (flag of the three ..._ex guide-network entry points; Cin = 3): guide_conv1 /
+ * guide_conv2 are the arrays hdrnet_guide_nn_prescale_f32 wrote from the exported ones -- per feature k the row
+ * {w0, b, w1, w2} * 2^-e_k ([n][4], 16-B aligned) and the mixing weight conv2[k] * 2^e_k ([n+1], 16-B aligned),
+ * with 2^e_k >= 2 (|b_k| + x_max * sum_j |w_kj|).  Powers of two commute with every rounding of the evaluation, so
+ * the guide is the plain evaluation's bit for bit for every input with |input_j| <= x_max (the hidden activation
+ * then never exceeds 2^e_k, and relu(h) 2^-e_k is the [0, 1] clamp modifier of the last multiply-add instead of
+ * separate maximum instructions: 128 instead of 208 vector instructions per 256 pixels in these instruction-bound
+ * kernels).  An input beyond x_max may saturate a feature at 2^e_k: the caller names the range (x_max; the
+ * shipped models pass 65536).  Prepared ONCE per parameter set -- a one-workgroup launch, on `stream`. */
+#define HDRNET_GUIDE_RELU_PRESCALED 0x20000u
+int hdrnet_guide_nn_prescale_f32(const float* guide_conv1, const float* guide_conv2, int n_feats, int Cin,
+                                 float x_max, float* conv1_out, float* conv2_out, void* stream);
+
 /* The standard model's one-pass inference: HDRNetCurves._guide (hdrnet/models.py:145-190) evaluated
  * in registers, then BilateralSliceApply, with the wire-format conversions of
  * hdrnet_bilateral_slice_apply_io -- what the reference's standard GL shader does
@@ -191,7 +204,7 @@ int hdrnet_bilateral_slice_apply_upadd_f32(const float* grid, const float* guide
                                            int GW, int GD, int Cin, int Cout, int has_offset,
                                            const float* guide_conv1, const float* guide_conv2,
                                            int n_feats, void* stream);
-/* ... with `flags`: HDRNET_GUIDE_SIGMOID_FAST (see hdrnet_bilateral_slice_apply_nnguide_f32) or 0. */
+/* ... with `flags`: HDRNET_GUIDE_SIGMOID_FAST (see hdrnet_bilateral_slice_apply_nnguide_f32), HDRNET_GUIDE_RELU_PRESCALED or 0. */
 int hdrnet_bilateral_slice_apply_upadd_f32_ex(const float* grid, const float* guide,
                                               const float* input, const float* coarse, int Hc,
                                               int Wc, float* out, int B, int H, int W, int GH,
@@ -261,7 +274,7 @@ int hdrnet_bilateral_slice_apply_io(const float* grid, const float* guide, const
                                     float input_white_level, int output_dtype,
                                     const float* guide_conv1, const float* guide_conv2,
                                     int n_feats, float* guide_out, void* stream);
-/* ... with `flags`: HDRNET_GUIDE_SIGMOID_FAST (guide network only; see ..._nnguide_f32) or 0. */
+/* ... with `flags`: HDRNET_GUIDE_SIGMOID_FAST, HDRNET_GUIDE_RELU_PRESCALED (guide network only; see ..._nnguide_f32) or 0. */
 int hdrnet_bilateral_slice_apply_io_ex(const float* grid, const float* guide, const void* input,
                                        void* out, int B, int H, int W, int GH, int GW, int GD,
                                        int Cin, int Cout, int has_offset, int input_dtype,

@@ -118,7 +118,7 @@ def test_new_entry_points_validate_without_gpu(libpath):
     U = ctypes.c_uint
     lib.hdrnet_bilateral_slice_apply_upadd_f32_ex.argtypes = [P] * 4 + [I, I, P] + [I] * 9 + [P, P, I, U, P]
     rc = lib.hdrnet_bilateral_slice_apply_upadd_f32_ex(None, None, None, None, 2, 2, None, 1, 4, 4, 2, 2, 2, 3, 3, 1,
-                                                       None, None, 0, 0x20000, None)
+                                                       None, None, 0, 0x40000, None)
     assert rc == 1 and b"HDRNET_GUIDE_SIGMOID_FAST" in lib.hdrnet_last_error()
     rc = lib.hdrnet_bilateral_slice_apply_upadd_f32_ex(None, None, None, None, 2, 2, None, 1, 4, 4, 2, 2, 2, 3, 3, 1,
                                                        None, None, 0, 0x10000, None)
@@ -132,8 +132,29 @@ def test_new_entry_points_validate_without_gpu(libpath):
     assert rc == 1 and b"null buffer" in lib.hdrnet_last_error()
     lib.hdrnet_bilateral_slice_apply_io_ex.argtypes = [P] * 4 + [I] * 10 + [ctypes.c_float, I] + [P] * 2 + [I, P, U, P]
     rc = lib.hdrnet_bilateral_slice_apply_io_ex(None, None, None, None, 1, 4, 4, 2, 2, 2, 3, 3, 1, 0, 1.0, 0, None, None, 0,
-                                                None, 0x30000, None)
+                                                None, 0x50000, None)
     assert rc == 1 and b"unknown flags" in lib.hdrnet_last_error()
+    # HDRNET_GUIDE_RELU_PRESCALED (0x20000): the arrays of hdrnet_guide_nn_prescale_f32 -- a guide NETWORK of three input
+    # channels with 16-B aligned arrays, or the call is refused; the helper itself validates before it launches
+    F = ctypes.c_float
+    rc = lib.hdrnet_bilateral_slice_apply_nnguide_f32_ex(0x1000, 0x1000, 0x1000, 0x1000, 0x1000, None, 1, 4, 4, 2, 2, 2, 1, 1,
+                                                         1, 16, 0x20000, None)
+    assert rc == 1 and b"HDRNET_GUIDE_RELU_PRESCALED needs a guide network with Cin = 3" in lib.hdrnet_last_error()
+    rc = lib.hdrnet_bilateral_slice_apply_nnguide_f32_ex(0x1000, 0x1000, 0x1004, 0x1000, 0x1000, None, 1, 4, 4, 2, 2, 2, 3, 3,
+                                                         1, 16, 0x30000, None)
+    assert rc == 1 and b"16-B aligned guide_conv1" in lib.hdrnet_last_error()
+    rc = lib.hdrnet_bilateral_slice_apply_io_ex(0x1000, 0x1000, 0x1000, 0x1000, 1, 4, 4, 2, 2, 2, 3, 3, 1, 0, 1.0, 0, None,
+                                                None, 0, None, 0x20000, None)  # a guide MAP: nothing to prescale
+    assert rc == 1 and b"HDRNET_GUIDE_RELU_PRESCALED" in lib.hdrnet_last_error()
+    lib.hdrnet_guide_nn_prescale_f32.argtypes = [P, P, I, I, F, P, P, P]
+    assert lib.hdrnet_guide_nn_prescale_f32(0x1000, 0x1000, 16, 1, 1.0, 0x1000, 0x1000, None) == 1
+    assert b"Cin = 3" in lib.hdrnet_last_error()
+    assert lib.hdrnet_guide_nn_prescale_f32(0x1000, 0x1000, 16, 3, 0.0, 0x1000, 0x1000, None) == 1
+    assert b"x_max" in lib.hdrnet_last_error()
+    assert lib.hdrnet_guide_nn_prescale_f32(0x1000, 0x1000, 16, 3, 1.0, 0x1004, 0x1000, None) == 1
+    assert b"16-B aligned output" in lib.hdrnet_last_error()
+    assert lib.hdrnet_guide_nn_prescale_f32(None, 0x1000, 16, 3, 1.0, 0x1000, 0x1000, None) == 1
+    assert b"null buffer" in lib.hdrnet_last_error()
 
 
 def test_curves_entry_points_validate_without_gpu(libpath):

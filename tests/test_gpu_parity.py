@@ -395,6 +395,74 @@ def test_inference_sigmoid_moves_the_guide_by_at_most_2_ulp(dev, ops):
     np.testing.assert_allclose(N(out_train)[..., 0], np.clip(g, 0.5 / GD, 1 - 0.5 / GD), rtol=0, atol=2e-4)
 
 
+@pytest.mark.parametrize("n", [16, 6, 3])
+def test_prescaled_guide_network_is_bit_identical(dev, ops, n):
+    """HDRNET_GUIDE_RELU_PRESCALED (round 5): the guide network's first layer scaled per feature by 2^-e_k, its mixing
+    weight by 2^e_k, relu taken from the CLAMP modifier of the feature's last v_pk_fma_f32.  Powers of two commute with
+    every rounding, so for inputs within the prescale's x_max the guide and the output are the plain evaluation's BIT
+    FOR BIT -- both sigmoids, the fp32 kernel, the up-add level and the uint8 wire format; n = 6 / 3 run the
+    remainder loop (features past a multiple of four)."""
+    B, H, W, GH, GW, GD = 2, 40, 256, 16, 16, 8
+    rng = np.random.default_rng(500 + n)
+    grid = T(rng.random((B, GH, GW, GD, 12)).astype(np.float32), dev)
+    inp = T(rng.random((B, H, W, 3)).astype(np.float32), dev)
+    conv1 = T((rng.standard_normal((n, 4)) * 0.8).astype(np.float32), dev)
+    conv2 = T((rng.standard_normal(n + 1) * 0.5).astype(np.float32), dev)
+    p1, p2 = ops.guide_nn_prescale(conv1, conv2, x_max=65536.0)
+    # the prescale itself: exact power-of-two scalings of the reordered row {w0, b, w1, w2}, bias copied
+    c1, q1 = N(conv1).astype(np.float64), N(p1).astype(np.float64)
+    ratio = q1[:, 0] / c1[:, 0]
+    e = -np.log2(ratio)
+    assert np.array_equal(e, np.round(e))
+    np.testing.assert_array_equal(q1, c1[:, [0, 3, 1, 2]] * ratio[:, None])
+    np.testing.assert_array_equal(N(p2)[:n].astype(np.float64), N(conv2)[:n].astype(np.float64) / ratio)
+    assert N(p2)[n] == N(conv2)[n]
+    bound = np.abs(c1[:, 3]) + 65536.0 * np.abs(c1[:, :3]).sum(1)
+    assert (2.0 ** e >= 2 * bound * (1 - 1e-6)).all() and (2.0 ** e <= 4 * bound * (1 + 1e-6)).all()
+    for fast in (False, True):
+        out, g = ops.bilateral_slice_apply_nnguide(grid, inp, conv1, conv2, return_guide=True, fast_sigmoid=fast)
+        out_p, g_p = ops.bilateral_slice_apply_nnguide(grid, inp, p1, p2, return_guide=True, fast_sigmoid=fast,
+                                                       prescaled=True)
+        assert ops.last_kernel() == "apply_fwd_seg/vec4+nnguide"
+        assert torch.equal(g_p, g) and torch.equal(out_p, out)
+    coarse = T(rng.random((B, H // 2, W // 2, 3)).astype(np.float32), dev)
+    up = ops.bilateral_slice_apply_upadd(grid, inp, coarse, guide_conv1=conv1, guide_conv2=conv2, fast_sigmoid=True)
+    up_p = ops.bilateral_slice_apply_upadd(grid, inp, coarse, guide_conv1=p1, guide_conv2=p2, fast_sigmoid=True,
+                                           prescaled=True)
+    assert torch.equal(up_p, up)
+    raw = torch.from_numpy(rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)).to(dev)
+    for od in (torch.uint8, torch.float32):
+        o8, g8 = ops.bilateral_slice_apply_io(grid, raw, guide_conv1=conv1, guide_conv2=conv2, out_dtype=od,
+                                              return_guide=True, fast_sigmoid=True)
+        o8p, g8p = ops.bilateral_slice_apply_io(grid, raw, guide_conv1=p1, guide_conv2=p2, out_dtype=od,
+                                                return_guide=True, fast_sigmoid=True, prescaled=True)
+        assert torch.equal(g8p, g8) and torch.equal(o8p, o8)
+    # inference only: a differentiable call refuses the prescaled layout
+    with pytest.raises(ValueError, match="inference-only"):
+        ops.bilateral_slice_apply_nnguide(grid.clone().requires_grad_(True), inp, p1, p2, prescaled=True)
+
+
+def test_prescaled_guide_network_saturates_beyond_x_max(dev, ops):
+    """The contract's other half: the clamp bounds a feature at 2^e_k, so an input far beyond the prescale's x_max can
+    saturate where the plain evaluation keeps growing -- inside x_max (here 4.0: inputs in [0, 4)) the two agree bit for
+    bit, and with the same parameters an input of 1e4 moves the guide."""
+    B, H, W, GH, GW, GD, n = 1, 16, 128, 8, 8, 8, 16
+    rng = np.random.default_rng(9)
+    grid = T(rng.random((B, GH, GW, GD, 12)).astype(np.float32), dev)
+    conv1 = T((np.abs(rng.standard_normal((n, 4))) * 0.8).astype(np.float32), dev)  # positive weights: h grows with x
+    # (mixing weights small enough that the sigmoid does not saturate on its own at |x| = 1e4: acc ~ +-1 there)
+    conv2 = T((rng.standard_normal(n + 1) * 2e-5).astype(np.float32), dev)
+    p1, p2 = ops.guide_nn_prescale(conv1, conv2, x_max=4.0)
+    inside = T((rng.random((B, H, W, 3)) * 4.0).astype(np.float32), dev)
+    _, g = ops.bilateral_slice_apply_nnguide(grid, inside, conv1, conv2, return_guide=True)
+    _, gp = ops.bilateral_slice_apply_nnguide(grid, inside, p1, p2, return_guide=True, prescaled=True)
+    assert torch.equal(gp, g)
+    far = torch.full((B, H, W, 3), 1e4, device=dev)
+    _, g = ops.bilateral_slice_apply_nnguide(grid, far, conv1, conv2, return_guide=True)
+    _, gp = ops.bilateral_slice_apply_nnguide(grid, far, p1, p2, return_guide=True, prescaled=True)
+    assert not torch.equal(gp, g)
+
+
 # ---- curves guide (the standard model) fused into slice-apply --------------------------------------
 @pytest.mark.parametrize("in_dtype,out_dtype", [("float32", "float32"), ("uint8", "uint8"), ("uint16", "float32")])
 def test_curves_guide_fused_matches_composed_oracle(dev, ops, port, in_dtype, out_dtype):

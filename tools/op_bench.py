@@ -98,22 +98,33 @@ def main():
     conv2 = (torch.randn((17,), device=dev, generator=gen) * 0.5).contiguous()
 
     FAST = _lib.GUIDE_SIGMOID_FAST  # the inference lines: the models' explicit choice (HDRNET_GUIDE_SIGMOID_FAST)
+    # ... and the guide network's parameters in their PRESCALED form (HDRNET_GUIDE_RELU_PRESCALED, what the models' inference
+    # passes since round 5: the same guide bit for bit); `pre=False` lines time the exported layout
+    PRE = _lib.GUIDE_RELU_PRESCALED
+    pconv1, pconv2 = torch.empty_like(conv1), torch.empty_like(conv2)
+    chk(lib.hdrnet_guide_nn_prescale_f32(conv1.data_ptr(), conv2.data_ptr(), 16, 3, 65536.0, pconv1.data_ptr(),
+                                         pconv2.data_ptr(), stream))
 
-    def apply_fwd_nnguide(k, flags=FAST):
+    def nnp(pre):
+        return (pconv1.data_ptr(), pconv2.data_ptr(), FAST | PRE) if pre else (conv1.data_ptr(), conv2.data_ptr(), FAST)
+
+    def apply_fwd_nnguide(k, pre=True):
         s = S[k % nsets]
+        c1, c2, fl = nnp(pre)
         chk(lib.hdrnet_bilateral_slice_apply_nnguide_f32_ex(
-            s["grid"].data_ptr(), s["inp"].data_ptr(), conv1.data_ptr(), conv2.data_ptr(), s["out"].data_ptr(),
-            None, B, H, W, GH, GW, GD, Cin, Cout, 1, 16, flags, stream))
+            s["grid"].data_ptr(), s["inp"].data_ptr(), c1, c2, s["out"].data_ptr(),
+            None, B, H, W, GH, GW, GD, Cin, Cout, 1, 16, fl, stream))
 
     u8 = [dict(inp=torch.randint(0, 256, (B, H, W, 3), device=dev, dtype=torch.uint8),
                out=torch.empty((B, H, W, 3), device=dev, dtype=torch.uint8)) for _ in range(nsets)]
 
-    def apply_io_u8(k, nn=True):
+    def apply_io_u8(k, nn=True, pre=True):
         s, t = S[k % nsets], u8[k % nsets]
+        c1, c2, fl = nnp(pre)
         chk(lib.hdrnet_bilateral_slice_apply_io_ex(
             s["grid"].data_ptr(), None if nn else s["guide"].data_ptr(), t["inp"].data_ptr(), t["out"].data_ptr(),
-            B, H, W, GH, GW, GD, 3, 3, 1, 1, 255.0, 1, conv1.data_ptr() if nn else None,
-            conv2.data_ptr() if nn else None, 16 if nn else 0, None, FAST if nn else 0, stream))
+            B, H, W, GH, GW, GD, 3, 3, 1, 1, 255.0, 1, c1 if nn else None,
+            c2 if nn else None, 16 if nn else 0, None, fl if nn else 0, stream))
 
     ccm = torch.cat([torch.eye(3, device=dev), torch.zeros((3, 1), device=dev)], 1) + 0.1 * torch.randn((3, 4), device=dev, generator=gen)
     shifts = torch.linspace(0, 1, 17, device=dev)[:-1, None].repeat(1, 3).contiguous()
@@ -130,12 +141,13 @@ def main():
     coarse = [torch.randn((B, H // 2, W // 2, 3), device=dev, generator=gen) for _ in range(nsets)]
     half = [torch.empty((B, H // 2, W // 2, 3), device=dev) for _ in range(nsets)]
 
-    def apply_upadd(k, nn=True):
+    def apply_upadd(k, nn=True, pre=True):
         s = S[k % nsets]
+        c1, c2, fl = nnp(pre)
         chk(lib.hdrnet_bilateral_slice_apply_upadd_f32_ex(
             s["grid"].data_ptr(), None if nn else s["guide"].data_ptr(), s["inp"].data_ptr(),
             coarse[k % nsets].data_ptr(), H // 2, W // 2, s["out"].data_ptr(), B, H, W, GH, GW, GD, 3, 3, 1,
-            conv1.data_ptr() if nn else None, conv2.data_ptr() if nn else None, 16 if nn else 0, FAST if nn else 0,
+            c1 if nn else None, c2 if nn else None, 16 if nn else 0, fl if nn else 0,
             stream))
 
     def resize_half(k):
@@ -193,13 +205,17 @@ def main():
     if u16 is not None:
         run("u16 / 32767 + guide map -> apply -> f32", apply_io_u16, npx * (4 + 6 + 12) + gridb)
     run("guide-NN(16) + apply fwd fused", apply_fwd_nnguide, 4 * npx * (Cin + Cout) + gridb)
+    run("... exported layout (no prescale)", lambda k: apply_fwd_nnguide(k, pre=False), 4 * npx * (Cin + Cout) + gridb)
     run("u8 -> guide-NN + apply -> u8", apply_io_u8, npx * 6 + gridb)
+    run("... exported layout (no prescale)", lambda k: apply_io_u8(k, pre=False), npx * 6 + gridb)
     run("u8 + guide map -> apply -> u8", lambda k: apply_io_u8(k, nn=False), npx * 10 + gridb)
     run("curves guide + apply fwd fused", lambda k: apply_io_curves(k, u8io=False), 4 * npx * (Cin + Cout) + gridb)
     run("u8 -> curves guide + apply -> u8", apply_io_curves, npx * 6 + gridb)
     run("apply + up-add of coarse level", lambda k: apply_upadd(k, nn=False),
         4 * npx * (1 + Cin + Cout) + gridb + 4 * npx * 3 // 4)
     run("guide-NN + apply + up-add", apply_upadd, 4 * npx * (Cin + Cout) + gridb + 4 * npx * 3 // 4)
+    run("... exported layout (no prescale)", lambda k: apply_upadd(k, pre=False),
+        4 * npx * (Cin + Cout) + gridb + 4 * npx * 3 // 4)
     run("resize bilinear 4K -> 1080p", resize_half, 4 * npx * 3 + 4 * npx * 3 // 4)
     run("apply bwd (all three)", apply_bwd, 4 * npx * (1 + Cin + Cout) + 4 * npx * (1 + Cin) + 2 * gridb)
     run("apply bwd dguide+dinput", lambda k: apply_bwd(k, dg=False), 4 * npx * (1 + Cin + Cout) + 4 * npx * (1 + Cin) + gridb)
