@@ -49,6 +49,7 @@ struct GuideNet {
   int n;               // NN: features                curves: knots per channel
   bool fast_sigmoid;   // NN: GuideNN::fast_sigmoid (rows_common.hip.h)
   bool prescaled;      // NN: GuideNN::prescaled
+  const float* prepared;  // curves: the uniform cell tables of hdrnet_curves_guide_prepare_f32 (CurveCells), or null
 };
 
 typedef __attribute__((address_space(4))) const float cfloat;  // wave-uniform parameters: s_load
@@ -230,6 +231,146 @@ __device__ __forceinline__ void guide_curves_quad(const float* __restrict__ tab,
       cv[q][c] = curve_lookup<CIN>(tab, c, t);
     }
   }
+#pragma unroll
+  for (int q = 0; q < kPxPerThread; ++q) {
+    float v = m[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) v = fmaf(m[c], cv[q][c], v);
+    g[q] = fminf(fmaxf(v, 0.0f), 1.0f);  // tf.clip_by_value(guidemap, 0, 1)
+  }
+}
+
+// ---- the curves guide through UNIFORM CELL TABLES prepared once per parameter set (round 5) ---------------------------
+// The sorted tables above are rebuilt by wave 0 of EVERY workgroup (~150 instructions + two wave barriers before the
+// workgroup's barrier) and searched with four dependent LDS reads per channel and pixel.  Both costs go with a table that
+// depends on the parameters only and is indexed by arithmetic: hdrnet_curves_guide_prepare_f32 cuts each channel's knot
+// range [s_min, s_max] into kCurveCells uniform cells by the MONOTONE map
+//     cell(t) = uint(clamp(fma(t, k16, o16), 0, 16 kCurveCells - 1)) >> 4,   k16 = 16 (kCurveCells - 1) / (s_max - s_min)
+// (the same fp32 instructions for a knot at prepare time and for a pixel here: t1 <= t2 => cell(t1) <= cell(t2), so every
+// knot of an earlier cell is <= t and every knot of a later cell is > t -- exactly, whatever the rounding) and stores per
+// cell one 16-byte entry (s, C, A_lo, A_hi): the knot inside the cell, the curve's value at it, the slopes before and
+// after it -- or, for a cell without a knot, the last knot to its left with A_lo = A_hi.  A pixel evaluates
+//     C + (t >= s ? A_hi : A_lo) (t - s)
+// -- one ds_read_b128 and 8 VALU instructions per channel instead of 4 + 1 dependent reads and 16; anchored at a knot at
+// most one cell away, with the float64-summed C and A of the sorted tables (curves_build_tables, run once by the prepare
+// kernel).  A cell can hold one knot only: if two knots of a channel share a cell (closer than 1/63 of the knot range, or
+// equal) the prepare kernel clears the table's `ok` word and the forward kernels keep the sorted tables -- same results
+// as without a prepared table.  Layout of the prepared buffer (floats): [CIN][kCurveCells][4] entries, then per channel
+// (k16, o16, 0, 0), then (ok, 0, 0, 0).
+constexpr int kCurveCells = 64;
+template <int CIN>
+struct CurveCells {
+  static constexpr int kEntries = 0;
+  static constexpr int kScale = CIN * kCurveCells * 4;  // [CIN][4]
+  static constexpr int kOk = kScale + CIN * 4;          // [4]
+  static constexpr int kFloats = kOk + 4;
+};
+
+__device__ __forceinline__ unsigned curve_cell_byte(float t, float k16, float o16) {
+  const float u = __builtin_amdgcn_fmed3f(__builtin_fmaf(t, k16, o16), 0.0f, (float)(16 * kCurveCells - 1));
+  return (unsigned)u & ~15u;
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void curves_prepare_kernel(const GuideNet gn, float* __restrict__ out) {
+  typedef CurveTab<CIN> T;
+  typedef CurveCells<CIN> L;
+  __shared__ __attribute__((aligned(16))) float tab[T::kFloats];
+  __shared__ int cell_of[CIN * 16];
+  __shared__ float kk[CIN], oo[CIN];
+  __shared__ int bad;
+  const int tid = threadIdx.x;
+  if (tid == 0) bad = 0;
+  if (tid < 64) curves_build_tables<CIN>(tab, gn, tid);  // sorted leaves (knot, value at it, slope after it, 0); dead: +inf
+  __syncthreads();
+  const float inf = __builtin_inff();
+  if (tid < CIN) {
+    const float* lf = tab + T::kLeaf + tid * 64;
+    const float smin = lf[0];
+    float smax = smin;
+    for (int i = 1; i < 16; ++i) {
+      const float s = lf[4 * i];
+      if (s < inf) smax = s;
+    }
+    float k16 = 0.0f, o16 = 0.0f;
+    if (smin < inf && smax > smin) {
+      k16 = (float)(16 * (kCurveCells - 1)) / (smax - smin);
+      o16 = -smin * k16;
+      if (!(k16 < inf) || !(fabsf(o16) < inf)) k16 = o16 = 0.0f;  // a range too narrow to scale: one cell (ok only for one knot)
+    }
+    kk[tid] = k16;
+    oo[tid] = o16;
+  }
+  __syncthreads();
+  if (tid < CIN * 16) {
+    const float s = tab[T::kLeaf + tid * 4];
+    cell_of[tid] = (s < inf) ? (int)(curve_cell_byte(s, kk[tid >> 4], oo[tid >> 4]) >> 4) : 0x7fffffff;  // dead knots: no cell
+  }
+  __syncthreads();
+  for (int e = tid; e < CIN * kCurveCells; e += (int)blockDim.x) {
+    const int c = e / kCurveCells, j = e - c * kCurveCells;
+    int here = -1, count = 0, last = -1;
+    for (int i = 0; i < 16; ++i) {  // sorted knots + a monotone cell map: cell_of is non-decreasing in i
+      const int ci = cell_of[c * 16 + i];
+      if (ci == j) {
+        here = i;
+        ++count;
+      }
+      if (ci < j) last = i;
+    }
+    if (count > 1) bad = 1;  // (every writer writes 1)
+    float4 ent = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // left of every knot: the curve is 0
+    const float4* leaves = reinterpret_cast<const float4*>(tab + T::kLeaf + c * 64);
+    if (here >= 0) {
+      const float4 lf = leaves[here];
+      ent = make_float4(lf.x, lf.y, here > 0 ? leaves[here - 1].z : 0.0f, lf.z);
+    } else if (last >= 0) {
+      const float4 lf = leaves[last];
+      ent = make_float4(lf.x, lf.y, lf.z, lf.z);
+    }
+    reinterpret_cast<float4*>(out + L::kEntries)[e] = ent;
+  }
+  __syncthreads();
+  if (tid < CIN) reinterpret_cast<float4*>(out + L::kScale)[tid] = make_float4(kk[tid], oo[tid], 0.0f, 0.0f);
+  if (tid == 0) reinterpret_cast<float4*>(out + L::kOk)[0] = make_float4(bad ? 0.0f : 1.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// The guide of a lane's 4 pixels from the cell tables (`cells`: the entries, copied into LDS by the workgroup).  The colour
+// matrix and the cell coordinate run on pixel pairs (v_pk_fma_f32, parameters from SGPRs); mixing and clip as above.
+template <int CIN>
+__device__ __forceinline__ void guide_curves_quad_cells(const float* __restrict__ cells, const GuideNet& gn, const float* inf,
+                                                        float (&g)[kPxPerThread]) {
+  typedef CurveCells<CIN> L;
+  cfloat* ccm = (cfloat*)gn.conv1;
+  cfloat* mix = (cfloat*)gn.conv2;
+  cfloat* sc = (cfloat*)(gn.prepared + L::kScale);
+  static_assert(kPxPerThread == 4, "two pixel pairs");
+  float cv[kPxPerThread][CIN];
+#pragma unroll
+  for (int c = 0; c < CIN; ++c) {
+    float w[CIN + 1];
+#pragma unroll
+    for (int j = 0; j <= CIN; ++j) w[j] = ccm[c * (CIN + 1) + j];
+    const float k16 = sc[4 * c], o16 = sc[4 * c + 1];
+    const char* base = reinterpret_cast<const char*>(cells + c * kCurveCells * 4);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x2 t = {w[CIN], w[CIN]};
+#pragma unroll
+      for (int j = 0; j < CIN; ++j)
+        t = __builtin_elementwise_fma(f32x2{w[j], w[j]}, f32x2{inf[(2 * h) * CIN + j], inf[(2 * h + 1) * CIN + j]}, t);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float ti = i ? t.y : t.x;
+        const f32x4 e = *reinterpret_cast<const f32x4*>(base + curve_cell_byte(ti, k16, o16));
+        const float d = ti - e.x;
+        cv[2 * h + i][c] = __builtin_fmaf(d >= 0.0f ? e.w : e.z, d, e.y);
+      }
+    }
+  }
+  float m[CIN + 1];
+#pragma unroll
+  for (int c = 0; c <= CIN; ++c) m[c] = mix[c];
 #pragma unroll
   for (int q = 0; q < kPxPerThread; ++q) {
     float v = m[CIN];
@@ -485,9 +626,15 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
   constexpr int kTabFloats = NN_MFMA ? NnTab::kWords : 0;
   float* const lds = lds_all + kTabFloats;
   [[maybe_unused]] float* ctab = nullptr;
+  [[maybe_unused]] float* ccells = nullptr;
+  [[maybe_unused]] bool use_cells = false;
   if constexpr (GUIDE == kGuideCurves) {
     __shared__ __attribute__((aligned(16))) float curve_tables[CurveTab<CIN>::kFloats];
+    __shared__ __attribute__((aligned(16))) float curve_cells[CIN * kCurveCells * 4];
     ctab = curve_tables;
+    ccells = curve_cells;
+    // wave-uniform (scalar load): a prepared table whose cells separate the knots
+    if (p.gn.prepared) use_cells = ((cfloat*)(p.gn.prepared + CurveCells<CIN>::kOk))[0] != 0.0f;
   }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -522,7 +669,12 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
   }
 
   if constexpr (GUIDE == kGuideCurves) {
-    if (wave == 0) curves_build_tables<CIN>(ctab, p.gn, lane);  // published by the barrier below
+    if (use_cells) {  // the prepared cell tables: 3 KB copied by the whole workgroup (published by the barrier below)
+      const f32x4* src = reinterpret_cast<const f32x4*>(p.gn.prepared);
+      for (int e = tid; e < CIN * kCurveCells; e += (int)blockDim.x) reinterpret_cast<f32x4*>(ccells)[e] = src[e];
+    } else if (wave == 0) {
+      curves_build_tables<CIN>(ctab, p.gn, lane);  // published by the barrier below
+    }
   }
   const SegCols sc = seg_cols_tab(p.tab, blockIdx.x, xs, xe, p.scale_x);
   const int colb = (p.GD + 2) * CB;
@@ -550,8 +702,10 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
         }
         if (!done) guide_nn_quad<CIN>(GuideNN{p.gn.conv1, p.gn.conv2, p.gn.guide_out, p.gn.n, p.gn.fast_sigmoid, p.gn.prescaled}, inf, gs);  // (writes nothing itself)
       }
-      else if constexpr (GUIDE == kGuideCurves)
-        guide_curves_quad<CIN>(ctab, p.gn, inf, gs);
+      else if constexpr (GUIDE == kGuideCurves) {
+        if (use_cells) guide_curves_quad_cells<CIN>(ccells, p.gn, inf, gs);
+        else guide_curves_quad<CIN>(ctab, p.gn, inf, gs);
+      }
       else
         guide_curves_scan_quad<CIN>(p.gn, inf, gs);
       if (p.gn.guide_out) *reinterpret_cast<float4*>(p.gn.guide_out + px) = make_float4(gs[0], gs[1], gs[2], gs[3]);
@@ -648,7 +802,8 @@ hipError_t launch_io(const ApplyIoArgs& a, const Plan&, hipStream_t s) {
   p.white = io_white_level(a.white_level);
   p.grid_image = a.GH * a.GW * a.GD * C;
   p.tab = make_seg_tab(a.W, g.pl.seg, g.pl.nseg, p.scale_x);
-  p.gn = GuideNet{a.guide_conv1, a.guide_conv2, a.guide_shifts, a.guide_slopes, a.guide_out, a.n_feats, a.fast_sigmoid, a.guide_prescaled};
+  p.gn = GuideNet{a.guide_conv1, a.guide_conv2, a.guide_shifts, a.guide_slopes, a.guide_out, a.n_feats, a.fast_sigmoid, a.guide_prescaled,
+                     (a.guide_shifts && a.n_feats <= kCurveMaxKnots) ? a.guide_prepared : nullptr};
 #ifdef HDRNET_TOOLS_BUILD
   p.nn_mfma = tools_knob(5);
 #else
@@ -685,7 +840,7 @@ bool plan_io(const ApplyIoArgs& a, Plan* pl) {
                          (a.input_dtype == 0 ? (uintptr_t)a.input : 0);
   if (bits & 15u) return false;
   if (((uintptr_t)a.input | (uintptr_t)a.out) & 3u) return false;
-  const IoGeom g = io_geom(a.W, a.GW, a.GD, 12, 3, CurveTab<3>::kFloats);  // + the curves kernel's static tables: the largest of the kernels
+  const IoGeom g = io_geom(a.W, a.GW, a.GD, 12, 3, CurveTab<3>::kFloats + 3 * kCurveCells * 4);  // + the curves kernel's static tables: the largest of the kernels
   *pl = g.pl;
   if (a.B > 65535 || a.H > 65535 || (long long)a.W * a.Cout * 4 >= (1LL << 31)) return false;
   if ((long long)(g.slab_off) >= (1 << 20)) return false;
@@ -697,6 +852,16 @@ bool plan_io(const ApplyIoArgs& a, Plan* pl) {
 bool apply_fwd_io_supported(const ApplyIoArgs& a) {
   Plan pl;
   return plan_io(a, &pl);
+}
+
+size_t curves_guide_prepared_bytes(int Cin) { return Cin == 3 ? CurveCells<3>::kFloats * sizeof(float) : 0; }
+
+hipError_t launch_curves_guide_prepare(const float* shifts, const float* slopes, int npts, int Cin, float* prepared,
+                                       hipStream_t s) {
+  if (Cin != 3 || npts > kCurveMaxKnots) return hipErrorInvalidValue;
+  const GuideNet gn{nullptr, nullptr, shifts, slopes, nullptr, npts, false, false, nullptr};
+  curves_prepare_kernel<3><<<1, 256, 0, s>>>(gn, prepared);
+  return hipGetLastError();
 }
 
 hipError_t launch_apply_fwd_io(const ApplyIoArgs& a, hipStream_t s, const char** name) {

@@ -117,7 +117,7 @@ int variant(unsigned flags) { return (int)((flags >> 8) & 0xffu); }
 
 extern "C" {
 
-int hdrnet_version(void) { return 240; /* 0.2.4: + hdrnet_guide_nn_prescale_f32, HDRNET_GUIDE_RELU_PRESCALED */ }
+int hdrnet_version(void) { return 240; /* 0.2.4: + hdrnet_guide_nn_prescale_f32 / HDRNET_GUIDE_RELU_PRESCALED, hdrnet_curves_guide_prepare_f32 / ..._io_curves_prepared */ }
 
 const char* hdrnet_last_error(void) { return g_error; }
 
@@ -653,6 +653,38 @@ int hdrnet_bilateral_slice_apply_io_curves(const float* grid, const void* input,
                                            const float* guide_shifts, const float* guide_slopes,
                                            const float* guide_mix, int npts, float* guide_out,
                                            void* stream) {
+  return hdrnet_bilateral_slice_apply_io_curves_prepared(grid, input, out, B, H, W, GH, GW, GD, Cin, Cout, has_offset,
+                                                         input_dtype, input_white_level, output_dtype, guide_ccm,
+                                                         guide_shifts, guide_slopes, guide_mix, npts, nullptr, guide_out,
+                                                         stream);
+}
+
+size_t hdrnet_curves_guide_prepared_bytes(int Cin) { return hdrnet_amd::curves_guide_prepared_bytes(Cin); }
+
+int hdrnet_curves_guide_prepare_f32(const float* guide_shifts, const float* guide_slopes, int npts, int Cin,
+                                    void* prepared, size_t prepared_bytes, void* stream) {
+  using namespace hdrnet_amd;
+  const size_t need = curves_guide_prepared_bytes(Cin);
+  if (need == 0 || npts <= 0 || npts > 16)
+    return fail(HDRNET_INVALID_ARGUMENT, "curves prepare needs Cin = 3 and 1 .. 16 knots per channel (Cin=%d, npts=%d)", Cin,
+                npts);
+  if (!guide_shifts || !guide_slopes || !prepared) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
+  if (((uintptr_t)prepared & 15u) || prepared_bytes < need)
+    return fail(HDRNET_INVALID_ARGUMENT, "curves prepare needs a 16-B aligned buffer of hdrnet_curves_guide_prepared_bytes()");
+  const int rc = check_launch(launch_curves_guide_prepare(guide_shifts, guide_slopes, npts, Cin, static_cast<float*>(prepared),
+                                                          static_cast<hipStream_t>(stream)),
+                              "CurvesGuidePrepare");
+  if (rc == HDRNET_OK) set_kernel("curves_prepare");
+  return rc;
+}
+
+int hdrnet_bilateral_slice_apply_io_curves_prepared(const float* grid, const void* input, void* out, int B, int H,
+                                                    int W, int GH, int GW, int GD, int Cin, int Cout,
+                                                    int has_offset, int input_dtype, float input_white_level,
+                                                    int output_dtype, const float* guide_ccm,
+                                                    const float* guide_shifts, const float* guide_slopes,
+                                                    const float* guide_mix, int npts, const void* prepared,
+                                                    float* guide_out, void* stream) {
   using namespace hdrnet_amd;
   if (int rc = check_common(B, H, W, GH, GW, GD)) return rc;
   if (Cin <= 0 || Cout <= 0) return fail(HDRNET_INVALID_ARGUMENT, "bad channel counts");
@@ -672,6 +704,12 @@ int hdrnet_bilateral_slice_apply_io_curves(const float* grid, const void* input,
   ApplyIoArgs a{grid, nullptr, input, out, B, H, W, GH, GW, GD, Cin, Cout, has_offset != 0,
                 input_dtype, output_dtype, input_white_level, guide_ccm, guide_mix, npts,
                 guide_out, guide_shifts, guide_slopes};
+  if (prepared) {
+    if (((uintptr_t)prepared & 15u) || Cin != 3 || npts > 16)
+      return fail(HDRNET_INVALID_ARGUMENT, "prepared curves tables need Cin = 3, npts <= 16 and the 16-B aligned buffer "
+                                           "hdrnet_curves_guide_prepare_f32 wrote");
+    a.guide_prepared = static_cast<const float*>(prepared);
+  }
   if (!apply_fwd_io_supported(a))
     return fail(HDRNET_INVALID_ARGUMENT,
                 "the fused curves-guide forward supports Cin = Cout = 3 with offset, W %% 4 == 0, aligned "

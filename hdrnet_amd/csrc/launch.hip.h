@@ -48,6 +48,7 @@ struct ApplyIoArgs {
   const float* guide_slopes = nullptr;  //                                    [n][Cin]
   bool fast_sigmoid = false;            // guide network: as ApplyArgs::fast_sigmoid
   bool guide_prescaled = false;         // guide network: as ApplyArgs::guide_prescaled
+  const float* guide_prepared = nullptr;  // curves guide: the cell tables of hdrnet_curves_guide_prepare_f32, or null
 };
 
 struct ApplyGradArgs {
@@ -182,6 +183,10 @@ hipError_t launch_resize_bilinear(const float* in, float* out, int B, int Hin, i
 
 bool apply_fwd_io_supported(const ApplyIoArgs& a);
 hipError_t launch_apply_fwd_io(const ApplyIoArgs& a, hipStream_t s, const char** name);
+// the curves guide's uniform cell tables (apply_fwd_io.hip: CurveCells), prepared once per parameter set
+size_t curves_guide_prepared_bytes(int Cin);  // 0: no cell tables for this channel count
+hipError_t launch_curves_guide_prepare(const float* shifts, const float* slopes, int npts, int Cin, float* prepared,
+                                       hipStream_t s);
 
 // apply_bwd_rows.hip -- LDS-staged per-pixel VJPs: dguide and dinput in one pass
 // (BilateralSliceApply), dguide (BilateralSlice).  dgrid is not their business.

@@ -36,7 +36,7 @@ from . import _lib
 
 __all__ = ["bilateral_slice", "bilateral_slice_apply", "bilateral_slice_apply_rows", "bilateral_slice_apply_nnguide",
            "bilateral_slice_apply_io", "bilateral_slice_apply_curves", "bilateral_slice_apply_upadd", "resize_bilinear", "input_moments",
-           "CoefficientWeights", "coefficients", "coefficients_train", "coefficients_train_supported", "guide_fold_batch", "guide_nn_prescale",
+           "CoefficientWeights", "coefficients", "coefficients_train", "coefficients_train_supported", "guide_fold_batch", "guide_nn_prescale", "curves_guide_prepare",
            "kernel_override", "last_kernel"]
 
 _tls = threading.local()
@@ -502,16 +502,19 @@ class _BilateralSliceApplyCurves(torch.autograd.Function):
 
 def bilateral_slice_apply_curves(grid: torch.Tensor, input: torch.Tensor, ccm: torch.Tensor,  # noqa: A002
                                  shifts: torch.Tensor, slopes: torch.Tensor, mix: torch.Tensor,
-                                 has_offset: bool = True) -> torch.Tensor:
+                                 has_offset: bool = True, prepared: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``HDRNetCurves._guide`` (hdrnet/models.py:145-190) fused with ``bilateral_slice_apply``, fp32,
     differentiable in ``grid``, ``input`` and the four guide parameter arrays (layouts of
     hdrnet/bin/freeze_graph.py:107-127: ccm [3, 4], shifts / slopes [16, 3], mix [4]).  The wire-format
-    inference variant is ``bilateral_slice_apply_io(..., guide_curves=...)``."""
+    inference variant is ``bilateral_slice_apply_io(..., guide_curves=...)``.  ``prepared`` (forward without autograd
+    only): the tables of ``curves_guide_prepare(shifts, slopes)``."""
     if torch.is_grad_enabled() and any(t.requires_grad for t in (grid, input, ccm, shifts, slopes, mix)):
+        if prepared is not None:
+            raise ValueError("bilateral_slice_apply_curves: prepared tables are inference-only")
         if input.dim() != 4 or input.shape[3] != 3 or shifts.dim() != 2 or shifts.shape[0] != 16:
             raise ValueError("the differentiable curves-guide op needs Cin = 3 and 16 knots per channel")
         return _BilateralSliceApplyCurves.apply(grid, input, ccm, shifts, slopes, mix, has_offset)
-    return _apply_io_curves(grid, input, (ccm, shifts, slopes, mix), None, torch.float32, has_offset, False)
+    return _apply_io_curves(grid, input, (ccm, shifts, slopes, mix), None, torch.float32, has_offset, False, prepared)
 
 
 def input_moments(input: torch.Tensor):  # noqa: A002
@@ -946,7 +949,35 @@ def _check_io(grid, input, has_offset):  # noqa: A002
     return B, H, W, GH, GW, GD, Cin, C // Cj
 
 
-def _apply_io_curves(grid, input, curves, input_white_level, out_dtype, has_offset, return_guide):  # noqa: A002
+def curves_guide_prepare(shifts: torch.Tensor, slopes: torch.Tensor) -> torch.Tensor:
+    """The curves guide's lookup tables, PREPARED once per parameter set (``hdrnet_curves_guide_prepare_f32``; Cin = 3,
+    at most 16 knots per channel): each channel's knot range cut into 64 uniform cells, per cell the knot inside it, the
+    curve's float64-summed value there and the slopes on either side.  Passed to ``bilateral_slice_apply_curves`` /
+    ``bilateral_slice_apply_io`` as ``prepared`` / ``curves_prepared``, a pixel finds its cell by arithmetic and reads ONE
+    table entry, where the plain call has every workgroup sort the knots and every pixel walk a search tree.  Same guide to
+    1e-6; if two knots of a channel share a cell the buffer says so and the kernels take the plain path.  ``shifts`` /
+    ``slopes``: ``[npts, 3]`` (hdrnet/bin/freeze_graph.py:107-127).  Returns an opaque float32 tensor."""
+    _require_f32("shifts", shifts)
+    _require_f32("slopes", slopes)
+    _require_gpu("shifts", shifts)
+    _require_gpu("slopes", slopes)
+    if shifts.dim() != 2 or shifts.shape[1] != 3 or tuple(slopes.shape) != tuple(shifts.shape) or not 0 < shifts.shape[0] <= 16:
+        raise ValueError(f"curves_guide_prepare: shifts / slopes [npts <= 16, 3] expected, got {tuple(shifts.shape)}, "
+                         f"{tuple(slopes.shape)}")
+    sh, sl = shifts.detach().contiguous(), slopes.detach().contiguous()
+    dev = sh.device
+    lib = _lib.load()
+    nbytes = lib.hdrnet_curves_guide_prepared_bytes(3)
+    out = torch.empty((nbytes // 4,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.hdrnet_curves_guide_prepare_f32(sh.data_ptr(), sl.data_ptr(), sh.shape[0], 3, out.data_ptr(), nbytes,
+                                                 _stream(dev))
+    _lib.check(rc, "CurvesGuidePrepare")
+    return out
+
+
+def _apply_io_curves(grid, input, curves, input_white_level, out_dtype, has_offset, return_guide,  # noqa: A002
+                     prepared=None):
     if len(curves) != 4:
         raise ValueError("guide_curves should be (ccm, shifts, slopes, mix)")
     ccm, shifts, slopes, mix = curves
@@ -965,14 +996,20 @@ def _apply_io_curves(grid, input, curves, input_white_level, out_dtype, has_offs
     grid, inp = grid.detach().contiguous(), input.detach().contiguous()
     ccm, shifts, slopes, mix = (t.detach().contiguous() for t in (ccm, shifts, slopes, mix))
     dev = inp.device
+    lib = _lib.load()
+    if prepared is not None:
+        _require_f32("prepared", prepared)
+        _require_gpu("prepared", prepared)
+        if not prepared.is_contiguous() or prepared.numel() * 4 < lib.hdrnet_curves_guide_prepared_bytes(Cin):
+            raise ValueError("prepared should be the tensor curves_guide_prepare returned")
     out = torch.empty((B, H, W, Cout), dtype=out_dtype, device=dev)
     gout = torch.empty((B, H, W), dtype=torch.float32, device=dev) if return_guide else None
-    lib = _lib.load()
     with torch.cuda.device(dev):
-        rc = lib.hdrnet_bilateral_slice_apply_io_curves(
+        rc = lib.hdrnet_bilateral_slice_apply_io_curves_prepared(
             grid.data_ptr(), inp.data_ptr(), out.data_ptr(), B, H, W, GH, GW, GD, Cin, Cout,
             int(bool(has_offset)), _DTYPE_CODE[input.dtype], float(input_white_level), _DTYPE_CODE[out_dtype],
-            ccm.data_ptr(), shifts.data_ptr(), slopes.data_ptr(), mix.data_ptr(), npts, _ptr(gout), _stream(dev))
+            ccm.data_ptr(), shifts.data_ptr(), slopes.data_ptr(), mix.data_ptr(), npts, _ptr(prepared), _ptr(gout),
+            _stream(dev))
     _lib.check(rc, "BilateralSliceApplyIOCurves")
     return (out, gout) if return_guide else out
 
@@ -985,7 +1022,8 @@ def bilateral_slice_apply_io(grid: torch.Tensor, input: torch.Tensor,  # noqa: A
                              out_dtype: torch.dtype = torch.float32,
                              has_offset: bool = True,
                              guide_curves: Optional[Tuple[torch.Tensor, ...]] = None,
-                             return_guide: bool = False, fast_sigmoid: bool = False, prescaled: bool = False):
+                             return_guide: bool = False, fast_sigmoid: bool = False, prescaled: bool = False,
+                             curves_prepared: Optional[torch.Tensor] = None):
     """Inference forward with the product's wire formats fused in: ``input`` may be uint8 / uint16
     (``value / input_white_level``: 255, 65535, or 32767 for HDR+ -- hdrnet/data_pipeline.py:202-232,
     :267-274) and the output may be uint8 ``= (uint8)(255 * clip(out, 0, 1))`` (hdrnet/bin/run.py:95).
@@ -997,7 +1035,8 @@ def bilateral_slice_apply_io(grid: torch.Tensor, input: torch.Tensor,  # noqa: A
     returns the guide map the kernel computed.  ``fast_sigmoid`` (guide network): the hardware exp / reciprocal
     sigmoid, <= 2 ulp of the guide away from the default (tf.nn.sigmoid's form) and ~10 % faster -- an explicit
     choice of the caller (HDRNET_GUIDE_SIGMOID_FAST), never implied by another argument.  ``prescaled`` (guide network):
-    ``guide_conv1`` / ``guide_conv2`` are ``guide_nn_prescale``'s arrays (HDRNET_GUIDE_RELU_PRESCALED).  No autograd."""
+    ``guide_conv1`` / ``guide_conv2`` are ``guide_nn_prescale``'s arrays (HDRNET_GUIDE_RELU_PRESCALED).
+    ``curves_prepared`` (``guide_curves``): the tables of ``curves_guide_prepare``.  No autograd."""
     if input.dim() != 4:
         raise ValueError(f"Input image should be 4D (batch_size, height, width, input_channels), got {tuple(input.shape)}")
     if input.dtype not in _DTYPE_CODE:
@@ -1007,7 +1046,8 @@ def bilateral_slice_apply_io(grid: torch.Tensor, input: torch.Tensor,  # noqa: A
     if guide_curves is not None:
         if guide is not None or guide_conv1 is not None or guide_conv2 is not None:
             raise ValueError("give exactly one of guide, (guide_conv1, guide_conv2), guide_curves")
-        return _apply_io_curves(grid, input, guide_curves, input_white_level, out_dtype, has_offset, return_guide)
+        return _apply_io_curves(grid, input, guide_curves, input_white_level, out_dtype, has_offset, return_guide,
+                                curves_prepared)
     if return_guide and guide is not None:
         raise ValueError("return_guide needs a guide computed by the kernel (guide network or guide_curves)")
     if (guide is None) == (guide_conv1 is None or guide_conv2 is None):

@@ -323,6 +323,22 @@ class _CurvesGuide(nn.Module):
             self._exported_cache = (key, out)  # inference replays these four arrays: no re-packing launches per frame
         return out
 
+    def prepared(self):
+        """The curves' lookup tables prepared once per parameter state (``hdrnet_ops.curves_guide_prepare``: uniform cells
+        instead of a per-workgroup sort + per-pixel tree search), or None off the GPU / for other shapes."""
+        _, shifts, slopes, _ = self.exported()
+        if not (shifts.is_cuda and shifts.shape[1] == 3 and shifts.shape[0] <= 16):
+            return None
+        key = _param_key(self.parameters())
+        cached = getattr(self, "_prepared_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        from . import hdrnet_ops
+        out = hdrnet_ops.curves_guide_prepare(shifts, slopes)
+        if _cacheable():
+            self._prepared_cache = (key, out)
+        return out
+
     def exported_differentiable(self):
         """Same arrays, attached to the autograd graph (training through the fused op)."""
         ccm = torch.cat([self.ccm, self.ccm_bias[None, :]], dim=0).t().contiguous()
@@ -453,6 +469,8 @@ class HDRNetCurves(nn.Module):
     # ... and the guide network's PRESCALED parameters (HDRNET_GUIDE_RELU_PRESCALED): bit-identical guide for |input| <=
     # _PointwiseNNGuide.prescale_x_max, relu from the clamp modifier.  Inference only, like fast_sigmoid.
     prescale_guide = True
+    # ... and the curves guide's lookup tables prepared once per parameter state (hdrnet_curves_guide_prepare_f32)
+    prepare_curves = True
 
     def forward(self, lowres_input: torch.Tensor, fullres_input: torch.Tensor) -> torch.Tensor:
         coeffs = self.coefficients(lowres_input)
@@ -466,8 +484,11 @@ class HDRNetCurves(nn.Module):
             differentiable = torch.is_grad_enabled() and (
                 fullres_input.requires_grad or any(p.requires_grad for p in self.parameters()))
             arrays = self.guide.exported_differentiable() if differentiable else self.guide.exported()
+            # inference: the curves' tables prepared once per parameter state (same guide to 1e-6, ~0.9 x the time)
+            prepared = None if (differentiable or not self.prepare_curves) else self.guide.prepared()
             return hdrnet_ops.bilateral_slice_apply_curves(
-                coeffs.reshape(gs[0], gs[1], gs[2], gs[3], gs[4] * gs[5]), fullres_input, *arrays, has_offset=True)
+                coeffs.reshape(gs[0], gs[1], gs[2], gs[3], gs[4] * gs[5]), fullres_input, *arrays, has_offset=True,
+                prepared=prepared)
         guide = self.guide(fullres_input)
         # models.py:193-196 -- the one call site of the hot path
         return layers.bilateral_slice_apply(coeffs, guide, fullres_input, has_offset=True, name="slice")

@@ -185,6 +185,29 @@ int hdrnet_bilateral_slice_apply_io_curves(const float* grid, const void* input,
                                            const float* guide_slopes, const float* guide_mix,
                                            int npts, float* guide_out, void* stream);
 
+/* The same pass with the curves' lookup tables PREPARED once per parameter set (Cin = 3, npts <= 16).
+ * hdrnet_curves_guide_prepare_f32 (one small launch on `stream`) sorts each channel's knots, sums the curve's value
+ * and slope at every knot in float64, and cuts the knot range into 64 uniform cells -- per cell the knot inside it (or
+ * the last one before it), the value there, the slopes on either side -- into `prepared`, a caller-owned, 16-B aligned
+ * buffer of hdrnet_curves_guide_prepared_bytes(Cin) bytes.  hdrnet_bilateral_slice_apply_io_curves_prepared takes that
+ * buffer beside the exported arrays: a pixel finds its cell by arithmetic (a monotone fp32 map, so the cell's knot is
+ * the only one left to compare with) and evaluates  C + (t >= s ? A_hi : A_lo) (t - s)  from ONE 16-byte table read,
+ * where the plain entry point has every workgroup sort the knots itself and every pixel walk a 4-level search tree.
+ * Same guide to 1e-6 (the anchor knot is at most one cell away).  If two knots of a channel fall into one cell the
+ * prepared buffer says so and the kernel uses the plain path: identical results to hdrnet_bilateral_slice_apply_io_curves.
+ * `prepared` == NULL: exactly hdrnet_bilateral_slice_apply_io_curves. */
+size_t hdrnet_curves_guide_prepared_bytes(int Cin);
+int hdrnet_curves_guide_prepare_f32(const float* guide_shifts, const float* guide_slopes, int npts, int Cin,
+                                    void* prepared, size_t prepared_bytes, void* stream);
+int hdrnet_bilateral_slice_apply_io_curves_prepared(const float* grid, const void* input, void* out, int B,
+                                                    int H, int W, int GH, int GW, int GD, int Cin,
+                                                    int Cout, int has_offset, int input_dtype,
+                                                    float input_white_level, int output_dtype,
+                                                    const float* guide_ccm, const float* guide_shifts,
+                                                    const float* guide_slopes, const float* guide_mix,
+                                                    int npts, const void* prepared, float* guide_out,
+                                                    void* stream);
+
 /* Multi-scale output of HDRNetGaussianPyrNN (hdrnet/models.py:277-289): per pyramid level
  *   out = BilateralSliceApply(grid_level, guide_level, input_level)
  *         + resize_bilinear(coarser level's result -> H x W, align_corners = True)

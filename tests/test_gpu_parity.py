@@ -493,14 +493,88 @@ def test_curves_guide_fused_matches_composed_oracle(dev, ops, port, in_dtype, ou
     assert ops.last_kernel() == f"apply_fwd_io/{ {'float32': 'f32', 'uint8': 'u8', 'uint16': 'u16'}[in_dtype]}->" \
                                 f"{ {'float32': 'f32', 'uint8': 'u8'}[out_dtype]}+curvesguide"
     np.testing.assert_allclose(N(gout), guide, rtol=0, atol=2e-6)
-    if out_dtype == "float32":
-        np.testing.assert_allclose(N(out), want, rtol=1e-5, atol=1e-5)
-    else:
-        q = np.clip(want, 0, 1) * np.float32(255)
-        got = N(out).astype(np.int32)
-        exact = q.astype(np.uint8).astype(np.int32)
-        near_edge = np.abs(q - np.round(q)) < 1e-5 * 255
-        assert np.all((got == exact) | (near_edge & (np.abs(got - exact) <= 1)))
+
+    def check(out):
+        if out_dtype == "float32":
+            np.testing.assert_allclose(N(out), want, rtol=1e-5, atol=1e-5)
+        else:
+            q = np.clip(want, 0, 1) * np.float32(255)
+            got = N(out).astype(np.int32)
+            exact = q.astype(np.uint8).astype(np.int32)
+            near_edge = np.abs(q - np.round(q)) < 1e-5 * 255
+            assert np.all((got == exact) | (near_edge & (np.abs(got - exact) <= 1)))
+
+    check(out)
+    # the same with the tables PREPARED once (hdrnet_curves_guide_prepare_f32: uniform cells, one table read per channel
+    # and pixel instead of a per-workgroup sort + a 4-level search): the same bars against the oracle, and within 5e-7 of
+    # the plain path's guide
+    prep = ops.curves_guide_prepare(T(shifts, dev), T(slopes, dev))
+    assert float(prep[3 * 64 * 4 + 12]) == 1.0  # the cells separate these knots
+    out_p, gout_p = ops.bilateral_slice_apply_io(
+        T(grid, dev), traw, guide_curves=tuple(T(a, dev) for a in (ccm, shifts, slopes, mix)),
+        input_white_level=wl, out_dtype=getattr(torch, out_dtype), return_guide=True, curves_prepared=prep)
+    np.testing.assert_allclose(N(gout_p), guide, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(N(gout_p), N(gout), rtol=0, atol=5e-7)
+    check(out_p)
+
+
+@pytest.mark.parametrize("case", ["shuffled", "five_knots", "one_knot", "wide_range", "tie", "cluster"])
+def test_curves_prepared_tables_cases(dev, ops, port, case):
+    """The prepared cell tables on knot sets other than the reference's initialisation: knots in any order, fewer than 16
+    knots, a single knot, a range far from [0, 1]; and the two cases a cell table cannot hold -- two equal knots, two knots
+    closer than a cell -- where the prepared buffer's `ok` word is 0 and the kernel takes the plain path (bit-identical to
+    the call without a prepared buffer).  Otherwise: the oracle's guide to 2e-6, the plain path's to 5e-7 x the curve's scale."""
+    import oracle
+    B, H, W = 1, 24, 128
+    rng = np.random.default_rng(len(case))
+    grid = T(rng.random((B, 16, 16, 8, 12)).astype(np.float32), dev)
+    x = rng.random((B, H, W, 3)).astype(np.float32)
+    ccm = (np.concatenate([np.eye(3), np.zeros((3, 1))], 1) + 0.2 * rng.standard_normal((3, 4))).astype(np.float32)
+    mix = np.array([0.4, 0.35, 0.25, 0.02], np.float32)
+    npts, scale, want_ok = 16, 1.0, True
+    shifts = np.tile(np.linspace(0, 1, 16, endpoint=False)[:, None], (1, 3)) + 0.01 * rng.standard_normal((16, 3))
+    if case == "shuffled":
+        for c in range(3):
+            shifts[:, c] = rng.permutation(shifts[:, c])
+    elif case == "five_knots":
+        npts = 5
+        shifts = np.sort(rng.random((5, 3)) * 0.8 + 0.1, axis=0)
+        shifts[:, 1] = shifts[::-1, 1]
+    elif case == "one_knot":
+        npts = 1
+        shifts = np.array([[0.1, 0.3, -0.2]])
+    elif case == "wide_range":
+        scale = 40.0
+        shifts = shifts * 40.0 - 7.0
+        x = (x * 40.0 - 7.0).astype(np.float32)
+    elif case == "tie":
+        shifts[5, 1] = shifts[4, 1]
+        want_ok = False
+    elif case == "cluster":
+        shifts[9, 2] = shifts[8, 2] + 1e-4
+        want_ok = False
+    shifts = shifts.astype(np.float32)
+    slopes = (0.3 * rng.standard_normal((npts, 3))).astype(np.float32)
+    slopes[0] += 1.0
+    if case == "wide_range":
+        slopes /= 40.0
+    guide = oracle.curves_guide(x, ccm, shifts, slopes, mix)
+    assert guide.std() > 0.02  # the clip does not swallow the test
+    curves = tuple(T(a, dev) for a in (ccm, shifts, slopes, mix))
+    prep = ops.curves_guide_prepare(curves[1], curves[2])
+    assert float(prep[3 * 64 * 4 + 12]) == (1.0 if want_ok else 0.0)
+    out, g = ops.bilateral_slice_apply_io(grid, T(x, dev), guide_curves=curves, return_guide=True)
+    out_p, g_p = ops.bilateral_slice_apply_io(grid, T(x, dev), guide_curves=curves, return_guide=True, curves_prepared=prep)
+    if not want_ok:
+        assert torch.equal(g_p, g) and torch.equal(out_p, out)
+        return
+    np.testing.assert_allclose(N(g_p), guide, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(N(g_p), N(g), rtol=0, atol=5e-7)
+    want = port.bilateral_slice_apply(N(grid), guide, x, True)
+    np.testing.assert_allclose(N(out_p), want, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(want).max())))
+    # the differentiable op refuses a prepared table
+    with pytest.raises(ValueError, match="inference-only"):
+        ops.bilateral_slice_apply_curves(grid.clone().requires_grad_(True), T(x, dev), *curves, prepared=prep)
 
 
 # ---- pyramid output (SURVEY.md section 8f row 4): resize + slice-apply fused with the up-add -------

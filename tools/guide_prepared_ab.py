@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""Interleaved A/B of the fused guide-network forwards with the exported parameter layout and with the PRESCALED one
-(HDRNET_GUIDE_RELU_PRESCALED, include/hdrnet_amd.h): same process, alternating rounds, rotating buffer sets.
+"""Interleaved A/B of the fused-guide forwards with the exported parameter arrays and with parameters PREPARED once per
+parameter set: same process, alternating rounds, rotating buffer sets.
 
-    python tools/nn_prescale_ab.py [--workload 4k] [--rounds 7] [--steps 100]
+    python tools/guide_prepared_ab.py [--workload 4k] [--rounds 7] [--steps 100]
 
-Cases: f32 -> guide network -> apply (apply_fwd_seg<GUIDE_NN>), uint8 -> guide network -> apply -> uint8 (apply_fwd_io),
-guide network + apply + up-add of the coarser pyramid level.  Checks first that the two forms give the same bits.
+Guide network (HDRNET_GUIDE_RELU_PRESCALED, hdrnet_guide_nn_prescale_f32): f32 -> guide network -> apply
+(apply_fwd_seg<GUIDE_NN>), uint8 -> guide network -> apply -> uint8 (apply_fwd_io), guide network + apply + up-add of the
+coarser pyramid level; the two forms give the same bits (checked).  Curves guide (hdrnet_curves_guide_prepare_f32 +
+..._io_curves_prepared): f32 -> f32 and uint8 -> uint8; the guide agrees to 1e-6 (max difference of the outputs printed).
 """
 import argparse
 import os
@@ -76,14 +78,36 @@ def main():
                                                           s["coarse"].data_ptr(), H // 2, W // 2, s["out"].data_ptr(), B, H, W,
                                                           GH, GW, GD, 3, 3, 1, c1, c2, 16, fl, stream))
 
+    ccm = torch.cat([torch.eye(3, device=dev), torch.zeros((3, 1), device=dev)], 1) + 0.1 * torch.randn((3, 4), device=dev, generator=gen)
+    shifts = (torch.linspace(0, 1, 17, device=dev)[:-1, None].repeat(1, 3)
+              + 0.01 * torch.randn((16, 3), device=dev, generator=gen)).contiguous()
+    slopes = (0.2 * torch.randn((16, 3), device=dev, generator=gen)).contiguous()
+    mixv = torch.tensor([0.4, 0.35, 0.25, 0.0], device=dev)
+    nprep = lib.hdrnet_curves_guide_prepared_bytes(3)
+    prep = torch.empty((nprep // 4,), device=dev)
+    chk(lib.hdrnet_curves_guide_prepare_f32(shifts.data_ptr(), slopes.data_ptr(), 16, 3, prep.data_ptr(), nprep, stream))
+    torch.cuda.synchronize()
+    print(f"curves tables prepared: ok = {float(prep[3 * 64 * 4 + 12])}")
+
+    def curves(k, pre, u8io):
+        s = S[k % nsets]
+        chk(lib.hdrnet_bilateral_slice_apply_io_curves_prepared(
+            s["grid"].data_ptr(), (s["u8"] if u8io else s["inp"]).data_ptr(), (s["o8"] if u8io else s["out"]).data_ptr(),
+            B, H, W, GH, GW, GD, 3, 3, 1, 1 if u8io else 0, 255.0 if u8io else 1.0, 1 if u8io else 0, ccm.data_ptr(),
+            shifts.data_ptr(), slopes.data_ptr(), mixv.data_ptr(), 16, prep.data_ptr() if pre else None, None, stream))
+
     print(f"{desc}; {nsets} rotating sets")
     for name, fn, key in (("f32 -> NN guide -> apply", f32, "out"), ("u8 -> NN guide -> apply -> u8", u8, "o8"),
-                          ("NN guide + apply + up-add", upadd, "out")):
+                          ("NN guide + apply + up-add", upadd, "out"),
+                          ("f32 -> curves guide -> apply", lambda k, pre: curves(k, pre, False), "out"),
+                          ("u8 -> curves guide -> apply -> u8", lambda k, pre: curves(k, pre, True), "o8")):
         fn(0, False)
         a = S[0][key].clone()
         fn(0, True)
         torch.cuda.synchronize()
         same = torch.equal(a, S[0][key])
+        if not same:
+            same = f"no, max |diff| = {float((a.float() - S[0][key].float()).abs().max()):.3g}"
         kern = lib.hdrnet_last_kernel().decode()
         t = {False: [], True: []}
         for k in range(600):  # pre-roll
@@ -101,7 +125,7 @@ def main():
                 torch.cuda.synchronize()
                 t[pre].append(e0.elapsed_time(e1) * 1e3 / args.steps)
         m0, m1 = statistics.median(t[False]), statistics.median(t[True])
-        print(f"{name:32s} {kern:34s} exported {m0:7.2f} us (min {min(t[False]):7.2f})   prescaled {m1:7.2f} us "
+        print(f"{name:34s} {kern:34s} exported {m0:7.2f} us (min {min(t[False]):7.2f})   prepared {m1:7.2f} us "
               f"(min {min(t[True]):7.2f})   x{m1 / m0:.3f}   bit-identical: {same}")
 
 

@@ -131,12 +131,19 @@ def main():
     slopes = (0.2 * torch.randn((16, 3), device=dev, generator=gen)).contiguous()
     mixv = torch.tensor([0.4, 0.35, 0.25, 0.0], device=dev)
 
-    def apply_io_curves(k, u8io=True):
+    # the curves' lookup tables prepared once per parameter set (hdrnet_curves_guide_prepare_f32; what the models' inference
+    # passes since round 5); `pre=False` lines time the exported arrays alone (every workgroup sorts the knots itself)
+    nprep = lib.hdrnet_curves_guide_prepared_bytes(3)
+    cprep = torch.empty((nprep // 4,), device=dev)
+    chk(lib.hdrnet_curves_guide_prepare_f32(shifts.data_ptr(), slopes.data_ptr(), 16, 3, cprep.data_ptr(), nprep, stream))
+
+    def apply_io_curves(k, u8io=True, pre=True):
         s, t = S[k % nsets], u8[k % nsets]
-        chk(lib.hdrnet_bilateral_slice_apply_io_curves(
+        chk(lib.hdrnet_bilateral_slice_apply_io_curves_prepared(
             s["grid"].data_ptr(), (t["inp"] if u8io else s["inp"]).data_ptr(), (t["out"] if u8io else s["out"]).data_ptr(),
             B, H, W, GH, GW, GD, 3, 3, 1, 1 if u8io else 0, 255.0 if u8io else 1.0, 1 if u8io else 0,
-            ccm.data_ptr(), shifts.data_ptr(), slopes.data_ptr(), mixv.data_ptr(), 16, None, stream))
+            ccm.data_ptr(), shifts.data_ptr(), slopes.data_ptr(), mixv.data_ptr(), 16, cprep.data_ptr() if pre else None,
+            None, stream))
 
     coarse = [torch.randn((B, H // 2, W // 2, 3), device=dev, generator=gen) for _ in range(nsets)]
     half = [torch.empty((B, H // 2, W // 2, 3), device=dev) for _ in range(nsets)]
@@ -210,7 +217,10 @@ def main():
     run("... exported layout (no prescale)", lambda k: apply_io_u8(k, pre=False), npx * 6 + gridb)
     run("u8 + guide map -> apply -> u8", lambda k: apply_io_u8(k, nn=False), npx * 10 + gridb)
     run("curves guide + apply fwd fused", lambda k: apply_io_curves(k, u8io=False), 4 * npx * (Cin + Cout) + gridb)
+    run("... exported arrays only (no prepared tables)", lambda k: apply_io_curves(k, u8io=False, pre=False),
+        4 * npx * (Cin + Cout) + gridb)
     run("u8 -> curves guide + apply -> u8", apply_io_curves, npx * 6 + gridb)
+    run("... exported arrays only (no prepared tables)", lambda k: apply_io_curves(k, pre=False), npx * 6 + gridb)
     run("apply + up-add of coarse level", lambda k: apply_upadd(k, nn=False),
         4 * npx * (1 + Cin + Cout) + gridb + 4 * npx * 3 // 4)
     run("guide-NN + apply + up-add", apply_upadd, 4 * npx * (Cin + Cout) + gridb + 4 * npx * 3 // 4)
