@@ -926,11 +926,12 @@ long long* g_gg_trace = nullptr;  // tools: phase-trace buffer (grid_grad_set_tr
 // Workgroups of `kfn` resident on the device at once (occupancy x CUs).  Queried once per kernel.
 typedef void (*Stage1Fn)(GGParams);
 
-long long resident_slots(Stage1Fn kfn, std::atomic<int>* cache) {
+long long resident_slots(Stage1Fn kfn, std::atomic<int>* cache, size_t dyn_lds = 0) {
+  if (dyn_lds) cache = nullptr;  // (tools: an occupancy experiment -- never cached)
   int occ = cache ? cache->load(std::memory_order_relaxed) : 0;
   if (occ <= 0) {
     occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kfn), kWaves * 64, 0) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kfn), kWaves * 64, dyn_lds) !=
             hipSuccess || occ <= 0)
       occ = 1;
     if (occ > kMaxOcc) occ = kMaxOcc;  // the workspace bound (gg_ws_bound) covers 1 .. kMaxOcc
@@ -993,13 +994,20 @@ hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int G
 #endif
     }
   }
+#ifdef HDRNET_TOOLS_BUILD
+  // tools knob 1: bytes of UNUSED dynamic LDS per workgroup -- lowers the resident workgroups per CU (and re-fits the
+  // row groups to the new round size) to measure what a resident wave is worth (profiles/r05/bwd_steps.md)
+  const size_t dyn_lds = (size_t)(tools_knob(1) > 0 ? tools_knob(1) : 0);
+#else
+  const size_t dyn_lds = 0;
+#endif
   GGPlan pl;
-  if (!gg_plan(B, H, W, GH, GW, GD, C, resident_slots(kfn, occ), &pl) || pl.ws_bytes > ws_bytes)
+  if (!gg_plan(B, H, W, GH, GW, GD, C, resident_slots(kfn, occ, dyn_lds), &pl) || pl.ws_bytes > ws_bytes)
     return hipErrorInvalidValue;
   GGParams p{q.guide, q.input, q.dout, q.grid, q.dguide, q.dinput, static_cast<float*>(ws), H, W, GH, GW, GD,
              pl.rg, pl.nyg, pl.ntasks, (float)GW / W, (float)GH / H, g_gg_trace};
   const dim3 nblocks((unsigned)(GW + 1), (unsigned)pl.nyg, (unsigned)B);
-  kfn<<<nblocks, kWaves * 64, 0, s>>>(p);
+  kfn<<<nblocks, kWaves * 64, dyn_lds, s>>>(p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   grid_grad_stage2<<<dim3((unsigned)GW, (unsigned)GH, (unsigned)B), 512, 0, s>>>(

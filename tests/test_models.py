@@ -725,6 +725,20 @@ def test_curves_model_fused_matches_composed():
         ref = m(low, full)
         assert hdrnet_ops.last_kernel() == "apply_fwd_seg/vec4"
     torch.testing.assert_close(out, ref, rtol=3e-5, atol=3e-5)
+    # the inference forward used the curves' PREPARED lookup tables (round 5), cached per parameter state: a changed knot
+    # set must rebuild them (and give the same result as without them: prepare_curves = False)
+    assert m.prepare_curves and getattr(m.guide, "_prepared_cache", None) is not None
+    with torch.no_grad():
+        m.guide.shifts.add_(torch.randn(3, 16, device=dev) * 0.02)
+        del m.fuse_guide
+        out2 = m(low, full)
+        m.prepare_curves = False
+        out3 = m(low, full)
+        m.fuse_guide = False
+        ref2 = m(low, full)
+    assert (out2 - out).abs().max() > 1e-4
+    torch.testing.assert_close(out2, ref2, rtol=3e-5, atol=3e-5)
+    torch.testing.assert_close(out2, out3, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.gpu

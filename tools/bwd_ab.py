@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--cases", default="all,gg,g")
     ap.add_argument("--variants", default="0,3,4,5")
     ap.add_argument("--smooth", action="store_true", help="a smooth luminance-like guide (bench.make_sets) instead of U[0,1)")
+    ap.add_argument("--lds-pad", default="", help="comma-separated bytes of unused dynamic LDS per stage-1 workgroup (tools knob 1): "
+                    "every (case, variant) is timed at each value, interleaved -- what a resident wave is worth")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load_tools()
@@ -90,17 +92,31 @@ def main():
 
     cases = args.cases.split(",")
     variants = [int(v) for v in args.variants.split(",")]
+    pads = [int(v) for v in args.lds_pad.split(",")] if args.lds_pad else [None]
     fns, names = {}, {}
+
+    def padded(f, pad):
+        if pad is None:
+            return f
+
+        def g(k):
+            lib.hdrnet_tools_set_knob(1, pad)
+            f(k)
+            lib.hdrnet_tools_set_knob(1, 0)
+        return g
+
     for c in cases:
         for v in variants:
-            try:
-                f = make(c, v)
-                f(0)
-                torch.cuda.synchronize()
-                fns[(c, v)] = f
-                names[(c, v)] = lib.hdrnet_last_kernel().decode()
-            except Exception as e:  # noqa: BLE001
-                print(f"case {c} variant {v}: unavailable ({e})")
+            for pad in pads:
+                try:
+                    f = padded(make(c, v), pad)
+                    f(0)
+                    torch.cuda.synchronize()
+                    key = (c, v) if pad is None else (c, v, pad)
+                    fns[key] = f
+                    names[key] = lib.hdrnet_last_kernel().decode() + ("" if pad is None else f" +{pad} B LDS")
+                except Exception as e:  # noqa: BLE001
+                    print(f"case {c} variant {v}: unavailable ({e})")
     time_launches(next(iter(fns.values())), 400)  # power-state pre-roll
     res = {k: [] for k in fns}
     for _ in range(args.rounds):
@@ -108,8 +124,9 @@ def main():
             time_launches(f, 20)  # settle (see tools/ab_bench.py)
             res[k].append(time_launches(f, args.steps))
     print(desc + ("; SMOOTH guide" if args.smooth else ""))
-    for (c, v), t in res.items():
-        print(f"case {c:4s} variant {v:3d} {names[(c, v)]:34s} median {statistics.median(t):8.2f} us  min {min(t):8.2f}"
+    for key, t in res.items():
+        c, v = key[0], key[1]
+        print(f"case {c:4s} variant {v:3d} {names[key]:34s} median {statistics.median(t):8.2f} us  min {min(t):8.2f}"
               f"   all: {[round(x, 1) for x in t]}")
 
 
