@@ -594,10 +594,12 @@ def test_resize_bilinear_matches_oracle(dev, ops, case):
 
 
 @pytest.mark.parametrize("fused_guide", [False, True])
-@pytest.mark.parametrize("case", [(2, 36, 64, 18, 32), (1, 45, 128, 22, 64), (1, 24, 256, 7, 100)])
+@pytest.mark.parametrize("case", [(2, 36, 64, 18, 32), (1, 45, 128, 22, 64), (1, 24, 256, 7, 100),
+                                  (1, 6, 3840, 4, 1920), (1, 5, 2048, 3, 1000), (1, 4, 1024, 2, 1), (1, 3, 1536, 3, 1536)])
 def test_upadd_matches_composed_oracle(dev, ops, port, case, fused_guide):
     """One pyramid level: oracle slice-apply + oracle resize of the coarse level + add, vs the one
-    fused kernel (with the guide given as a map, or evaluated in registers from the folded net)."""
+    fused kernel (with the guide given as a map, or evaluated in registers from the folded net).  The wide cases have
+    several segments per row, a one-column coarse level, a coarse level as wide as the fine one."""
     import oracle
     B, H, W, Hc, Wc = case
     rng = np.random.default_rng(sum(case) + int(fused_guide))

@@ -144,12 +144,15 @@ def main():
                     B, H, W, GH, GW, GD, 3, 3, 1, 1 if u else 0, 255.0 if u else 1.0, 1 if u else 0,
                     ccm.data_ptr(), shifts.data_ptr(), slopes.data_ptr(), mix.data_ptr(), 16, None, stream))
             return fn
-        if case == "upadd":
+        if case in ("upadd", "nnupadd"):  # one pyramid level: (guide map | guide network) + apply + up-add of the coarser level
+            nn = case == "nnupadd"
+
             def fn(k):
                 s = S[k % nsets]
                 chk(lib.hdrnet_bilateral_slice_apply_upadd_f32(
-                    s["grid"].data_ptr(), s["guide"].data_ptr(), s["inp"].data_ptr(), coarse[k % nsets].data_ptr(),
-                    H // 2, W // 2, s["out"].data_ptr(), B, H, W, GH, GW, GD, 3, 3, 1, None, None, 0, stream))
+                    s["grid"].data_ptr(), None if nn else s["guide"].data_ptr(), s["inp"].data_ptr(), coarse[k % nsets].data_ptr(),
+                    H // 2, W // 2, s["out"].data_ptr(), B, H, W, GH, GW, GD, 3, 3, 1, conv1.data_ptr() if nn else None,
+                    conv2.data_ptr() if nn else None, 16 if nn else 0, stream))
             return fn
         dg, dgu, di = {"all": (1, 1, 1), "gg": (1, 1, 0), "g": (1, 0, 0), "v": (0, 1, 1)}[case]
 
