@@ -55,6 +55,8 @@ exit 0
 fi
 # 2. the default bench command, un-profiled and under rocprofv3 --kernel-trace --stats
 python $R/bench.py > $O/bench.json 2> $O/bench.err
+# ... and, on the same box, the whole -m gpu suite with its printed error figures (-s) and the smoke entry point
+(cd $R && python -m pytest tests -q -m gpu -s 2>&1 | grep -v amdgpu.ids > $O/gpu_suite.txt; python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" >> $O/gpu_suite.txt 2>&1)
 # the same command under rocprofv3 --kernel-trace --stats (its per-kernel average must agree with the line above)
 rocprofv3 --kernel-trace --stats -d $O/stats -o fwd --output-format csv -- python $R/bench.py --no-cpu-baseline --no-pipelined > $O/bench_under_rocprof.log 2>&1
 grep '^{"metric' $O/bench_under_rocprof.log > $O/bench_under_rocprof.json
@@ -81,9 +83,11 @@ python tools/ab_bench.py --variants 0,19,106,108 --rounds 9 --steps 200 > $O/ab_
 python tools/ab_bench.py --workload 1080p --variants 0,19,106,108 --rounds 7 --steps 400 > $O/ab_variants_1080p.txt 2>&1
 python tools/ab_bench.py --workload hdrp --variants 0,19,106,108 --rounds 5 --steps 100 > $O/ab_variants_hdrp.txt 2>&1
 if [ -f $PREV ]; then
-  python tools/prev_vs_new.py --prev $PREV --workload 4k --cases fwd,nn,u8,u8nn,curves,u8curves,all,gg,g,v,slice_fwd > $O/prev_vs_new_4k.txt 2>&1
-  python tools/prev_vs_new.py --prev $PREV --workload 1080p --steps 150 --cases fwd,u8,u8nn,curves,u8curves,all > $O/prev_vs_new_1080p.txt 2>&1
+  python tools/prev_vs_new.py --prev $PREV --workload 4k --cases fwd,nn,u8,u8nn,curves,u8curves,upadd,nnupadd,all,gg,g,v,slice_fwd > $O/prev_vs_new_4k.txt 2>&1
+  python tools/prev_vs_new.py --prev $PREV --workload 1080p --steps 150 --cases fwd,nn,u8,u8nn,curves,u8curves,all > $O/prev_vs_new_1080p.txt 2>&1
 fi
+# the guide forwards with the exported arrays and with the parameters prepared once per parameter set (round 5), interleaved
+for w in 4k 1080p; do python tools/guide_prepared_ab.py --workload $w 2>&1 | grep -v amdgpu.ids; done > $O/guide_prepared_ab.txt
 python tools/bwd_ab.py --rounds 5 --steps 50 --cases all,gg,g,sl,v --variants 0,2,3,4,5,6,7,8 > $O/bwd_ab_4k.txt 2>&1
 python tools/bwd_ab.py --workload 1080p --rounds 5 --steps 100 --cases all,gg,g,sl,v --variants 0,3 > $O/bwd_ab_1080p.txt 2>&1
 python tools/bwd_ab.py --smooth --rounds 5 --steps 50 --cases all,gg,g --variants 0 > $O/bwd_ab_4k_smooth_guide.txt 2>&1

@@ -72,6 +72,19 @@ def main():
                out=torch.empty((B, H, W, 3), device=dev, dtype=torch.uint8)) for _ in range(nsets)]
     coarse = [torch.randn((B, H // 2, W // 2, 3), device=dev, generator=gen) for _ in range(nsets)]
     stream = torch.cuda.current_stream(dev).cuda_stream
+    # The guide-network / curves-guide cases call each build the way its round's models did: a build with the round-5
+    # prepare-once helpers gets the guide network's PRESCALED parameters (HDRNET_GUIDE_RELU_PRESCALED: the same bits) and
+    # the curves guide's PREPARED tables (the same guide to 1e-6); older builds the exported arrays.
+    prepared = {}
+    for k, lib in libs.items():
+        if hasattr(lib, "hdrnet_guide_nn_prescale_f32") and hasattr(lib, "hdrnet_curves_guide_prepare_f32"):
+            p1, p2 = torch.empty_like(conv1), torch.empty_like(conv2)
+            assert lib.hdrnet_guide_nn_prescale_f32(conv1.data_ptr(), conv2.data_ptr(), 16, 3, 65536.0, p1.data_ptr(),
+                                                    p2.data_ptr(), stream) == 0
+            nb = lib.hdrnet_curves_guide_prepared_bytes(3)
+            cp = torch.empty((nb // 4,), device=dev)
+            assert lib.hdrnet_curves_guide_prepare_f32(shifts.data_ptr(), slopes.data_ptr(), 16, 3, cp.data_ptr(), nb, stream) == 0
+            prepared[k] = (p1, p2, cp)
     ws, ws2 = {}, {}
     for k, lib in libs.items():
         n = lib.hdrnet_bilateral_slice_apply_grad_workspace_bytes(B, H, W, GH, GW, GD, Cin, Cout, 1)
@@ -81,6 +94,9 @@ def main():
 
     def make(case, which):
         lib = libs[which]
+        prep = prepared.get(which)
+        nn1, nn2 = (prep[0], prep[1]) if prep else (conv1, conv2)
+        nnflags = _lib.GUIDE_SIGMOID_FAST | (_lib.GUIDE_RELU_PRESCALED if prep else 0)
 
         def chk(rc):
             if rc:
@@ -111,8 +127,8 @@ def main():
                 # (a build with the ..._ex twin chooses its sigmoid by flag; older builds: fast when guide_out is NULL)
                 if hasattr(lib, "hdrnet_bilateral_slice_apply_nnguide_f32_ex"):
                     chk(lib.hdrnet_bilateral_slice_apply_nnguide_f32_ex(
-                        s["grid"].data_ptr(), s["inp"].data_ptr(), conv1.data_ptr(), conv2.data_ptr(), s["out"].data_ptr(),
-                        None, B, H, W, GH, GW, GD, Cin, Cout, 1, 16, _lib.GUIDE_SIGMOID_FAST, stream))
+                        s["grid"].data_ptr(), s["inp"].data_ptr(), nn1.data_ptr(), nn2.data_ptr(), s["out"].data_ptr(),
+                        None, B, H, W, GH, GW, GD, Cin, Cout, 1, 16, nnflags, stream))
                     return
                 chk(lib.hdrnet_bilateral_slice_apply_nnguide_f32(
                     s["grid"].data_ptr(), s["inp"].data_ptr(), conv1.data_ptr(), conv2.data_ptr(), s["out"].data_ptr(),
@@ -126,8 +142,8 @@ def main():
                 if hasattr(lib, "hdrnet_bilateral_slice_apply_io_ex"):
                     chk(lib.hdrnet_bilateral_slice_apply_io_ex(
                         s["grid"].data_ptr(), None if nn else s["guide"].data_ptr(), t["inp"].data_ptr(), t["out"].data_ptr(),
-                        B, H, W, GH, GW, GD, 3, 3, 1, 1, 255.0, 1, conv1.data_ptr() if nn else None,
-                        conv2.data_ptr() if nn else None, 16 if nn else 0, None, _lib.GUIDE_SIGMOID_FAST if nn else 0, stream))
+                        B, H, W, GH, GW, GD, 3, 3, 1, 1, 255.0, 1, nn1.data_ptr() if nn else None,
+                        nn2.data_ptr() if nn else None, 16 if nn else 0, None, nnflags if nn else 0, stream))
                     return
                 chk(lib.hdrnet_bilateral_slice_apply_io(
                     s["grid"].data_ptr(), None if nn else s["guide"].data_ptr(), t["inp"].data_ptr(), t["out"].data_ptr(),
@@ -139,6 +155,12 @@ def main():
 
             def fn(k):
                 s, t = S[k % nsets], u8[k % nsets]
+                if prep:
+                    chk(lib.hdrnet_bilateral_slice_apply_io_curves_prepared(
+                        s["grid"].data_ptr(), (t if u else s)["inp"].data_ptr(), (t if u else s)["out"].data_ptr(),
+                        B, H, W, GH, GW, GD, 3, 3, 1, 1 if u else 0, 255.0 if u else 1.0, 1 if u else 0,
+                        ccm.data_ptr(), shifts.data_ptr(), slopes.data_ptr(), mix.data_ptr(), 16, prep[2].data_ptr(), None, stream))
+                    return
                 chk(lib.hdrnet_bilateral_slice_apply_io_curves(
                     s["grid"].data_ptr(), (t if u else s)["inp"].data_ptr(), (t if u else s)["out"].data_ptr(),
                     B, H, W, GH, GW, GD, 3, 3, 1, 1 if u else 0, 255.0 if u else 1.0, 1 if u else 0,
@@ -149,6 +171,13 @@ def main():
 
             def fn(k):
                 s = S[k % nsets]
+                if hasattr(lib, "hdrnet_bilateral_slice_apply_upadd_f32_ex"):
+                    chk(lib.hdrnet_bilateral_slice_apply_upadd_f32_ex(
+                        s["grid"].data_ptr(), None if nn else s["guide"].data_ptr(), s["inp"].data_ptr(),
+                        coarse[k % nsets].data_ptr(), H // 2, W // 2, s["out"].data_ptr(), B, H, W, GH, GW, GD, 3, 3, 1,
+                        nn1.data_ptr() if nn else None, nn2.data_ptr() if nn else None, 16 if nn else 0, nnflags if nn else 0,
+                        stream))
+                    return
                 chk(lib.hdrnet_bilateral_slice_apply_upadd_f32(
                     s["grid"].data_ptr(), None if nn else s["guide"].data_ptr(), s["inp"].data_ptr(), coarse[k % nsets].data_ptr(),
                     H // 2, W // 2, s["out"].data_ptr(), B, H, W, GH, GW, GD, 3, 3, 1, conv1.data_ptr() if nn else None,
