@@ -257,7 +257,9 @@ def timed(step_fn, steps, dist_on, dev):
     ev1.record()
     # The closing synchronize is entered with the work already done: a blocking wait wakes up 30-60 us late,
     # which is 5 % of a 20-launch region (profiles/r03/bench_steps20.txt: 41.5 us wall vs 38.9 us events per
-    # launch); polling the closing event first costs one core for the length of the region.
+    # launch); polling the closing event first costs one core for the length of the region.  What is left of the closing
+    # synchronize once the event has fired is ~14-15 us of the call itself, with or without hipDeviceScheduleSpin
+    # (tools/exp/spin_probe.py, round 5); the region's other ~9 us are the first launch reaching an idle device.
     while not ev1.query():
         pass
     tq = time.perf_counter()
