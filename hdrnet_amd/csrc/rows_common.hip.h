@@ -298,9 +298,19 @@ typedef int v4i32 __attribute__((ext_vector_type(4)));
 constexpr int kAuxPlain = 0, kAuxNt = 2, kAuxSc1 = 16, kAuxSc0Sc1 = 17;
 constexpr int kAuxStream = kAuxNt;  // the policy the product kernels store with
 
-// Raw buffer descriptor over `bytes` bytes at `base` (gfx9 family: dword 3 = 0x00020000).
+// Raw buffer descriptor over `bytes` bytes at `base` (gfx9 family: dword 3 = 0x00020000).  `base` and `bytes` are
+// WAVE-UNIFORM at every call site (a row segment, a wave's run), and the instruction wants the descriptor in SGPRs -- but a
+// 64-bit `row * W + x` is multiplied on the VALU (v_mad_u64_u32), so the compiler finds the descriptor in VGPRs and wraps
+// every buffer store in a WATERFALL LOOP (4 v_readfirstlane + 2 v_cmp_eq_u64 + exec bookkeeping + a branch per store, three
+// stores per wave in the forward: ~30 instructions in front of the stores; found in round 5 in the ISA of every kernel
+// that stores through a descriptor).  Reading the three words through readfirstlane here says what the call sites
+// guarantee: one v_readfirstlane per word, no loop; for a base the compiler already holds in SGPRs it folds away.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+  const unsigned long long a = (unsigned long long)base;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+  const int n = __builtin_amdgcn_readfirstlane((int)bytes);
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, n, 0x00020000);
 }
 
 template <int AUX>
