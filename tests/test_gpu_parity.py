@@ -577,6 +577,55 @@ def test_curves_prepared_tables_cases(dev, ops, port, case):
         ops.bilateral_slice_apply_curves(grid.clone().requires_grad_(True), T(x, dev), *curves, prepared=prep)
 
 
+def test_prepared_guide_parameters_fuzz(dev, ops):
+    """The shipped models' inference calls the guide forwards with parameters PREPARED once per parameter set (round 5).
+    Random parameter sets against the exported-arrays path of the same kernels: the prescaled guide network must give
+    the same BITS (any width 1 .. 20, weight scales 1e-3 .. 1e3, inputs up to the prescale's x_max); the curves guide's
+    cell tables the same guide to 2e-6 of the curve's scale -- or, when two knots share a cell (`ok` = 0), the same bits."""
+    rng = np.random.default_rng(2025)
+    B, H, W = 1, 8, 256
+    grid6 = np.zeros((B, 4, 4, 8, 3, 4), np.float32)
+    grid6[..., :, 3] = ((np.arange(8, dtype=np.float32) + 0.5) / 8)[None, None, None, :, None]  # out == guide (to the tent)
+    grid = T(grid6.reshape(B, 4, 4, 8, 12), dev)
+    for trial in range(24):
+        n = int(rng.integers(1, 21))
+        wscale = float(10.0 ** rng.uniform(-3, 3))
+        x_max = float(10.0 ** rng.uniform(0, 4))
+        conv1 = T((rng.standard_normal((n, 4)) * wscale).astype(np.float32), dev)
+        conv2 = T((rng.standard_normal(n + 1) / (wscale * max(x_max, 1.0) * n)).astype(np.float32), dev)
+        inp = T((rng.random((B, H, W, 3)) * x_max).astype(np.float32), dev)
+        p1, p2 = ops.guide_nn_prescale(conv1, conv2, x_max=x_max)
+        _, g = ops.bilateral_slice_apply_nnguide(grid, inp, conv1, conv2, return_guide=True)
+        _, gp = ops.bilateral_slice_apply_nnguide(grid, inp, p1, p2, return_guide=True, prescaled=True)
+        assert torch.equal(gp, g), (trial, n, wscale, x_max)
+    n_ok = 0
+    for trial in range(32):
+        npts = int(rng.integers(1, 17))
+        lo, span = float(rng.uniform(-5, 5)), float(10.0 ** rng.uniform(-2, 2))
+        shifts = (lo + span * rng.random((npts, 3))).astype(np.float32)
+        if trial % 4 == 3 and npts > 2:  # a cluster / a tie now and then
+            shifts[1, trial % 3] = shifts[0, trial % 3] + (0.0 if trial % 8 == 3 else 1e-4 * span)
+        slopes = (rng.standard_normal((npts, 3)) / span).astype(np.float32)
+        ccm = (np.concatenate([np.eye(3), np.zeros((3, 1))], 1) + 0.2 * rng.standard_normal((3, 4))).astype(np.float32)
+        mix = np.array([0.4, 0.35, 0.25, 0.1], np.float32)
+        x = (lo - 0.2 * span + 1.4 * span * rng.random((B, H, W, 3))).astype(np.float32)
+        curves = tuple(T(a, dev) for a in (ccm, shifts, slopes, mix))
+        prep = ops.curves_guide_prepare(curves[1], curves[2])
+        ok = float(prep[3 * 64 * 4 + 12]) == 1.0
+        n_ok += ok
+        out, g = ops.bilateral_slice_apply_io(grid, T(x, dev), guide_curves=curves, return_guide=True)
+        out_p, gp = ops.bilateral_slice_apply_io(grid, T(x, dev), guide_curves=curves, return_guide=True, curves_prepared=prep)
+        if not ok:
+            assert torch.equal(gp, g) and torch.equal(out_p, out), trial
+        else:
+            # the guide is clip(mix . curves): compare where the clip does not hide a difference, at the curve's own scale
+            scale = float(np.abs(slopes).sum(0).max() * span) + 1.0
+            np.testing.assert_allclose(N(gp), N(g), rtol=0, atol=2e-6 * scale, err_msg=f"trial {trial} npts {npts}")
+    # both branches were exercised (knots drawn uniformly at random share a cell more often than not -- 16 of them in 63
+    # cells collide with probability ~0.85; the reference's knots start equidistant, hdrnet/models.py:150-154)
+    assert 4 <= n_ok <= 31
+
+
 # ---- pyramid output (SURVEY.md section 8f row 4): resize + slice-apply fused with the up-add -------
 @pytest.mark.parametrize("case", [(2, 37, 53, 3, 18, 26), (1, 64, 96, 3, 128, 192), (1, 9, 13, 1, 1, 1),
                                   (1, 20, 30, 5, 20, 30)])
