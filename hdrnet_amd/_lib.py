@@ -42,7 +42,7 @@ SIGNATURES = {
     "hdrnet_bilateral_slice_apply_nnguide_f32_ex": (_I, [_FP] * 6 + [_I] * 10 + [_U, _VP]),
     "hdrnet_bilateral_slice_apply_io_curves": (_I, [_FP] * 3 + [_I] * 10 + [ctypes.c_float, _I] + [_FP] * 4 + [_I, _FP, _VP]),
     "hdrnet_curves_guide_prepared_bytes": (_SZ, [_I]),
-    "hdrnet_curves_guide_prepare_f32": (_I, [_FP, _FP, _I, _I, _VP, _SZ, _VP]),
+    "hdrnet_curves_guide_prepare_f32": (_I, [_FP, _FP, _I, _I, _VP, _SZ, ctypes.POINTER(ctypes.c_int), _VP]),
     "hdrnet_bilateral_slice_apply_io_curves_prepared": (_I, [_FP] * 3 + [_I] * 10 + [ctypes.c_float, _I] + [_FP] * 4 + [_I, _VP, _FP, _VP]),
     "hdrnet_bilateral_slice_apply_upadd_f32": (_I, [_FP] * 4 + [_I, _I, _FP] + [_I] * 9 + [_FP, _FP, _I, _VP]),
     "hdrnet_bilateral_slice_apply_upadd_f32_ex": (_I, [_FP] * 4 + [_I, _I, _FP] + [_I] * 9 + [_FP, _FP, _I, _U, _VP]),

@@ -39,6 +39,7 @@ using namespace rows;
 // guide_slopes_f32_16x3.bin, guide_mix_matrix_f32_1x4.bin).
 constexpr int kGuideMap = 0, kGuideNN = 1, kGuideCurves = 2;
 constexpr int kGuideCurvesScan = 3;  // the curves guide evaluated knot by knot: more than kCurveMaxKnots knots per channel
+constexpr int kGuideCurvesCells = 4;  // the curves guide from the PREPARED uniform cell tables (CurveCells below)
 
 struct GuideNet {
   const float* conv1;  // NN: [n][CIN + 1]            curves: ccm [CIN][CIN + 1] (row = output channel)
@@ -254,8 +255,10 @@ __device__ __forceinline__ void guide_curves_quad(const float* __restrict__ tab,
 // -- one ds_read_b128 and 8 VALU instructions per channel instead of 4 + 1 dependent reads and 16; anchored at a knot at
 // most one cell away, with the float64-summed C and A of the sorted tables (curves_build_tables, run once by the prepare
 // kernel).  A cell can hold one knot only: if two knots of a channel share a cell (closer than 1/63 of the knot range, or
-// equal) the prepare kernel clears the table's `ok` word and the forward kernels keep the sorted tables -- same results
-// as without a prepared table.  Layout of the prepared buffer (floats): [CIN][kCurveCells][4] entries, then per channel
+// equal) the prepare kernel clears the table's `ok` word: the table is NOT USABLE, hdrnet_curves_guide_prepare_f32 reads
+// the word back and says so, and its caller passes no prepared buffer -- the sorted tables above, the same results.  (The
+// two forms are two kernel instantiations chosen on the host: one kernel with both behind a run-time switch took 70-74
+// VGPRs instead of 54-64.)  Layout of the prepared buffer (floats): [CIN][kCurveCells][4] entries, then per channel
 // (k16, o16, 0, 0), then (ok, 0, 0, 0).
 constexpr int kCurveCells = 64;
 template <int CIN>
@@ -625,16 +628,17 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
   // dynamic array's link-time base every step paid a v_add).  The coefficient image and the slabs stay dynamic.
   constexpr int kTabFloats = NN_MFMA ? NnTab::kWords : 0;
   float* const lds = lds_all + kTabFloats;
+  // (static LDS costs resident workgroups here: 3 KB more measured 8 %, and a kernel carrying BOTH table forms behind a
+  //  run-time switch took 70-74 VGPRs instead of 54-64 -- profiles/r05/f2_prepared_guides.md -- so the two forms are two
+  //  instantiations, chosen on the host by whether the caller passed a prepared buffer)
   [[maybe_unused]] float* ctab = nullptr;
-  [[maybe_unused]] float* ccells = nullptr;
-  [[maybe_unused]] bool use_cells = false;
   if constexpr (GUIDE == kGuideCurves) {
     __shared__ __attribute__((aligned(16))) float curve_tables[CurveTab<CIN>::kFloats];
-    __shared__ __attribute__((aligned(16))) float curve_cells[CIN * kCurveCells * 4];
     ctab = curve_tables;
-    ccells = curve_cells;
-    // wave-uniform (scalar load): a prepared table whose cells separate the knots
-    if (p.gn.prepared) use_cells = ((cfloat*)(p.gn.prepared + CurveCells<CIN>::kOk))[0] != 0.0f;
+  }
+  if constexpr (GUIDE == kGuideCurvesCells) {
+    __shared__ __attribute__((aligned(16))) float curve_cells[CIN * kCurveCells * 4];
+    ctab = curve_cells;
   }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -669,12 +673,11 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
   }
 
   if constexpr (GUIDE == kGuideCurves) {
-    if (use_cells) {  // the prepared cell tables: 3 KB copied by the whole workgroup (published by the barrier below)
-      const f32x4* src = reinterpret_cast<const f32x4*>(p.gn.prepared);
-      for (int e = tid; e < CIN * kCurveCells; e += (int)blockDim.x) reinterpret_cast<f32x4*>(ccells)[e] = src[e];
-    } else if (wave == 0) {
-      curves_build_tables<CIN>(ctab, p.gn, lane);  // published by the barrier below
-    }
+    if (wave == 0) curves_build_tables<CIN>(ctab, p.gn, lane);  // published by the barrier below
+  }
+  if constexpr (GUIDE == kGuideCurvesCells) {  // the prepared cell tables: 3 KB copied by the whole workgroup (barrier below)
+    const f32x4* src = reinterpret_cast<const f32x4*>(p.gn.prepared);
+    for (int e = tid; e < CIN * kCurveCells; e += (int)blockDim.x) reinterpret_cast<f32x4*>(ctab)[e] = src[e];
   }
   const SegCols sc = seg_cols_tab(p.tab, blockIdx.x, xs, xe, p.scale_x);
   const int colb = (p.GD + 2) * CB;
@@ -702,10 +705,10 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
         }
         if (!done) guide_nn_quad<CIN>(GuideNN{p.gn.conv1, p.gn.conv2, p.gn.guide_out, p.gn.n, p.gn.fast_sigmoid, p.gn.prescaled}, inf, gs);  // (writes nothing itself)
       }
-      else if constexpr (GUIDE == kGuideCurves) {
-        if (use_cells) guide_curves_quad_cells<CIN>(ccells, p.gn, inf, gs);
-        else guide_curves_quad<CIN>(ctab, p.gn, inf, gs);
-      }
+      else if constexpr (GUIDE == kGuideCurves)
+        guide_curves_quad<CIN>(ctab, p.gn, inf, gs);
+      else if constexpr (GUIDE == kGuideCurvesCells)
+        guide_curves_quad_cells<CIN>(ctab, p.gn, inf, gs);
       else
         guide_curves_scan_quad<CIN>(p.gn, inf, gs);
       if (p.gn.guide_out) *reinterpret_cast<float4*>(p.gn.guide_out + px) = make_float4(gs[0], gs[1], gs[2], gs[3]);
@@ -840,7 +843,7 @@ bool plan_io(const ApplyIoArgs& a, Plan* pl) {
                          (a.input_dtype == 0 ? (uintptr_t)a.input : 0);
   if (bits & 15u) return false;
   if (((uintptr_t)a.input | (uintptr_t)a.out) & 3u) return false;
-  const IoGeom g = io_geom(a.W, a.GW, a.GD, 12, 3, CurveTab<3>::kFloats + 3 * kCurveCells * 4);  // + the curves kernel's static tables: the largest of the kernels
+  const IoGeom g = io_geom(a.W, a.GW, a.GD, 12, 3, CurveTab<3>::kFloats > 3 * kCurveCells * 4 ? CurveTab<3>::kFloats : 3 * kCurveCells * 4);  // + the curves kernel's static tables: the largest of the kernels
   *pl = g.pl;
   if (a.B > 65535 || a.H > 65535 || (long long)a.W * a.Cout * 4 >= (1LL << 31)) return false;
   if ((long long)(g.slab_off) >= (1 << 20)) return false;
@@ -855,6 +858,7 @@ bool apply_fwd_io_supported(const ApplyIoArgs& a) {
 }
 
 size_t curves_guide_prepared_bytes(int Cin) { return Cin == 3 ? CurveCells<3>::kFloats * sizeof(float) : 0; }
+size_t curves_guide_prepared_ok_offset(int Cin) { return Cin == 3 ? (size_t)CurveCells<3>::kOk : 0; }
 
 hipError_t launch_curves_guide_prepare(const float* shifts, const float* slopes, int npts, int Cin, float* prepared,
                                        hipStream_t s) {
@@ -871,10 +875,13 @@ hipError_t launch_apply_fwd_io(const ApplyIoArgs& a, hipStream_t s, const char**
   static const char* const suffix[3] = {"", "+nnguide", "+curvesguide"};
   static thread_local char label[64];
   const int kind = a.guide ? kGuideMap : (a.guide_shifts ? kGuideCurves : kGuideNN);
-  snprintf(label, sizeof label, "apply_fwd_io/%s%s", io[a.input_dtype][a.output_dtype], suffix[kind]);
+  const bool cells = kind == kGuideCurves && a.guide_prepared && a.n_feats <= kCurveMaxKnots;
+  snprintf(label, sizeof label, "apply_fwd_io/%s%s%s", io[a.input_dtype][a.output_dtype], suffix[kind], cells ? "/cells" : "");
   *name = label;
-  if (kind == kGuideCurves)
-    return a.n_feats <= kCurveMaxKnots ? dispatch_types<kGuideCurves>(a, pl, s) : dispatch_types<kGuideCurvesScan>(a, pl, s);
+  if (kind == kGuideCurves) {
+    if (a.n_feats > kCurveMaxKnots) return dispatch_types<kGuideCurvesScan>(a, pl, s);
+    return cells ? dispatch_types<kGuideCurvesCells>(a, pl, s) : dispatch_types<kGuideCurves>(a, pl, s);
+  }
   return kind == kGuideNN ? dispatch_types<kGuideNN>(a, pl, s) : dispatch_types<kGuideMap>(a, pl, s);
 }
 

@@ -662,7 +662,7 @@ int hdrnet_bilateral_slice_apply_io_curves(const float* grid, const void* input,
 size_t hdrnet_curves_guide_prepared_bytes(int Cin) { return hdrnet_amd::curves_guide_prepared_bytes(Cin); }
 
 int hdrnet_curves_guide_prepare_f32(const float* guide_shifts, const float* guide_slopes, int npts, int Cin,
-                                    void* prepared, size_t prepared_bytes, void* stream) {
+                                    void* prepared, size_t prepared_bytes, int* usable, void* stream) {
   using namespace hdrnet_amd;
   const size_t need = curves_guide_prepared_bytes(Cin);
   if (need == 0 || npts <= 0 || npts > 16)
@@ -671,11 +671,23 @@ int hdrnet_curves_guide_prepare_f32(const float* guide_shifts, const float* guid
   if (!guide_shifts || !guide_slopes || !prepared) return fail(HDRNET_INVALID_ARGUMENT, "null buffer");
   if (((uintptr_t)prepared & 15u) || prepared_bytes < need)
     return fail(HDRNET_INVALID_ARGUMENT, "curves prepare needs a 16-B aligned buffer of hdrnet_curves_guide_prepared_bytes()");
+  if (!usable) return fail(HDRNET_INVALID_ARGUMENT, "curves prepare: `usable` must point to an int");
+  *usable = 0;
   const int rc = check_launch(launch_curves_guide_prepare(guide_shifts, guide_slopes, npts, Cin, static_cast<float*>(prepared),
                                                           static_cast<hipStream_t>(stream)),
                               "CurvesGuidePrepare");
-  if (rc == HDRNET_OK) set_kernel("curves_prepare");
-  return rc;
+  if (rc != HDRNET_OK) return rc;
+  set_kernel("curves_prepare");
+  // a SET-UP call, once per parameter set: the table's `ok` word comes back to the host (this waits for `stream`), because
+  // which forward kernel a prepared buffer selects is decided on the host
+  float ok = 0.0f;
+  hipError_t e = hipMemcpyAsync(&ok, static_cast<const float*>(prepared) + curves_guide_prepared_ok_offset(Cin),
+                                sizeof(float), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream));
+  if (e == hipSuccess) e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+  if (e != hipSuccess)
+    return fail(HDRNET_RUNTIME_FAILURE, "curves prepare: reading the table's ok word back: %s", hipGetErrorString(e));
+  *usable = ok != 0.0f ? 1 : 0;
+  return HDRNET_OK;
 }
 
 int hdrnet_bilateral_slice_apply_io_curves_prepared(const float* grid, const void* input, void* out, int B, int H,
@@ -707,7 +719,7 @@ int hdrnet_bilateral_slice_apply_io_curves_prepared(const float* grid, const voi
   if (prepared) {
     if (((uintptr_t)prepared & 15u) || Cin != 3 || npts > 16)
       return fail(HDRNET_INVALID_ARGUMENT, "prepared curves tables need Cin = 3, npts <= 16 and the 16-B aligned buffer "
-                                           "hdrnet_curves_guide_prepare_f32 wrote");
+                                           "hdrnet_curves_guide_prepare_f32 wrote (and reported usable)");
     a.guide_prepared = static_cast<const float*>(prepared);
   }
   if (!apply_fwd_io_supported(a))

@@ -185,6 +185,7 @@ bool apply_fwd_io_supported(const ApplyIoArgs& a);
 hipError_t launch_apply_fwd_io(const ApplyIoArgs& a, hipStream_t s, const char** name);
 // the curves guide's uniform cell tables (apply_fwd_io.hip: CurveCells), prepared once per parameter set
 size_t curves_guide_prepared_bytes(int Cin);  // 0: no cell tables for this channel count
+size_t curves_guide_prepared_ok_offset(int Cin);  // float index of the buffer's `ok` word
 hipError_t launch_curves_guide_prepare(const float* shifts, const float* slopes, int npts, int Cin, float* prepared,
                                        hipStream_t s);
 

@@ -27,6 +27,7 @@ must live on an AMD GPU and ``libhdrnet_amd.so`` must load, otherwise the call r
 from __future__ import annotations
 
 import contextlib
+import ctypes
 import threading
 from typing import Optional, Tuple
 
@@ -949,14 +950,16 @@ def _check_io(grid, input, has_offset):  # noqa: A002
     return B, H, W, GH, GW, GD, Cin, C // Cj
 
 
-def curves_guide_prepare(shifts: torch.Tensor, slopes: torch.Tensor) -> torch.Tensor:
+def curves_guide_prepare(shifts: torch.Tensor, slopes: torch.Tensor) -> Optional[torch.Tensor]:
     """The curves guide's lookup tables, PREPARED once per parameter set (``hdrnet_curves_guide_prepare_f32``; Cin = 3,
     at most 16 knots per channel): each channel's knot range cut into 64 uniform cells, per cell the knot inside it, the
     curve's float64-summed value there and the slopes on either side.  Passed to ``bilateral_slice_apply_curves`` /
     ``bilateral_slice_apply_io`` as ``prepared`` / ``curves_prepared``, a pixel finds its cell by arithmetic and reads ONE
     table entry, where the plain call has every workgroup sort the knots and every pixel walk a search tree.  Same guide to
-    1e-6; if two knots of a channel share a cell the buffer says so and the kernels take the plain path.  ``shifts`` /
-    ``slopes``: ``[npts, 3]`` (hdrnet/bin/freeze_graph.py:107-127).  Returns an opaque float32 tensor."""
+    1e-6.  A SET-UP call: it waits for the stream (one word comes back -- whether the cells separate the knots) and must not
+    run inside a stream capture.  Returns an opaque float32 tensor, or ``None`` when two knots of a channel share a cell
+    (closer than 1/63 of the channel's knot range): call the ops without ``prepared`` then.  ``shifts`` / ``slopes``:
+    ``[npts, 3]`` (hdrnet/bin/freeze_graph.py:107-127)."""
     _require_f32("shifts", shifts)
     _require_f32("slopes", slopes)
     _require_gpu("shifts", shifts)
@@ -969,11 +972,12 @@ def curves_guide_prepare(shifts: torch.Tensor, slopes: torch.Tensor) -> torch.Te
     lib = _lib.load()
     nbytes = lib.hdrnet_curves_guide_prepared_bytes(3)
     out = torch.empty((nbytes // 4,), dtype=torch.float32, device=dev)
+    usable = ctypes.c_int(0)
     with torch.cuda.device(dev):
         rc = lib.hdrnet_curves_guide_prepare_f32(sh.data_ptr(), sl.data_ptr(), sh.shape[0], 3, out.data_ptr(), nbytes,
-                                                 _stream(dev))
+                                                 ctypes.byref(usable), _stream(dev))
     _lib.check(rc, "CurvesGuidePrepare")
-    return out
+    return out if usable.value else None
 
 
 def _apply_io_curves(grid, input, curves, input_white_level, out_dtype, has_offset, return_guide,  # noqa: A002

@@ -325,7 +325,8 @@ class _CurvesGuide(nn.Module):
 
     def prepared(self):
         """The curves' lookup tables prepared once per parameter state (``hdrnet_ops.curves_guide_prepare``: uniform cells
-        instead of a per-workgroup sort + per-pixel tree search), or None off the GPU / for other shapes."""
+        instead of a per-workgroup sort + per-pixel tree search), or None -- off the GPU, for other shapes, when two knots of
+        a channel share a cell, or while a stream capture is running with nothing cached (the set-up call synchronises)."""
         _, shifts, slopes, _ = self.exported()
         if not (shifts.is_cuda and shifts.shape[1] == 3 and shifts.shape[0] <= 16):
             return None
@@ -333,10 +334,11 @@ class _CurvesGuide(nn.Module):
         cached = getattr(self, "_prepared_cache", None)
         if cached is not None and cached[0] == key:
             return cached[1]
+        if not _cacheable():
+            return None
         from . import hdrnet_ops
         out = hdrnet_ops.curves_guide_prepare(shifts, slopes)
-        if _cacheable():
-            self._prepared_cache = (key, out)
+        self._prepared_cache = (key, out)
         return out
 
     def exported_differentiable(self):

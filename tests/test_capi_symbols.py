@@ -183,15 +183,18 @@ def test_curves_entry_points_validate_without_gpu(libpath):
     lib.hdrnet_curves_guide_prepared_bytes.argtypes = [I]
     assert lib.hdrnet_curves_guide_prepared_bytes(3) == (3 * 64 * 4 + 3 * 4 + 4) * 4
     assert lib.hdrnet_curves_guide_prepared_bytes(1) == 0
-    lib.hdrnet_curves_guide_prepare_f32.argtypes = [P, P, I, I, P, SZ, P]
-    assert lib.hdrnet_curves_guide_prepare_f32(0x1000, 0x1000, 17, 3, 0x1000, 1 << 20, None) == 1
+    lib.hdrnet_curves_guide_prepare_f32.argtypes = [P, P, I, I, P, SZ, ctypes.POINTER(I), P]
+    us = I(7)
+    assert lib.hdrnet_curves_guide_prepare_f32(0x1000, 0x1000, 17, 3, 0x1000, 1 << 20, ctypes.byref(us), None) == 1
     assert b"1 .. 16 knots" in lib.hdrnet_last_error()
-    assert lib.hdrnet_curves_guide_prepare_f32(0x1000, 0x1000, 16, 1, 0x1000, 1 << 20, None) == 1
-    assert lib.hdrnet_curves_guide_prepare_f32(None, 0x1000, 16, 3, 0x1000, 1 << 20, None) == 1
+    assert lib.hdrnet_curves_guide_prepare_f32(0x1000, 0x1000, 16, 1, 0x1000, 1 << 20, ctypes.byref(us), None) == 1
+    assert lib.hdrnet_curves_guide_prepare_f32(None, 0x1000, 16, 3, 0x1000, 1 << 20, ctypes.byref(us), None) == 1
     assert b"null buffer" in lib.hdrnet_last_error()
-    assert lib.hdrnet_curves_guide_prepare_f32(0x1000, 0x1000, 16, 3, 0x1000, 64, None) == 1
+    assert lib.hdrnet_curves_guide_prepare_f32(0x1000, 0x1000, 16, 3, 0x1000, 64, ctypes.byref(us), None) == 1
     assert b"hdrnet_curves_guide_prepared_bytes" in lib.hdrnet_last_error()
-    assert lib.hdrnet_curves_guide_prepare_f32(0x1000, 0x1000, 16, 3, 0x1004, 1 << 20, None) == 1
+    assert lib.hdrnet_curves_guide_prepare_f32(0x1000, 0x1000, 16, 3, 0x1004, 1 << 20, ctypes.byref(us), None) == 1
+    assert lib.hdrnet_curves_guide_prepare_f32(0x1000, 0x1000, 16, 3, 0x1000, 1 << 20, None, None) == 1  # where to report?
+    assert b"usable" in lib.hdrnet_last_error()
     lib.hdrnet_bilateral_slice_apply_io_curves_prepared.argtypes = [P] * 3 + [I] * 10 + [F, I] + [P] * 4 + [I, P, P, P]
     rc = lib.hdrnet_bilateral_slice_apply_io_curves_prepared(0x1000, 0x1000, 0x1000, 1, 4, 4, 2, 2, 2, 3, 3, 1, 0, 1.0, 0,
                                                              0x1000, 0x1000, 0x1000, 0x1000, 16, 0x1004, None, None)

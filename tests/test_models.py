@@ -720,7 +720,7 @@ def test_curves_model_fused_matches_composed():
     full = torch.rand(1, 270, 480, 3, device=dev)
     with torch.no_grad():
         out = m(low, full)
-        assert hdrnet_ops.last_kernel() == "apply_fwd_io/f32->f32+curvesguide"
+        assert hdrnet_ops.last_kernel() == "apply_fwd_io/f32->f32+curvesguide/cells"  # the prepared tables (round 5)
         m.fuse_guide = False
         ref = m(low, full)
         assert hdrnet_ops.last_kernel() == "apply_fwd_seg/vec4"
@@ -729,14 +729,15 @@ def test_curves_model_fused_matches_composed():
     # set must rebuild them (and give the same result as without them: prepare_curves = False)
     assert m.prepare_curves and getattr(m.guide, "_prepared_cache", None) is not None
     with torch.no_grad():
-        m.guide.shifts.add_(torch.randn(3, 16, device=dev) * 0.02)
+        m.guide.shifts.add_(torch.randn(3, 16, device=dev) * 0.004)  # (knots stay more than a cell apart)
         del m.fuse_guide
         out2 = m(low, full)
+        assert hdrnet_ops.last_kernel() == "apply_fwd_io/f32->f32+curvesguide/cells"
         m.prepare_curves = False
         out3 = m(low, full)
         m.fuse_guide = False
         ref2 = m(low, full)
-    assert (out2 - out).abs().max() > 1e-4
+    assert (out2 - out).abs().max() > 1e-5
     torch.testing.assert_close(out2, ref2, rtol=3e-5, atol=3e-5)
     torch.testing.assert_close(out2, out3, rtol=1e-5, atol=1e-5)
 

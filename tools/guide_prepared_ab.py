@@ -85,9 +85,12 @@ def main():
     mixv = torch.tensor([0.4, 0.35, 0.25, 0.0], device=dev)
     nprep = lib.hdrnet_curves_guide_prepared_bytes(3)
     prep = torch.empty((nprep // 4,), device=dev)
-    chk(lib.hdrnet_curves_guide_prepare_f32(shifts.data_ptr(), slopes.data_ptr(), 16, 3, prep.data_ptr(), nprep, stream))
-    torch.cuda.synchronize()
-    print(f"curves tables prepared: ok = {float(prep[3 * 64 * 4 + 12])}")
+    import ctypes
+    usable = ctypes.c_int(0)
+    chk(lib.hdrnet_curves_guide_prepare_f32(shifts.data_ptr(), slopes.data_ptr(), 16, 3, prep.data_ptr(), nprep,
+                                            ctypes.byref(usable), stream))
+    print(f"curves tables prepared: usable = {usable.value}")
+    assert usable.value == 1
 
     def curves(k, pre, u8io):
         s = S[k % nsets]

@@ -135,7 +135,11 @@ def main():
     # passes since round 5); `pre=False` lines time the exported arrays alone (every workgroup sorts the knots itself)
     nprep = lib.hdrnet_curves_guide_prepared_bytes(3)
     cprep = torch.empty((nprep // 4,), device=dev)
-    chk(lib.hdrnet_curves_guide_prepare_f32(shifts.data_ptr(), slopes.data_ptr(), 16, 3, cprep.data_ptr(), nprep, stream))
+    import ctypes
+    usable = ctypes.c_int(0)
+    chk(lib.hdrnet_curves_guide_prepare_f32(shifts.data_ptr(), slopes.data_ptr(), 16, 3, cprep.data_ptr(), nprep,
+                                            ctypes.byref(usable), stream))
+    assert usable.value == 1, "the bench's equidistant knots fit the cell tables"
 
     def apply_io_curves(k, u8io=True, pre=True):
         s, t = S[k % nsets], u8[k % nsets]

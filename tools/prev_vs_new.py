@@ -83,7 +83,9 @@ def main():
                                                     p2.data_ptr(), stream) == 0
             nb = lib.hdrnet_curves_guide_prepared_bytes(3)
             cp = torch.empty((nb // 4,), device=dev)
-            assert lib.hdrnet_curves_guide_prepare_f32(shifts.data_ptr(), slopes.data_ptr(), 16, 3, cp.data_ptr(), nb, stream) == 0
+            usable = ctypes.c_int(0)
+            assert lib.hdrnet_curves_guide_prepare_f32(shifts.data_ptr(), slopes.data_ptr(), 16, 3, cp.data_ptr(), nb,
+                                                       ctypes.byref(usable), stream) == 0 and usable.value == 1
             prepared[k] = (p1, p2, cp)
     ws, ws2 = {}, {}
     for k, lib in libs.items():
