@@ -117,7 +117,7 @@ int variant(unsigned flags) { return (int)((flags >> 8) & 0xffu); }
 
 extern "C" {
 
-int hdrnet_version(void) { return 240; /* 0.2.4: + hdrnet_guide_nn_prescale_f32 / HDRNET_GUIDE_RELU_PRESCALED, hdrnet_curves_guide_prepare_f32 / ..._io_curves_prepared */ }
+int hdrnet_version(void) { return 241; /* 0.2.4.1: + hdrnet_guide_nn_prescale_f32 / HDRNET_GUIDE_RELU_PRESCALED, hdrnet_curves_guide_prepare_f32 (with `usable`) / ..._io_curves_prepared */ }
 
 const char* hdrnet_last_error(void) { return g_error; }
 

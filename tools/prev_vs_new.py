@@ -83,9 +83,15 @@ def main():
                                                     p2.data_ptr(), stream) == 0
             nb = lib.hdrnet_curves_guide_prepared_bytes(3)
             cp = torch.empty((nb // 4,), device=dev)
-            usable = ctypes.c_int(0)
-            assert lib.hdrnet_curves_guide_prepare_f32(shifts.data_ptr(), slopes.data_ptr(), 16, 3, cp.data_ptr(), nb,
-                                                       ctypes.byref(usable), stream) == 0 and usable.value == 1
+            if lib.hdrnet_version() >= 241:
+                usable = ctypes.c_int(0)
+                assert lib.hdrnet_curves_guide_prepare_f32(shifts.data_ptr(), slopes.data_ptr(), 16, 3, cp.data_ptr(), nb,
+                                                           ctypes.byref(usable), stream) == 0 and usable.value == 1
+            else:  # a mid-round build: the set-up call did not report usability yet (the kernels read the ok word themselves)
+                fn = lib.hdrnet_curves_guide_prepare_f32
+                fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                               ctypes.c_void_p]
+                assert fn(shifts.data_ptr(), slopes.data_ptr(), 16, 3, cp.data_ptr(), nb, stream) == 0
             prepared[k] = (p1, p2, cp)
     ws, ws2 = {}, {}
     for k, lib in libs.items():
