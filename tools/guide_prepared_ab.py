@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--workload", default="4k")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--only", choices=("exported", "prepared"), default=None,
+                    help="launch ONE form only, 20 times per case, no timing: for counter passes (rocprofv3 --pmc), whose "
+                         "per-kernel means would otherwise mix the two forms of a kernel that switches at run time")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
@@ -104,6 +107,12 @@ def main():
                           ("NN guide + apply + up-add", upadd, "out"),
                           ("f32 -> curves guide -> apply", lambda k, pre: curves(k, pre, False), "out"),
                           ("u8 -> curves guide -> apply -> u8", lambda k, pre: curves(k, pre, True), "o8")):
+        if args.only:
+            for k in range(20):
+                fn(k, args.only == "prepared")
+            torch.cuda.synchronize()
+            print(f"{name}: 20 launches, {args.only} form, kernel {lib.hdrnet_last_kernel().decode()}")
+            continue
         fn(0, False)
         a = S[0][key].clone()
         fn(0, True)
