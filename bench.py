@@ -402,6 +402,104 @@ def pipelined(lib, sets, dims, dev, nstreams=2, launches=2000, rounds=3):
     return best
 
 
+def extra_ops(lib, dev, budget_s=0.3):
+    """Short measurements of the OTHER rows of the scope table for the driver's line (`extra`), taken AFTER the headline's
+    timed region and its sustained / pipelined blocks, on the same stream: config #2 (one 1080p frame), config #5 as
+    stated (uint16 / 32767, 4000x3000, grid 32x32x8x12), the guide network fused into the 4K forward (config #3's hot
+    kernel), all three gradients of a 4K frame (config #4's kernels at 4K), and the same backward on a luma_bins = 16
+    grid.  Each: rotating buffer sets larger than the Infinity Cache, 10 warm-up launches, then launches for about
+    `budget_s` / 2 seconds bracketed by HIP events on the launch stream; `frac` = SURVEY.md section 8d's algorithmic
+    bytes over that time over 8 TB/s.  tools/op_bench.py times the same entry points with 5 x 50 launches
+    (profiles/r06/ops_*.txt)."""
+    import ctypes
+    c_int, c_vp, c_f, c_sz, c_u = ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_size_t, ctypes.c_uint
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    gen = torch.Generator(device=dev).manual_seed(4321)
+    out = {}
+
+    def ints(*v):
+        return tuple(c_int(x) for x in v)
+
+    def measure(name, fn, calls, abytes, est_us):
+        n = len(calls)
+        lib.hdrnet_enable_kernel_names(1)
+        if fn(*calls[0]):
+            raise RuntimeError(lib.hdrnet_last_error().decode())
+        kernel = lib.hdrnet_last_kernel().decode()
+        lib.hdrnet_enable_kernel_names(0)
+        for k in range(10):
+            fn(*calls[k % n])
+        steps = int(min(4000, max(30, 0.5 * budget_s / (est_us * 1e-6))))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for k in range(steps):
+            if fn(*calls[k % n]):
+                raise RuntimeError(lib.hdrnet_last_error().decode())
+        e1.record()
+        torch.cuda.synchronize(dev)
+        us = e0.elapsed_time(e1) * 1e3 / steps
+        out[name] = {"kernel": kernel, "us": round(us, 2), "frac": round(abytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                     "algorithmic_bytes": abytes, "launches": steps}
+
+    def nsets_for(abytes):
+        return max(3, -(-int(CACHE_BYTES * 1.5) // abytes))
+
+    # config #2: one 1080p frame
+    B, H, W, GH, GW, GD = WORKLOADS["1080p"][:6]
+    ab = algorithmic_bytes(B, H, W, GH, GW, GD)
+    sets = make_sets(dev, nsets_for(ab), B, H, W, GH, GW, GD, seed=2)
+    calls = [(c_vp(g.data_ptr()), c_vp(gu.data_ptr()), c_vp(i.data_ptr()), c_vp(o.data_ptr())) +
+             ints(B, H, W, GH, GW, GD, 3, 3, 1) + (c_vp(stream),) for (g, gu, i, o) in sets]
+    measure("fwd_1080p (config #2)", lib.hdrnet_bilateral_slice_apply_f32, calls, ab, 11.0)
+    del sets, calls
+
+    # config #5 as stated: uint16 / 32767 -> f32, 4000x3000, grid 32x32x8x12
+    B, H, W, GH, GW, GD = 1, 3000, 4000, 32, 32, 8
+    ab = B * (H * W * 22 + 4 * GH * GW * GD * 12)
+    sets = [(torch.rand((B, GH, GW, GD, 12), device=dev, generator=gen), torch.rand((B, H, W), device=dev, generator=gen),
+             torch.randint(0, 32768, (B, H, W, 3), device=dev, generator=gen, dtype=torch.int32).to(torch.uint16),
+             torch.empty((B, H, W, 3), device=dev)) for _ in range(nsets_for(ab))]
+    calls = [(c_vp(g.data_ptr()), c_vp(gu.data_ptr()), c_vp(i.data_ptr()), c_vp(o.data_ptr())) +
+             ints(B, H, W, GH, GW, GD, 3, 3, 1, 2) + (c_f(32767.0), c_int(0), None, None, c_int(0), None, c_vp(stream))
+             for (g, gu, i, o) in sets]
+    measure("fwd_hdrp_u16 (config #5)", lib.hdrnet_bilateral_slice_apply_io, calls, ab, 51.0)
+    del sets, calls
+
+    # 4K: the guide network fused into the forward, all three gradients (luma_bins = 8 and 16)
+    B, H, W, GH, GW = WORKLOADS["4k"][:5]
+    npx = B * H * W
+    conv1 = (torch.randn((16, 4), device=dev, generator=gen) * 0.8).contiguous()
+    conv2 = (torch.randn((17,), device=dev, generator=gen) * 0.5).contiguous()
+    pconv1, pconv2 = torch.empty_like(conv1), torch.empty_like(conv2)
+    from hdrnet_amd import _lib
+    if lib.hdrnet_guide_nn_prescale_f32(c_vp(conv1.data_ptr()), c_vp(conv2.data_ptr()), 16, 3, c_f(65536.0),
+                                        c_vp(pconv1.data_ptr()), c_vp(pconv2.data_ptr()), c_vp(stream)):
+        raise RuntimeError(lib.hdrnet_last_error().decode())
+    for GD in (8, 16):
+        gridb = 4 * B * GH * GW * GD * 12
+        ab_bwd = 4 * npx * 7 + 4 * npx * 4 + 2 * gridb  # section 8d: 44 B/px + grid in, dgrid out
+        sets = make_sets(dev, nsets_for(4 * npx * 11), B, H, W, GH, GW, GD, seed=3 + GD)
+        dout = [torch.randn((B, H, W, 3), device=dev, generator=gen) for _ in sets]
+        if GD == 8:
+            calls = [(c_vp(g.data_ptr()), c_vp(i.data_ptr()), c_vp(pconv1.data_ptr()), c_vp(pconv2.data_ptr()),
+                      c_vp(o.data_ptr()), None) + ints(B, H, W, GH, GW, GD, 3, 3, 1, 16) +
+                     (c_u(_lib.GUIDE_SIGMOID_FAST | _lib.GUIDE_RELU_PRESCALED), c_vp(stream)) for (g, gu, i, o) in sets]
+            measure("fwd_4k_nnguide (config #3's hot kernel)", lib.hdrnet_bilateral_slice_apply_nnguide_f32_ex, calls,
+                    4 * npx * 6 + gridb, 41.0)
+        wsb = lib.hdrnet_bilateral_slice_apply_grad_workspace_bytes(B, H, W, GH, GW, GD, 3, 3, 1)
+        ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
+        dg = torch.empty((B, GH, GW, GD, 12), device=dev)
+        dgu = torch.empty((B, H, W), device=dev)
+        calls = [(c_vp(g.data_ptr()), c_vp(gu.data_ptr()), c_vp(i.data_ptr()), c_vp(d.data_ptr()), c_vp(dg.data_ptr()),
+                  c_vp(dgu.data_ptr()), c_vp(o.data_ptr())) + ints(B, H, W, GH, GW, GD, 3, 3, 1) +
+                 (c_vp(ws.data_ptr()), c_sz(wsb), c_vp(stream)) for (g, gu, i, o), d in zip(sets, dout)]
+        measure("bwd_4k_all_three" + ("" if GD == 8 else "_luma_bins_16"), lib.hdrnet_bilateral_slice_apply_grad_f32, calls,
+                ab_bwd, 108.0 if GD == 8 else 150.0)
+        del sets, dout, calls, ws, dg, dgu
+    return out
+
+
 def preroll(step_fn, sync_fn, min_seconds=0.25, chunk=64, max_launches=100000):
     """Untimed launches until >= min_seconds have passed (device out of the idle power state)."""
     n = 0
@@ -433,6 +531,9 @@ def main():
                     help="also time the cache-resident rate and 1080p (same kernel name at other "
                          "sizes: keep off when collecting rocprofv3 --stats for the roofline line)")
     ap.add_argument("--no-extra", action="store_true", help=argparse.SUPPRESS)  # old spelling, no-op
+    ap.add_argument("--no-extra-ops", action="store_true",
+                    help="skip `extra.ops`: the short timings of the other configs / the backward after the headline "
+                         "(other kernels: keep them out of a rocprofv3 --stats summary of this command)")
     ap.add_argument("--batch-norm", action="store_true",
                     help="train_1080p_b4: the model WITH batch norm in training mode (rounds 1-3 benched this graph).  "
                          "The default is without, as every training script of the reference runs it (scripts/*/*.sh: "
@@ -578,6 +679,10 @@ def main():
             extra["smooth_guide_avg_kernel_us"] = round(g3 / args.steps * 1e6, 3)
             extra["smooth_guide_hbm_frac"] = round(abytes / (g3 / args.steps) / 1e9 / HBM_PEAK_GBPS, 4)
             del s3
+        if not args.no_extra_ops:
+            t_x = time.perf_counter()
+            extra["ops"] = extra_ops(lib, dev)
+            extra["ops_seconds"] = round(time.perf_counter() - t_x, 2)
         result["extra"] = extra
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(H, W, GH, GW, GD)

@@ -62,6 +62,20 @@ int check_launch(hipError_t e, const char* what) {
 
 bool positive(int v) { return v > 0; }
 
+// A grid gradient on the generic gather kernel (the reference's own design, bilateral_slice_apply.cc:84-138: every grid
+// element loops over its +-1-cell pixel window) is ~100x slower than the contraction pass.  HDRNET_KERNEL_AUTO falls
+// back to it for shapes the pass has no specialisation for (GD > 16, C > 16, an unlisted channel combination) or
+// without a workspace; on a frame-sized call that is a performance cliff worth one line on stderr per process.
+constexpr long long kWarnGenericPixels = 65536;
+void warn_generic_grid_grad(const char* op, long long npix, int GD, int C, bool have_workspace) {
+  static std::atomic<bool> said{false};
+  if (npix <= kWarnGenericPixels || said.exchange(true)) return;
+  fprintf(stderr, "hdrnet_amd: %s on %lld pixels (GD=%d, C=%d) takes the generic grid-gradient kernel, ~100x slower "
+          "than the fast pass (%s)\n", op, npix, GD, C,
+          have_workspace ? "no fast specialisation for this shape: needs GD <= 16, C <= 16 and a listed channel combination"
+                         : "no workspace passed: see hdrnet_bilateral_slice*_grad_workspace_bytes");
+}
+
 // Extents >= 0; a zero-sized batch / image is a legal no-op, a zero-sized grid is not.
 int check_common(int B, int H, int W, int GH, int GW, int GD) {
   if (B < 0 || H < 0 || W < 0)
@@ -809,6 +823,8 @@ int hdrnet_bilateral_slice_apply_grad_f32_ex(const float* grid, const float* gui
   }
   const char* rest_name = "";
   if (rest.dgrid || rest.dguide || rest.dinput) {
+    if (rest.dgrid && family(flags) == HDRNET_KERNEL_AUTO)
+      warn_generic_grid_grad("BilateralSliceApplyGrad", npix, GD, Cout * Cj, workspace != nullptr);
     const int rc = check_launch(launch_apply_grad_generic(rest, s), "BilateralSliceApplyGrad");
     if (rc != HDRNET_OK) return rc;
     rest_name = "apply_grad_generic";
@@ -926,6 +942,8 @@ int hdrnet_bilateral_slice_grad_f32_ex(const float* grid, const float* guide, co
   }
   const char* rest_name = "";
   if (rest.dgrid || rest.dguide) {
+    if (rest.dgrid && family(flags) == HDRNET_KERNEL_AUTO)
+      warn_generic_grid_grad("BilateralSliceGrad", (long long)B * H * W, GD, C, workspace != nullptr);
     const int rc = check_launch(launch_slice_grad_generic(rest, s), "BilateralSliceGrad");
     if (rc != HDRNET_OK) return rc;
     rest_name = "slice_grad_generic";

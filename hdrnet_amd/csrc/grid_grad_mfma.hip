@@ -213,12 +213,20 @@ constexpr int kTStride = 68;  // floats per operand row: 64 pixels + 4 (16-B ali
 // like apply_fwd_seg.hip: 2 x (GD + 2) x C floats per wave, re-blended by the wave at the start of
 // each row from grid rows it prefetched with the row's first pixel batch.  The z tent and its
 // derivative share one v_sqrt_f32 per tap with the dgrid weights.
-template <int CIN, int COUT, bool OFFSET, bool APPLY, bool SPLIT, bool WG = false, bool WI = false, int ABL = 0>
+//
+// NH (plane halves): the 16 rows of the A tile are (x corner, plane 0 .. 7).  A grid of 9 .. 16 planes (luma_bins = 16,
+// hdrnet/bin/train.py:235) is NH = 2 tiles per task, planes 0 .. 7 and 8 .. 15, each with its own accumulators; per
+// 64-pixel chunk the wave ballots which halves hold a live tap and contracts only those (an image-like guide rarely
+// straddles plane 7 | 8 inside 64 neighbouring pixels: then the chunk costs what it costs at GD <= 8).  Both halves go
+// through the SAME 16-row A slab, scattered, contracted and re-zeroed once per live half.
+template <int CIN, int COUT, bool OFFSET, bool APPLY, bool SPLIT, bool WG = false, bool WI = false, int ABL = 0, int NH = 1>
 __global__ __launch_bounds__(kWaves * 64)
-__attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET ? 1 : 0) : 1) <= 12) ? 4 : 1))) void grid_grad_stage1(GGParams p) {
+__attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET ? 1 : 0) : 1) <= 12) ? (NH == 1 ? 4 : 3) : 1))) void grid_grad_stage1(GGParams p) {
   constexpr int CJ = APPLY ? CIN + (OFFSET ? 1 : 0) : 1;
   constexpr int C = COUT * CJ;
   static_assert(C <= 16, "one 16-column MFMA tile");
+  static_assert(NH == 1 || NH == 2, "8 or 16 planes");
+  static_assert(NH == 1 || (!SPLIT && ABL == 0), "the tools variants exist for GD <= 8 only");
   constexpr bool FUSED = WG || WI;
   static_assert(!FUSED || C % 4 == 0, "fused backward: float4 coefficient vectors");
   static_assert(!WI || (APPLY && CIN > 0), "dinput needs an input");
@@ -230,10 +238,10 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
   // chunk ahead brings the pass from 3 to 4 waves / SIMD and 115 -> 110 us at 4K.
   constexpr int kBatch = (!APPLY && COUT >= 12) ? 1 : 2;
   constexpr int kLoadAux = FUSED ? rows::kAuxNt : 0;  // fused pass is an HBM stream: nontemporal pixel loads
-  // [A, D = x difference, dzA = z difference of A, dzD][plane 0 .. GD + 1 (GD <= 8)][c]  (round 5: + the two z differences)
-  constexpr int kImg = FUSED ? 4 * 10 * C : 0;
-  constexpr int kSlab = (16 + C) * kTStride + kImg;  // floats per wave: A^T [16][68], V^T [C][68], image
-  static_assert(kSlab >= kTileFloats, "the final reduction reuses the slabs");
+  // [A, D = x difference, dzA = z difference of A, dzD][plane 0 .. GD + 1 (GD <= 8 NH)][c]
+  constexpr int kImg = FUSED ? 4 * (8 * NH + 2) * C : 0;
+  constexpr int kSlabOps = (16 + C) * kTStride + kImg;  // floats per wave: A^T [16][68], V^T [C][68], image
+  constexpr int kSlab = kSlabOps >= NH * kTileFloats ? kSlabOps : NH * kTileFloats;  // the final reduction reuses the slabs
   __shared__ __attribute__((aligned(16))) float lds[kWaves * kSlab];
   if constexpr (ABL == 5) return;  // tools ablation: the launch alone
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -267,15 +275,22 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
   const int span = x_hi - x_lo;
   const int nbr = (span + 64 * kBatch - 1) / (64 * kBatch);  // batches per row
   // fused: this lane's element of the row's coefficient image (2 columns x GD planes x C / 4 float4)
+  // (element e = lane + 64 s of slot s; NH = 2: up to 2 x 16 x 4 = 128 elements, two per lane)
   constexpr int C4 = C / 4 > 0 ? C / 4 : 1;
+  constexpr int NSLOT = NH;
   const int nst = 2 * p.GD * C4;
-  // (decoded for min(lane, nst - 1): every lane issues the two staging loads -- a VMEM op under an exec
+  // (decoded for min(e, nst - 1): every lane issues the two staging loads -- a VMEM op under an exec
   //  mask makes the compiler's vmcnt bookkeeping fall back to vmcnt(0), which drains the prefetch)
-  const int st_lane = min(lane, nst - 1);
-  const int st_col = st_lane / (p.GD * C4), st_rem = st_lane - st_col * (p.GD * C4);
-  const int st_src = (min(max(g + st_col, 0), p.GW - 1) * p.GD * C4 + st_rem);  // float4 index in a grid row
-  const int st_z = st_rem / C4;
-  const int st_dst = (st_col * (p.GD + 2) + st_z + 1) * C4 + (st_rem - st_z * C4);
+  int st_col[NSLOT], st_src[NSLOT], st_z[NSLOT], st_dst[NSLOT];
+#pragma unroll
+  for (int sl = 0; sl < NSLOT; ++sl) {
+    const int st_e = min(lane + 64 * sl, nst - 1);
+    st_col[sl] = st_e / (p.GD * C4);
+    const int st_rem = st_e - st_col[sl] * (p.GD * C4);
+    st_src[sl] = (min(max(g + st_col[sl], 0), p.GW - 1) * p.GD * C4 + st_rem);  // float4 index in a grid row
+    st_z[sl] = st_rem / C4;
+    st_dst[sl] = (st_col[sl] * (p.GD + 2) + st_z[sl] + 1) * C4 + (st_rem - st_z[sl] * C4);
+  }
   const float* grid_b = FUSED ? p.grid + (size_t)b * p.GH * p.GW * p.GD * C : nullptr;
   const int colb = (p.GD + 2) * CB;
   const float zhi = (float)(p.GD - 1);
@@ -295,9 +310,12 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
   const unsigned a_addr = (unsigned)(uintptr_t)((lds_float*)at + bc * kTStride + rd_off);
   const unsigned v_addr = (unsigned)(uintptr_t)((lds_float*)vt + min(bc, C - 1) * kTStride + rd_off);
 
-  f32x4 acc[3];
+  f32x4 acc[NH][3];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int h = 0; h < NH; ++h) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) acc[h][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   struct Batch {
     float g[kBatch], in[kBatch][CIN_Q], d[kBatch][COUT];
@@ -349,13 +367,18 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
   if constexpr (kAhead > 1 && ABL != 1 && ABL != 4) load_batch(ring[1], nbt > 1);
   // fused: this lane's element of the two grid rows the coefficient image blends.  They change only when
   // gy0 does (once per cell height), so they stay in registers across the wave's rows.
-  f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = sa;
+  f32x4 sa[NSLOT], sb[NSLOT];
+#pragma unroll
+  for (int sl = 0; sl < NSLOT; ++sl) sa[sl] = sb[sl] = f32x4{0.f, 0.f, 0.f, 0.f};
   int gy0_held = -0x7fffffff;
   auto load_grid_rows = [&](int gy0) {
     gy0_held = gy0;
     const int gy0c = clamp_index(gy0, 0, p.GH - 1), gy1c = clamp_index(gy0 + 1, 0, p.GH - 1);
-    sa = reinterpret_cast<const f32x4*>(grid_b + (size_t)gy0c * p.GW * p.GD * C)[st_src];
-    sb = reinterpret_cast<const f32x4*>(grid_b + (size_t)gy1c * p.GW * p.GD * C)[st_src];
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl) {
+      sa[sl] = reinterpret_cast<const f32x4*>(grid_b + (size_t)gy0c * p.GW * p.GD * C)[st_src[sl]];
+      sb[sl] = reinterpret_cast<const f32x4*>(grid_b + (size_t)gy1c * p.GW * p.GD * C)[st_src[sl]];
+    }
   };
   if constexpr (FUSED) {
     if (nbt > 0) load_grid_rows(floor_to_int(mul_rn(y_first + wave + 0.5f, p.scale_y) - 0.5f));
@@ -372,7 +395,9 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
   float dxc[kXW];
 #pragma unroll
   for (int cb = 0; cb < kXW; ++cb) dxc[cb] = x_offset(x_lo + 64 * cb + lane);
-  f32x4 dacc = {0.f, 0.f, 0.f, 0.f}, dacc2 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 dacc[NH], dacc2[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) dacc[h] = dacc2[h] = f32x4{0.f, 0.f, 0.f, 0.f};
   // y terms of the row being contracted (bilateral_slice_apply.cc:42,47,55-56), formed once per row
   int row_gy0 = 0;
   float row_wy0 = 0.0f, row_wy1 = 0.0f;
@@ -398,36 +423,62 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
         const int gy0 = row_gy0;
         const float wy0 = row_wy0, wy1 = row_wy1;
         if (gy0 != gy0_held) load_grid_rows(gy0);  // wave-uniform; at most once more per wave (rg <= cell height)
-        // column g + 1 is stored as its difference to column g (the lane GD * C4 below holds that element)
-        f32x4 v = wy0 * sa + wy1 * sb;
-        {
-          const int partner = max(lane - p.GD * C4, 0);
-          f32x4 o;
+        // column g + 1 is stored as its difference to column g (element e - GD * C4 holds that element: always one of
+        // slot 0, GD * C4 <= 64)
+        f32x4 v[NSLOT];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = __shfl(v[e], partner);
-          if (st_col == 1) v = v - o;
+        for (int sl = 0; sl < NSLOT; ++sl) v[sl] = wy0 * sa[sl] + wy1 * sb[sl];
+        {
+          f32x4 o[NSLOT];
+#pragma unroll
+          for (int sl = 0; sl < NSLOT; ++sl) {
+            const int partner = max(lane + 64 * sl - p.GD * C4, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[sl][e] = __shfl(v[0][e], partner);
+          }
+#pragma unroll
+          for (int sl = 0; sl < NSLOT; ++sl)
+            if (st_col[sl] == 1) v[sl] = v[sl] - o[sl];
         }
-        // (round 5) ... and beside every plane its z DIFFERENCE to the plane above (the lane C4 above holds plane z + 1 of
+        // (round 5) ... and beside every plane its z DIFFERENCE to the plane above (element e + C4 holds plane z + 1 of
         // the same column; the topmost plane's neighbour is its own clamped copy: 0): dguide contracts this difference
         // directly instead of subtracting two contracted taps (below).  Formed from the blended values: its rounding,
         // ~1 ulp of a coefficient, is far below what the contraction of two full taps carried.
-        f32x4 dv;
-        {
-          const int up = min(lane + C4, 63);
+        f32x4 dv[NSLOT];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) dv[e] = __shfl(v[e], up) - v[e];
-          if (st_z == p.GD - 1) dv = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (lane < nst) {
-          f32x4* d4 = reinterpret_cast<f32x4*>(img);
-          const int dzo = 2 * (p.GD + 2) * C4;  // the difference planes follow the two columns
-          d4[st_dst] = v;
-          d4[st_dst + dzo] = dv;
-          if (st_z == 0) {
-            d4[st_dst - C4] = v;
-            d4[st_dst - C4 + dzo] = f32x4{0.f, 0.f, 0.f, 0.f};  // plane -1 is the clamped copy of plane 0
+        for (int sl = 0; sl < NSLOT; ++sl) {
+          const int ue = lane + 64 * sl + C4;  // the element above; slot ue / 64
+          f32x4 upv;
+          if constexpr (NSLOT == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) upv[e] = __shfl(v[0][e], min(ue, 63));
+          } else if (sl == NSLOT - 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) upv[e] = __shfl(v[NSLOT - 1][e], min(ue - 64 * sl, 63));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float same = __shfl(v[sl][e], min(ue - 64 * sl, 63));
+              const float next = __shfl(v[NSLOT - 1][e], max(ue - 64 * (sl + 1), 0));
+              upv[e] = (ue - 64 * sl < 64) ? same : next;
+            }
           }
-          if (st_z == p.GD - 1) d4[st_dst + C4] = v;
+          dv[sl] = upv - v[sl];
+          if (st_z[sl] == p.GD - 1) dv[sl] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) {
+          if (lane + 64 * sl < nst) {
+            f32x4* d4 = reinterpret_cast<f32x4*>(img);
+            const int dzo = 2 * (p.GD + 2) * C4;  // the difference planes follow the two columns
+            d4[st_dst[sl]] = v[sl];
+            d4[st_dst[sl] + dzo] = dv[sl];
+            if (st_z[sl] == 0) {
+              d4[st_dst[sl] - C4] = v[sl];
+              d4[st_dst[sl] - C4 + dzo] = f32x4{0.f, 0.f, 0.f, 0.f};  // plane -1 is the clamped copy of plane 0
+            }
+            if (st_z[sl] == p.GD - 1) d4[st_dst[sl] + C4] = v[sl];
+          }
         }
         wave_lds_order();
       }
@@ -616,13 +667,13 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
         const float wP = edge ? 1.0f : __builtin_amdgcn_fmed3f(1.0f - sza, 0.0f, 1.0f);
         const float wQ = edge ? 0.0f : __builtin_amdgcn_fmed3f(1.0f - szb, 0.0f, 1.0f);
         const int zP = (int)__builtin_amdgcn_fmed3f(fz, 0.0f, zhi), zQ = min(zP + 1, p.GD - 1);
-        float* aP = at + __umul24((unsigned)zP, (unsigned)kTStride) + lane;
-        float* aQ = at + __umul24((unsigned)zQ, (unsigned)kTStride) + lane;
+        // (NH = 2: plane z lives in row z & 7 of half z >> 3's tile; the scatter itself happens per live half, below)
+        float* aP = at + __umul24((unsigned)(NH == 1 ? zP : (zP & 7)), (unsigned)kTStride) + lane;
+        float* aQ = at + __umul24((unsigned)(NH == 1 ? zQ : (zQ & 7)), (unsigned)kTStride) + lane;
         auto enc = [](float v) { return SPLIT ? split_pack(v) : v; };
         auto enc2 = [](f32x2 v) { return SPLIT ? f32x2(split_pack2(v)) : v; };
-        {
-          const f32x2 wx = {w0, w1};
-          const f32x2 q2 = enc2(wx * f32x2{wQ, wQ}), p2 = enc2(wx * f32x2{wP, wP});
+        const f32x2 q2 = enc2(f32x2{w0, w1} * f32x2{wQ, wQ}), p2 = enc2(f32x2{w0, w1} * f32x2{wP, wP});
+        if constexpr (NH == 1) {
           aQ[0] = q2.x;
           aQ[8 * kTStride] = q2.y;
           aP[0] = p2.x;
@@ -668,7 +719,7 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
                : "memory")
 #define HDRNET_GG_OUT(x) "=&v"(x)
 #define HDRNET_GG_INOUT(x) "+v"(x)
-        auto contract = [&]() {
+        auto contract = [&](f32x4& dacc, f32x4& dacc2) {
           if constexpr (SPLIT) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -699,20 +750,47 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
           }
         };
         if constexpr (ABL == 6) ts1 = clock64();  // VALU phase + staging writes issued
-        HDRNET_GG_READS(0, HDRNET_GG_OUT);
-        if constexpr (ABL == 6) ts2 = clock64();  // first half's operands have arrived
-        contract();
-        HDRNET_GG_READS(64, HDRNET_GG_INOUT);
-        if constexpr (ABL == 6) ts3 = clock64();  // first half's MFMAs issued, second half's operands arrived
-        contract();
+        if constexpr (NH == 1) {
+          HDRNET_GG_READS(0, HDRNET_GG_OUT);
+          if constexpr (ABL == 6) ts2 = clock64();  // first half's operands have arrived
+          contract(dacc[0], dacc2[0]);
+          HDRNET_GG_READS(64, HDRNET_GG_INOUT);
+          if constexpr (ABL == 6) ts3 = clock64();  // first half's MFMAs issued, second half's operands arrived
+          contract(dacc[0], dacc2[0]);
+          wave_lds_order();
+          aQ[0] = 0.0f;
+          aQ[8 * kTStride] = 0.0f;
+          aP[0] = 0.0f;
+          aP[8 * kTStride] = 0.0f;
+        } else {
+          // which plane halves hold a tap of this chunk (zQ >= zP: half 0 is live iff some zP < 8, half 1 iff some
+          // zQ >= 8); a pixel's tap outside the half being contracted is staged as 0 (a zero written into a zeroed
+          // slab: rows z & 7 of the two taps differ, or Q's slot is P's and P is written last)
+          const bool live_h[2] = {__ballot(zP < 8) != 0ull, __ballot(zQ >= 8) != 0ull};
+#pragma unroll
+          for (int h = 0; h < NH; ++h) {
+            if (live_h[h]) {  // wave-uniform
+              const bool inP = (zP >> 3) == h, inQ = (zQ >> 3) == h;
+              aQ[0] = inQ ? q2.x : 0.0f;
+              aQ[8 * kTStride] = inQ ? q2.y : 0.0f;
+              aP[0] = inP ? p2.x : 0.0f;
+              aP[8 * kTStride] = inP ? p2.y : 0.0f;
+              wave_lds_order();
+              HDRNET_GG_READS(0, HDRNET_GG_OUT);
+              contract(dacc[h], dacc2[h]);
+              HDRNET_GG_READS(64, HDRNET_GG_INOUT);
+              contract(dacc[h], dacc2[h]);
+              wave_lds_order();
+              aQ[0] = 0.0f;
+              aQ[8 * kTStride] = 0.0f;
+              aP[0] = 0.0f;
+              aP[8 * kTStride] = 0.0f;
+            }
+          }
+        }
 #undef HDRNET_GG_READS
 #undef HDRNET_GG_OUT
 #undef HDRNET_GG_INOUT
-        wave_lds_order();
-        aQ[0] = 0.0f;
-        aQ[8 * kTStride] = 0.0f;
-        aP[0] = 0.0f;
-        aP[8 * kTStride] = 0.0f;
         if constexpr (ABL == 6) {
           const int nch = t * kBatch + cb;  // chunk ordinal of this wave
           if (wave == 0 && lane == 0 && nch < kTraceChunks) {
@@ -731,14 +809,17 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
       const float wy0 = row_wy0, wy1 = row_wy1;
       const int rel0 = clamp_index(gy0, 0, p.GH - 1) - gy_base;
       const int rel1 = clamp_index(gy0 + 1, 0, p.GH - 1) - gy_base;
-      dacc += dacc2;
 #pragma unroll
-      for (int rr = 0; rr < 3; ++rr) {
-        const float sr = (rel0 == rr ? wy0 : 0.0f) + (rel1 == rr ? wy1 : 0.0f);
-        acc[rr] += sr * dacc;
+      for (int h = 0; h < NH; ++h) {
+        dacc[h] += dacc2[h];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          const float sr = (rel0 == rr ? wy0 : 0.0f) + (rel1 == rr ? wy1 : 0.0f);
+          acc[h][rr] += sr * dacc[h];
+        }
+        dacc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dacc2[h] = dacc[h];
       }
-      dacc = f32x4{0.f, 0.f, 0.f, 0.f};
-      dacc2 = dacc;
     }
   };
   if constexpr (ABL == 1 || ABL == 4) {
@@ -760,13 +841,16 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
   __syncthreads();
   float* red = lds + wave * kSlab;
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
+  for (int h = 0; h < NH; ++h) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) red[(r * 16 + 4 * sub + q) * 16 + bc] = acc[r][q];
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[((h * 3 + r) * 16 + 4 * sub + q) * 16 + bc] = acc[h][r][q];
+    }
   }
   __syncthreads();
-  float* dst = p.partial + (size_t)task * kTileFloats;
-  for (int e = threadIdx.x; e < kTileFloats; e += kWaves * 64) {
+  float* dst = p.partial + (size_t)task * (NH * kTileFloats);  // [half][rel 3][k 16][c 16]
+  for (int e = threadIdx.x; e < NH * kTileFloats; e += kWaves * 64) {
     float sum = lds[e];
 #pragma unroll
     for (int w = 1; w < kWaves; ++w) sum += lds[w * kSlab + e];
@@ -780,16 +864,19 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
 // then the 4 partial sums are added in fixed order.  A wave reads 256-B runs (4 planes x 16 channels of one tile);
 // the result is deterministic.  (Round 2: one 256-thread workgroup per (column, plane), 16 parts: 5.6 us of device
 // time per call at 4K, profiles/r03/bwd_kernel_stats.csv.)
-constexpr int kS2Parts = 4;
+// NH = 2 (9 .. 16 planes): 16 plane slots x 2 parts; a task's tile is [half][rel][k][c], plane z in half z >> 3, row z & 7.
+template <int NH>
 __global__ __launch_bounds__(512) void grid_grad_stage2(const float* __restrict__ partial,
                                                         float* __restrict__ dgrid, int GH, int GW,
                                                         int GD, int C, int rg, int nyg,
                                                         float scale_y) {
-  __shared__ float red[kS2Parts][8 * 16 + 1];
-  const int c = threadIdx.x & 15, z = (threadIdx.x >> 4) & 7, part = threadIdx.x >> 7;
+  constexpr int kNZ = 8 * NH, kS2Parts = 32 / kNZ, kTile = NH * kTileFloats;
+  __shared__ float red[kS2Parts][kNZ * 16 + 1];
+  const int c = threadIdx.x & 15, z = (threadIdx.x >> 4) & (kNZ - 1), part = threadIdx.x / (16 * kNZ);
   const int gx = blockIdx.x, gy = blockIdx.y;
   const long long b = blockIdx.z;
   const int nint = GW + 1;
+  const int zrow = (z >> 3) * 3 * 16 + (z & 7);  // + rel * 16: row of plane z, x corner 0
   // Conservative window of row groups that can touch gy; exact membership is `rel`.
   const int yg_lo = max(0, (int)floorf((gy - 2.0f) / scale_y) / rg - 1);
   const int yg_hi = min(nyg, (int)ceilf((gy + 2.5f) / scale_y) / rg + 2);
@@ -799,12 +886,12 @@ __global__ __launch_bounds__(512) void grid_grad_stage2(const float* __restrict_
       const int rel = gy - gy_base_of(yg * rg, scale_y, GH);
       if (rel < 0 || rel > 2) continue;
       const size_t t0 = ((size_t)b * nyg + yg) * nint;
-      float v0 = partial[(t0 + gx + 1) * kTileFloats + (rel * 16 + z) * 16 + c];
-      float v1 = partial[(t0 + gx) * kTileFloats + (rel * 16 + 8 + z) * 16 + c];
+      float v0 = partial[(t0 + gx + 1) * kTile + (rel * 16 + zrow) * 16 + c];
+      float v1 = partial[(t0 + gx) * kTile + (rel * 16 + 8 + zrow) * 16 + c];
       // clamp-to-edge: interval g = -1's corner 0 and interval g = GW - 1's corner 1 land on the edge columns
       float v2 = 0.0f, v3 = 0.0f;
-      if (gx == 0) v2 = partial[t0 * kTileFloats + (rel * 16 + z) * 16 + c];
-      if (gx == GW - 1) v3 = partial[(t0 + GW) * kTileFloats + (rel * 16 + 8 + z) * 16 + c];
+      if (gx == 0) v2 = partial[t0 * kTile + (rel * 16 + zrow) * 16 + c];
+      if (gx == GW - 1) v3 = partial[(t0 + GW) * kTile + (rel * 16 + 8 + zrow) * 16 + c];
       s += v0;
       s += v1;
       if (gx == 0) s += v2;
@@ -839,7 +926,8 @@ constexpr int kMinRg = 4, kMaxRounds = 6;
 constexpr int kMaxOcc = 8;  // workgroups per CU a stage-1 kernel can have (8 waves per SIMD, 4-wave workgroups)
 
 bool gg_plan(int B, int H, int W, int GH, int GW, int GD, int C, long long slots, GGPlan* pl) {
-  if (GD > 8 || C > 16 || C < 1) return false;
+  if (GD > 16 || C > 16 || C < 1) return false;
+  const int nh = GD > 8 ? 2 : 1;  // plane halves: a task writes one [3][16][16] tile per half
   const int cell = H / GH > 1 ? H / GH : 1;
   const int rg_lo = cell < kMinRg ? cell : kMinRg;
   const long long cols = (long long)B * (GW + 1);
@@ -870,7 +958,7 @@ bool gg_plan(int B, int H, int W, int GH, int GW, int GD, int C, long long slots
   pl->nyg = (H + rg - 1) / rg;
   pl->ntasks = cols * pl->nyg;
   if (pl->ntasks > 0x7fffffffLL || (long long)B * GH * GW * GD > 0x7fffffffLL || pl->nyg > 65535 || B > 65535 || GH > 65535) return false;
-  pl->ws_bytes = (size_t)pl->ntasks * kTileFloats * sizeof(float);
+  pl->ws_bytes = (size_t)pl->ntasks * nh * kTileFloats * sizeof(float);
   return true;
 }
 
@@ -952,7 +1040,7 @@ hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int G
   const bool wg = q.dguide != nullptr, wi = q.dinput != nullptr;
   Stage1Fn kfn = nullptr;
   std::atomic<int>* occ = nullptr;
-  static std::atomic<int> occ_cache[8];  // per (split, dguide, dinput) of this shape
+  static std::atomic<int> occ_cache[16];  // per (plane halves, split, dguide, dinput) of this shape
 #ifdef HDRNET_TOOLS_BUILD
   if constexpr (APPLY && CIN == 3 && COUT == 3 && OFFSET) {  // ablations (tools variants 4 .. 8): timing only
     if (ablate >= 1 && ablate <= 6) {
@@ -966,31 +1054,35 @@ hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int G
     }
   }
 #endif
+  const bool two = GD > 8;  // NH = 2: planes 8 .. 15 in a second tile per task
+  if (two && (split || kfn)) return hipErrorNotSupported;  // the tools variants exist for GD <= 8 only
   if (!kfn) {
-    occ = &occ_cache[(split ? 4 : 0) + (wg ? 2 : 0) + (wi ? 1 : 0)];
+    occ = &occ_cache[(two ? 8 : 0) + (split ? 4 : 0) + (wg ? 2 : 0) + (wi ? 1 : 0)];
     if constexpr (C % 4 == 0) {
       constexpr bool CAN_WI = APPLY && CIN > 0;
       if (wi && !CAN_WI) return hipErrorInvalidValue;
-#define GG_PICK(SPL)                                                                                  \
-  (wg && wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, true, CAN_WI>                 \
-            : wg ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, true, false>             \
-                 : wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, false, CAN_WI>      \
-                      : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, false, false>)
+#define GG_PICK(SPL, NH)                                                                              \
+  (wg && wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, true, CAN_WI, 0, NH>          \
+            : wg ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, true, false, 0, NH>      \
+                 : wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, false, CAN_WI, 0, NH> \
+                      : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, false, false, 0, NH>)
 #ifdef HDRNET_TOOLS_BUILD  // the bf16-split contraction is an experiment: not in the product library
-      kfn = split ? GG_PICK(true) : GG_PICK(false);
+      kfn = two ? GG_PICK(false, 2) : split ? GG_PICK(true, 1) : GG_PICK(false, 1);
 #else
       if (split) return hipErrorNotSupported;
-      kfn = GG_PICK(false);
+      kfn = two ? GG_PICK(false, 2) : GG_PICK(false, 1);
 #endif
 #undef GG_PICK
     } else {
       if (wg || wi) return hipErrorInvalidValue;  // fused VJPs read the coefficient image as float4
 #ifdef HDRNET_TOOLS_BUILD
-      kfn = split ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, true>
-                  : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false>;
+      kfn = two ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, false, false, 0, 2>
+                : split ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, true>
+                        : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false>;
 #else
       if (split) return hipErrorNotSupported;
-      kfn = (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false>;
+      kfn = two ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, false, false, 0, 2>
+                : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false>;
 #endif
     }
   }
@@ -1010,8 +1102,13 @@ hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int G
   kfn<<<nblocks, kWaves * 64, dyn_lds, s>>>(p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  grid_grad_stage2<<<dim3((unsigned)GW, (unsigned)GH, (unsigned)B), 512, 0, s>>>(
-      static_cast<const float*>(ws), q.dgrid, GH, GW, GD, C, pl.rg, pl.nyg, (float)GH / H);
+  const dim3 ncols((unsigned)GW, (unsigned)GH, (unsigned)B);
+  if (two)
+    grid_grad_stage2<2><<<ncols, 512, 0, s>>>(static_cast<const float*>(ws), q.dgrid, GH, GW, GD, C, pl.rg, pl.nyg,
+                                              (float)GH / H);
+  else
+    grid_grad_stage2<1><<<ncols, 512, 0, s>>>(static_cast<const float*>(ws), q.dgrid, GH, GW, GD, C, pl.rg, pl.nyg,
+                                              (float)GH / H);
   return hipGetLastError();
 }
 

@@ -47,12 +47,24 @@ def timeit(fn, steps, rounds=5):
     return statistics.median(out), min(out)
 
 
+def smooth_guide(dev, gen, B, H, W):
+    """Luminance-like guide: a low-pass ramp + 2 % noise (the form of bench.make_sets(smooth_guide=True))."""
+    yy = torch.linspace(0, 1, H, device=dev)[:, None]
+    xx = torch.linspace(0, 1, W, device=dev)[None, :]
+    base = 0.5 + 0.25 * torch.sin(6.28318 * (xx * 1.5 + yy)) + 0.2 * (xx - 0.5)
+    return (base[None] + 0.02 * torch.rand((B, H, W), device=dev, generator=gen)).clamp(0, 1).contiguous()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="4k")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--json", default=None)
     ap.add_argument("--tools", action="store_true")
+    ap.add_argument("--luma-bins", type=int, default=None, help="override the grid depth GD (hdrnet/bin/train.py:235)")
+    ap.add_argument("--smooth-guide", action="store_true",
+                    help="an image-like guide (bench.make_sets' low-pass ramp + 2 %% noise) instead of U[0, 1)")
+    ap.add_argument("--only", default=None, help="comma-separated substrings: run only the ops whose name contains one")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load_tools() if args.tools else _lib.load()
@@ -60,6 +72,11 @@ def main():
     if args.workload == "refbench":
         return refbench(lib, dev, args)
     B, H, W, GH, GW, GD, desc = WORKLOADS[args.workload]
+    if args.luma_bins:
+        desc = desc.replace(f"x{GD}x12", f"x{args.luma_bins}x12")
+        GD = args.luma_bins
+    if args.smooth_guide:
+        desc += ", smooth (image-like) guide"
     Cin, Cout, C = 3, 3, 12
     npx = B * H * W
     gridb = 4 * B * GH * GW * GD * C
@@ -69,7 +86,7 @@ def main():
     for _ in range(nsets):
         S.append(dict(
             grid=torch.rand((B, GH, GW, GD, C), device=dev, generator=gen),
-            guide=torch.rand((B, H, W), device=dev, generator=gen),
+            guide=smooth_guide(dev, gen, B, H, W) if args.smooth_guide else torch.rand((B, H, W), device=dev, generator=gen),
             inp=torch.rand((B, H, W, Cin), device=dev, generator=gen),
             dout=torch.randn((B, H, W, Cout), device=dev, generator=gen),
             out=torch.empty((B, H, W, Cout), device=dev),
@@ -197,7 +214,11 @@ def main():
 
     rows = []
 
+    only = [t.strip() for t in args.only.split(",")] if args.only else None
+
     def run(name, fn, nbytes):
+        if only and not any(t in name for t in only):
+            return
         fn(0)
         torch.cuda.synchronize()
         kern = lib.hdrnet_last_kernel().decode()
