@@ -286,6 +286,19 @@ def cpu_baseline(H, W, GH, GW, GD):
     return cpu_bench.run(H, W, GH, GW, GD)
 
 
+def device_index(local_rank, device_count):
+    """One process per GPU: rank -> cuda:<local_rank>; on a box with fewer GPUs than ranks (the 1-GPU development box)
+    the ranks wrap around and share devices."""
+    return local_rank % max(int(device_count), 1)
+
+
+def launch_command(gpus, port, argv):
+    """The command `python bench.py --gpus N` becomes from a bare shell -- the driver's own launch line:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ..."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def self_launch(args):
     """`python bench.py --gpus N` from a bare shell: become N ranks under torch.distributed.run."""
     import socket
@@ -293,11 +306,9 @@ def self_launch(args):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.call(cmd, env=env)
+    return subprocess.call(launch_command(args.gpus, port, sys.argv[1:]), env=env)
 
 
 class _PowerProbe:
@@ -542,6 +553,10 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="train_1080p_b4 at N = 1: create a one-rank RCCL communicator and issue the flat-bucket all-reduce "
                          "in every step all the same (the multi-rank structure with the real collective kernel on one GPU)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1: create the (one-rank) process group all the same, so that the barrier and the "
+                         "max-over-ranks of the timed region run through RCCL on the device exactly as at N = 8 "
+                         "(the dry run of what the driver launches; tests/test_gpu_bench_dryrun.py)")
     ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)  # tests: gloo + a stub timed body
     args = ap.parse_args()
 
@@ -565,13 +580,14 @@ def main():
     # One process per GPU.  (On a box with fewer GPUs than ranks -- the 1-GPU development box -- the
     # ranks share devices; RCCL refuses two ranks on one device, so that smoke test of the N > 1 path
     # sets HDRNET_BENCH_BACKEND=gloo.  The driver's 8-GPU runs use the default: nccl = RCCL.)
-    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+    dev = torch.device("cuda", device_index(local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
-    dist_on = world > 1
+    single = bool(args.force_dist) and world == 1
+    dist_on = world > 1 or single
     from hdrnet_amd import dist as hd
     backend = os.environ.get("HDRNET_BENCH_BACKEND", "nccl")
     if dist_on:
-        hd.init(backend=backend, device=dev)  # RCCL over xGMI; control plane only (barrier, max-time)
+        hd.init(backend=backend, device=dev, single=single)  # RCCL over xGMI; control plane only (barrier, max-time)
 
     from hdrnet_amd import _lib
     lib = _lib.load()  # raises loudly if the HIP library is missing
@@ -631,7 +647,9 @@ def main():
                    "working_set_MB": round(nsets * frame_bytes / 1e6, 1),
                    "parallelism": (f"row-split x{world} (one frame over all ranks)" if band
                                    else f"image-shard x{world}"),
-                   "kernel": kernel},
+                   "kernel": kernel,
+                   # the communicator behind the barrier / max-over-ranks of the timed region (None: N = 1, no group)
+                   "process_group": ({"backend": backend, "world": world, "device": str(dev)} if dist_on else None)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4),
                      "traffic": (traffic or {}).get("bytes_per_launch"),
@@ -703,7 +721,7 @@ def _init_ranks(world, local_rank, cpu=False, single=False):
     else:
         if not torch.cuda.is_available():
             sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
-        dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+        dev = torch.device("cuda", device_index(local_rank, torch.cuda.device_count()))
         torch.cuda.set_device(dev)
         backend = os.environ.get("HDRNET_BENCH_BACKEND", "nccl")
     if world > 1 or single:
@@ -899,11 +917,23 @@ def stub_main(args, rank, world):
     if world > 1:
         hd.barrier()
     (wall_max,) = hd.max_over_ranks([wall], device=torch.device("cpu"))
+    # what every rank read from the launcher's environment and the device it would bind (main()'s rule); the device
+    # count of the box is faked in tests (HDRNET_BENCH_FAKE_DEVICE_COUNT: this container has no GPU)
+    ndev = int(os.environ.get("HDRNET_BENCH_FAKE_DEVICE_COUNT", torch.cuda.device_count()))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    mine = {"rank": rank, "local_rank": local_rank, "world": world, "device_index": device_index(local_rank, ndev),
+            "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")),
+            "ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+    ranks = [mine]
+    if world > 1:
+        import torch.distributed as dist
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
     if rank == 0:
         emit({"metric": "stub", "workload": args.workload, "value": round(world * args.steps / wall_max, 1), "unit": "steps/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(wall_max / max(args.steps, 1) * 1e3, 5),
-                          "higher_is_better": True, "scaling": "weak"})
+                          "higher_is_better": True, "scaling": "weak", "ranks": ranks})
     if world > 1:
         import torch.distributed as dist
         hd.barrier()

@@ -53,10 +53,11 @@ def tf_same_pad(x: torch.Tensor, kernel: int, stride: int) -> torch.Tensor:
 
 
 def _param_key(tensors) -> tuple:
-    """Identity + in-place version of every tensor, + the package's parameter-state generation (``_state``): changes
-    when a parameter is stepped, loaded or replaced -- also by the writers that bypass the version counters
-    (``optim.FlatAdam``'s raw-pointer update, a replayed training hipGraph)."""
-    return (_state.generation(),) + tuple((t.data_ptr(), t._version) for t in tensors)
+    """Identity + in-place version of every tensor + the generation of the raw writers attached to THAT tensor
+    (``_state``): changes when a parameter is stepped, loaded or replaced -- also by the writers that bypass the version
+    counters (``optim.FlatAdam``'s raw-pointer update, a replayed training hipGraph) -- and only then: another model's
+    optimizer step does not touch this key."""
+    return tuple((t.data_ptr(), t._version, _state.generation_of(t)) for t in tensors)
 
 
 def _cacheable() -> bool:

@@ -43,6 +43,7 @@ class FlatAdam:
                 view = seg.as_strided(p.shape, gview.stride())  # the gradient view's strides = the parameter's own
                 view.copy_(p.data)
                 p.data = view
+        self._writer = _state.Writer(b.params)  # this optimizer's generation cell on the parameters it updates
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.steps = torch.zeros((1,), dtype=torch.float32, device=self.flat.device)
@@ -81,7 +82,7 @@ class FlatAdam:
         if any(p.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size() for p, off in zip(b.params, b.offsets)):
             raise RuntimeError("FlatAdam: a parameter no longer lives in the flat buffer (module.to(...) or a re-allocated "
                                "parameter after construction): the update would not reach it")
-        _state.bump()  # the update below does not touch the parameters' version counters: invalidate derived caches
+        self._writer.bump()  # the update below does not touch the parameters' version counters: invalidate THEIR caches
         if self.flat.is_cuda:
             from . import _lib
             from .hdrnet_ops import _stream

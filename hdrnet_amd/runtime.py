@@ -45,7 +45,7 @@ class GraphedInference:
 
     def _parameter_state(self) -> tuple:
         m = self.module
-        return (_state.generation(),) + tuple((t.data_ptr(), t._version) for t in list(m.parameters()) + list(m.buffers()))
+        return tuple((t.data_ptr(), t._version, _state.generation_of(t)) for t in list(m.parameters()) + list(m.buffers()))
 
     def recapture(self) -> None:
         """(Re-)capture the graph with the module's current parameters; the static input buffers are kept."""
@@ -198,6 +198,9 @@ class GraphedTrainStep(TrainStep):
         if feeds < 1:
             raise ValueError("feeds >= 1")
         super().__init__(module, loss_fn, optimizer)
+        # this step's generation cell on everything a replay may write behind the version counters: the parameters
+        # (a capturable optimizer inside the graph) and the buffers (batch norm's running statistics)
+        self._writer = _state.Writer(list(module.parameters()) + list(module.buffers()))
         self.split = self.distributed or flat_bucket  # graph = forward + backward only; the rest eager
         self._inputs = [[t.clone() for t in example_inputs] for _ in range(feeds)]
         self._targets = [[t.clone() for t in example_targets] for _ in range(feeds)]
@@ -262,7 +265,7 @@ class GraphedTrainStep(TrainStep):
         slot = self._staged.pop(0)
         torch.cuda.current_stream(self._copy_stream.device).wait_event(self._ready[slot])
         self.graphs[slot].replay()  # gradients land in the flat bucket
-        _state.bump()  # the replay wrote parameters / batch-norm statistics behind the version counters' back
+        self._writer.bump()  # the replay wrote parameters / batch-norm statistics behind the version counters' back
         if self.split:
             self._after_backward()
         return self._losses[slot]
@@ -275,7 +278,7 @@ class GraphedTrainStep(TrainStep):
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         self.graph.replay()  # gradients land in the flat bucket
-        _state.bump()  # the replay wrote parameters / batch-norm statistics behind the version counters' back
+        self._writer.bump()  # the replay wrote parameters / batch-norm statistics behind the version counters' back
         if self.split:
             self._after_backward()
         return self.static_loss

@@ -27,6 +27,56 @@ def test_bench_self_launches_two_ranks():
     assert out["ms_per_step"] * 4 >= 19.0
 
 
+def test_bench_eight_rank_launch_line(monkeypatch):
+    """`--gpus 8` from a bare shell becomes the driver's own command -- python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ... -- with dmabuf IPC kept in the
+    environment; checked on the command itself (nothing is spawned)."""
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    import subprocess as sp
+    monkeypatch.setattr(sp, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    import argparse
+    assert bench.self_launch(argparse.Namespace(gpus=8)) == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 <= int(cmd[cmd.index("--master-port") + 1]) <= 65535
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # one process per GPU; ranks wrap around on a box with fewer devices
+    assert [bench.device_index(r, 8) for r in range(8)] == list(range(8))
+    assert [bench.device_index(r, 1) for r in range(8)] == [0] * 8
+    assert bench.device_index(3, 0) == 0
+
+
+def test_bench_eight_ranks_end_to_end_on_gloo():
+    """The 8-rank job itself, on CPU: `bench.py --gpus 8` spawns 8 ranks under torch.distributed.run; every rank reads
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher, binds device local_rank % device_count (8 faked
+    devices: one each), joins the barrier and the max-over-ranks; rank 0 alone prints the ONE JSON line."""
+    os.environ["HDRNET_BENCH_FAKE_DEVICE_COUNT"] = "8"
+    try:
+        out = _run(["--gpus", "8"])
+    finally:
+        del os.environ["HDRNET_BENCH_FAKE_DEVICE_COUNT"]
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak"
+    ranks = sorted(out["ranks"], key=lambda r: r["rank"])
+    assert [r["rank"] for r in ranks] == list(range(8))
+    assert [r["local_rank"] for r in ranks] == list(range(8))
+    assert [r["device_index"] for r in ranks] == list(range(8))
+    assert all(r["world"] == 8 and r["master"].startswith("127.0.0.1:") and r["ipc_legacy"] == "0" for r in ranks)
+    assert len({r["master"] for r in ranks}) == 1
+    # max over ranks: rank 7 sleeps 80 ms
+    assert out["ms_per_step"] * 4 >= 79.0
+
+
 def test_bench_single_rank_needs_no_launcher():
     out = _run(["--gpus", "1"])
     assert out["n_gpus"] == 1

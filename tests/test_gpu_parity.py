@@ -55,6 +55,14 @@ def grads_close(got, want, what, rtol=1e-4):
     np.testing.assert_allclose(got, want, rtol=rtol, atol=1e-5 * max(scale, 1.0), err_msg=what)
 
 
+@pytest.fixture(scope="module")
+def mt_port_parity(port):
+    import os
+    port.set_threads(os.cpu_count() or 1)
+    yield port
+    port.set_threads(1)
+
+
 # ---- library really is the thing running ---------------------------------------------------
 def test_native_library_loaded(dev, ops):
     from hdrnet_amd import _lib
@@ -999,3 +1007,111 @@ def test_grid_optimisation_converges(dev, ops):
         opt.step()
         first = loss.item() if first is None else first
     assert loss.item() < first / 50, (first, loss.item())
+
+
+# ---- the TOOLS kernels DESIGN.md quotes numbers for -------------------------
+# Both live in libhdrnet_amd_tools.so only.  If they drift from what they are claimed to compute, the timings quoted
+# for them (profiles/r05/pyramid_onepass.md, bwd_steps.md; DESIGN.md sections 4.2 / 4.3) compare nothing.
+def _tools_or_skip():
+    from hdrnet_amd import _lib
+    try:
+        return _lib.load_tools()
+    except (OSError, RuntimeError) as e:
+        pytest.skip(f"tools library not built: {e}")
+
+
+@pytest.mark.parametrize("B,H,W,GH,GW,GD,seg", [(1, 64, 1024, 16, 16, 8, 512), (2, 136, 1536, 8, 12, 8, 768)])
+def test_tools_pyramid_onepass_equals_the_per_level_chain_bit_for_bit(dev, B, H, W, GH, GW, GD, seg):
+    """hdrnet_tools_pyramid_onepass_f32 (csrc/pyramid_onepass.hip: the whole multi-scale output of
+    HDRNetGaussianPyrNN, hdrnet/models.py:277-289 / benchmark/assets/gpyrnn.frag:65-86, in ONE launch) against the
+    product's chain of three launches (guide network + slice-apply at 1/4; + up-add at 1/2; + up-add at 1/1)."""
+    import ctypes
+    from hdrnet_amd import _lib
+    lib = _tools_or_skip()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    gen = torch.Generator(device=dev).manual_seed(B * 1000 + W)
+    FAST = _lib.GUIDE_SIGMOID_FAST
+
+    def chk(rc):
+        assert rc == 0, lib.hdrnet_last_error().decode()
+
+    full = torch.rand((B, H, W, 3), device=dev, generator=gen)
+    half = torch.empty((B, H // 2, W // 2, 3), device=dev)
+    quarter = torch.empty((B, H // 4, W // 4, 3), device=dev)
+    chk(lib.hdrnet_resize_bilinear_f32(full.data_ptr(), half.data_ptr(), B, H, W, H // 2, W // 2, 3, stream))
+    chk(lib.hdrnet_resize_bilinear_f32(half.data_ptr(), quarter.data_ptr(), B, H // 2, W // 2, H // 4, W // 4, 3, stream))
+    ins = [full, half, quarter]
+    grids = []
+    for _l in range(3):
+        g6 = torch.zeros((B, GH, GW, GD, 3, 4), device=dev)
+        for i in range(3):
+            g6[..., i, i] = 0.4
+        grids.append((g6 + 0.15 * torch.randn(g6.shape, device=dev, generator=gen)).reshape(B, GH, GW, GD, 12).contiguous())
+    conv1 = [(torch.randn((16, 4), device=dev, generator=gen) * 0.8).contiguous() for _ in range(3)]
+    conv2 = [(torch.randn((17,), device=dev, generator=gen) * 0.5).contiguous() for _ in range(3)]
+    l2 = torch.empty((B, H // 4, W // 4, 3), device=dev)
+    l1 = torch.empty((B, H // 2, W // 2, 3), device=dev)
+    out_chain = torch.full((B, H, W, 3), float("nan"), device=dev)
+    out_one = torch.full((B, H, W, 3), float("nan"), device=dev)
+    chk(lib.hdrnet_bilateral_slice_apply_nnguide_f32_ex(
+        grids[2].data_ptr(), ins[2].data_ptr(), conv1[2].data_ptr(), conv2[2].data_ptr(), l2.data_ptr(), None,
+        B, H // 4, W // 4, GH, GW, GD, 3, 3, 1, 16, FAST, stream))
+    chk(lib.hdrnet_bilateral_slice_apply_upadd_f32_ex(
+        grids[1].data_ptr(), None, ins[1].data_ptr(), l2.data_ptr(), H // 4, W // 4, l1.data_ptr(),
+        B, H // 2, W // 2, GH, GW, GD, 3, 3, 1, conv1[1].data_ptr(), conv2[1].data_ptr(), 16, FAST, stream))
+    chk(lib.hdrnet_bilateral_slice_apply_upadd_f32_ex(
+        grids[0].data_ptr(), None, ins[0].data_ptr(), l1.data_ptr(), H // 2, W // 2, out_chain.data_ptr(),
+        B, H, W, GH, GW, GD, 3, 3, 1, conv1[0].data_ptr(), conv2[0].data_ptr(), 16, FAST, stream))
+    P3 = ctypes.c_void_p * 3
+    chk(lib.hdrnet_tools_pyramid_onepass_f32(
+        P3(*[t.data_ptr() for t in grids]), P3(*[t.data_ptr() for t in ins]), P3(*[t.data_ptr() for t in conv1]),
+        P3(*[t.data_ptr() for t in conv2]), 16, out_one.data_ptr(), B, H, W, GH, GW, GD, seg, FAST, stream))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out_chain).all() and torch.isfinite(out_one).all()
+    diff = float((out_one - out_chain).abs().max())
+    print(f"pyramid one pass vs chain ({B}, {H}, {W}) seg={seg}: max|diff| = {diff:.3e} on values up to "
+          f"{float(out_chain.abs().max()):.3g}")
+    assert torch.equal(out_one, out_chain), diff
+
+
+@pytest.mark.parametrize("H,W", [(270, 480), (1080, 1920)])
+def test_tools_bf16_split_contraction_stays_within_1e5_of_scale(dev, mt_port_parity, H, W):
+    """Tools variant 2 of the gradient pass (grid_grad_mfma.hip, SPLIT: every f32 operand as two bf16 terms on the
+    bf16 matrix pipe; DESIGN.md section 4.2 quotes -8 % / -4 % / -2 % for it and "6e-6 of dgrid's scale away from the
+    exact contraction") against the oracle's dgrid: within 1e-5 x max|want|, and the per-pixel VJPs it leaves
+    untouched within the product's tolerances."""
+    from conftest import check_pixel_grad
+    from hdrnet_amd import _lib
+    lib = _tools_or_skip()
+    lib.hdrnet_enable_kernel_names(1)
+    B, GH, GW, GD = 1, 16, 16, 8
+    rng = np.random.default_rng(H + W)
+    grid = rng.random((B, GH, GW, GD, 12), dtype=np.float32)
+    guide = (rng.random((B, H, W), dtype=np.float32) * 1.04 - 0.02).astype(np.float32)
+    inp = rng.random((B, H, W, 3), dtype=np.float32)
+    dout = rng.standard_normal((B, H, W, 3)).astype(np.float32)
+    wg, wgu, wi = mt_port_parity.bilateral_slice_apply_grad(grid, guide, inp, dout, True)
+    tg, tgu, ti, td = (T(a, dev) for a in (grid, guide, inp, dout))
+    dg, dgu, di = torch.empty_like(tg), torch.empty_like(tgu), torch.empty_like(ti)
+    wsb = lib.hdrnet_bilateral_slice_apply_grad_workspace_bytes(B, H, W, GH, GW, GD, 3, 3, 1)
+    ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    res = {}
+    for variant in (0, 2):
+        rc = lib.hdrnet_bilateral_slice_apply_grad_f32_ex(
+            tg.data_ptr(), tgu.data_ptr(), ti.data_ptr(), td.data_ptr(), dg.data_ptr(), dgu.data_ptr(), di.data_ptr(),
+            B, H, W, GH, GW, GD, 3, 3, 1, ws.data_ptr(), wsb, _lib.KERNEL_AUTO | (variant << 8), stream)
+        assert rc == 0, lib.hdrnet_last_error().decode()
+        torch.cuda.synchronize()
+        kern = lib.hdrnet_last_kernel().decode()
+        assert kern == ("apply_bwd_fused/mfma-bf16x2" if variant == 2 else "apply_bwd_fused/mfma"), kern
+        res[variant] = (N(dg), N(dgu), N(di))
+    scale = float(np.abs(wg).max())
+    e_exact = np.abs(res[0][0] - wg).max() / scale
+    e_split = np.abs(res[2][0] - wg).max() / scale
+    e_between = np.abs(res[2][0] - res[0][0]).max() / scale
+    print(f"bf16-split dgrid {H}x{W}: |split - oracle| = {e_split:.2e} x scale, |f32 pass - oracle| = {e_exact:.2e}, "
+          f"|split - f32 pass| = {e_between:.2e}")
+    assert e_split < 1e-5, e_split
+    check_pixel_grad(res[2][1], wgu, "bf16-split", "dguide")
+    check_pixel_grad(res[2][2], wi, "bf16-split", "dinput")

@@ -1189,8 +1189,8 @@ def test_train_header_symbols_are_exported_and_bound():
 def test_derived_array_caches_follow_flat_adam_cpu():
     """optim.FlatAdam updates the flat parameter buffer behind the parameters' version counters (a raw pointer on the
     GPU, the flat tensor on the CPU): the caches of derived arrays (guide network folded with batch norm, the curves
-    guide's exported layout) are keyed on those counters PLUS hdrnet_amd._state.generation(), which FlatAdam.step()
-    bumps -- eval -> train -> eval must see the new weights."""
+    guide's exported layout) are keyed on those counters PLUS hdrnet_amd._state.generation_of(parameter), which
+    FlatAdam.step() bumps for ITS parameters -- eval -> train -> eval must see the new weights."""
     from hdrnet_amd import optim
     torch.manual_seed(3)
     for guide, get in ((models._PointwiseNNGuide(16), lambda g: g.folded()),
@@ -1208,6 +1208,33 @@ def test_derived_array_caches_follow_flat_adam_cpu():
         fresh = guide.folded(detach=False) if isinstance(guide, models._PointwiseNNGuide) else guide.exported_differentiable()
         for a, b in zip(after, fresh):
             torch.testing.assert_close(a, b.detach(), rtol=0, atol=0)
+
+
+def test_a_train_step_on_one_model_leaves_another_model_s_caches_alone_cpu():
+    """the generation is scoped to the tensors a writer actually wrote.  FlatAdam steps on model A
+    must not invalidate the derived-array caches (nor the GraphedInference staleness key) of an untouched model B -- a
+    frozen teacher or an EMA copy evaluated during training -- while A's own caches still follow A's parameters."""
+    from hdrnet_amd import _state, optim
+    from hdrnet_amd.runtime import GraphedInference
+    torch.manual_seed(4)
+    a, b = models._PointwiseNNGuide(16).eval(), models._PointwiseNNGuide(16).eval()
+    fa0, fb0 = a.folded(), b.folded()
+    key_b = GraphedInference._parameter_state(type("G", (), {"module": b})())
+    opt = optim.FlatAdam([p for p in a.parameters() if p.requires_grad], lr=0.05)
+    opt.bucket.flat.fill_(1.0)
+    for _ in range(3):
+        opt.step()
+    assert all(x is y for x, y in zip(b.folded(), fb0)), "B's cache was invalidated by A's optimizer"
+    assert GraphedInference._parameter_state(type("G", (), {"module": b})()) == key_b
+    assert any(not torch.equal(x, y) for x, y in zip(a.folded(), fa0)), "A's cache served the old parameters"
+    assert all(_state.generation_of(p) == 3 for p in opt.bucket.params)
+    assert all(_state.generation_of(p) == 0 for p in b.parameters())
+    # two writers on one tensor (an optimizer and a graphed step): their generations add up
+    w = _state.Writer(opt.bucket.params)
+    w.bump()
+    assert all(_state.generation_of(p) == 4 for p in opt.bucket.params)
+    w.attach(opt.bucket.params)  # idempotent
+    assert all(len(getattr(p, "_hdrnet_writers")) == 2 for p in opt.bucket.params)
 
 
 def test_flat_adam_state_dict_round_trip_and_detached_parameter_cpu():
@@ -1277,3 +1304,31 @@ def test_eval_train_eval_sees_the_trained_weights_and_stale_graph_raises():
         gi(low, full)
     gi.recapture()
     torch.testing.assert_close(gi(low, full), out1, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_training_model_a_leaves_a_captured_teacher_replayable():
+    """GraphedTrainStep replays + FlatAdam steps on a student must neither make a frozen teacher's
+    GraphedInference raise "parameters changed" nor invalidate the teacher's derived-array caches; the student's own
+    captured inference graph still refuses to replay."""
+    from hdrnet_amd import metrics, optim
+    from hdrnet_amd.runtime import GraphedInference, GraphedTrainStep
+    dev = torch.device("cuda:0")
+    torch.manual_seed(21)
+    student = models.HDRNetPointwiseNNGuide(dict(batch_norm=False)).to(dev)
+    teacher = models.HDRNetPointwiseNNGuide(dict(batch_norm=False)).to(dev).eval()
+    low = torch.rand(2, 256, 256, 3, device=dev)
+    full = torch.rand(2, 96, 128, 3, device=dev)
+    with torch.no_grad():
+        want = teacher(low, full).clone()
+    g_teacher = GraphedInference(teacher, [low, full])
+    g_student = GraphedInference(student, [low, full])
+    student.train()
+    opt = optim.FlatAdam([p for p in student.parameters() if p.requires_grad], lr=1e-2, epsilon_hat=True)
+    step = GraphedTrainStep(student, lambda out, tgt: metrics.l2_loss(tgt, out), opt, [low, full], [want])
+    for _ in range(3):
+        step([low, full], [want])
+        torch.testing.assert_close(g_teacher(low, full), want, rtol=1e-6, atol=1e-6)  # no "call recapture()"
+    student.eval()
+    with pytest.raises(RuntimeError, match="recapture"):
+        g_student(low, full)
