@@ -143,6 +143,24 @@ def _run(cmd: List[str], verbose: bool) -> None:
         print(res.stdout + res.stderr, flush=True)
 
 
+def _sweep_stale(objdir: str) -> None:
+    """Remove what a KILLED build left behind (the `finally` below never ran for it): per-process objects
+    `*.o.<pid>` in `objdir` and `*.tmp` link outputs / digests beside the library.  Called with the build lock held,
+    so nothing found here belongs to a live build."""
+    for d, pred in ((objdir, lambda f: ".o." in f), (LIB_DIR, lambda f: f.endswith(".tmp") or ".digest." in f)):
+        try:
+            names = os.listdir(d)
+        except OSError:
+            continue
+        for f in names:
+            path = os.path.join(d, f)
+            if pred(f) and os.path.isfile(path):
+                try:
+                    os.remove(path)
+                except OSError:
+                    pass
+
+
 def build(force: bool = False, verbose: bool = False, tools: bool = False) -> str:
     """Compile every HIP source for gfx950 and link libhdrnet_amd.so (tools=True:
     libhdrnet_amd_tools.so).  Returns its path.
@@ -165,6 +183,7 @@ def build(force: bool = False, verbose: bool = False, tools: bool = False) -> st
             digest = source_digest(tools)  # of the sources as they are read now
             objdir = os.path.join(LIB_DIR, "obj_tools" if tools else "obj")
             os.makedirs(objdir, exist_ok=True)
+            _sweep_stale(objdir)
             tag = ".%d" % os.getpid()
             define = ["-DHDRNET_TOOLS_BUILD"] if tools else []
             objs = []

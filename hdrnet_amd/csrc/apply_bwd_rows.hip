@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void apply_vjp_rows_vec4(
       }
     }
     if constexpr (WANT_GUIDE)  // descriptor over the row segment (wave-uniform base), lane offset 16 B * tid
-      buf_store16<kAuxStream>(dgv, make_rsrc(dguide + ((size_t)row * W + xs), (unsigned)(xe - xs) * 4u),
+      buf_store16<kAuxStream>(dgv, make_rsrc_uniform(dguide + ((size_t)row * W + xs), (unsigned)(xe - xs) * 4u),
                               16u * threadIdx.x);
   }
   if constexpr (WANT_INPUT) {
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void apply_vjp_rows_vec4(
     const int nvalid = (min(xe, wave_x0 + 64 * kPxPerThread) - wave_x0) * CIN / 4;
     // nontemporal buffer stores on a descriptor over exactly this wave's run (rows_common.hip.h)
     const __amdgpu_buffer_rsrc_t orsrc =
-        make_rsrc(dinput + ((size_t)row * W + wave_x0) * CIN, nvalid > 0 ? (unsigned)nvalid * 16u : 0u);
+        make_rsrc_uniform(dinput + ((size_t)row * W + wave_x0) * CIN, nvalid > 0 ? (unsigned)nvalid * 16u : 0u);
 #pragma unroll
     for (int k = 0; k < CIN; ++k) buf_store16<kAuxStream>(slab[lane + 64 * k], orsrc, (unsigned)(lane + 64 * k) * 16u);
   }

@@ -755,7 +755,7 @@ __global__ __launch_bounds__(256) void apply_fwd_io_rows(const IoParams p) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const unsigned wpx = kPxPerThread * 64u * (unsigned)wave;
     float* oseg = static_cast<float*>(p.out) + (row * p.W + xs) * COUT;
-    const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(oseg, (unsigned)(xe - xs) * COUT * 4u);
+    const __amdgpu_buffer_rsrc_t orsrc = make_rsrc_uniform(oseg, (unsigned)(xe - xs) * COUT * 4u);
 #pragma unroll
     for (int k = 0; k < COUT; ++k)
       buf_store16<kAuxStream>(slab[lane + 64 * k], orsrc, (wpx * COUT + 4u * (unsigned)(lane + 64 * k)) * 4u);

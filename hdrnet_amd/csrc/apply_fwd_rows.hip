@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void apply_fwd_rows_vec4(
   // nontemporal buffer stores on a descriptor over exactly this wave's run (rows_common.hip.h)
   const int nvalid = wave_px * COUT / 4;  // float4s
   const __amdgpu_buffer_rsrc_t orsrc =
-      make_rsrc(out + ((size_t)row * W + wave_x0) * COUT, nvalid > 0 ? (unsigned)nvalid * 16u : 0u);
+      make_rsrc_uniform(out + ((size_t)row * W + wave_x0) * COUT, nvalid > 0 ? (unsigned)nvalid * 16u : 0u);
 #pragma unroll
   for (int k = 0; k < COUT; ++k) buf_store16<kAuxStream>(slab[lane + 64 * k], orsrc, (unsigned)(lane + 64 * k) * 16u);
 }

@@ -1,11 +1,11 @@
-// BilateralSliceApply forward for gfx950 -- the north-star kernel (second generation).
+// BilateralSliceApply forward for gfx950 -- the north-star kernel.
 //
 // Reference semantics: hdrnet/ops/bilateral_slice_apply.cc:24-82 (the CUDA twin,
 // bilateral_slice_apply.cu.cc:36-126, assigns one thread per output CHANNEL and re-derives all
 // weights for each of its 32 scattered grid loads).
 //
 // The op is an HBM stream -- 4 B guide + 4*Cin B input in, 4*Cout B out per pixel -- next to a
-// 96 KiB grid that never leaves L2.  Decomposition (DESIGN.md section 4):
+// 96 KiB grid that never leaves L2.  Decomposition (DESIGN.md section 4.1):
 //
 //   * a workgroup owns one SEGMENT OF ONE IMAGE ROW (<= 1024 px, 4 px per lane).  For a row,
 //     gy0 / gy1 and both y weights are wave-uniform, so the workgroup first blends the two grid
@@ -17,31 +17,22 @@
 //     per workgroup a pixel's four coefficient vectors sit at a0, a0 + CB, a0 + colb,
 //     a0 + colb + CB: one address, immediate offsets, no per-pixel min / max.  One vector is C
 //     contiguous floats read as ds_read_b128; the 48-B stride (C = 12) keeps the data-dependent
-//     z gather bank-conflict-free.
-//   * the z-corner chain (offsets, squares, 1 - sqrt) runs on 2-wide vectors, both corners at
-//     once; the blend is 24 v_pk_fma_f32 / v_pk_mul_f32 per pixel.
-//   * PIXEL LOADS are LDS-DMA (`global_load_lds_dwordx4 ... nt`): each wave streams its 256-pixel
-//     run (1 KiB of guide, Cin KiB of input) lane-contiguously straight into its LDS slab with the
-//     nontemporal policy, no VGPRs held while in flight; a lane then reads its own 4 pixels back
-//     with ds_read_b128.  Nontemporal loads lower the no-compute floor of this byte mix from
-//     40.8 to 39.4 us per 4K frame, but only as dense per-instruction runs (a per-pixel 48-B
-//     stride re-fetches lines).
+//     z gather at its conflict floor.
+//   * PIXEL LOADS are LDS-DMA (`buffer_load_dwordx4 ... lds`, nontemporal): each wave streams its
+//     256-pixel run (1 KiB of guide, Cin KiB of input) lane-contiguously straight into its LDS slab,
+//     no VGPRs held while in flight; a lane then reads its own 4 pixels back with ds_read_b128.  A
+//     grid of about one round of workgroups (a single 1080p frame) takes per-lane loads instead.
 //   * STORES leave through the same slab, transposed to lane-contiguous 16-B runs, as
-//     `buffer_store_dwordx4` with a streaming cache policy on a descriptor that covers exactly the
-//     row segment (lanes past the run are dropped by the bounds check -- no predicate).  Plain stores
-//     leave up to an L2's worth of dirty lines for the end-of-kernel write-back; streaming them out is
-//     worth 1.5 us per 4K frame and 0.7 us per 1080p frame.  Write-through (sc0 sc1) is the fastest
-//     where segments are whole 128-B lines and 10 % worse than `nt` where they are not, so the
-//     flavour is chosen per launch (launch_apply_fwd_seg below; rows_common.hip.h; profiles/r02/).
-//   * 3-D launch grid (segment, row, batch): no integer division in the kernel.
-//   * ROUND 3 -- the LEAN per-pixel code of seg_common.hip.h (v_fract x weight, float byte addresses, clamp-modifier
-//     tents), the pixel runs as `buffer_load_dwordx4 ... lds`, the segment's grid-column window from a host-side table.
-//     The plain forward ships the SCALAR blend (kPixLeanScalar: 419 VALU + 113 SALU per wave; bit-identical to the packed
-//     form's 323 + 114, same time on steady boxes, less time in the power manager's braked state); the instruction-bound
-//     guide-network / wire-format kernels keep the packed blend.
-//   * ROUND 4 -- the resident waves per CU are CAPPED (resident_cap_lds below).  Everything else about the launch shape
-//     was measured and left as it is (docs/EXPERIMENTS.md section 4.1, profiles/r04/fwd_launch_shape.md): per launch
-//     ~2.5-3 us lie outside the workgroups' span -- the gap between dependent kernels of one stream.
+//     `buffer_store_dwordx4` on a descriptor that covers exactly the row segment (lanes past the run
+//     are dropped by the bounds check -- no predicate): write-through (sc0 sc1) where segments are
+//     whole 128-B lines, nontemporal where not; the flavour is chosen per launch
+//     (launch_apply_fwd_seg below; rows_common.hip.h).
+//   * the per-pixel code is the LEAN form of seg_common.hip.h (v_fract x weight, float byte addresses,
+//     clamp-modifier tents); the plain forward ships its SCALAR blend (kPixLeanScalar), the
+//     instruction-bound guide-network / wire-format kernels the packed one; the segment's grid-column
+//     window comes from a host-side table.
+//   * 3-D launch grid (segment, row, batch): no integer division in the kernel; the resident waves
+//     per CU are CAPPED (resident_cap_lds below).
 //
 // Numerics: the coordinate and weight expressions of the reference in the reference's order
 // (products (x+.5)*scale_x, guide*GD explicitly rounded, see numerics.hip.h: mul_rn); wy is folded
@@ -51,12 +42,8 @@
 // and test_gpu_fullsize.py hold rtol = atol = 1e-5 against the oracle and report the reference's own
 // 1e-6 bar: worst / bar <= 0.25 at every config size).
 //
-// ROUND 5 (prune): this file holds the PRODUCT's configurations only.  The alternatives this design was chosen against --
-// per-lane / nontemporal lane-contiguous / plain-DMA loads, global / plain / sc1 stores, the round-2 pixel phase, the
-// ticketed tail (flat grid, the last tasks drawn from counters), the first-round stagger, the per-workgroup timeline
-// trace -- were instantiated here behind HDRNET_TOOLS_BUILD through round 4; their measurements are profiles/r02/
-// d_ab_variants_*.txt, profiles/r03/ab_variants_4k*.txt, profiles/r04/fwd_launch_shape.md, and the code is in the
-// history (git show 13f95df:hdrnet_amd/csrc/apply_fwd_seg.hip).
+// This file holds the PRODUCT's configurations only; the alternatives it was chosen against and their
+// measurements: docs/EXPERIMENTS.md section 4.1 and "Kernel-file lab notes".
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -173,10 +160,10 @@ __device__ __forceinline__ void seg_task(const SegParams& p, float* __restrict__
     if (wave_px > 0) {
       const unsigned voff = 16u * (unsigned)lane;
       if constexpr (!GUIDE_NN) {
-        const __amdgpu_buffer_rsrc_t grs = make_rsrc(gseg + wpx, (unsigned)wave_px * 4u);
+        const __amdgpu_buffer_rsrc_t grs = make_rsrc_uniform(gseg + wpx, (unsigned)wave_px * 4u);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(grs, (lptr_t) reinterpret_cast<float*>(gslab), 16, voff, 0, 0, kAuxNt);
       }
-      const __amdgpu_buffer_rsrc_t irs = make_rsrc(iseg + wpx * CIN, (unsigned)wave_px * (4u * CIN));
+      const __amdgpu_buffer_rsrc_t irs = make_rsrc_uniform(iseg + wpx * CIN, (unsigned)wave_px * (4u * CIN));
       buf_dma_pieces<0, CIN>(irs, reinterpret_cast<float*>(slab), voff);
     }
   }
@@ -242,7 +229,7 @@ __device__ __forceinline__ void seg_task(const SegParams& p, float* __restrict__
   float* oseg = p.out + (row * p.W + xs) * COUT;  // uniform
   {
     // descriptor over exactly this row segment: lanes past the run are dropped by the bounds check
-    const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(oseg, (unsigned)(xe - xs) * COUT * 4u);
+    const __amdgpu_buffer_rsrc_t orsrc = make_rsrc_uniform(oseg, (unsigned)(xe - xs) * COUT * 4u);
 #pragma unroll
     for (int k = 0; k < COUT; ++k)
       buf_store16<store_aux<STORES>()>(slab[lane + 64 * k], orsrc, (wpx * COUT + 4u * (unsigned)(lane + 64 * k)) * 4u);

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void apply_vjp_seg(const VjpSegParams p) {
       }
     }
     if constexpr (WANT_GUIDE)  // descriptor over the row segment (wave-uniform base), lane offset 16 B * tid
-      buf_store16<kAuxStream>(dgv, make_rsrc(p.dguide + (row * p.W + xs), (unsigned)(xe - xs) * 4u), 16u * (unsigned)tid);
+      buf_store16<kAuxStream>(dgv, make_rsrc_uniform(p.dguide + (row * p.W + xs), (unsigned)(xe - xs) * 4u), 16u * (unsigned)tid);
     if constexpr (WANT_INPUT) {
       // in place: a lane overwrites only ITS input entries of the slab (read above)
 #pragma unroll
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void apply_vjp_seg(const VjpSegParams p) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(p.dinput + (row * p.W + xs) * CIN, (unsigned)(xe - xs) * CIN * 4u);
+    const __amdgpu_buffer_rsrc_t orsrc = make_rsrc_uniform(p.dinput + (row * p.W + xs) * CIN, (unsigned)(xe - xs) * CIN * 4u);
 #pragma unroll
     for (int k = 0; k < CIN; ++k)
       buf_store16<kAuxStream>(islab[lane + 64 * k], orsrc, (wpx * CIN + 4u * (unsigned)(lane + 64 * k)) * 4u);

@@ -131,7 +131,11 @@ int variant(unsigned flags) { return (int)((flags >> 8) & 0xffu); }
 
 extern "C" {
 
-int hdrnet_version(void) { return 241; /* 0.2.4.1: + hdrnet_guide_nn_prescale_f32 / HDRNET_GUIDE_RELU_PRESCALED, hdrnet_curves_guide_prepare_f32 (with `usable`) / ..._io_curves_prepared */ }
+// 0.2.4.1: + hdrnet_guide_nn_prescale_f32 / HDRNET_GUIDE_RELU_PRESCALED, hdrnet_curves_guide_prepare_f32 (with `usable`) /
+//          ..._io_curves_prepared; the non-_ex guide-network entry points use the exact sigmoid (flags = 0)
+// 0.2.5.0: the gradient entry points take grids of up to 16 planes on the fast pass (the workspace bound grows with it:
+//          query ..._grad_workspace_bytes again); one stderr line when a frame-sized dgrid falls back to the generic kernel
+int hdrnet_version(void) { return 250; }
 
 const char* hdrnet_last_error(void) { return g_error; }
 

@@ -1,4 +1,5 @@
-// Grid VJP (dgrid) of BilateralSliceApply / BilateralSlice for gfx950.
+// Grid VJP (dgrid) of BilateralSliceApply / BilateralSlice for gfx950, with the per-pixel VJPs (dguide, dinput)
+// optionally fused into the same pass.
 //
 // Reference semantics: BilateralSliceApplyGridGrad, hdrnet/ops/bilateral_slice_apply.cc:84-138,
 // and BilateralSliceGridGrad, hdrnet/ops/bilateral_slice.cc:72-118 (CPU code; the CUDA twin
@@ -18,42 +19,9 @@
 // K = pixels, not a reshaped gather -- the one place in this library where MFMA fits.  What it
 // buys is the data movement (the z scatter becomes dense rows; no atomics, deterministic), NOT
 // arithmetic rate: on gfx950 the f32-input MFMA runs at the VALU's own 32 FMA / cycle / SIMD and
-// does not overlap with VALU work of any wave on that SIMD (tools/debug/ubench/
-// mfma_valu_overlap.hip: MFMA-only 483 us + VALU-only 469 us -> 919 us interleaved), and the
-// tile is 19 % dense (4 live weights x 12 channels of 16 x 16).  Stage 1 is therefore bound by
-// FP32 issue: a per-chunk phase trace (tools variant 9, profiles/r02/exp29) shows 866 cycles per
-// 64-pixel chunk per SIMD at the ~1.95 GHz the power manager grants under this load -- 512 of them
-// the 16 MFMAs.
-// The sparse alternative -- a wave-level counting sort of every 64-pixel chunk by z bin, then
-// v_mfma_f32_4x4x1_16B_f32 blocks of (4 weights) x (4 channels) with every MAC live -- was built
-// and measured in round 2 (git history: "dgrid: sorted 4x4x1-MFMA stage 1"; profiles/r02/
-// exp6, exp7): bit-correct, MFMA busy cycles 70.8 M -> 27.8 M per launch as planned, but the
-// sort / slot bookkeeping costs 260 VALU + 267 SALU per chunk (dense: 168 + 82) and LDS float
-// atomics (ds_add_f32) retire ~1 lane per 2.7 cycles: 389 us vs 80 us.  Even with the flush
-// rewritten without atomics the issue count equals the dense kernel's, so it was dropped.
-//
-// ROUND 3 (profiles/r03/bwd_*.txt): PMC passes put the pass at (4 N_valu + 32 N_mfma) / SIMDs cycles at the
-// ~1.95 GHz granted under this load + 9 us of launches / stage 2 -- every VALU instruction of a wave costs
-// about four cycles of its SIMD here, and the "memory wait" that the loads-once ablation seemed to show is
-// mostly the higher clock of a run that draws no HBM power (2.3 vs 1.95 GHz).  So the round removed
-// instructions: the run-time integer divisions of the batch cursors (~20 instructions each, twice per batch),
-// compare + select tents (now the clamp modifier), the edge-cell select chain, per-row y terms formed three
-// times; it made the VMEM count the same on every path so that the prefetched batch really stays in flight
-// (s_waitcnt vmcnt takes a compile-time count: with the refill under `if (t + 1 < nbt)` it had been waiting
-// for the batch just requested), and packed the fused VJP's contractions.  dgrid 72.3 -> 64.9 us, dgrid +
-// dguide 90.9 -> 87.4, all three 110.6 -> 109.7 (interleaved with the previous build, same box; results
-// bit-identical until the packed VJP).  Stage 2 is 5.6 us of device time per call and there is no gap
-// between the two kernels (profiles/r03/bwd_kernel_stats.csv; the 8-9 us of the "launches alone" ablation
-// is the HOST's two launches of empty kernels): folding it into the last-arriving workgroup of stage 1
-// would need zero-initialised or epoch-tagged counters in a caller-owned workspace, for <= 5 %; not done.
-// Late in the round the fused VJPs went from the four-corner form to an x-lerped one: the coefficient image
-// keeps column g and the DIFFERENCE to column g + 1, so a z tap's blended vector is one FMA per coefficient
-// and dguide / dinput contract two vectors per pixel instead of four (2 (2 C + 3 CIN) FMAs instead of
-// 4 (C + 3 CIN): -23 VALU instructions per chunk with dinput fused), one vector of a tap read ahead at a time
-// to stay within 4 waves per SIMD; s and 1 / s of the smoothed |dz| from one v_rsq_f32; 24-bit multiplies
-// for the LDS / pixel offsets (v_mad_u64_u32 and v_mul_lo_u32 are quarter-rate).  All three 108.1 -> 104.5 /
-// 109.5 -> 107.9 us at 4K on two boxes, 36.3 -> 34.3 / 34.6 -> 33.6 at 1080p (interleaved, profiles/r03/
-// bwd_step_r03k_*.txt); dgrid alone and dgrid + dguide unchanged within 1 %.
+// does not overlap with VALU work of any wave on that SIMD, and the tile is 19 % dense (4 live
+// weights x 12 channels of 16 x 16): stage 1 is bound by FP32 issue.
+// Grids of 9 .. 16 planes (luma_bins = 16) take two such tiles per task (template parameter NH).
 //
 // Stage 1 (grid_grad_stage1): one workgroup of 4 waves owns one x-interval (all pixels with
 //   gx0 == g, g = -1 .. GW-1) of rg consecutive rows (rg fitted per launch to whole rounds of
@@ -69,6 +37,9 @@
 // Stage 2 (grid_grad_stage2): one workgroup per grid column (all planes) adds, in fixed order, the partial
 //   tiles of the row groups and the two intervals that cover it (+ the clamp-to-edge halves of the
 //   border intervals).
+//
+// What was tried and measured on the way here (the sorted 4x4x1-MFMA form, the bf16 split, launch shapes,
+// folding stage 2 into stage 1, ...): docs/EXPERIMENTS.md section 4.2 and "Kernel-file lab notes".
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -639,11 +610,11 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
           {  // nontemporal buffer stores; descriptors end at the interval, so dead lanes are dropped
             const unsigned px = (unsigned)(x0 + lane);
             if constexpr (WG) {
-              const __amdgpu_buffer_rsrc_t rs = rows::make_rsrc(p.dguide + prow_out, (unsigned)x_hi * 4u);
+              const __amdgpu_buffer_rsrc_t rs = rows::make_rsrc_uniform(p.dguide + prow_out, (unsigned)x_hi * 4u);
               __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dgv), rs, px * 4u, 0, rows::kAuxStream);
             }
             if constexpr (WI) {
-              const __amdgpu_buffer_rsrc_t rs = rows::make_rsrc(p.dinput + prow_out * CIN, (unsigned)x_hi * (4u * CIN));
+              const __amdgpu_buffer_rsrc_t rs = rows::make_rsrc_uniform(p.dinput + prow_out * CIN, (unsigned)x_hi * (4u * CIN));
               if constexpr (CIN == 3) {
                 const u32x3 v = {__float_as_uint(div01.x), __float_as_uint(div01.y), __float_as_uint(div23.x)};
                 __builtin_amdgcn_raw_buffer_store_b96(v, rs, __umul24(px, 12u), 0, rows::kAuxStream);

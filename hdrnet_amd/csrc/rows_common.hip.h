@@ -305,8 +305,19 @@ constexpr int kAuxStream = kAuxNt;  // the policy the product kernels store with
 // stores per wave in the forward: ~30 instructions in front of the stores; found in round 5 in the ISA of every kernel
 // that stores through a descriptor).  Reading the three words through readfirstlane here says what the call sites
 // guarantee: one v_readfirstlane per word, no loop; for a base the compiler already holds in SGPRs it folds away.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+// The name says the contract: a per-lane `base` / `bytes` (or a call inside divergent control flow with differing
+// values) would silently take the FIRST ACTIVE LANE's.  The tools build traps on it, so that a violation fails the parity
+// suite's tools-library tests instead of corrupting an output.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_uniform(const void* base, unsigned bytes) {
   const unsigned long long a = (unsigned long long)base;
+#ifdef HDRNET_TOOLS_BUILD
+  {
+    const unsigned long long a0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    const unsigned n0 = (unsigned)__builtin_amdgcn_readfirstlane((int)bytes);
+    if (__builtin_amdgcn_ballot_w64(a != a0 || bytes != n0) != 0ull) __builtin_trap();
+  }
+#endif
   const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a);
   const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
   const int n = __builtin_amdgcn_readfirstlane((int)bytes);

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void slice_fwd_rows(
     // (the descriptor ends at the run's last float: the bounds check is per dword, so a final
     //  partial float4 -- possible for C < 4 -- is written up to the run's end and no further)
     const unsigned run_bytes = (unsigned)(min(xe, xk0 + 64) - xk0) * (unsigned)C * 4u;
-    const __amdgpu_buffer_rsrc_t orsrc = make_rsrc(out + (prow + xk0) * C, run_bytes);
+    const __amdgpu_buffer_rsrc_t orsrc = make_rsrc_uniform(out + (prow + xk0) * C, run_bytes);
     constexpr int NQ = (64 * C / 4 + 63) / 64;  // store instructions per run: C / 4, or 1 for C < 4
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {

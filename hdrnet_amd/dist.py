@@ -150,6 +150,7 @@ class GradBucket:
             self.offsets.append(off)
             off += pad(p.numel())
         self.flat = torch.zeros(off, device=dev, dtype=dt)
+        self.no_grad_last: list = []  # parameters the last gather() found without a gradient (none before the first)
         self.views = []
         for p, off in zip(self.params, self.offsets):
             n = p.numel()

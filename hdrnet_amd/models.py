@@ -475,6 +475,23 @@ class HDRNetCurves(nn.Module):
     # ... and the curves guide's lookup tables prepared once per parameter state (hdrnet_curves_guide_prepare_f32)
     prepare_curves = True
 
+    # INPUT-RANGE CONTRACT of the inference defaults above.  The prescaled guide network equals the exported one bit for
+    # bit only while |full-resolution input| <= _PointwiseNNGuide.prescale_x_max (65536: normalised images and every
+    # uint8 / uint16 wire format); beyond it a hidden feature saturates at 2^e_k and the guide is silently wrong --
+    # un-normalised HDR floats must switch it off.  fast_sigmoid moves the guide by <= 2 ulp, prepare_curves by <= 5e-7.
+    # ``exact_inference()`` switches all three off at once: tf.nn.sigmoid's form, the exported parameter layout and
+    # the sorted knot tables -- no range limit, the arithmetic of the training forward.
+    def exact_inference(self, on: bool = True):
+        """``on``: inference uses the exact guide arithmetic (no fast sigmoid, no prescaled parameters, no prepared curve
+        tables) -- for inputs beyond ``prescale_x_max`` or bit-level comparisons with the training graph.  ``False``
+        restores the class defaults.  Returns ``self``."""
+        if on:
+            self.fast_sigmoid = self.prescale_guide = self.prepare_curves = False
+        else:
+            for k in ("fast_sigmoid", "prescale_guide", "prepare_curves"):
+                self.__dict__.pop(k, None)
+        return self
+
     def forward(self, lowres_input: torch.Tensor, fullres_input: torch.Tensor) -> torch.Tensor:
         coeffs = self.coefficients(lowres_input)
         if (self.fuse_guide and isinstance(self.guide, _CurvesGuide) and fullres_input.is_cuda

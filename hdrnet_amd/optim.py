@@ -55,15 +55,20 @@ class FlatAdam:
                 "lr": self.lr, "betas": self.betas, "eps": self.eps, "epsilon_hat": self.epsilon_hat,
                 "numel": int(self.flat.numel())}
 
-    def load_state_dict(self, state: dict) -> None:
+    def load_state_dict(self, state: dict, hyperparameters: bool = True) -> None:
+        """Restore the Adam slots and the step count.  ``hyperparameters=True`` (the default, what ``torch.optim``'s
+        ``load_state_dict`` does with its param groups and what a resumed ``hdrnet/bin/train.py`` run gets from its
+        checkpoint): lr, betas, eps and the epsilon form of the CHECKPOINT replace the constructor's; ``False`` keeps the
+        constructor's -- resuming with a new learning rate."""
         if int(state["numel"]) != int(self.flat.numel()):
             raise ValueError(f"optimizer state of {state['numel']} elements does not fit {self.flat.numel()}")
         with torch.no_grad():
             self.exp_avg.copy_(state["exp_avg"])
             self.exp_avg_sq.copy_(state["exp_avg_sq"])
             self.steps.copy_(state["steps"])
-        self.lr, self.betas, self.eps = float(state["lr"]), tuple(float(b) for b in state["betas"]), float(state["eps"])
-        self.epsilon_hat = bool(state["epsilon_hat"])
+        if hyperparameters:
+            self.lr, self.betas, self.eps = float(state["lr"]), tuple(float(b) for b in state["betas"]), float(state["eps"])
+            self.epsilon_hat = bool(state["epsilon_hat"])
 
     @property
     def param_groups(self):  # enough of torch.optim's surface for code that reads the learning rate

@@ -75,7 +75,14 @@ extern "C" {
  * non-zero variant. */
 #define HDRNET_VARIANT(n) (((unsigned)(n) & 0xffu) << 8)
 
-/* ABI version: major*10000 + minor*100 + patch. */
+/* ABI version: major*10000 + minor*100 + patch.
+ * Changes a C caller can observe:
+ *   241  the non-_ex guide-network entry points (..._nnguide_f32, ..._upadd_f32, ..._io) evaluate the EXACT sigmoid
+ *        (flags = 0); through 240 they used the hardware exp / rcp form whenever guide_out == NULL.  Pass
+ *        HDRNET_GUIDE_SIGMOID_FAST to the _ex twins for the old behaviour (<= 2 ulp of the guide, ~10 % faster).
+ *   250  gradients of grids with 9 .. 16 planes (luma_bins = 16) run on the fast pass; their workspace bound is twice
+ *        the 8-plane one (..._grad_workspace_bytes).  A frame-sized grid gradient that still falls back to the generic
+ *        gather kernel under HDRNET_KERNEL_AUTO prints one line on stderr per process. */
 int hdrnet_version(void);
 
 /* Text of the last error raised on the calling thread ("" if none). */

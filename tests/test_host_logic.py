@@ -227,3 +227,21 @@ def test_curves_lookup_tables_equal_the_knot_scan(case):
         cv = np.stack([_curve_lookup(*_curve_tables(shifts[:, c], slopes[:, c]), t[:, c]) for c in range(3)], -1)
         g = np.clip((cv @ mix[:-1] + mix[-1]).astype(np.float32), 0, 1)
         np.testing.assert_allclose(g, oracle.curves_guide(x, ccm2, shifts, slopes, mix), rtol=0, atol=2e-6)
+
+
+def test_build_sweeps_what_a_killed_build_left_behind(tmp_path, monkeypatch):
+    """A killed build never reaches its `finally`: per-process objects `*.o.<pid>`, `*.tmp` link outputs and
+    `.digest.<pid>` files stay in the tree (24 stale objects, 5 MB).  The next build removes them under
+    the build lock -- and nothing else."""
+    from hdrnet_amd import build as hb
+    lib = tmp_path / "lib"
+    obj = lib / "obj"
+    obj.mkdir(parents=True)
+    stale = [obj / "capi.o.4242", obj / "apply_fwd_seg.o.17", lib / "libhdrnet_amd.so.4242.tmp", lib / "libhdrnet_amd.so.digest.4242"]
+    keep = [lib / "libhdrnet_amd.so", lib / "libhdrnet_amd.so.digest", obj / "notes.txt"]
+    for f in stale + keep:
+        f.write_text("x")
+    monkeypatch.setattr(hb, "LIB_DIR", str(lib))
+    hb._sweep_stale(str(obj))
+    assert not any(f.exists() for f in stale)
+    assert all(f.exists() for f in keep)

@@ -1332,3 +1332,34 @@ def test_training_model_a_leaves_a_captured_teacher_replayable():
     student.eval()
     with pytest.raises(RuntimeError, match="recapture"):
         g_student(low, full)
+
+
+def test_exact_inference_switch_cpu():
+    """one switch for the three inference-only numerics choices (fast sigmoid, prescaled guide parameters
+    with their |input| <= 65536 contract, prepared curve tables)."""
+    m = models.HDRNetPointwiseNNGuide(dict(batch_norm=False))
+    assert m.fast_sigmoid and m.prescale_guide and m.prepare_curves
+    assert m.exact_inference() is m
+    assert not (m.fast_sigmoid or m.prescale_guide or m.prepare_curves)
+    m.exact_inference(False)
+    assert m.fast_sigmoid and m.prescale_guide and m.prepare_curves
+    assert models.HDRNetCurves.fast_sigmoid  # the class defaults were never touched
+
+
+@pytest.mark.gpu
+def test_exact_inference_handles_inputs_beyond_the_prescale_range():
+    """Un-normalised HDR floats (|x| >> 65536): the default prescaled guide saturates, exact_inference() follows the
+    composed torch graph."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(31)
+    m = models.HDRNetPointwiseNNGuide(dict(batch_norm=False)).to(dev).eval()
+    low = torch.rand(1, 256, 256, 3, device=dev)
+    full = torch.rand(1, 64, 256, 3, device=dev) * 3.0e6
+    with torch.no_grad():
+        got = m.exact_inference()(low, full).clone()
+        m.fuse_guide = False
+        try:
+            want = m(low, full).clone()
+        finally:
+            del m.fuse_guide
+    torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5 * float(want.abs().max()))
