@@ -78,6 +78,26 @@ __device__ __forceinline__ f32x2_sp split_pack2(f32x2_sp x) {
 
 __device__ __forceinline__ float split_pack(float x) { return split_pack2(f32x2_sp{x, x}).x; }
 
+// SPLIT = 2 (tools variant 10, round 6): the f16 form with fp32-grade products.  x travels as one dword {hi, lo'} of two
+// f16: hi = f16(x) (round to nearest: the remainder x - hi is exact in f32), lo' = f16((x - hi) * 2^11) -- the remainder
+// re-scaled into f16's normal range, so hi + 2^-11 lo' carries ~22 bits.  [a_hi, 0] x [v_hi, v_lo'] accumulates hi hi into
+// one tile, [a_hi, a_lo'] x [v_lo', v_hi] (the dword rotated) the two cross terms hi lo' + lo' hi into a second; the row
+// fold combines them as acc0 + 2^-11 acc1.  The dropped lo' lo' term is 2^-22 relative.  Per pair: 2 cvt_pk, 2 cvt back,
+// 1 v_pk_add, 1 v_pk_mul, 2 v_perm = 4 per value.  RANGE: f16 holds 6e-8 .. 65504 -- V = dout x [in; 1] of a real
+// training step (dout ~ 1 / pixels ~ 1e-7) sits in f16's denormals, where hi keeps a few bits and only lo' is normal:
+// ~12 bits in all (measured: profiles/r06/bwd_steps.md).  An experiment, not a product path.
+typedef _Float16 f16x2_sp __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x2_sp split_pack2_f16(f32x2_sp x) {
+  const f16x2_sp h = __builtin_convertvector(x, f16x2_sp);
+  const f32x2_sp hf = __builtin_convertvector(h, f32x2_sp);
+  const f32x2_sp r = (x - hf) * f32x2_sp{2048.0f, 2048.0f};
+  const f16x2_sp l = __builtin_convertvector(r, f16x2_sp);
+  const unsigned hp = __builtin_bit_cast(unsigned, h), lp = __builtin_bit_cast(unsigned, l);
+  return f32x2_sp{__uint_as_float(__builtin_amdgcn_perm(lp, hp, 0x05040100u)),   // {lp[15:0], hp[15:0]}: hi in the low half
+                  __uint_as_float(__builtin_amdgcn_perm(lp, hp, 0x07060302u))};  // {lp[31:16], hp[31:16]}
+}
+
 constexpr int kWaves = 4;      // waves per workgroup; they share ONE task and split its rows
 constexpr int kTileFloats = 3 * 16 * 16;  // partial tile: [rel 3][k 16][c 16]
 constexpr int kTraceChunks = 16;          // tools phase trace: chunks recorded per workgroup
@@ -190,9 +210,9 @@ constexpr int kTStride = 68;  // floats per operand row: 64 pixels + 4 (16-B ali
 // 64-pixel chunk the wave ballots which halves hold a live tap and contracts only those (an image-like guide rarely
 // straddles plane 7 | 8 inside 64 neighbouring pixels: then the chunk costs what it costs at GD <= 8).  Both halves go
 // through the SAME 16-row A slab, scattered, contracted and re-zeroed once per live half.
-template <int CIN, int COUT, bool OFFSET, bool APPLY, bool SPLIT, bool WG = false, bool WI = false, int ABL = 0, int NH = 1>
+template <int CIN, int COUT, bool OFFSET, bool APPLY, int SPLIT, bool WG = false, bool WI = false, int ABL = 0, int NH = 1>
 __global__ __launch_bounds__(kWaves * 64)
-__attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET ? 1 : 0) : 1) <= 12) ? (NH == 1 ? 4 : 3) : 1))) void grid_grad_stage1(GGParams p) {
+__attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET ? 1 : 0) : 1) <= 12) ? ((NH == 1 && SPLIT == 0) ? 4 : 3) : 1))) void grid_grad_stage1(GGParams p) {
   constexpr int CJ = APPLY ? CIN + (OFFSET ? 1 : 0) : 1;
   constexpr int C = COUT * CJ;
   static_assert(C <= 16, "one 16-column MFMA tile");
@@ -641,8 +661,8 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
         // (NH = 2: plane z lives in row z & 7 of half z >> 3's tile; the scatter itself happens per live half, below)
         float* aP = at + __umul24((unsigned)(NH == 1 ? zP : (zP & 7)), (unsigned)kTStride) + lane;
         float* aQ = at + __umul24((unsigned)(NH == 1 ? zQ : (zQ & 7)), (unsigned)kTStride) + lane;
-        auto enc = [](float v) { return SPLIT ? split_pack(v) : v; };
-        auto enc2 = [](f32x2 v) { return SPLIT ? f32x2(split_pack2(v)) : v; };
+        auto enc2 = [](f32x2 v) { return SPLIT == 1 ? f32x2(split_pack2(v)) : SPLIT == 2 ? f32x2(split_pack2_f16(v)) : v; };
+        auto enc = [&](float v) { return SPLIT ? enc2(f32x2{v, v}).x : v; };
         const f32x2 q2 = enc2(f32x2{w0, w1} * f32x2{wQ, wQ}), p2 = enc2(f32x2{w0, w1} * f32x2{wP, wP});
         if constexpr (NH == 1) {
           aQ[0] = q2.x;
@@ -691,21 +711,30 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
 #define HDRNET_GG_OUT(x) "=&v"(x)
 #define HDRNET_GG_INOUT(x) "+v"(x)
         auto contract = [&](f32x4& dacc, f32x4& dacc2) {
-          if constexpr (SPLIT) {
+          if constexpr (SPLIT != 0) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
               typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
               const f32x4 a4 = {av[2 * q][0], av[2 * q][1], av[2 * q + 1][0], av[2 * q + 1][1]};
               const f32x4 b4 = {bv[2 * q][0], bv[2 * q][1], bv[2 * q + 1][0], bv[2 * q + 1][1]};
               const u32x4_t vb = __builtin_bit_cast(u32x4_t, b4);
-              const bf16x8 a8 = __builtin_bit_cast(bf16x8, a4);
               // [a_hi, a_lo] x [v_hi, v_lo] = hi hi + lo lo, then x the ROTATED dword [v_lo, v_hi] = the two cross terms:
               // all four products, one v_alignbit per B dword (round 2: three products, a perm and a shift per dword)
               u32x4_t br;
 #pragma unroll
               for (int e = 0; e < 4; ++e) br[e] = __builtin_amdgcn_alignbit(vb[e], vb[e], 16);
-              dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, vb), dacc, 0, 0, 0);
-              dacc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, br), dacc2, 0, 0, 0);
+              if constexpr (SPLIT == 1) {
+                const bf16x8 a8 = __builtin_bit_cast(bf16x8, a4);
+                dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, vb), dacc, 0, 0, 0);
+                dacc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, __builtin_bit_cast(bf16x8, br), dacc2, 0, 0, 0);
+              } else {
+                // f16 hi / lo': dacc takes hi hi alone ([a_hi, 0]: the lo' lo' product has the wrong scale), dacc2 the
+                // cross terms (scale 2^-11, applied at the row fold)
+                const u32x4_t ua = __builtin_bit_cast(u32x4_t, a4);
+                const u32x4_t ah = {ua[0] & 0xffffu, ua[1] & 0xffffu, ua[2] & 0xffffu, ua[3] & 0xffffu};
+                dacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, vb), dacc, 0, 0, 0);
+                dacc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ua), __builtin_bit_cast(f16x8, br), dacc2, 0, 0, 0);
+              }
             }
           } else {
 #pragma unroll
@@ -782,7 +811,8 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
       const int rel1 = clamp_index(gy0 + 1, 0, p.GH - 1) - gy_base;
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
-        dacc[h] += dacc2[h];
+        if constexpr (SPLIT == 2) dacc[h] += 0x1p-11f * dacc2[h];  // hi hi + 2^-11 (hi lo' + lo' hi)
+        else dacc[h] += dacc2[h];
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr) {
           const float sr = (rel0 == rr ? wy0 : 0.0f) + (rel1 == rr ? wy1 : 0.0f);
@@ -1006,7 +1036,7 @@ struct GGPtrs {
 
 template <int CIN, int COUT, bool OFFSET, bool APPLY>
 hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int GD, void* ws, size_t ws_bytes,
-                     hipStream_t s, bool split, int ablate = 0) {
+                     hipStream_t s, int split, int ablate = 0) {
   constexpr int C = APPLY ? COUT * (CIN + (OFFSET ? 1 : 0)) : COUT;
   const bool wg = q.dguide != nullptr, wi = q.dinput != nullptr;
   Stage1Fn kfn = nullptr;
@@ -1017,9 +1047,9 @@ hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int G
     if (ablate >= 1 && ablate <= 6) {
       if (ablate == 6 && !g_gg_trace) return hipErrorInvalidValue;
 #define GG_ABL(A)                                                                              \
-  (wg && wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, true, true, A>       \
-            : wg ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, true, false, A> \
-                 : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, false, false, A>)
+  (wg && wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, 0, true, true, A>       \
+            : wg ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, 0, true, false, A> \
+                 : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, 0, false, false, A>)
       kfn = ablate == 1 ? GG_ABL(1) : ablate == 2 ? GG_ABL(2) : ablate == 3 ? GG_ABL(3) : ablate == 4 ? GG_ABL(4) : ablate == 5 ? GG_ABL(5) : GG_ABL(6);
 #undef GG_ABL
     }
@@ -1028,7 +1058,7 @@ hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int G
   const bool two = GD > 8;  // NH = 2: planes 8 .. 15 in a second tile per task
   if (two && (split || kfn)) return hipErrorNotSupported;  // the tools variants exist for GD <= 8 only
   if (!kfn) {
-    occ = &occ_cache[(two ? 8 : 0) + (split ? 4 : 0) + (wg ? 2 : 0) + (wi ? 1 : 0)];
+    occ = &occ_cache[(two ? 12 : 4 * split) + (wg ? 2 : 0) + (wi ? 1 : 0)];
     if constexpr (C % 4 == 0) {
       constexpr bool CAN_WI = APPLY && CIN > 0;
       if (wi && !CAN_WI) return hipErrorInvalidValue;
@@ -1037,23 +1067,24 @@ hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int G
             : wg ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, true, false, 0, NH>      \
                  : wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, false, CAN_WI, 0, NH> \
                       : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, false, false, 0, NH>)
-#ifdef HDRNET_TOOLS_BUILD  // the bf16-split contraction is an experiment: not in the product library
-      kfn = two ? GG_PICK(false, 2) : split ? GG_PICK(true, 1) : GG_PICK(false, 1);
+#ifdef HDRNET_TOOLS_BUILD  // the split contractions are experiments: not in the product library
+      kfn = two ? GG_PICK(0, 2) : split == 1 ? GG_PICK(1, 1) : split == 2 ? GG_PICK(2, 1) : GG_PICK(0, 1);
 #else
       if (split) return hipErrorNotSupported;
-      kfn = two ? GG_PICK(false, 2) : GG_PICK(false, 1);
+      kfn = two ? GG_PICK(0, 2) : GG_PICK(0, 1);
 #endif
 #undef GG_PICK
     } else {
       if (wg || wi) return hipErrorInvalidValue;  // fused VJPs read the coefficient image as float4
 #ifdef HDRNET_TOOLS_BUILD
-      kfn = two ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, false, false, 0, 2>
-                : split ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, true>
-                        : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false>;
+      kfn = two ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, 0, false, false, 0, 2>
+                : split == 1 ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, 1>
+                : split == 2 ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, 2>
+                             : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, 0>;
 #else
       if (split) return hipErrorNotSupported;
-      kfn = two ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false, false, false, 0, 2>
-                : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, false>;
+      kfn = two ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, 0, false, false, 0, 2>
+                : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, 0>;
 #endif
     }
   }
@@ -1117,7 +1148,7 @@ bool apply_grid_grad_mfma_supported(const ApplyGradArgs& a) {
 static hipError_t apply_gg(const ApplyGradArgs& a, bool fused, hipStream_t s) {
   const GGPtrs q{a.guide, a.input, a.dout, a.grid, a.dgrid, fused ? a.dguide : nullptr,
                  fused ? a.dinput : nullptr};
-  const bool split = a.variant == 2;
+  const int split = a.variant == 2 ? 1 : a.variant == 10 ? 2 : 0;  // tools: bf16 split / f16 hi-lo' split
 #define HDRNET_CASE(CI, CO, OFF)                                                                  \
   if constexpr (CO * (CI + (OFF ? 1 : 0)) <= 16) {                                                \
     if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF)                                       \
@@ -1130,7 +1161,7 @@ static hipError_t apply_gg(const ApplyGradArgs& a, bool fused, hipStream_t s) {
 }
 
 hipError_t launch_apply_grid_grad_mfma(const ApplyGradArgs& a, hipStream_t s, const char** name) {
-  *name = a.variant == 2 ? "grid_grad_mfma/bf16x2" : "grid_grad_mfma";
+  *name = a.variant == 2 ? "grid_grad_mfma/bf16x2" : a.variant == 10 ? "grid_grad_mfma/f16hilo" : "grid_grad_mfma";
   return apply_gg(a, false, s);
 }
 
@@ -1143,7 +1174,7 @@ bool apply_bwd_fused_supported(const ApplyGradArgs& a) {
 }
 
 hipError_t launch_apply_bwd_fused(const ApplyGradArgs& a, hipStream_t s, const char** name) {
-  *name = a.variant == 2 ? "apply_bwd_fused/mfma-bf16x2" : "apply_bwd_fused/mfma";
+  *name = a.variant == 2 ? "apply_bwd_fused/mfma-bf16x2" : a.variant == 10 ? "apply_bwd_fused/mfma-f16hilo" : "apply_bwd_fused/mfma";
   return apply_gg(a, true, s);
 }
 
@@ -1163,7 +1194,7 @@ bool slice_grid_grad_mfma_supported(const SliceGradArgs& a) {
 
 static hipError_t slice_gg(const SliceGradArgs& a, bool fused, hipStream_t s) {
   const GGPtrs q{a.guide, nullptr, a.dout, a.grid, a.dgrid, fused ? a.dguide : nullptr, nullptr};
-  const bool split = a.variant == 2;
+  const int split = a.variant == 2 ? 1 : a.variant == 10 ? 2 : 0;
 #define HDRNET_CASE(CC)                                                                            \
   if (a.C == CC)                                                                                   \
   return gg_launch<0, CC, false, false>(q, a.B, a.H, a.W, a.GH, a.GW, a.GD, a.workspace, a.workspace_bytes, s, split)

@@ -1074,12 +1074,15 @@ def test_tools_pyramid_onepass_equals_the_per_level_chain_bit_for_bit(dev, B, H,
     assert torch.equal(out_one, out_chain), diff
 
 
+@pytest.mark.parametrize("variant,kname", [(2, "bf16x2"), (10, "f16hilo")])
 @pytest.mark.parametrize("H,W", [(270, 480), (1080, 1920)])
-def test_tools_bf16_split_contraction_stays_within_1e5_of_scale(dev, mt_port_parity, H, W):
-    """Tools variant 2 of the gradient pass (grid_grad_mfma.hip, SPLIT: every f32 operand as two bf16 terms on the
-    bf16 matrix pipe; DESIGN.md section 4.2 quotes -8 % / -4 % / -2 % for it and "6e-6 of dgrid's scale away from the
-    exact contraction") against the oracle's dgrid: within 1e-5 x max|want|, and the per-pixel VJPs it leaves
-    untouched within the product's tolerances."""
+def test_tools_split_contractions_stay_within_1e5_of_scale(dev, mt_port_parity, H, W, variant, kname):
+    """The reduced-precision contractions of the gradient pass (grid_grad_mfma.hip, SPLIT; tools variants 2 and 10:
+    every f32 operand as two bf16 terms resp. as f16 {hi, lo' = remainder x 2^11} on the 16-bit matrix pipe; DESIGN.md
+    section 4.2 and profiles/r06/bwd_steps.md quote times and distances for them) against the oracle's dgrid: within
+    1e-5 x max|want| on unit-scale data, and the per-pixel VJPs they leave untouched within the product's tolerances.
+    (Round 6: this test caught the all-three instantiation of variant 2 computing channels 4 and 6 wrong after an
+    unrelated refactoring -- a 128-register cap with spills; the split kernels now take 3 waves per SIMD.)"""
     from conftest import check_pixel_grad
     from hdrnet_amd import _lib
     lib = _tools_or_skip()
@@ -1092,26 +1095,31 @@ def test_tools_bf16_split_contraction_stays_within_1e5_of_scale(dev, mt_port_par
     dout = rng.standard_normal((B, H, W, 3)).astype(np.float32)
     wg, wgu, wi = mt_port_parity.bilateral_slice_apply_grad(grid, guide, inp, dout, True)
     tg, tgu, ti, td = (T(a, dev) for a in (grid, guide, inp, dout))
-    dg, dgu, di = torch.empty_like(tg), torch.empty_like(tgu), torch.empty_like(ti)
     wsb = lib.hdrnet_bilateral_slice_apply_grad_workspace_bytes(B, H, W, GH, GW, GD, 3, 3, 1)
     ws = torch.empty((max(wsb, 16),), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    res = {}
-    for variant in (0, 2):
-        rc = lib.hdrnet_bilateral_slice_apply_grad_f32_ex(
-            tg.data_ptr(), tgu.data_ptr(), ti.data_ptr(), td.data_ptr(), dg.data_ptr(), dgu.data_ptr(), di.data_ptr(),
-            B, H, W, GH, GW, GD, 3, 3, 1, ws.data_ptr(), wsb, _lib.KERNEL_AUTO | (variant << 8), stream)
-        assert rc == 0, lib.hdrnet_last_error().decode()
-        torch.cuda.synchronize()
-        kern = lib.hdrnet_last_kernel().decode()
-        assert kern == ("apply_bwd_fused/mfma-bf16x2" if variant == 2 else "apply_bwd_fused/mfma"), kern
-        res[variant] = (N(dg), N(dgu), N(di))
     scale = float(np.abs(wg).max())
-    e_exact = np.abs(res[0][0] - wg).max() / scale
-    e_split = np.abs(res[2][0] - wg).max() / scale
-    e_between = np.abs(res[2][0] - res[0][0]).max() / scale
-    print(f"bf16-split dgrid {H}x{W}: |split - oracle| = {e_split:.2e} x scale, |f32 pass - oracle| = {e_exact:.2e}, "
-          f"|split - f32 pass| = {e_between:.2e}")
-    assert e_split < 1e-5, e_split
-    check_pixel_grad(res[2][1], wgu, "bf16-split", "dguide")
-    check_pixel_grad(res[2][2], wi, "bf16-split", "dinput")
+    for need_gu, need_in in ((True, True), (True, False), (False, False)):
+        res = {}
+        for v in (0, variant):
+            dg, dgu, di = torch.empty_like(tg), torch.empty_like(tgu), torch.empty_like(ti)
+            rc = lib.hdrnet_bilateral_slice_apply_grad_f32_ex(
+                tg.data_ptr(), tgu.data_ptr(), ti.data_ptr(), td.data_ptr(), dg.data_ptr(),
+                dgu.data_ptr() if need_gu else None, di.data_ptr() if need_in else None,
+                B, H, W, GH, GW, GD, 3, 3, 1, ws.data_ptr(), wsb, _lib.KERNEL_AUTO | (v << 8), stream)
+            assert rc == 0, lib.hdrnet_last_error().decode()
+            torch.cuda.synchronize()
+            kern = lib.hdrnet_last_kernel().decode()
+            base = "apply_bwd_fused/mfma" if (need_gu or need_in) else "grid_grad_mfma"
+            assert kern == (base + ("-" if "fused" in base else "/") + kname if v else base), kern
+            res[v] = (N(dg), N(dgu), N(di))
+        e_exact = np.abs(res[0][0] - wg).max() / scale
+        e_split = np.abs(res[variant][0] - wg).max() / scale
+        e_between = np.abs(res[variant][0] - res[0][0]).max() / scale
+        print(f"{kname} dgrid {H}x{W} (dguide {need_gu}, dinput {need_in}): |split - oracle| = {e_split:.2e} x scale, "
+              f"|f32 pass - oracle| = {e_exact:.2e}, |split - f32 pass| = {e_between:.2e}")
+        assert e_split < 1e-5, e_split
+        if need_gu:
+            check_pixel_grad(res[variant][1], wgu, kname, "dguide")
+        if need_in:
+            check_pixel_grad(res[variant][2], wi, kname, "dinput")
