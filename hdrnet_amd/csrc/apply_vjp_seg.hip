@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void apply_vjp_seg(const VjpSegParams p) {
   constexpr int CB = C * (int)sizeof(float);
   constexpr int RUN = 64 * kPxPerThread;            // pixels of a wave's run
   constexpr int SLAB = RUN * (1 + CIN + COUT);      // floats per wave: guide | input (-> dinput) | dout
+  constexpr bool kZDiff = CJ == 4 && CIN >= 1;      // shapes whose coefficient rows are one float4: the z-difference form
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,6 +113,97 @@ __global__ __launch_bounds__(256) void apply_vjp_seg(const VjpSegParams p) {
       for (int j = 0; j < CIN; ++j) in[j] = inf[k * CIN + j];
 #pragma unroll
       for (int i = 0; i < COUT; ++i) d[i] = df[k * COUT + i];
+      float dgk = 0.0f;
+      if constexpr (kZDiff) {
+        // The fused pass's evaluation (grid_grad_mfma.hip, "dguide from the z difference"), streamed one float4 of the
+        // four corner vectors at a time: with X_t = the x-blended vector of z tap t (A_t + wx1 (B_t - A_t)) and
+        // U = dout_i [in; 1],
+        //   dguide = dw1 <X1 - X0, U> + (dw0 + dw1) <X0, U>,  dw0 + dw1 = GD eps (D_b - D_a) / (D_a D_b), D = s (s + |dz|)
+        //   dinput = (wz0 + wz1) T(X0) + wz1 T(X1 - X0),      T(G)_j = sum_i dout_i G[i, j]
+        // -- no subtraction of two derivative weights near -+GD and none of two contracted taps of magnitude ~10: the
+        // cancellation happens per coefficient before the contraction.  (Round 5 wrote the same algebra on whole
+        // CoefVec taps: 205 VGPRs.  Here a tap never exists as a whole: 4 reads -> 2 vectors -> 4 + 4 scalars.)
+        float wz0, wz1, dw1 = 0.0f, dwsum = 0.0f;
+        int a0;
+        {
+#pragma clang fp contract(off)
+          const float gzf = mul_rn(gs[k], gd_f);
+          const float fzl = floorf(gzf - 0.5f);
+          const float dza = (fzl + 0.5f) - gzf, dzb = ((fzl + 1.0f) + 0.5f) - gzf;
+          const float qza = __builtin_fmaf(dza, dza, kSmoothEps), qzb = __builtin_fmaf(dzb, dzb, kSmoothEps);
+          float sza, szb;
+          if constexpr (WANT_GUIDE) {
+            // smoothed |dz| and its reciprocal from ONE v_rsq_f32 per tap: s = q rsq(q) (1.5 ulp; rsq(1.0f) is exact)
+            const float rza = __builtin_amdgcn_rsqf(qza), rzb = __builtin_amdgcn_rsqf(qzb);
+            sza = qza * rza;
+            szb = qzb * rzb;
+            // GD * SmoothedLerpWeightGrad (:186-187); the s > 1 branch (decided on q = s^2: grid_grad_mfma.hip's note)
+            // binds only for wild guides -- |guide * GD| beyond 2^23, where a tap's offset rounds to 2 -- and is taken
+            // per lane with selects: a branch on a ballot inside this unrolled loop costs the kernel 120 registers
+            dw1 = (qzb > 1.0f) ? 0.0f : gd_f * (dzb * rzb);
+            const float dw0 = (qza > 1.0f) ? 0.0f : gd_f * (dza * rza);
+            const float Da = sza * (sza + fabsf(dza)), Db = szb * (szb + fabsf(dzb));
+            dwsum = (gd_f * kSmoothEps) * ((Db - Da) * __builtin_amdgcn_rcpf(Da * Db));
+            dwsum = (qza > 1.0f || qzb > 1.0f) ? dw0 + dw1 : dwsum;
+          } else {
+            sza = __builtin_amdgcn_sqrtf(qza);
+            szb = __builtin_amdgcn_sqrtf(qzb);
+          }
+          wz0 = __builtin_amdgcn_fmed3f(1.0f - sza, 0.0f, 1.0f);  // max(1 - s, 0): s > 0
+          wz1 = __builtin_amdgcn_fmed3f(1.0f - szb, 0.0f, 1.0f);
+          const int iz = (int)__builtin_amdgcn_fmed3f(fzl, -1.0f, zhi);
+          a0 = __mul24(iz, CB) + xt[k].xbp;
+        }
+        constexpr int NQ = C / 4;  // float4 q = row i of [COUT][CJ = 4]
+        const f32x2 i01 = {in[0], CIN > 1 ? in[CIN > 1 ? 1 : 0] : 1.0f};
+        const f32x2 i23 = {CIN > 2 ? in[CIN > 2 ? 2 : 0] : 1.0f, CIN > 3 ? in[CIN > 3 ? 3 : 0] : 1.0f};
+        const f32x4 wx1 = {xt[k].wx1, xt[k].wx1, xt[k].wx1, xt[k].wx1};
+        const char* ibase = reinterpret_cast<const char*>(lds) + a0;
+        f32x2 acc0 = {0.0f, 0.0f}, accd = {0.0f, 0.0f};                       // <X0, U>, <X1 - X0, U> two columns at a time
+        f32x2 t0a = {0.0f, 0.0f}, t0b = {0.0f, 0.0f}, tda = {0.0f, 0.0f}, tdb = {0.0f, 0.0f};  // T(X0), T(X1 - X0)
+        f32x4 nA0 = *reinterpret_cast<const f32x4*>(ibase), nA1 = *reinterpret_cast<const f32x4*>(ibase + CB);
+        f32x4 nB0 = *reinterpret_cast<const f32x4*>(ibase + colb), nB1 = *reinterpret_cast<const f32x4*>(ibase + colb + CB);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const f32x4 X0 = __builtin_elementwise_fma(wx1, nB0 - nA0, nA0);
+          const f32x4 X1 = __builtin_elementwise_fma(wx1, nB1 - nA1, nA1);
+          const f32x4 Xd = X1 - X0;
+          if (q + 1 < NQ) {
+            const int o = (q + 1) * 16;
+            nA0 = *reinterpret_cast<const f32x4*>(ibase + o);
+            nA1 = *reinterpret_cast<const f32x4*>(ibase + CB + o);
+            nB0 = *reinterpret_cast<const f32x4*>(ibase + colb + o);
+            nB1 = *reinterpret_cast<const f32x4*>(ibase + colb + CB + o);
+          }
+          const f32x2 dq = {d[q], d[q]};
+          if constexpr (WANT_GUIDE) {
+            const f32x2 U01 = i01 * dq, U23 = i23 * dq;
+            acc0 = __builtin_elementwise_fma(f32x2{X0.x, X0.y}, U01, acc0);
+            acc0 = __builtin_elementwise_fma(f32x2{X0.z, X0.w}, U23, acc0);
+            accd = __builtin_elementwise_fma(f32x2{Xd.x, Xd.y}, U01, accd);
+            accd = __builtin_elementwise_fma(f32x2{Xd.z, Xd.w}, U23, accd);
+          }
+          if constexpr (WANT_INPUT) {
+            t0a = __builtin_elementwise_fma(f32x2{X0.x, X0.y}, dq, t0a);
+            tda = __builtin_elementwise_fma(f32x2{Xd.x, Xd.y}, dq, tda);
+            if constexpr (CIN > 3) {
+              t0b = __builtin_elementwise_fma(f32x2{X0.z, X0.w}, dq, t0b);
+              tdb = __builtin_elementwise_fma(f32x2{Xd.z, Xd.w}, dq, tdb);
+            } else if constexpr (CIN > 2) {
+              t0b.x = fmaf(X0.z, d[q], t0b.x);
+              tdb.x = fmaf(Xd.z, d[q], tdb.x);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);  // one vector of read-ahead: a whole tap in registers costs occupancy
+        }
+        if constexpr (WANT_GUIDE) dgk = fmaf(dw1, accd.x + accd.y, dwsum * (acc0.x + acc0.y));
+        if constexpr (WANT_INPUT) {
+          const float wzs = wz0 + wz1;
+          const float t0[4] = {t0a.x, t0a.y, t0b.x, t0b.y}, td[4] = {tda.x, tda.y, tdb.x, tdb.y};
+#pragma unroll
+          for (int j = 0; j < CIN; ++j) di[j] = fmaf(wz1, td[j], wzs * t0[j]);
+        }
+      } else {
       // z terms as the forward forms them (seg_common.hip.h: seg_pixel) + the tent's derivative
       float wz0, wz1, dw0, dw1;
       int a0;
@@ -130,9 +222,9 @@ __global__ __launch_bounds__(256) void apply_vjp_seg(const VjpSegParams p) {
         const int iz = (int)__builtin_amdgcn_fmed3f(fzl, -1.0f, zhi);
         a0 = __mul24(iz, CB) + xt[k].xbp;
       }
-      float dgk = 0.0f;
       vjp_blend<CIN, COUT, OFFSET, WANT_GUIDE, WANT_INPUT>(lds, a0, a0 + CB, a0 + colb, a0 + colb + CB, xt[k].wx0,
                                                           xt[k].wx1, wz0, wz1, dw0, dw1, in, d, dgk, di);
+      }
       dgf[k] = dgk;
       if constexpr (WANT_INPUT) {
 #pragma unroll
