@@ -210,26 +210,14 @@ constexpr int kTStride = 68;  // floats per operand row: 64 pixels + 4 (16-B ali
 // 64-pixel chunk the wave ballots which halves hold a live tap and contracts only those (an image-like guide rarely
 // straddles plane 7 | 8 inside 64 neighbouring pixels: then the chunk costs what it costs at GD <= 8).  Both halves go
 // through the SAME 16-row A slab, scattered, contracted and re-zeroed once per live half.
-//
-// BLK (block form for plane-coherent chunks; round 6): the dense tile spends 16 rows on a pixel's 4 live weights.  When
-// all 64 pixels of a chunk have their lower tap in ONE plane or in two NEIGHBOURING planes (a ballot; every image-like
-// guide most of the time, a U[0,1) guide never) the chunk is contracted with v_mfma_f32_4x4x1_16B_f32 instead: 16
-// independent 4 x 4 blocks per issue, a = one pixel's 4 weights (x corner x z tap), b = 4 of its channels, every MAC of
-// the 12 used blocks live -- 16 issues of 8 cycles per plane present instead of 16 of 32.  Lane (sub, bc) supplies the
-// SAME B value as in the dense tile (pixel slot sub, channel bc) and weight bc & 3 of that pixel, so the V^T slab and its
-// read pattern are shared; the A slab's rows 0-3 / 4-7 take the weights of the pixels in the window's lower / upper
-// plane.  The 4 x 16 block sums (one per pixel slot) stay in 4 + 4 registers across the chunks of a row while the
-// window {zb, zb + 1} holds, and are moved into the row's dense 16 x 16 tile -- summed over the slots and placed in
-// their plane rows -- by 4 dense MFMAs against a one-hot A (exact: x 1.0f) when the window moves and at the row's end.
-template <int CIN, int COUT, bool OFFSET, bool APPLY, int SPLIT, bool WG = false, bool WI = false, int ABL = 0, int NH = 1, bool BLK = false>
+template <int CIN, int COUT, bool OFFSET, bool APPLY, int SPLIT, bool WG = false, bool WI = false, int ABL = 0, int NH = 1>
 __global__ __launch_bounds__(kWaves * 64)
-__attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET ? 1 : 0) : 1) <= 12) ? ((NH == 1 && SPLIT == 0 && !BLK) ? 4 : 3) : 1))) void grid_grad_stage1(GGParams p) {
+__attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET ? 1 : 0) : 1) <= 12) ? ((NH == 1 && SPLIT == 0) ? 4 : 3) : 1))) void grid_grad_stage1(GGParams p) {
   constexpr int CJ = APPLY ? CIN + (OFFSET ? 1 : 0) : 1;
   constexpr int C = COUT * CJ;
   static_assert(C <= 16, "one 16-column MFMA tile");
   static_assert(NH == 1 || NH == 2, "8 or 16 planes");
   static_assert(NH == 1 || (!SPLIT && ABL == 0), "the tools variants exist for GD <= 8 only");
-  static_assert(!BLK || (!SPLIT && ABL == 0), "the block form contracts f32 operands");
   constexpr bool FUSED = WG || WI;
   static_assert(!FUSED || C % 4 == 0, "fused backward: float4 coefficient vectors");
   static_assert(!WI || (APPLY && CIN > 0), "dinput needs an input");
@@ -401,33 +389,6 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
   f32x4 dacc[NH], dacc2[NH];
 #pragma unroll
   for (int h = 0; h < NH; ++h) dacc[h] = dacc2[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // BLK: block sums of the window's lower / upper plane (lane (sub, bc), register r: weight r of pixel slot sub x
-  // channel bc), the window's base plane, which of the two sets hold anything
-  [[maybe_unused]] f32x4 bd[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  [[maybe_unused]] int blk_zb = -64;
-  [[maybe_unused]] bool blk_live[2] = {false, false};
-  [[maybe_unused]] const unsigned a_addr_blk = (unsigned)(uintptr_t)((lds_float*)at + (bc & 3) * kTStride + rd_off);
-  // block sums -> the row's dense tile: D[k, c] += sum_slot onehot(k == row of weight r) * bd[r][slot, c]
-  auto blk_flush = [&]() {
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      if (blk_live[st]) {  // wave-uniform
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int plane = min(blk_zb + st + (r & 1), p.GD - 1);  // (a top-plane pixel's upper tap carries weight 0)
-          const float hot = (bc == 8 * (r >> 1) + (plane & 7)) ? 1.0f : 0.0f;
-          if constexpr (NH == 1) {
-            dacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(hot, bd[st][r], dacc[0], 0, 0, 0);
-          } else {
-            if (plane >> 3) dacc[NH - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(hot, bd[st][r], dacc[NH - 1], 0, 0, 0);
-            else dacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(hot, bd[st][r], dacc[0], 0, 0, 0);
-          }
-        }
-        bd[st] = f32x4{0.f, 0.f, 0.f, 0.f};
-        blk_live[st] = false;
-      }
-    }
-  };
   // y terms of the row being contracted (bilateral_slice_apply.cc:42,47,55-56), formed once per row
   int row_gy0 = 0;
   float row_wy0 = 0.0f, row_wy1 = 0.0f;
@@ -703,44 +664,11 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
         auto enc2 = [](f32x2 v) { return SPLIT == 1 ? f32x2(split_pack2(v)) : SPLIT == 2 ? f32x2(split_pack2_f16(v)) : v; };
         auto enc = [&](float v) { return SPLIT ? enc2(f32x2{v, v}).x : v; };
         const f32x2 q2 = enc2(f32x2{w0, w1} * f32x2{wQ, wQ}), p2 = enc2(f32x2{w0, w1} * f32x2{wP, wP});
-        // BLK: is the chunk's lower tap in one plane, or in two neighbouring ones?  (lanes past the interval carry the
-        // last pixel's guide: they never break the coherence)
-        [[maybe_unused]] bool blk = false, blk_has[2] = {false, false};
-        [[maybe_unused]] float* aS = at;
-        if constexpr (BLK) {
-          const int z0 = __builtin_amdgcn_readfirstlane(zP);
-          const unsigned long long eq = __ballot(zP == z0), up = __ballot(zP == z0 + 1), dn = __ballot(zP == z0 - 1);
-          int lo = z0;
-          bool two = false;
-          if ((eq | up) == ~0ull) {
-            blk = true;
-            two = up != 0ull;
-          } else if ((eq | dn) == ~0ull) {
-            blk = true;
-            lo = z0 - 1;
-            two = true;
-          }
-          if (blk) {  // wave-uniform
-            if (lo < blk_zb || lo + (two ? 1 : 0) > blk_zb + 1) {  // outside the held window: move it
-              blk_flush();
-              blk_zb = lo;
-            }
-            blk_has[0] = lo == blk_zb;
-            blk_has[1] = blk_has[0] ? two : true;
-            aS = at + __umul24((unsigned)(zP - blk_zb), 4u * kTStride) + lane;  // rows 0-3: plane zb, rows 4-7: zb + 1
-            aS[0] = p2.x;
-            aS[kTStride] = q2.x;
-            aS[2 * kTStride] = p2.y;
-            aS[3 * kTStride] = q2.y;
-          }
-        }
         if constexpr (NH == 1) {
-          if (!blk) {
-            aQ[0] = q2.x;
-            aQ[8 * kTStride] = q2.y;
-            aP[0] = p2.x;
-            aP[8 * kTStride] = p2.y;
-          }
+          aQ[0] = q2.x;
+          aQ[8 * kTStride] = q2.y;
+          aP[0] = p2.x;
+          aP[8 * kTStride] = p2.y;
         }
         // V^T[c][px]: dout x [in; 1] (slice: dout)
         if constexpr (UPAIRS) {
@@ -770,8 +698,7 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
         // registers (the second half's reads are tied to the first half's variables, so they issue after the
         // first half's MFMAs have read them).
         f32x2 av[4], bv[4];
-#define HDRNET_GG_READS(OFF, TIE) HDRNET_GG_READS_AT(OFF, TIE, a_addr)
-#define HDRNET_GG_READS_AT(OFF, TIE, AADDR)                                                                        \
+#define HDRNET_GG_READS(OFF, TIE)                                                                          \
   asm volatile("ds_read_b64 %0, %8 offset:" #OFF "+0\n\tds_read_b64 %4, %9 offset:" #OFF "+0\n\t"           \
                "ds_read_b64 %1, %8 offset:" #OFF "+16\n\tds_read_b64 %5, %9 offset:" #OFF "+16\n\t"         \
                "ds_read_b64 %2, %8 offset:" #OFF "+32\n\tds_read_b64 %6, %9 offset:" #OFF "+32\n\t"         \
@@ -779,7 +706,7 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
                "s_waitcnt lgkmcnt(0)"                                                                      \
                : TIE(av[0]), TIE(av[1]), TIE(av[2]), TIE(av[3]), TIE(bv[0]), TIE(bv[1]), TIE(bv[2]),       \
                  TIE(bv[3])                                                                                \
-               : "v"(AADDR), "v"(v_addr)                                                                   \
+               : "v"(a_addr), "v"(v_addr)                                                                  \
                : "memory")
 #define HDRNET_GG_OUT(x) "=&v"(x)
 #define HDRNET_GG_INOUT(x) "+v"(x)
@@ -823,31 +750,7 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
           }
         };
         if constexpr (ABL == 6) ts1 = clock64();  // VALU phase + staging writes issued
-        if (BLK && blk) {  // wave-uniform
-#pragma unroll
-          for (int st = 0; st < 2; ++st) {
-            if (blk_has[st]) {
-              const unsigned aa = a_addr_blk + st * (4 * kTStride * (int)sizeof(float));
-              auto contract_blk = [&](f32x4& d) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  d = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e][0], bv[e][0], d, 0, 0, 0);
-                  d = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e][1], bv[e][1], d, 0, 0, 0);
-                }
-              };
-              HDRNET_GG_READS_AT(0, HDRNET_GG_OUT, aa);
-              contract_blk(bd[st]);
-              HDRNET_GG_READS_AT(64, HDRNET_GG_INOUT, aa);
-              contract_blk(bd[st]);
-              blk_live[st] = true;
-            }
-          }
-          wave_lds_order();
-          aS[0] = 0.0f;
-          aS[kTStride] = 0.0f;
-          aS[2 * kTStride] = 0.0f;
-          aS[3 * kTStride] = 0.0f;
-        } else if constexpr (NH == 1) {
+        if constexpr (NH == 1) {
           HDRNET_GG_READS(0, HDRNET_GG_OUT);
           if constexpr (ABL == 6) ts2 = clock64();  // first half's operands have arrived
           contract(dacc[0], dacc2[0]);
@@ -886,7 +789,6 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
           }
         }
 #undef HDRNET_GG_READS
-#undef HDRNET_GG_READS_AT
 #undef HDRNET_GG_OUT
 #undef HDRNET_GG_INOUT
         if constexpr (ABL == 6) {
@@ -907,7 +809,6 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
       const float wy0 = row_wy0, wy1 = row_wy1;
       const int rel0 = clamp_index(gy0, 0, p.GH - 1) - gy_base;
       const int rel1 = clamp_index(gy0 + 1, 0, p.GH - 1) - gy_base;
-      if constexpr (BLK) blk_flush();
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         if constexpr (SPLIT == 2) dacc[h] += 0x1p-11f * dacc2[h];  // hi hi + 2^-11 (hi lo' + lo' hi)
@@ -1135,12 +1036,12 @@ struct GGPtrs {
 
 template <int CIN, int COUT, bool OFFSET, bool APPLY>
 hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int GD, void* ws, size_t ws_bytes,
-                     hipStream_t s, int split, int ablate = 0, bool blk = false) {
+                     hipStream_t s, int split, int ablate = 0) {
   constexpr int C = APPLY ? COUT * (CIN + (OFFSET ? 1 : 0)) : COUT;
   const bool wg = q.dguide != nullptr, wi = q.dinput != nullptr;
   Stage1Fn kfn = nullptr;
   std::atomic<int>* occ = nullptr;
-  static std::atomic<int> occ_cache[24];  // per (plane halves, split / block form, dguide, dinput) of this shape
+  static std::atomic<int> occ_cache[16];  // per (plane halves, split, dguide, dinput) of this shape
 #ifdef HDRNET_TOOLS_BUILD
   if constexpr (APPLY && CIN == 3 && COUT == 3 && OFFSET) {  // ablations (tools variants 4 .. 8): timing only
     if (ablate >= 1 && ablate <= 6) {
@@ -1156,28 +1057,25 @@ hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int G
 #endif
   const bool two = GD > 8;  // NH = 2: planes 8 .. 15 in a second tile per task
   if (two && (split || kfn)) return hipErrorNotSupported;  // the tools variants exist for GD <= 8 only
-  if (blk && (split || kfn)) return hipErrorNotSupported;
   if (!kfn) {
-    occ = &occ_cache[(blk ? (two ? 20 : 16) : two ? 12 : 4 * split) + (wg ? 2 : 0) + (wi ? 1 : 0)];
+    occ = &occ_cache[(two ? 12 : 4 * split) + (wg ? 2 : 0) + (wi ? 1 : 0)];
     if constexpr (C % 4 == 0) {
       constexpr bool CAN_WI = APPLY && CIN > 0;
       if (wi && !CAN_WI) return hipErrorInvalidValue;
-#define GG_PICK(SPL, NH, BLK)                                                                              \
-  (wg && wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, true, CAN_WI, 0, NH, BLK>          \
-            : wg ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, true, false, 0, NH, BLK>      \
-                 : wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, false, CAN_WI, 0, NH, BLK> \
-                      : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, false, false, 0, NH, BLK>)
+#define GG_PICK(SPL, NH)                                                                              \
+  (wg && wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, true, CAN_WI, 0, NH>          \
+            : wg ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, true, false, 0, NH>      \
+                 : wi ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, false, CAN_WI, 0, NH> \
+                      : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, SPL, false, false, 0, NH>)
 #ifdef HDRNET_TOOLS_BUILD  // the split contractions are experiments: not in the product library
-      kfn = blk ? (two ? GG_PICK(0, 2, true) : GG_PICK(0, 1, true))
-                : two ? GG_PICK(0, 2, false) : split == 1 ? GG_PICK(1, 1, false) : split == 2 ? GG_PICK(2, 1, false) : GG_PICK(0, 1, false);
+      kfn = two ? GG_PICK(0, 2) : split == 1 ? GG_PICK(1, 1) : split == 2 ? GG_PICK(2, 1) : GG_PICK(0, 1);
 #else
-      if (split || blk) return hipErrorNotSupported;
-      kfn = two ? GG_PICK(0, 2, false) : GG_PICK(0, 1, false);
+      if (split) return hipErrorNotSupported;
+      kfn = two ? GG_PICK(0, 2) : GG_PICK(0, 1);
 #endif
 #undef GG_PICK
     } else {
       if (wg || wi) return hipErrorInvalidValue;  // fused VJPs read the coefficient image as float4
-      if (blk) return hipErrorNotSupported;
 #ifdef HDRNET_TOOLS_BUILD
       kfn = two ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, 0, false, false, 0, 2>
                 : split == 1 ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, APPLY, 1>
@@ -1255,7 +1153,7 @@ static hipError_t apply_gg(const ApplyGradArgs& a, bool fused, hipStream_t s) {
   if constexpr (CO * (CI + (OFF ? 1 : 0)) <= 16) {                                                \
     if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF)                                       \
       return gg_launch<CI, CO, OFF, true>(q, a.B, a.H, a.W, a.GH, a.GW, a.GD, a.workspace, a.workspace_bytes, s, \
-                                          split, (a.variant >= 4 && a.variant <= 9) ? a.variant - 3 : 0, a.variant == 11); \
+                                          split, (a.variant >= 4 && a.variant <= 9) ? a.variant - 3 : 0); \
   }
   HDRNET_APPLY_FAST_SHAPES(HDRNET_CASE)
 #undef HDRNET_CASE
@@ -1263,7 +1161,7 @@ static hipError_t apply_gg(const ApplyGradArgs& a, bool fused, hipStream_t s) {
 }
 
 hipError_t launch_apply_grid_grad_mfma(const ApplyGradArgs& a, hipStream_t s, const char** name) {
-  *name = a.variant == 2 ? "grid_grad_mfma/bf16x2" : a.variant == 10 ? "grid_grad_mfma/f16hilo" : a.variant == 11 ? "grid_grad_mfma/blk" : "grid_grad_mfma";
+  *name = a.variant == 2 ? "grid_grad_mfma/bf16x2" : a.variant == 10 ? "grid_grad_mfma/f16hilo" : "grid_grad_mfma";
   return apply_gg(a, false, s);
 }
 
@@ -1276,7 +1174,7 @@ bool apply_bwd_fused_supported(const ApplyGradArgs& a) {
 }
 
 hipError_t launch_apply_bwd_fused(const ApplyGradArgs& a, hipStream_t s, const char** name) {
-  *name = a.variant == 2 ? "apply_bwd_fused/mfma-bf16x2" : a.variant == 10 ? "apply_bwd_fused/mfma-f16hilo" : a.variant == 11 ? "apply_bwd_fused/mfma-blk" : "apply_bwd_fused/mfma";
+  *name = a.variant == 2 ? "apply_bwd_fused/mfma-bf16x2" : a.variant == 10 ? "apply_bwd_fused/mfma-f16hilo" : "apply_bwd_fused/mfma";
   return apply_gg(a, true, s);
 }
 
@@ -1299,7 +1197,7 @@ static hipError_t slice_gg(const SliceGradArgs& a, bool fused, hipStream_t s) {
   const int split = a.variant == 2 ? 1 : a.variant == 10 ? 2 : 0;
 #define HDRNET_CASE(CC)                                                                            \
   if (a.C == CC)                                                                                   \
-  return gg_launch<0, CC, false, false>(q, a.B, a.H, a.W, a.GH, a.GW, a.GD, a.workspace, a.workspace_bytes, s, split, 0, a.variant == 11)
+  return gg_launch<0, CC, false, false>(q, a.B, a.H, a.W, a.GH, a.GW, a.GD, a.workspace, a.workspace_bytes, s, split)
   HDRNET_CASE(1);
   HDRNET_CASE(2);
   HDRNET_CASE(4);
@@ -1311,7 +1209,7 @@ static hipError_t slice_gg(const SliceGradArgs& a, bool fused, hipStream_t s) {
 }
 
 hipError_t launch_slice_grid_grad_mfma(const SliceGradArgs& a, hipStream_t s, const char** name) {
-  *name = a.variant == 2 ? "grid_grad_mfma/bf16x2" : a.variant == 11 ? "grid_grad_mfma/blk" : "grid_grad_mfma";
+  *name = a.variant == 2 ? "grid_grad_mfma/bf16x2" : "grid_grad_mfma";
   return slice_gg(a, false, s);
 }
 
@@ -1322,7 +1220,7 @@ bool slice_bwd_fused_supported(const SliceGradArgs& a) {
 }
 
 hipError_t launch_slice_bwd_fused(const SliceGradArgs& a, hipStream_t s, const char** name) {
-  *name = a.variant == 11 ? "slice_bwd_fused/mfma-blk" : "slice_bwd_fused/mfma";
+  *name = "slice_bwd_fused/mfma";
   return slice_gg(a, true, s);
 }
 

@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--cases", default="all,gg,g")
     ap.add_argument("--variants", default="0,3,4,5")
     ap.add_argument("--smooth", action="store_true", help="a smooth luminance-like guide (bench.make_sets) instead of U[0,1)")
+    ap.add_argument("--guide", default="", choices=["", "const", "smooth0", "photo"],
+                    help="const: 0.4 everywhere (every chunk in one plane); smooth0: the smooth guide without its 2 %% noise; "
+                         "photo: smooth + 0.5 %% noise (a denoised image)")
     ap.add_argument("--lds-pad", default="", help="comma-separated bytes of unused dynamic LDS per stage-1 workgroup (tools knob 1): "
                     "every (case, variant) is timed at each value, interleaved -- what a resident wave is worth")
     args = ap.parse_args()
@@ -61,6 +64,17 @@ def main():
               dgrid=torch.empty((B, GH, GW, GD, C), device=dev),
               dguide=torch.empty((B, H, W), device=dev),
               dinput=torch.empty((B, H, W, Cin), device=dev)) for i in range(nsets)]
+    if args.guide:
+        yy = torch.linspace(0, 1, H, device=dev)[:, None]
+        xx = torch.linspace(0, 1, W, device=dev)[None, :]
+        for i, s in enumerate(S):
+            base = 0.5 + 0.4 * torch.sin(5.0 * xx + 3.0 * yy + i) * torch.cos(2.0 * yy - xx)
+            if args.guide == "const":
+                s["guide"] = torch.full((B, H, W), 0.4, device=dev)
+            elif args.guide == "smooth0":
+                s["guide"] = base[None].expand(B, H, W).contiguous()
+            else:
+                s["guide"] = (base[None] + 0.005 * torch.randn((B, H, W), device=dev, generator=gen)).clamp(0, 1).contiguous()
     sl = [torch.randn((B, H, W, C), device=dev, generator=gen) for _ in range(2)]
     stream = torch.cuda.current_stream(dev).cuda_stream
     wsb = lib.hdrnet_bilateral_slice_apply_grad_workspace_bytes(B, H, W, GH, GW, GD, Cin, Cout, 1)
@@ -123,7 +137,7 @@ def main():
         for k, f in fns.items():
             time_launches(f, 20)  # settle (see tools/ab_bench.py)
             res[k].append(time_launches(f, args.steps))
-    print(desc + ("; SMOOTH guide" if args.smooth else ""))
+    print(desc + ("; SMOOTH guide" if args.smooth else "") + (f"; guide {args.guide}" if args.guide else ""))
     for key, t in res.items():
         c, v = key[0], key[1]
         print(f"case {c:4s} variant {v:3d} {names[key]:34s} median {statistics.median(t):8.2f} us  min {min(t):8.2f}"
