@@ -17,7 +17,7 @@ O=$R/gpurun_out/profiles
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 MODE=${1:-timing}
-PREV=$R/tools/exp/prev/libhdrnet_amd_r04.so
+PREV=$R/tools/exp/prev/libhdrnet_amd_r05.so
 if [ "$MODE" = pmc ]; then
 # 1. HBM traffic of the forward kernel: separate --pmc passes (never combined with trace domains), each
 #    with a calibration twin on the memory skeleton (known byte count, same access widths)
@@ -76,6 +76,11 @@ python $R/bench.py --extra --no-cpu-baseline --no-pipelined > $O/bench_extra_smo
 cd $R
 python tools/op_bench.py --tools --workload 4k --json $O/ops_4k.json > $O/ops_4k.txt 2>&1
 python tools/op_bench.py --tools --workload 1080p --json $O/ops_1080p.json > $O/ops_1080p.txt 2>&1
+# luma_bins = 4 / 16 (hdrnet/bin/train.py:235): the grid depths beside BASELINE.json's 8, random and smooth guide
+for lb in 4 16; do
+  python tools/op_bench.py --workload 4k --luma-bins $lb > $O/ops_4k_lb$lb.txt 2>&1
+  python tools/op_bench.py --workload 4k --luma-bins $lb --smooth-guide --only "apply bwd,apply fwd" > $O/ops_4k_lb${lb}_smooth.txt 2>&1
+done
 python tools/op_bench.py --workload 1080p_b4 --json $O/ops_1080p_b4.json > $O/ops_1080p_b4.txt 2>&1
 python tools/op_bench.py --workload hdrp --json $O/ops_hdrp.json > $O/ops_hdrp.txt 2>&1
 python tools/op_bench.py --workload refbench --json $O/ops_refbench.json > $O/ops_refbench.txt 2>&1
@@ -88,7 +93,7 @@ if [ -f $PREV ]; then
 fi
 # the guide forwards with the exported arrays and with the parameters prepared once per parameter set (round 5), interleaved
 for w in 4k 1080p; do python tools/guide_prepared_ab.py --workload $w 2>&1 | grep -v amdgpu.ids; done > $O/guide_prepared_ab.txt
-python tools/bwd_ab.py --rounds 5 --steps 50 --cases all,gg,g,sl,v --variants 0,2,3,4,5,6,7,8 > $O/bwd_ab_4k.txt 2>&1
+python tools/bwd_ab.py --rounds 5 --steps 50 --cases all,gg,g,sl,v --variants 0,2,10,3,4,5,6,7,8 > $O/bwd_ab_4k.txt 2>&1
 python tools/bwd_ab.py --workload 1080p --rounds 5 --steps 100 --cases all,gg,g,sl,v --variants 0,3 > $O/bwd_ab_1080p.txt 2>&1
 python tools/bwd_ab.py --smooth --rounds 5 --steps 50 --cases all,gg,g --variants 0 > $O/bwd_ab_4k_smooth_guide.txt 2>&1
 python tools/pyramid_onepass_bench.py --workload 4k --segs 512,768,1024 > $O/pyramid_onepass_4k.txt 2>&1
