@@ -21,12 +21,12 @@ PREV=$R/tools/exp/prev/libhdrnet_amd_r05.so
 if [ "$MODE" = pmc ]; then
 # 1. HBM traffic of the forward kernel: separate --pmc passes (never combined with trace domains), each
 #    with a calibration twin on the memory skeleton (known byte count, same access widths)
-rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-ops > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-ops > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/cal_fetch -o p --output-format csv -- python $R/tools/ab_bench.py --variants 106 --rounds 1 --steps 20 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/cal_write -o p --output-format csv -- python $R/tools/ab_bench.py --variants 106 --rounds 1 --steps 20 > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -d $O/pmc_sq -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD -d $O/pmc_sq2 -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -d $O/pmc_sq -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-ops > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD -d $O/pmc_sq2 -o p --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-ops > /dev/null 2>&1
 python $R/tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_sq2 --match apply_fwd > $O/fwd_pmc.txt 2>&1
 python $R/tools/pmc_summary.py $O/cal_fetch $O/cal_write --match skeleton > $O/fwd_pmc_calibration.txt 2>&1
 python $R/tools/make_traffic.py --fetch $O/pmc_fetch --write $O/pmc_write --calib-fetch $O/cal_fetch --calib-write $O/cal_write --workload 4k --out $O/traffic.json > $O/traffic.log 2>&1
@@ -62,7 +62,7 @@ rocprofv3 --kernel-trace --stats -d $O/stats -o fwd --output-format csv -- pytho
 grep '^{"metric' $O/bench_under_rocprof.log > $O/bench_under_rocprof.json
 find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/fwd_kernel_stats.csv \;
 rm -rf $O/stats
-for i in 1 2 3; do python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline; done > $O/bench_steps20.txt 2>> $O/bench.err
+for i in 1 2 3; do python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-ops; done > $O/bench_steps20.txt 2>> $O/bench.err
 python $R/bench.py --workload 1080p --no-cpu-baseline > $O/bench_1080p.json 2>> $O/bench.err
 python $R/bench.py --workload 1080p_b4 --no-cpu-baseline > $O/bench_1080p_b4.json 2>> $O/bench.err
 python $R/bench.py --workload hdrp --no-cpu-baseline > $O/bench_hdrp.json 2>> $O/bench.err
