@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void apply_vjp_seg(const VjpSegParams p) {
   constexpr int CB = C * (int)sizeof(float);
   constexpr int RUN = 64 * kPxPerThread;            // pixels of a wave's run
   constexpr int SLAB = RUN * (1 + CIN + COUT);      // floats per wave: guide | input (-> dinput) | dout
-  constexpr bool kZDiff = CJ == 4 && CIN >= 1;      // shapes whose coefficient rows are one float4: the z-difference form
+  constexpr bool kZDiff = C % 4 == 0 && CIN >= 1;   // coefficient vectors of whole float4s: the z-difference form
+  constexpr bool kRowVec = CJ == 4;                 // ... and one float4 = one output row (packed pairs); else by element
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(256) void apply_vjp_seg(const VjpSegParams p) {
         const char* ibase = reinterpret_cast<const char*>(lds) + a0;
         f32x2 acc0 = {0.0f, 0.0f}, accd = {0.0f, 0.0f};                       // <X0, U>, <X1 - X0, U> two columns at a time
         f32x2 t0a = {0.0f, 0.0f}, t0b = {0.0f, 0.0f}, tda = {0.0f, 0.0f}, tdb = {0.0f, 0.0f};  // T(X0), T(X1 - X0)
+        [[maybe_unused]] float t0s[4] = {0.0f, 0.0f, 0.0f, 0.0f}, tds[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // the same, by element
         f32x4 nA0 = *reinterpret_cast<const f32x4*>(ibase), nA1 = *reinterpret_cast<const f32x4*>(ibase + CB);
         f32x4 nB0 = *reinterpret_cast<const f32x4*>(ibase + colb), nB1 = *reinterpret_cast<const f32x4*>(ibase + colb + CB);
 #pragma unroll
@@ -175,7 +177,34 @@ __global__ __launch_bounds__(256) void apply_vjp_seg(const VjpSegParams p) {
             nB0 = *reinterpret_cast<const f32x4*>(ibase + colb + o);
             nB1 = *reinterpret_cast<const f32x4*>(ibase + colb + CB + o);
           }
-          const f32x2 dq = {d[q], d[q]};
+          if constexpr (!kRowVec) {
+            // (4 -> 4 with offset, C = 20: a float4 straddles output rows) element c = 4 q + e is coefficient (i, j) =
+            // (c / CJ, c % CJ), known at compile time after unrolling
+            const float x0[4] = {X0.x, X0.y, X0.z, X0.w}, xd[4] = {Xd.x, Xd.y, Xd.z, Xd.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int c = 4 * q + e, i = c / CJ, j = c % CJ;
+              if constexpr (WANT_GUIDE) {
+                const float u = j < CIN ? d[i] * in[j < CIN ? j : 0] : d[i];
+                if (e & 1) {
+                  acc0.y = fmaf(x0[e], u, acc0.y);
+                  accd.y = fmaf(xd[e], u, accd.y);
+                } else {
+                  acc0.x = fmaf(x0[e], u, acc0.x);
+                  accd.x = fmaf(xd[e], u, accd.x);
+                }
+              }
+              if constexpr (WANT_INPUT) {
+                if (j < CIN) {
+                  t0s[j < 4 ? j : 0] = fmaf(x0[e], d[i], t0s[j < 4 ? j : 0]);
+                  tds[j < 4 ? j : 0] = fmaf(xd[e], d[i], tds[j < 4 ? j : 0]);
+                }
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            continue;
+          }
+          const f32x2 dq = {d[q < COUT ? q : 0], d[q < COUT ? q : 0]};
           if constexpr (WANT_GUIDE) {
             const f32x2 U01 = i01 * dq, U23 = i23 * dq;
             acc0 = __builtin_elementwise_fma(f32x2{X0.x, X0.y}, U01, acc0);
@@ -190,8 +219,8 @@ __global__ __launch_bounds__(256) void apply_vjp_seg(const VjpSegParams p) {
               t0b = __builtin_elementwise_fma(f32x2{X0.z, X0.w}, dq, t0b);
               tdb = __builtin_elementwise_fma(f32x2{Xd.z, Xd.w}, dq, tdb);
             } else if constexpr (CIN > 2) {
-              t0b.x = fmaf(X0.z, d[q], t0b.x);
-              tdb.x = fmaf(Xd.z, d[q], tdb.x);
+              t0b.x = fmaf(X0.z, d[q < COUT ? q : 0], t0b.x);
+              tdb.x = fmaf(Xd.z, d[q < COUT ? q : 0], tdb.x);
             }
           }
           __builtin_amdgcn_sched_barrier(0);  // one vector of read-ahead: a whole tap in registers costs occupancy
@@ -201,7 +230,8 @@ __global__ __launch_bounds__(256) void apply_vjp_seg(const VjpSegParams p) {
           const float wzs = wz0 + wz1;
           const float t0[4] = {t0a.x, t0a.y, t0b.x, t0b.y}, td[4] = {tda.x, tda.y, tdb.x, tdb.y};
 #pragma unroll
-          for (int j = 0; j < CIN; ++j) di[j] = fmaf(wz1, td[j], wzs * t0[j]);
+          for (int j = 0; j < CIN; ++j)
+            di[j] = kRowVec ? fmaf(wz1, td[j], wzs * t0[j]) : fmaf(wz1, tds[j < 4 ? j : 0], wzs * t0s[j < 4 ? j : 0]);
         }
       } else {
       // z terms as the forward forms them (seg_common.hip.h: seg_pixel) + the tent's derivative

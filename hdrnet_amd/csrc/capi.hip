@@ -64,7 +64,7 @@ bool positive(int v) { return v > 0; }
 
 // A grid gradient on the generic gather kernel (the reference's own design, bilateral_slice_apply.cc:84-138: every grid
 // element loops over its +-1-cell pixel window) is ~100x slower than the contraction pass.  HDRNET_KERNEL_AUTO falls
-// back to it for shapes the pass has no specialisation for (GD > 16, C > 16, an unlisted channel combination) or
+// back to it for shapes the pass has no specialisation for (GD > 16, C > 32, an unlisted channel combination) or
 // without a workspace; on a frame-sized call that is a performance cliff worth one line on stderr per process.
 constexpr long long kWarnGenericPixels = 65536;
 void warn_generic_grid_grad(const char* op, long long npix, int GD, int C, bool have_workspace) {
@@ -72,7 +72,7 @@ void warn_generic_grid_grad(const char* op, long long npix, int GD, int C, bool 
   if (npix <= kWarnGenericPixels || said.exchange(true)) return;
   fprintf(stderr, "hdrnet_amd: %s on %lld pixels (GD=%d, C=%d) takes the generic grid-gradient kernel, ~100x slower "
           "than the fast pass (%s)\n", op, npix, GD, C,
-          have_workspace ? "no fast specialisation for this shape: needs GD <= 16, C <= 16 and a listed channel combination"
+          have_workspace ? "no fast specialisation for this shape: needs GD <= 16, C <= 32 and a listed channel combination"
                          : "no workspace passed: see hdrnet_bilateral_slice*_grad_workspace_bytes");
 }
 
@@ -135,7 +135,9 @@ extern "C" {
 //          ..._io_curves_prepared; the non-_ex guide-network entry points use the exact sigmoid (flags = 0)
 // 0.2.5.0: the gradient entry points take grids of up to 16 planes on the fast pass (the workspace bound grows with it:
 //          query ..._grad_workspace_bytes again); one stderr line when a frame-sized dgrid falls back to the generic kernel
-int hdrnet_version(void) { return 250; }
+// 0.2.5.1: 4 -> 4 with offset (C = 20): dgrid on the contraction pass as two channel windows (the workspace bound doubles
+//          for that shape: query again); apply_vjp_seg's dguide in the z-difference form (bits change; closer to float64)
+int hdrnet_version(void) { return 251; }
 
 const char* hdrnet_last_error(void) { return g_error; }
 

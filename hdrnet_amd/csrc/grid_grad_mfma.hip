@@ -210,12 +210,21 @@ constexpr int kTStride = 68;  // floats per operand row: 64 pixels + 4 (16-B ali
 // 64-pixel chunk the wave ballots which halves hold a live tap and contracts only those (an image-like guide rarely
 // straddles plane 7 | 8 inside 64 neighbouring pixels: then the chunk costs what it costs at GD <= 8).  Both halves go
 // through the SAME 16-row A slab, scattered, contracted and re-zeroed once per live half.
-template <int CIN, int COUT, bool OFFSET, bool APPLY, int SPLIT, bool WG = false, bool WI = false, int ABL = 0, int NH = 1>
+//
+// CW (column windows): the tile has 16 columns.  A shape of 17 .. 32 grid channels (4 -> 4 with offset: C = 20) is two
+// launches of this kernel, window CW staging the channels 16 CW .. 16 CW + 15 as its V rows and writing its own partial
+// tiles; stage 2 runs once per window.  Each launch re-reads the pixels (2 x 28 B/px): a shape outside the reference's
+// configurations, kept off the ~100 x slower generic gather rather than tuned.  dgrid only (the fused VJPs read whole
+// coefficient vectors).
+template <int CIN, int COUT, bool OFFSET, bool APPLY, int SPLIT, bool WG = false, bool WI = false, int ABL = 0, int NH = 1, int CW = 0>
 __global__ __launch_bounds__(kWaves * 64)
 __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET ? 1 : 0) : 1) <= 12) ? ((NH == 1 && SPLIT == 0) ? 4 : 3) : 1))) void grid_grad_stage1(GGParams p) {
   constexpr int CJ = APPLY ? CIN + (OFFSET ? 1 : 0) : 1;
-  constexpr int C = COUT * CJ;
-  static_assert(C <= 16, "one 16-column MFMA tile");
+  constexpr int CFULL = COUT * CJ;
+  constexpr int C0 = 16 * CW;                                  // first grid channel of this window
+  constexpr int C = CFULL - C0 < 16 ? CFULL - C0 : 16;         // columns of this window's tile
+  static_assert(C >= 1 && C <= 16 && CFULL <= 32, "one 16-column MFMA tile per window, two windows");
+  static_assert(CFULL <= 16 || (!WG && !WI && SPLIT == 0 && ABL == 0 && APPLY), "channel windows: apply dgrid only");
   static_assert(NH == 1 || NH == 2, "8 or 16 planes");
   static_assert(NH == 1 || (!SPLIT && ABL == 0), "the tools variants exist for GD <= 8 only");
   constexpr bool FUSED = WG || WI;
@@ -516,7 +525,7 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
         const float szb = WG ? qzb * rzb : __builtin_amdgcn_sqrtf(qzb);
         // U[i] = dout_i * [in; 1]: the rows of V the dgrid contraction stages AND the vectors the fused dguide
         // contracts with, as column pairs (CJ = 4 shapes; two packed multiplies per output channel)
-        constexpr bool UPAIRS = APPLY && CJ == 4;
+        constexpr bool UPAIRS = APPLY && CJ == 4 && CFULL <= 16;
         [[maybe_unused]] f32x2 U01[COUT], U23[COUT];
         if constexpr (UPAIRS) {
           const f32x2 i01 = {cur.in[cb][0], CIN > 1 ? cur.in[cb][CIN > 1 ? 1 : 0] : 1.0f};
@@ -684,9 +693,14 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
 #pragma unroll
           for (int i = 0; i < COUT; ++i) {
 #pragma unroll
-            for (int j = 0; j < CJ; ++j)
-              vt[(i * CJ + j) * kTStride + lane] =
-                  enc((j < CIN) ? cur.d[cb][i] * cur.in[cb][j < CIN ? j : 0] : cur.d[cb][i]);
+            for (int j = 0; j < CJ; ++j) {
+              constexpr int kUnused = 0;
+              (void)kUnused;
+              const int c = i * CJ + j;  // (compile-time after unrolling: only this window's channels are staged)
+              if (c >= C0 && c < C0 + C)
+                vt[(c - C0) * kTStride + lane] =
+                    enc((j < CIN) ? cur.d[cb][i] * cur.in[cb][j < CIN ? j : 0] : cur.d[cb][i]);
+            }
           }
         } else {
 #pragma unroll
@@ -870,7 +884,7 @@ template <int NH>
 __global__ __launch_bounds__(512) void grid_grad_stage2(const float* __restrict__ partial,
                                                         float* __restrict__ dgrid, int GH, int GW,
                                                         int GD, int C, int rg, int nyg,
-                                                        float scale_y) {
+                                                        float scale_y, int c0 = 0, int Cw = 16) {
   constexpr int kNZ = 8 * NH, kS2Parts = 32 / kNZ, kTile = NH * kTileFloats;
   __shared__ float red[kS2Parts][kNZ * 16 + 1];
   const int c = threadIdx.x & 15, z = (threadIdx.x >> 4) & (kNZ - 1), part = threadIdx.x / (16 * kNZ);
@@ -901,11 +915,11 @@ __global__ __launch_bounds__(512) void grid_grad_stage2(const float* __restrict_
   }
   red[part][z * 16 + c] = s;
   __syncthreads();
-  if (part == 0 && z < GD && c < C) {
+  if (part == 0 && z < GD && c < Cw && c0 + c < C) {  // (C: the grid's channels; this launch's window: c0 .. c0 + Cw - 1)
     float t = red[0][z * 16 + c];
 #pragma unroll
     for (int q = 1; q < kS2Parts; ++q) t += red[q][z * 16 + c];
-    dgrid[((((size_t)b * GH + gy) * GW + gx) * GD + z) * C + c] = t;
+    dgrid[((((size_t)b * GH + gy) * GW + gx) * GD + z) * C + c0 + c] = t;
   }
 }
 
@@ -927,8 +941,9 @@ constexpr int kMinRg = 4, kMaxRounds = 6;
 constexpr int kMaxOcc = 8;  // workgroups per CU a stage-1 kernel can have (8 waves per SIMD, 4-wave workgroups)
 
 bool gg_plan(int B, int H, int W, int GH, int GW, int GD, int C, long long slots, GGPlan* pl) {
-  if (GD > 16 || C > 16 || C < 1) return false;
+  if (GD > 16 || C > 32 || C < 1) return false;
   const int nh = GD > 8 ? 2 : 1;  // plane halves: a task writes one [3][16][16] tile per half
+  const int nw = C > 16 ? 2 : 1;  // channel windows: one stage-1 launch and one set of partial tiles per window
   const int cell = H / GH > 1 ? H / GH : 1;
   const int rg_lo = cell < kMinRg ? cell : kMinRg;
   const long long cols = (long long)B * (GW + 1);
@@ -959,7 +974,7 @@ bool gg_plan(int B, int H, int W, int GH, int GW, int GD, int C, long long slots
   pl->nyg = (H + rg - 1) / rg;
   pl->ntasks = cols * pl->nyg;
   if (pl->ntasks > 0x7fffffffLL || (long long)B * GH * GW * GD > 0x7fffffffLL || pl->nyg > 65535 || B > 65535 || GH > 65535) return false;
-  pl->ws_bytes = (size_t)pl->ntasks * nh * kTileFloats * sizeof(float);
+  pl->ws_bytes = (size_t)pl->ntasks * nh * nw * kTileFloats * sizeof(float);
   return true;
 }
 
@@ -1114,9 +1129,48 @@ hipError_t gg_launch(const GGPtrs& q, int B, int H, int W, int GH, int GW, int G
   return hipGetLastError();
 }
 
-// the shared fast-shape table (launch.hip.h) restricted to one 16-column MFMA tile
+// 17 .. 32 grid channels (4 -> 4 with offset): dgrid as two channel windows of 16 columns (grid_grad_stage1's CW) --
+// stage 1 and stage 2 once per window, the second window's partial tiles behind the first's in the workspace.
+template <int CIN, int COUT, bool OFFSET>
+hipError_t gg_launch_windows(const GGPtrs& q, int B, int H, int W, int GH, int GW, int GD, void* ws, size_t ws_bytes,
+                             hipStream_t s) {
+  constexpr int C = COUT * (CIN + (OFFSET ? 1 : 0));
+  static_assert(C > 16 && C <= 32, "two windows");
+  if (q.dguide || q.dinput) return hipErrorInvalidValue;  // the per-pixel VJPs of these shapes run in apply_vjp_seg
+  const bool two = GD > 8;
+  static std::atomic<int> occ_cache[2];
+  const Stage1Fn k0 = two ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, true, 0, false, false, 0, 2, 0>
+                          : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, true, 0, false, false, 0, 1, 0>;
+  const Stage1Fn k1 = two ? (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, true, 0, false, false, 0, 2, 1>
+                          : (Stage1Fn)grid_grad_stage1<CIN, COUT, OFFSET, true, 0, false, false, 0, 1, 1>;
+  GGPlan pl;
+  if (!gg_plan(B, H, W, GH, GW, GD, C, resident_slots(k0, &occ_cache[two ? 1 : 0]), &pl) || pl.ws_bytes > ws_bytes)
+    return hipErrorInvalidValue;
+  const size_t window_floats = (size_t)pl.ntasks * (two ? 2 : 1) * kTileFloats;
+  const dim3 nblocks((unsigned)(GW + 1), (unsigned)pl.nyg, (unsigned)B);
+  const dim3 ncols((unsigned)GW, (unsigned)GH, (unsigned)B);
+  for (int w = 0; w < 2; ++w) {
+    float* part = static_cast<float*>(ws) + w * window_floats;
+    GGParams p{q.guide, q.input, q.dout, q.grid, nullptr, nullptr, part, H, W, GH, GW, GD,
+               pl.rg, pl.nyg, pl.ntasks, (float)GW / W, (float)GH / H, nullptr};
+    (w == 0 ? k0 : k1)<<<nblocks, kWaves * 64, 0, s>>>(p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int c0 = 16 * w, cw = w == 0 ? 16 : C - 16;
+    if (two)
+      grid_grad_stage2<2><<<ncols, 512, 0, s>>>(part, q.dgrid, GH, GW, GD, C, pl.rg, pl.nyg, (float)GH / H, c0, cw);
+    else
+      grid_grad_stage2<1><<<ncols, 512, 0, s>>>(part, q.dgrid, GH, GW, GD, C, pl.rg, pl.nyg, (float)GH / H, c0, cw);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+// the shared fast-shape table (launch.hip.h) restricted to what the contraction pass covers: one 16-column tile, or two
+// channel windows for dgrid alone
 bool apply_shape_ok(int Cin, int Cout, bool off) {
-  return apply_fast_shape(Cin, Cout, off) && Cout * (Cin + (off ? 1 : 0)) <= 16;
+  return apply_fast_shape(Cin, Cout, off) && Cout * (Cin + (off ? 1 : 0)) <= 32;
 }
 
 bool slice_c_ok(int C) { return C == 1 || C == 2 || C == 4 || C == 8 || C == 12 || C == 16; }
@@ -1154,6 +1208,11 @@ static hipError_t apply_gg(const ApplyGradArgs& a, bool fused, hipStream_t s) {
     if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF)                                       \
       return gg_launch<CI, CO, OFF, true>(q, a.B, a.H, a.W, a.GH, a.GW, a.GD, a.workspace, a.workspace_bytes, s, \
                                           split, (a.variant >= 4 && a.variant <= 9) ? a.variant - 3 : 0); \
+  } else if constexpr (CO * (CI + (OFF ? 1 : 0)) <= 32) {                                         \
+    if (a.Cin == CI && a.Cout == CO && a.has_offset == OFF) {                                     \
+      if (a.variant != 0 && a.variant != 3) return hipErrorNotSupported;                          \
+      return gg_launch_windows<CI, CO, OFF>(q, a.B, a.H, a.W, a.GH, a.GW, a.GD, a.workspace, a.workspace_bytes, s); \
+    }                                                                                             \
   }
   HDRNET_APPLY_FAST_SHAPES(HDRNET_CASE)
 #undef HDRNET_CASE
@@ -1168,7 +1227,7 @@ hipError_t launch_apply_grid_grad_mfma(const ApplyGradArgs& a, hipStream_t s, co
 // Fused backward: dgrid AND dguide / dinput in one pass over the pixels (C % 4 == 0 shapes).
 bool apply_bwd_fused_supported(const ApplyGradArgs& a) {
   if (!a.dgrid || !(a.dguide || a.dinput) || !a.grid) return false;
-  if ((a.Cout * a.Cj) % 4 != 0 || ((uintptr_t)a.grid & 15u)) return false;
+  if ((a.Cout * a.Cj) % 4 != 0 || a.Cout * a.Cj > 16 || a.Cj != 4 || ((uintptr_t)a.grid & 15u)) return false;
   if (a.dinput && a.Cin == 0) return false;
   return apply_grid_grad_mfma_supported(a);
 }

@@ -118,8 +118,8 @@ struct SliceGradArgs {
 
 // The (Cin, Cout, has_offset) shapes every fast BilateralSliceApply path specialises -- ONE table for the
 // forward (apply_fwd_seg / apply_fwd_rows), the per-pixel VJPs (apply_vjp_seg / apply_vjp_rows) and the
-// grid VJP (grid_grad_mfma, which additionally needs C = Cout * Cj <= 16, one MFMA tile: (4, 4, offset)
-// has C = 20 and takes the generic dgrid kernel).  X(CIN, COUT, OFFSET).
+// grid VJP (grid_grad_mfma: one 16-column MFMA tile for C = Cout * Cj <= 16, fused with the per-pixel VJPs where Cj = 4;
+// (4, 4, offset) has C = 20 and runs dgrid as two channel windows beside apply_vjp_seg).  X(CIN, COUT, OFFSET).
 #define HDRNET_APPLY_FAST_SHAPES(X) \
   X(3, 3, true) X(3, 3, false) X(3, 4, true) X(1, 1, true) X(1, 1, false) X(1, 3, true) X(4, 4, true) X(4, 4, false)
 

@@ -143,8 +143,9 @@ def test_forward_1080p_other_shapes_vs_oracle(dev, ops, mt_port, Cin, Cout, off)
 @pytest.mark.parametrize("off", [False, True])
 def test_four_by_four_both_directions(dev, ops, mt_port, off):
     """hdrnet/test/ops_test.py:345-365 uses has_offset = False -> Cout = 4 on 4-channel inputs.  Forward
-    and per-pixel VJPs have a fast specialisation for both settings; dgrid rides the MFMA pass where
-    C = Cout * Cj <= 16 (no offset: 16) and the generic kernel where not (offset: 20)."""
+    and per-pixel VJPs have a fast specialisation for both settings; dgrid rides the MFMA pass -- fused with the
+    per-pixel VJPs where C = Cout * Cj <= 16 (no offset: 16), as two 16-column channel windows beside the per-pixel
+    kernel where not (offset: 20; the generic gather until round 6)."""
     B, H, W, GH, GW, GD = 2, 270, 480, 8, 8, 8
     Cj = 4 + (1 if off else 0)
     rng = np.random.default_rng(44 + Cj)
@@ -160,7 +161,7 @@ def test_four_by_four_both_directions(dev, ops, mt_port, off):
     np.testing.assert_allclose(N(out), want, **FWD_TOL)
     out.backward(T(dout, dev))
     kern = ops.last_kernel()
-    assert kern == ("apply_vjp_seg/vec4+apply_grad_generic" if off else "apply_bwd_fused/mfma"), kern
+    assert kern == ("apply_vjp_seg/vec4+grid_grad_mfma" if off else "apply_bwd_fused/mfma"), kern
     check_dgrid(N(tg.grad), wg, f"(4,4,{off})")
     check_pixel_grad(N(tgu.grad), wgu, f"(4,4,{off})", "dguide")
     check_pixel_grad(N(ti.grad), wi, f"(4,4,{off})", "dinput")

@@ -172,6 +172,11 @@ def test_slice_plane_halves(dev, ops, mt_port, GD, C, kind):
     (3, 135, 240, 16, 12, 16, 1, 3, True, "apply_fwd_seg/vec4", None),                     # C = 6
     (1, 270, 480, 16, 16, 16, 3, 3, False, "apply_fwd_seg/vec4", None),                    # C = 9
     (1, 37, 53, 16, 16, 16, 3, 3, True, None, None),
+    # C = 20 (round 6): dgrid as two 16-column channel windows of the MFMA pass beside the per-pixel VJP kernel -- the
+    # last listed shape that took the generic gather
+    (1, 270, 480, 16, 16, 8, 4, 4, True, "apply_fwd_seg/vec4", "apply_vjp_seg/vec4+grid_grad_mfma"),
+    (2, 270, 480, 8, 16, 16, 4, 4, True, "apply_fwd_seg/vec4", "apply_vjp_seg/vec4+grid_grad_mfma"),
+    (1, 540, 960, 16, 16, 4, 4, 4, True, "apply_fwd_seg/vec4", "apply_vjp_seg/vec4+grid_grad_mfma"),
 ])
 def test_apply_other_shapes_deep_grid(dev, ops, mt_port, case):
     B, H, W, GH, GW, GD, Cin, Cout, off, fk, bk = case
