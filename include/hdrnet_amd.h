@@ -82,7 +82,10 @@ extern "C" {
  *        HDRNET_GUIDE_SIGMOID_FAST to the _ex twins for the old behaviour (<= 2 ulp of the guide, ~10 % faster).
  *   250  gradients of grids with 9 .. 16 planes (luma_bins = 16) run on the fast pass; their workspace bound is twice
  *        the 8-plane one (..._grad_workspace_bytes).  A frame-sized grid gradient that still falls back to the generic
- *        gather kernel under HDRNET_KERNEL_AUTO prints one line on stderr per process. */
+ *        gather kernel under HDRNET_KERNEL_AUTO prints one line on stderr per process.
+ *   251  4 -> 4 with offset (20 grid channels): dgrid runs on the fast pass as two channel windows; the workspace bound of
+ *        that shape is no longer 0 (..._grad_workspace_bytes).  dguide of a call with dgrid == NULL changes in its last
+ *        bits (contraction of the grid's z difference: closer to the float64 value than before). */
 int hdrnet_version(void);
 
 /* Text of the last error raised on the calling thread ("" if none). */
