@@ -980,6 +980,41 @@ def test_wild_guide_values_fast_equals_generic(dev, ops):
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("want_dgrid", [True, False])
+def test_wild_guide_values_gradients_fast_equal_generic(dev, ops, want_dgrid):
+    """The same wild guides through the VJPs: a z tap whose smoothed |dz| exceeds 1 has weight AND derivative 0
+    (numerics.h:108-126), far-out guides clamp both taps onto an edge plane.  Both fast per-pixel paths carry their own
+    handling of it -- the fused pass (grid_grad_mfma.hip: a wave-uniform branch on a ballot) and apply_vjp_seg (per-lane
+    selects, round 6) -- and the dgrid contraction forces the edge half cells to weight 1 (bilateral_slice_apply.cc:121-125);
+    all against the generic kernels, which are the reference's arithmetic."""
+    gen = torch.Generator(device=dev).manual_seed(5)
+    B, H, W, GD = 1, 64, 256, 8
+    grid = torch.rand((B, 16, 16, GD, 12), device=dev, generator=gen)
+    inp = torch.rand((B, H, W, 3), device=dev, generator=gen)
+    dout = torch.randn((B, H, W, 3), device=dev, generator=gen)
+    vals = torch.tensor([1e8, -1e8, 3.1e7, -3.1e7, 2.0 ** 21, 2.0 ** 21 + 0.25, 2.0 ** 20 + 0.125, 1.0e6 + 0.3,
+                         -5.0, 7.5, 1.0, 0.0, 2097151.9, 1048576.06, 12345678.0, -2.0 ** 22,
+                         0.5, 0.0625, 0.9375, 0.31, 0.999999, 1e-7, 0.4375, 0.5625], device=dev)
+    guide = vals.repeat(-(-B * H * W // vals.numel()))[:B * H * W].reshape(B, H, W).contiguous()
+    res = {}
+    for which in ("generic", "fast"):
+        tg = grid.clone().requires_grad_(want_dgrid)
+        tgu, ti = guide.clone().requires_grad_(True), inp.clone().requires_grad_(True)
+        with ops.kernel_override(which):
+            ops.bilateral_slice_apply(tg, tgu, ti, has_offset=True).backward(dout)
+            res[which] = (tg.grad, tgu.grad, ti.grad, ops.last_kernel())
+    assert res["fast"][3] == ("apply_bwd_fused/mfma" if want_dgrid else "apply_vjp_seg/vec4"), res["fast"][3]
+    for k, nm, atol in ((1, "dguide", 2e-5), (2, "dinput", 1e-5)):
+        a, b = res["fast"][k], res["generic"][k]
+        assert torch.isfinite(a).all(), nm
+        print(f"wild guides, dgrid {want_dgrid}: {nm} max|fast - generic| = {float((a - b).abs().max()):.3e} on values up to "
+              f"{float(b.abs().max()):.3g}")
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=atol)
+    if want_dgrid:
+        a, b = res["fast"][0], res["generic"][0]
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()))
+
+
 def test_fast_flag_rejects_unsupported_shape(dev, ops):
     from hdrnet_amd import _lib
     with ops.kernel_override("fast"):
