@@ -201,26 +201,27 @@ __global__ __launch_bounds__(256) void apply_vjp_seg(const VjpSegParams p) {
                 }
               }
             }
-            __builtin_amdgcn_sched_barrier(0);
-            continue;
-          }
-          const f32x2 dq = {d[q < COUT ? q : 0], d[q < COUT ? q : 0]};
-          if constexpr (WANT_GUIDE) {
-            const f32x2 U01 = i01 * dq, U23 = i23 * dq;
-            acc0 = __builtin_elementwise_fma(f32x2{X0.x, X0.y}, U01, acc0);
-            acc0 = __builtin_elementwise_fma(f32x2{X0.z, X0.w}, U23, acc0);
-            accd = __builtin_elementwise_fma(f32x2{Xd.x, Xd.y}, U01, accd);
-            accd = __builtin_elementwise_fma(f32x2{Xd.z, Xd.w}, U23, accd);
-          }
-          if constexpr (WANT_INPUT) {
-            t0a = __builtin_elementwise_fma(f32x2{X0.x, X0.y}, dq, t0a);
-            tda = __builtin_elementwise_fma(f32x2{Xd.x, Xd.y}, dq, tda);
-            if constexpr (CIN > 3) {
-              t0b = __builtin_elementwise_fma(f32x2{X0.z, X0.w}, dq, t0b);
-              tdb = __builtin_elementwise_fma(f32x2{Xd.z, Xd.w}, dq, tdb);
-            } else if constexpr (CIN > 2) {
-              t0b.x = fmaf(X0.z, d[q < COUT ? q : 0], t0b.x);
-              tdb.x = fmaf(Xd.z, d[q < COUT ? q : 0], tdb.x);
+          } else {
+            // one float4 = output row q: its two column pairs against U = dout_q [in; 1], packed
+            const float dqs = d[q < COUT ? q : 0];
+            const f32x2 dq = {dqs, dqs};
+            if constexpr (WANT_GUIDE) {
+              const f32x2 U01 = i01 * dq, U23 = i23 * dq;
+              acc0 = __builtin_elementwise_fma(f32x2{X0.x, X0.y}, U01, acc0);
+              acc0 = __builtin_elementwise_fma(f32x2{X0.z, X0.w}, U23, acc0);
+              accd = __builtin_elementwise_fma(f32x2{Xd.x, Xd.y}, U01, accd);
+              accd = __builtin_elementwise_fma(f32x2{Xd.z, Xd.w}, U23, accd);
+            }
+            if constexpr (WANT_INPUT) {
+              t0a = __builtin_elementwise_fma(f32x2{X0.x, X0.y}, dq, t0a);
+              tda = __builtin_elementwise_fma(f32x2{Xd.x, Xd.y}, dq, tda);
+              if constexpr (CIN > 3) {
+                t0b = __builtin_elementwise_fma(f32x2{X0.z, X0.w}, dq, t0b);
+                tdb = __builtin_elementwise_fma(f32x2{Xd.z, Xd.w}, dq, tdb);
+              } else if constexpr (CIN > 2) {
+                t0b.x = fmaf(X0.z, dqs, t0b.x);
+                tdb.x = fmaf(Xd.z, dqs, tdb.x);
+              }
             }
           }
           __builtin_amdgcn_sched_barrier(0);  // one vector of read-ahead: a whole tap in registers costs occupancy

@@ -694,8 +694,6 @@ __attribute__((amdgpu_waves_per_eu(((WG || WI) && COUT * (APPLY ? CIN + (OFFSET 
           for (int i = 0; i < COUT; ++i) {
 #pragma unroll
             for (int j = 0; j < CJ; ++j) {
-              constexpr int kUnused = 0;
-              (void)kUnused;
               const int c = i * CJ + j;  // (compile-time after unrolling: only this window's channels are staged)
               if (c >= C0 && c < C0 + C)
                 vt[(c - C0) * kTStride + lane] =
