@@ -147,20 +147,31 @@ __global__ __launch_bounds__(kThreads, 2) void guide_nn_grad(
       float w[CJ];
 #pragma unroll
       for (int j = 0; j < CJ; ++j) w[j] = conv1[f * CJ + j];  // wave-uniform -> scalar loads
-      const float w2 = conv2[f];
+      [[maybe_unused]] const float w2 = conv2[f];
 #pragma unroll
       for (int k = 0; k < kPx; ++k) {
         float h = w[CIN];
 #pragma unroll
         for (int j = 0; j < CIN; ++j) h = fmaf(w[j], in[k][j], h);
-        acc[NF * CJ + f] = fmaf(da[k], fmaxf(h, 0.0f), acc[NF * CJ + f]);  // d conv2[f]
-        const float dh = (h > 0.0f) ? da[k] * w2 : 0.0f;                   // through the ReLU
+        if constexpr (DIN == 0) {
+          // parameters only (a training step): with md = [h > 0] da the three sums are sum md x_j, sum md and sum md h;
+          // the factor w2 of d conv1 leaves the loop (applied once below): 10 instead of 12 instructions per feature
+          // and pixel on a kernel bound by VALU issue (62 us against a 22-us memory floor at 4 x 1080p)
+          const float md = (h > 0.0f) ? da[k] : 0.0f;
 #pragma unroll
-        for (int j = 0; j < CIN; ++j) {
-          acc[f * CJ + j] = fmaf(dh, in[k][j], acc[f * CJ + j]);  // d conv1[f][j]
-          if constexpr (DIN != 0) din[k][j] = fmaf(dh, w[j], din[k][j]);  // d input_j
+          for (int j = 0; j < CIN; ++j) acc[f * CJ + j] = fmaf(md, in[k][j], acc[f * CJ + j]);
+          acc[f * CJ + CIN] += md;
+          acc[NF * CJ + f] = fmaf(md, h, acc[NF * CJ + f]);  // d conv2[f] = sum da relu(h)
+        } else {
+          acc[NF * CJ + f] = fmaf(da[k], fmaxf(h, 0.0f), acc[NF * CJ + f]);  // d conv2[f]
+          const float dh = (h > 0.0f) ? da[k] * w2 : 0.0f;                   // through the ReLU
+#pragma unroll
+          for (int j = 0; j < CIN; ++j) {
+            acc[f * CJ + j] = fmaf(dh, in[k][j], acc[f * CJ + j]);  // d conv1[f][j]
+            din[k][j] = fmaf(dh, w[j], din[k][j]);                  // d input_j
+          }
+          acc[f * CJ + CIN] += dh;  // d conv1 bias
         }
-        acc[f * CJ + CIN] += dh;  // d conv1 bias
       }
     }
     if constexpr (DIN != 0) {
@@ -195,6 +206,14 @@ __global__ __launch_bounds__(kThreads, 2) void guide_nn_grad(
           }
         }
       }
+    }
+  }
+  if constexpr (DIN == 0) {
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const float w2 = conv2[f];
+#pragma unroll
+      for (int j = 0; j < CJ; ++j) acc[f * CJ + j] *= w2;
     }
   }
   block_reduce_store<NA>(acc, partial + (size_t)blockIdx.x * NA);
